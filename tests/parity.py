@@ -1,0 +1,135 @@
+"""Parity metrics shared by the CPU (oracle-vs-reference) and GPU (HIP-vs-oracle) tests.
+
+SURVEY.md §8(d): a resting stack has ||x_ref|| ~ 1e-15 and analytically-zero gradients,
+so plain relative errors are meaningless there.  Errors are therefore scaled by the
+free-motion magnitudes (what the quantity would be with no contact constraint):
+
+    x_free  = Q^-1 p            dx_free = Q^-1 dl_dx
+    err_x   = ||x - x_ref|| / max(||x_ref||, ||x_free||)
+    err_g   = ||g - g_ref||_F / max(||g_ref||_F, S_g)
+
+with dimensionally consistent floors S_g built from ||dx_free||, ||x_free||, ||z_ref||,
+||y_ref|| (see `grad_floors`).  All norms are per scene.
+"""
+import torch
+
+
+def _n(t):
+    return t.reshape(t.shape[0], -1).double().norm(dim=1)
+
+
+def free_scales(Q, p, cot=None):
+    Qd = Q.double()
+    xf = torch.linalg.solve(Qd, p.double().unsqueeze(-1)).squeeze(-1)
+    out = {"x_free": _n(xf)}
+    if cot is not None:
+        df = torch.linalg.solve(Qd, cot.double().unsqueeze(-1)).squeeze(-1)
+        out["dx_free"] = _n(df)
+    return out
+
+
+def err_x(x, x_ref, Q, p):
+    sc = free_scales(Q, p)["x_free"]
+    return _n(x.double() - x_ref.double()) / torch.maximum(_n(x_ref), sc).clamp_min(1e-300)
+
+
+def rel_err(a, a_ref, floor=1e-300):
+    return _n(a.double() - a_ref.double()) / _n(a_ref).clamp_min(floor)
+
+
+def grad_floors(Q, p, cot, x_ref, z_ref, y_ref=None):
+    sc = free_scales(Q, p, cot)
+    xf = torch.maximum(sc["x_free"], _n(x_ref)).clamp_min(1e-300)
+    df = sc["dx_free"]
+    zn = _n(z_ref)
+    fl = {"p": df, "Q": df * xf, "G": df * zn, "h": df * zn / xf, "F": df * zn * zn / xf}
+    if y_ref is not None:
+        yn = _n(y_ref)
+        fl["A"] = df * torch.maximum(yn, zn)
+        fl["b"] = df * torch.maximum(yn, zn) / xf
+    return fl
+
+
+def err_grads(grads, grads_ref, floors):
+    """grads / grads_ref: dicts keyed by 'Q','p','G','h','A','b','F' (None entries skipped)."""
+    out = {}
+    for k, g_ref in grads_ref.items():
+        if g_ref is None or grads.get(k) is None:
+            continue
+        den = torch.maximum(_n(g_ref), floors[k]).clamp_min(1e-300)
+        out[k] = _n(grads[k].double() - g_ref.double()) / den
+    return out
+
+
+def active_sets(z, s, nc=None):
+    """Contact index set {i : z_i > s_i}.  Returns a bool mask [B,m]."""
+    return z > s
+
+
+# ----------------------------------------------------------------------------
+# backward parity that is well-posed on degenerate contact LCPs
+# ----------------------------------------------------------------------------
+# With two opposite friction directions per contact (world.py:191-192) a sticking
+# contact has BOTH friction multipliers active, and only their difference is determined
+# by the limiting KKT system; the (1,1) component of dlam is fixed by diag(s/z) ~ 1e-17
+# entries, i.e. by rounding.  The reference's own fp64 result is therefore not
+# reproducible in dG/dh/dF by any other elimination order (measured: O(1e-1) between
+# the reference and an algebraically identical block solve), while dp, dQ, dA, db and
+# every gradient w.r.t. a *physical* parameter (where the +/- friction rows are tied
+# together by the assembly) agree to rounding.  Hence three checks:
+#   1. direct scaled parity on dp, dQ, dA, db (always), all 7 on non-degenerate LCPs;
+#   2. the KKT residual of (dx, dlam, dnu) in the system the reference solves;
+#   3. parity of the gradients contracted through the assembly (`physical_grads`).
+
+
+def kkt_backward_residual(Q, G, A, F, z, s, cot, dx, dlam, dnu=None):
+    """Row-block scaled residuals of lcp.py:47-50's system, ds eliminated (ds = -dz/d):
+         Q dx + G^T dlam + A^T dnu = -cot ;  G dx - dlam/d - F dlam = 0 ;  A dx = 0.
+    ||dx|| is floored by the free-motion ||Q^-1 cot|| (a fully constrained dx is noise)."""
+    D = lambda t: None if t is None else t.double()
+    Q, G, A, F, z, s, cot, dx, dlam, dnu = map(D, (Q, G, A, F, z, s, cot, dx, dlam, dnu))
+    mv = lambda M, v: torch.bmm(M, v.unsqueeze(-1)).squeeze(-1)
+    mtv = lambda M, v: torch.bmm(M.transpose(1, 2), v.unsqueeze(-1)).squeeze(-1)
+    ndx = torch.maximum(_n(dx), _n(torch.linalg.solve(Q, cot.unsqueeze(-1))))
+    r1 = mv(Q, dx) + mtv(G, dlam) + cot
+    den1 = _n(Q) * ndx + _n(G) * _n(dlam) + _n(cot)
+    if A is not None:
+        r1 = r1 + mtv(A, dnu)
+        den1 = den1 + _n(A) * _n(dnu)
+    sd = (s / z) * dlam
+    r3 = mv(G, dx) - sd - mv(F, dlam)
+    den3 = _n(G) * ndx + _n(sd) + _n(F) * _n(dlam)
+    out = {"dual": _n(r1) / den1.clamp_min(1e-300), "ineq": _n(r3) / den3.clamp_min(1e-300)}
+    if A is not None:
+        out["eq"] = _n(mv(A, dx)) / (_n(A) * ndx).clamp_min(1e-300)
+    return out
+
+
+PHYS_KEYS = ["Mdiag", "v", "f", "c_n", "c_p1", "c_p2", "rest", "fric"]
+
+
+def physical_grads(phys, dt, grads, oracle):
+    """Contract LCP-level grads (dict Q,p,G,h,F) through the engine assembly
+    (engines.py:31-32,50-74; world.py:144-234) with autograd of the oracle's restatement.
+    phys: dict with PHYS_KEYS (+ c_i1, c_i2, Je), batched."""
+    ins = {k: phys[k].double().clone().requires_grad_(True) for k in PHYS_KEYS}
+    Je = phys.get("Je")
+    Q, p, G, h, A, b, F = oracle.assemble_lcp(
+        ins["Mdiag"], ins["v"], ins["f"], dt, ins["c_n"], ins["c_p1"], ins["c_p2"],
+        phys["c_i1"], phys["c_i2"], ins["rest"], ins["fric"],
+        None if Je is None else Je.double())
+    outs = [Q, p, G, h, F]
+    gos = [grads[k].double() for k in "QpGhF"]
+    g = torch.autograd.grad(outs, [ins[k] for k in PHYS_KEYS], gos, allow_unused=True)
+    return {k: (torch.zeros_like(ins[k]) if gi is None else gi) for k, gi in zip(PHYS_KEYS, g)}
+
+
+def err_physical(pg, pg_ref, phys, floor):
+    """Joint error of d(loss)/d(log-ish theta): blocks weighted by max(||theta||, 1)."""
+    num = 0.0
+    den = 0.0
+    for k in PHYS_KEYS:
+        w = _n(phys[k]).clamp_min(1.0)
+        num = num + (w * _n(pg[k] - pg_ref[k])) ** 2
+        den = den + (w * _n(pg_ref[k])) ** 2
+    return num.sqrt() / torch.maximum(den.sqrt(), floor).clamp_min(1e-300)
