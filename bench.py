@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py - the BASELINE.json metric on MI355X.
+
+metric : sim steps/sec at batch=4096 x 16 contacts, forward + backward (implicit diff)
+step   : one pass of the hot path over one batch of synthetic scenes already resident in HBM:
+         LCP forward solve (lcp_pdipm_forward_f32) + LCP backward (lcp_pdipm_backward_f32) for
+         B = 4096 scenes per GPU (floor + 4-box stack, 4 contact points per interface:
+         nz 15, nineq 64, neq 3).  `--mode fused` times the fused step kernel (assembly + solve +
+         integrate) + backward instead.
+N GPUs : one process per GPU (torchrun), every rank owns its own 4096 scenes (weak scaling,
+         config 4 = 8 x 4096); no collective on the solve path - torch.distributed (RCCL) is only
+         used for the barriers and the MAX-over-ranks wall time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - dominant kernel (the forward PDIPM kernel): algorithmic FLOPs (SURVEY.md §8d,
+                 lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by
+                 its average launch duration measured with HIP events on the launch stream inside
+                 the timed region; peak = the FP64 vector/matrix rate when the parity path
+                 (fp64 arithmetic) runs, the FP32 rate for --compute f32.
+  cpu_baseline - the oracle (a port, torch CPU fp64) timed on this host's cores on the same
+                 workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X FP64 / FP32 vector = matrix rates (datasheet; MI355X_MICROARCH.md lists FP32)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="scenes per GPU")
+    ap.add_argument("--nbox", type=int, default=4)
+    ap.add_argument("--pts", type=int, default=4)
+    ap.add_argument("--compute", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--mode", default="dense", choices=["dense", "fused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
+    return ap.parse_args()
+
+
+def cpu_baseline(sc_cpu, sample, cot):
+    """Oracle (port of the reference algorithm) on the host cores: forward + backward."""
+    from oracle import pdipm_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sub = sc_cpu.slice(0, sample).to(dtype=torch.float64)
+    lcp = O.assemble_lcp(*sub.assembly_args())
+    warm = [None if t is None else t[:64] for t in lcp]
+    O.lcp_backward(O.lcp_forward(*warm), *warm, cot[:64].double())
+    t0 = time.perf_counter()
+    sol = O.lcp_forward(*lcp)
+    O.lcp_backward(sol, *lcp, cot[:sample].double())
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "sim steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the same scenes, 1 pass fwd+bwd, vectorised torch fp64 oracle, %.2f s" % (sample, dt)}
+
+
+def main():
+    args = parse()
+    from lcp_physics_amd import flops, scenes, shard
+    from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    from lcp_physics_amd.physics.batched_world import solution_of_step
+
+    rank, local_rank, world = shard.init_process_group()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    B = args.batch
+    nb, nc = args.nbox + 1, args.nbox * args.pts
+    nz, m, e = 3 * nb, 4 * nc, 3
+
+    # synthetic scenes, generated on the host, then resident in HBM before any timing
+    sc_cpu = scenes.make_stack_scenes(B=B, nbox=args.nbox, pts_per_interface=args.pts, seed=1236 + 1000 * rank,
+                                      dtype=torch.float32)
+    sc = sc_cpu.to(device=dev)
+    g = torch.Generator().manual_seed(4321 + rank)
+    cot_cpu = torch.randn(B, nz, generator=g, dtype=torch.float32)
+    cot = cot_cpu.to(dev)
+    lcp = assemble_contacts(sc)            # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel
+    G, A = lcp[2], lcp[4]
+    sol = lcp_solve(*lcp, compute=args.compute)
+    grads = lcp_backward(sol, cot)
+    step_out = fused_step(sc, compute=args.compute) if args.mode == "fused" else None
+    torch.cuda.synchronize()
+
+    def one_step(ev=None):
+        nonlocal sol, step_out
+        if ev is not None:
+            ev[0].record()
+        if args.mode == "dense":
+            lcp_solve(*lcp, compute=args.compute, ws=sol.ws, out=sol)
+            s_ = sol
+        else:
+            step_out = fused_step(sc, compute=args.compute, ws=step_out["ws"], out=step_out)
+            s_ = solution_of_step(sc, step_out, G, A, compute=args.compute)
+        if ev is not None:
+            ev[1].record()
+        lcp_backward(s_, cot, out=grads)
+        if ev is not None:
+            ev[2].record()
+
+    for _ in range(args.warmup):
+        one_step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    shard.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(events[k])
+    torch.cuda.synchronize()
+    shard.barrier()
+    wall = time.perf_counter() - t0
+    wall = shard.max_over_ranks(wall, device=dev)
+
+    fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in events) / args.steps
+    bwd_ms = sum(ev[1].elapsed_time(ev[2]) for ev in events) / args.steps
+    iters = (sol.iters if args.mode == "dense" else step_out["iters"]).double()
+    status = (sol.status if args.mode == "dense" else step_out["status"])
+    mean_it = float(iters.mean())
+    fl_fwd = float(sum(flops.flops_forward(nz, m, e, it) for it in iters.cpu().tolist()))
+    fl_bwd = flops.flops_backward(nz, m, e) * B
+    total_steps = B * world * args.steps
+    value = total_steps / wall
+    achieved = fl_fwd / (fwd_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.compute]
+    out = {
+        "metric": "sim steps/sec at batch=4096x16 contacts, fwd+bwd",
+        "value": value,
+        "unit": "sim steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.compute,
+        "data": "synthetic",
+        "config": {"workload": "configs[2]: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
+                               "neq %d) per GPU, fp32 I/O, LCP forward + backward (implicit diff), mode=%s"
+                               % (B, nc, args.nbox, args.pts, nz, m, e, args.mode),
+                   "global_batch": B * world, "parallelism": "scenes sharded x%d, no collectives" % world,
+                   "mean_pdipm_iters": mean_it, "nonzero_status": int((status != 0).sum())},
+        "roofline": {"bound": "mfma", "kernel": "lcp_fwd_kernel (PDIPM forward)", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+                     "bwd_achieved": fl_bwd / (bwd_ms * 1e-3) / 1e12,
+                     "algorithmic_bytes_per_launch": flops.bytes_forward(nz, m, e) * B,
+                     "hbm_frac_algorithmic": flops.bytes_forward(nz, m, e) * B / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc_cpu, min(args.cpu_sample, B), cot_cpu)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

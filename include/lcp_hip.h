@@ -1,0 +1,133 @@
+/*
+ * lcp_hip.h - C ABI of the MI355X-native batched LCP contact solver (liblcp_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of locuslab/lcp-physics.  The reference
+ * is pure Python and has no FFI of its own; each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference/lcp_physics).  The reference-
+ * side binding a maintainer would add (a ctypes stub inside lcp/lcp.py and
+ * physics/engines.py) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless stated otherwise; all tensors are
+ *    row-major, contiguous, batch-major ([B, rows, cols]);
+ *  - the caller owns every buffer, including the workspace (`lcp_workspace_bytes`);
+ *    nothing is allocated, freed or synchronised inside; launches are ordered on `stream`
+ *    (a hipStream_t passed as void*, NULL = the default stream);
+ *  - return value: 0 = launched, <0 = invalid arguments / unsupported size (LCP_E_*);
+ *    numerical trouble is NOT an error (the reference returns its best iterate silently,
+ *    lcp/solvers/pdipm.py:99-102,133-136,176-179): it is reported per scene in `status`;
+ *  - sizes: nz = number of primal variables, m = nineq (rows of G), e = neq (rows of A,
+ *    may be 0: then A, b, y and their gradients may be NULL).
+ *  - `compute`: arithmetic type used inside the kernels.  LCP_COMPUTE_F64 is the parity
+ *    path (fp32 I/O, fp64 arithmetic); LCP_COMPUTE_F32 computes everything in fp32.
+ */
+#ifndef LCP_HIP_H
+#define LCP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCP_COMPUTE_F32 0
+#define LCP_COMPUTE_F64 1
+
+#define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
+#define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan  */
+#define LCP_E_LAUNCH   (-3)   /* hipLaunchKernel reported an error                     */
+
+/* per-scene status bits written to `status[B]` */
+#define LCP_ST_SINGULAR_Q   1  /* zero/NaN pivot while inverting Q   (pdipm.py:361-368 raises) */
+#define LCP_ST_SINGULAR_S11 2  /* zero/NaN pivot in A Q^-1 A^T                                  */
+#define LCP_ST_SINGULAR_T   4  /* exact zero pivot in LU(T): best iterate returned (pdipm.py:99-102) */
+#define LCP_ST_NAN          8  /* the returned iterate contains NaN                             */
+
+/* Library / build identification: returns a static string such as
+ * "lcp_hip 0.1.0 gfx950".  Host-only, never touches the GPU. */
+const char* lcp_version(void);
+
+/* Bytes of workspace the forward/backward pair needs for a batch (caller allocates,
+ * 256-byte aligned).  Holds what the reference keeps on the op instance between forward
+ * and backward (lcp/lcp.py:28-29: Q_LU, S_LU, R, nus, lams, slacks): R, Q^-1, G Q^-1 A^T,
+ * (A Q^-1 A^T)^-1 and the best iterate in compute precision.  Host-only. */
+size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute);
+
+/* Replaces LCPFunction.forward (lcp/lcp.py:22-35) = pdipm.pre_factor_kkt
+ * (lcp/solvers/pdipm.py:357-408) + pdipm.forward (pdipm.py:49-179) with factor_kkt
+ * (:414-454), solve_kkt (:325-354) and get_step (:182-186), per-scene (batch-1) semantics.
+ *   in : Q[B,nz,nz] p[B,nz] G[B,m,nz] h[B,m] A[B,e,nz] b[B,e] F[B,m,m]
+ *   out: x[B,nz] (zhats)  y[B,e] (nus)  z[B,m] (lams)  s[B,m] (slacks)
+ *        iters[B]  (PDIPM loop iterations executed = factorisations inside the loop)
+ *        status[B] (LCP_ST_* bits)
+ * eps / max_iter / not_improved_lim: lcp/lcp.py:12-13 (1e-12, 10, 3). */
+int lcp_pdipm_forward_f32(int B, int nz, int m, int e,
+                          const float* Q, const float* p, const float* G, const float* h,
+                          const float* A, const float* b, const float* F,
+                          double eps, int max_iter, int not_improved_lim, int compute,
+                          float* x, float* y, float* z, float* s,
+                          int32_t* iters, int32_t* status, void* ws, void* stream);
+
+/* Same, fp64 I/O and fp64 arithmetic (the reference's default dtype, physics/utils.py:34). */
+int lcp_pdipm_forward_f64(int B, int nz, int m, int e,
+                          const double* Q, const double* p, const double* G, const double* h,
+                          const double* A, const double* b, const double* F,
+                          double eps, int max_iter, int not_improved_lim,
+                          double* x, double* y, double* z, double* s,
+                          int32_t* iters, int32_t* status, void* ws, void* stream);
+
+/* Replaces LCPFunction.backward (lcp/lcp.py:37-64): d = lams/slacks, factor_kkt, one
+ * solve_kkt with rhs (dl_dx, 0, 0, 0), then the outer products.  Uses the workspace left
+ * by the matching forward call (same B, nz, m, e, compute).  The reference solves with K,
+ * not K^T (exact only for symmetric F); that formula is reproduced.
+ *   in : G[B,m,nz] A[B,e,nz] dl_dx[B,nz]
+ *   out: dQ[B,nz,nz] dp[B,nz] dG[B,m,nz] dh[B,m] dA[B,e,nz] db[B,e] dF[B,m,m]
+ *        (any output pointer may be NULL to skip that gradient) */
+int lcp_pdipm_backward_f32(int B, int nz, int m, int e,
+                           const float* G, const float* A, const float* dl_dx, int compute,
+                           float* dQ, float* dp, float* dG, float* dh,
+                           float* dA, float* db, float* dF,
+                           void* ws, void* stream);
+
+int lcp_pdipm_backward_f64(int B, int nz, int m, int e,
+                           const double* G, const double* A, const double* dl_dx,
+                           double* dQ, double* dp, double* dG, double* dh,
+                           double* dA, double* db, double* dF,
+                           void* ws, void* stream);
+
+/* Replaces the contact branch of PdipmEngine.solve_dynamics (physics/engines.py:26-78)
+ * for B independent scenes: assembles u = M v + dt f (engines.py:31-32), Jc / Jf / mu / E /
+ * restitutions (physics/world.py:144-234) into the dense (Q,p,G,h,A,b,F) the reference hands
+ * to LCPFunction (engines.py:67-76).  nb bodies (3 DoF each, nz = 3 nb), nc contacts
+ * (m = 4 nc, two friction directions), e joint rows.
+ *   in : Mdiag[B,nb,3] v[B,nb,3] f[B,nb,3] rest[B,nb] fric[B,nb]
+ *        c_n[B,nc,2] c_p1[B,nc,2] c_p2[B,nc,2] c_i1[B,nc] c_i2[B,nc] (int32)  Je[B,e,nz]
+ *   out: Q[B,nz,nz] p[B,nz] G[B,m,nz] h[B,m] A[B,e,nz] b[B,e] F[B,m,m] */
+int lcp_assemble_contacts_f32(int B, int nb, int nc, int e,
+                              const float* Mdiag, const float* v, const float* f,
+                              const float* rest, const float* fric,
+                              const float* c_n, const float* c_p1, const float* c_p2,
+                              const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                              float* Q, float* p, float* G, float* h, float* A, float* b, float* F,
+                              void* stream);
+
+/* One fused simulation step for B scenes in a single launch: the assembly above, the LCP
+ * solve (as lcp_pdipm_forward_f32), new_v = -x (engines.py:76-77) and the semi-implicit
+ * integrator p <- p + new_v dt of Body.move (physics/bodies.py:80-82).  Dense LCP data
+ * never leaves the chip.  Leaves the same workspace as the forward so that
+ * lcp_pdipm_backward_f32 can follow (with G from lcp_assemble_contacts_f32).
+ *   out: v_new[B,nb,3]  p_new[B,nb,3]  z[B,m]  s[B,m]  y[B,e]  iters[B]  status[B] */
+int lcp_step_fused_f32(int B, int nb, int nc, int e,
+                       const float* pos, const float* Mdiag, const float* v, const float* f,
+                       const float* rest, const float* fric,
+                       const float* c_n, const float* c_p1, const float* c_p2,
+                       const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                       double eps, int max_iter, int not_improved_lim, int compute,
+                       float* v_new, float* p_new, float* z, float* s, float* y,
+                       int32_t* iters, int32_t* status, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCP_HIP_H */

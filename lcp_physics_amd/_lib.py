@@ -1,0 +1,90 @@
+"""ctypes binding of liblcp_hip.so (the C ABI in include/lcp_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, the
+caller gets an exception.  PyTorch is only used for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblcp_hip.so")
+
+COMPUTE_F32 = 0
+COMPUTE_F64 = 1
+
+ST_SINGULAR_Q = 1
+ST_SINGULAR_S11 = 2
+ST_SINGULAR_T = 4
+ST_NAN = 8
+
+_ERRORS = {-1: "LCP_E_BADARG", -2: "LCP_E_TOOLARGE", -3: "LCP_E_LAUNCH"}
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+
+# symbol -> (restype, argtypes); must list every function include/lcp_hip.h declares
+SIGNATURES = {
+    "lcp_version": (_c.c_char_p, []),
+    "lcp_workspace_bytes": (_c.c_size_t, [_I, _I, _I, _I, _I]),
+    "lcp_pdipm_forward_f32": (_I, [_I] * 4 + [_P] * 7 + [_c.c_double, _I, _I, _I] + [_P] * 4 + [_P, _P, _P, _P]),
+    "lcp_pdipm_forward_f64": (_I, [_I] * 4 + [_P] * 7 + [_c.c_double, _I, _I] + [_P] * 4 + [_P, _P, _P, _P]),
+    "lcp_pdipm_backward_f32": (_I, [_I] * 4 + [_P] * 3 + [_I] + [_P] * 7 + [_P, _P]),
+    "lcp_pdipm_backward_f64": (_I, [_I] * 4 + [_P] * 3 + [_P] * 7 + [_P, _P]),
+    "lcp_assemble_contacts_f32": (_I, [_I] * 4 + [_P] * 11 + [_c.c_float] + [_P] * 7 + [_P]),
+    "lcp_step_fused_f32": (_I, [_I] * 4 + [_P] * 12 + [_c.c_float, _c.c_double, _I, _I, _I] + [_P] * 5
+                           + [_P, _P, _P, _P]),
+    "lcp_debug_set_trace": (None, [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise - never degrade silently."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "liblcp_hip.so not found at %s - build it with `make -C lcp_physics_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, _ERRORS.get(rc, "unknown"), rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def workspace_bytes(B, nz, m, e, compute):
+    return int(load().lcp_workspace_bytes(B, nz, m, e, compute))

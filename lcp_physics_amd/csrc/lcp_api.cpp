@@ -1,0 +1,147 @@
+// lcp_api.cpp - the C ABI declared in include/lcp_hip.h: argument checking, launch planning and
+// dispatch to the kernel translation units.  No torch types, no allocation, no synchronisation.
+#include <stdlib.h>
+#include <string.h>
+
+#include "lcp_kernels.h"
+
+namespace {
+
+double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
+
+inline int csize_of(int io_f64, int compute) { return (io_f64 || compute == LCP_COMPUTE_F64) ? 8 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+const char* lcp_version(void) { return "lcp_hip 0.1.0 gfx950"; }
+
+size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
+  if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return 0;
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  return (size_t)B * pl.ws_stride * cs;
+}
+
+// Debugging aid (not part of the drop-in surface): when set, the dense forward writes
+// trace[B, max_iter, 4] = (resid, mu, sigma, alpha) per PDIPM iteration.  Pass NULL to disable.
+void lcp_debug_set_trace(double* device_trace) { g_trace = device_trace; }
+
+static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q, const void* p, const void* G,
+                          const void* h, const void* A, const void* b, const void* F, double eps, int max_iter,
+                          int lim, int compute, void* x, void* y, void* z, void* s, int32_t* iters,
+                          int32_t* status, void* ws, void* stream) {
+  if (B <= 0 || nz <= 0 || m <= 0 || e < 0 || max_iter < 0) return LCP_E_BADARG;
+  if (!Q || !p || !G || !h || !F || !x || !z || !s || !ws) return LCP_E_BADARG;
+  if (e > 0 && (!A || !b)) return LCP_E_BADARG;
+  const int cs = csize_of(io_f64, compute);
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  lcp::FwdArgs P;
+  memset(&P, 0, sizeof(P));
+  P.B = B; P.nz = nz; P.m = m; P.e = e;
+  P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b; P.F = F;
+  P.x = x; P.y = y; P.z = z; P.s = s; P.iters = iters; P.status = status;
+  P.ws = ws; P.ws_stride = pl.ws_stride; P.eps = eps; P.max_iter = max_iter; P.lim = lim;
+  P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds; P.trace = g_trace;
+  return lcp::generic_forward(P, io_f64, compute, pl.lds_bytes, stream);
+}
+
+int lcp_pdipm_forward_f32(int B, int nz, int m, int e, const float* Q, const float* p, const float* G,
+                          const float* h, const float* A, const float* b, const float* F, double eps,
+                          int max_iter, int not_improved_lim, int compute, float* x, float* y, float* z,
+                          float* s, int32_t* iters, int32_t* status, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  return forward_common(0, B, nz, m, e, Q, p, G, h, A, b, F, eps, max_iter, not_improved_lim, compute, x, y,
+                        z, s, iters, status, ws, stream);
+}
+
+int lcp_pdipm_forward_f64(int B, int nz, int m, int e, const double* Q, const double* p, const double* G,
+                          const double* h, const double* A, const double* b, const double* F, double eps,
+                          int max_iter, int not_improved_lim, double* x, double* y, double* z, double* s,
+                          int32_t* iters, int32_t* status, void* ws, void* stream) {
+  return forward_common(1, B, nz, m, e, Q, p, G, h, A, b, F, eps, max_iter, not_improved_lim,
+                        LCP_COMPUTE_F64, x, y, z, s, iters, status, ws, stream);
+}
+
+static int backward_common(int io_f64, int B, int nz, int m, int e, const void* G, const void* A,
+                           const void* dl_dx, int compute, void* dQ, void* dp, void* dG, void* dh, void* dA,
+                           void* db, void* dF, void* ws, void* stream) {
+  if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return LCP_E_BADARG;
+  if (!G || !dl_dx || !ws) return LCP_E_BADARG;
+  if (e > 0 && !A) return LCP_E_BADARG;
+  const int cs = csize_of(io_f64, compute);
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  lcp::BwdArgs P;
+  memset(&P, 0, sizeof(P));
+  P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
+  P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
+  P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
+}
+
+int lcp_pdipm_backward_f32(int B, int nz, int m, int e, const float* G, const float* A, const float* dl_dx,
+                           int compute, float* dQ, float* dp, float* dG, float* dh, float* dA, float* db,
+                           float* dF, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  return backward_common(0, B, nz, m, e, G, A, dl_dx, compute, dQ, dp, dG, dh, dA, db, dF, ws, stream);
+}
+
+int lcp_pdipm_backward_f64(int B, int nz, int m, int e, const double* G, const double* A,
+                           const double* dl_dx, double* dQ, double* dp, double* dG, double* dh, double* dA,
+                           double* db, double* dF, void* ws, void* stream) {
+  return backward_common(1, B, nz, m, e, G, A, dl_dx, LCP_COMPUTE_F64, dQ, dp, dG, dh, dA, db, dF, ws,
+                         stream);
+}
+
+static int fill_step(lcp::StepArgs& P, int B, int nb, int nc, int e, const float* pos, const float* Mdiag,
+                     const float* v, const float* f, const float* rest, const float* fric, const float* c_n,
+                     const float* c_p1, const float* c_p2, const int32_t* c_i1, const int32_t* c_i2,
+                     const float* Je, float dt) {
+  if (B <= 0 || nb <= 0 || nc <= 0 || e < 0) return LCP_E_BADARG;
+  if (!Mdiag || !v || !f || !rest || !fric || !c_n || !c_p1 || !c_p2 || !c_i1 || !c_i2) return LCP_E_BADARG;
+  if (e > 0 && !Je) return LCP_E_BADARG;
+  memset(&P, 0, sizeof(P));
+  P.B = B; P.nb = nb; P.nc = nc; P.e = e;
+  P.pos = pos; P.Mdiag = Mdiag; P.v = v; P.f = f; P.rest = rest; P.fric = fric;
+  P.c_n = c_n; P.c_p1 = c_p1; P.c_p2 = c_p2; P.c_i1 = c_i1; P.c_i2 = c_i2; P.Je = Je; P.dt = dt;
+  return 0;
+}
+
+int lcp_assemble_contacts_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
+                              const float* rest, const float* fric, const float* c_n, const float* c_p1,
+                              const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je,
+                              float dt, float* Q, float* p, float* G, float* h, float* A, float* b, float* F,
+                              void* stream) {
+  lcp::StepArgs P;
+  int rc = fill_step(P, B, nb, nc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
+  if (rc) return rc;
+  if (!Q || !p || !G || !h || !F) return LCP_E_BADARG;
+  if (e > 0 && (!A || !b)) return LCP_E_BADARG;
+  return lcp::generic_assemble(P, Q, p, G, h, A, b, F, stream);
+}
+
+int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const float* Mdiag, const float* v,
+                       const float* f, const float* rest, const float* fric, const float* c_n,
+                       const float* c_p1, const float* c_p2, const int32_t* c_i1, const int32_t* c_i2,
+                       const float* Je, float dt, double eps, int max_iter, int not_improved_lim, int compute,
+                       float* v_new, float* p_new, float* z, float* s, float* y, int32_t* iters,
+                       int32_t* status, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  lcp::StepArgs P;
+  int rc = fill_step(P, B, nb, nc, e, pos, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
+  if (rc) return rc;
+  if (!pos || !v_new || !p_new || !ws || max_iter < 0) return LCP_E_BADARG;
+  const int nz = 3 * nb, m = 4 * nc;
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
+  P.v_new = v_new; P.p_new = p_new; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
+  P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_step(P, compute, pl.lds_bytes, stream);
+}
+
+}  // extern "C"

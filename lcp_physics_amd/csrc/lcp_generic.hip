@@ -1,0 +1,871 @@
+// lcp_generic.hip - any-size batched PDIPM LCP kernels for gfx950 (one workgroup per scene).
+//
+// This is the GENERIC path: runtime sizes (nz, m, e), T = R + diag(s/z) kept in LDS when it
+// fits (else in the HBM workspace), 256-thread workgroups.  The wave-per-scene register-resident
+// kernels for m <= 64 live in lcp_wave64.hip; both implement the same algorithm:
+//
+//   reference (paths under /root/reference/lcp_physics)          here
+//   lcp/solvers/pdipm.py:357-408  pre_factor_kkt                  prefactor()
+//   lcp/solvers/pdipm.py:414-454  factor_kkt                      factor_T()
+//   lcp/solvers/pdipm.py:325-354  solve_kkt                       solve_kkt()
+//   lcp/solvers/pdipm.py:182-186  get_step                        step_pair()
+//   lcp/solvers/pdipm.py:49-179   forward                         lcp_fwd_kernel
+//   lcp/lcp.py:37-64              LCPFunction.backward            lcp_bwd_kernel
+//   physics/engines.py:31-32,50-74, physics/world.py:144-234      assemble_scene()
+//   physics/bodies.py:80-82       Body.move                       epilogue of the fused kernel
+//
+// Numerics: TC is the arithmetic type.  With TC = double the iterates follow the reference's
+// fp64 trajectory (T is numerically singular in fp32 for sticking friction pairs).
+// LU(T) uses no pivoting for TC = double (the reference itself does not pivot on GPUs,
+// pdipm.py:18) and partial pivoting for TC = float.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcp_kernels.h"
+
+namespace lcp {
+
+constexpr int NT = 256;          // threads per workgroup (4 waves)
+constexpr int NW = NT / 64;
+
+template <typename T> __device__ __forceinline__ T nan_of();
+template <> __device__ __forceinline__ float nan_of<float>() { return __builtin_nanf(""); }
+template <> __device__ __forceinline__ double nan_of<double>() { return __builtin_nan(""); }
+template <typename T> __device__ __forceinline__ T inf_of();
+template <> __device__ __forceinline__ float inf_of<float>() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_of<double>() { return __builtin_huge_val(); }
+
+// `mu > 1e100` (pdipm.py:133): in fp32 only +inf compares greater than 1e100.
+template <typename T> __device__ __forceinline__ T mu_limit();
+template <> __device__ __forceinline__ float mu_limit<float>() { return 3.402823466e+38f; }
+template <> __device__ __forceinline__ double mu_limit<double>() { return 1e100; }
+
+// NaN-propagating min / max (Tensor.min()/max() and torch.min(a,b) semantics).
+template <typename T> __device__ __forceinline__ T pmin(T a, T b) {
+  return (a != a || b != b) ? nan_of<T>() : (a < b ? a : b);
+}
+template <typename T> __device__ __forceinline__ T pmax(T a, T b) {
+  return (a != a || b != b) ? nan_of<T>() : (a > b ? a : b);
+}
+
+struct OpSum { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return pmin(a, b); } };
+struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return pmax(a, b); } };
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off);
+template <> __device__ __forceinline__ float shfl_xor_t<float>(float v, int off) { return __shfl_xor(v, off, 64); }
+template <> __device__ __forceinline__ double shfl_xor_t<double>(double v, int off) { return __shfl_xor(v, off, 64); }
+template <typename T> __device__ __forceinline__ T shfl_t(T v, int src);
+template <> __device__ __forceinline__ float shfl_t<float>(float v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ double shfl_t<double>(double v, int src) { return __shfl(v, src, 64); }
+
+// Workgroup reduction of two values at once (all threads receive the results).
+template <typename T, typename Op>
+__device__ void block_reduce2(T& a, T& b, Op op, T* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a = op(a, shfl_xor_t(a, off));
+    b = op(b, shfl_xor_t(b, off));
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+  __syncthreads();
+  a = red[0]; b = red[1];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) { a = op(a, red[2 * i]); b = op(b, red[2 * i + 1]); }
+}
+
+// All per-scene state.  Pointers into LDS unless noted.
+template <typename TC>
+struct Scene {
+  int nz, m, e, ldT;
+  int nc;                 // contacts (fused path) : F is structured, m = 4 nc
+  // matrices
+  TC *Q, *Qi, *G, *A, *GA, *S11i, *scr;   // scr: m*nz scratch (G Q^-1) during prefactor
+  TC *T;                                  // LU(T): LDS or workspace
+  TC *R;                                  // HBM workspace
+  TC *mu_c;                               // fused: friction coefficient per contact [nc]
+  // vectors
+  TC *p, *h, *b, *x, *s, *z, *y, *d;
+  TC *rx, *rs, *rz, *ry;
+  TC *ax, *as, *az, *ay;                  // affine direction
+  TC *cx, *cs, *cz, *cy;                  // solve output / combined direction
+  TC *bx, *bs, *bz, *by;                  // best iterate
+  TC *v, *hy, *hz, *g1, *t, *u, *tmp;     // temporaries
+  TC *red;                                // reduction scratch (2*NW)
+  int *perm;                              // row permutation of LU(T) (pivoting)
+  int *flag;                              // LDS status word
+};
+
+// Carve the per-scene LDS block.  Called with smem == nullptr on the host to size it.
+template <typename TC>
+__host__ __device__ inline size_t carve(Scene<TC>& S, unsigned char* smem, int nz, int m, int e, int ldT,
+                                        bool t_in_lds, TC* T_ws) {
+  TC* q = reinterpret_cast<TC*>(smem);
+  auto take = [&](size_t n) { TC* r = q; q += n; return r; };
+  S.nz = nz; S.m = m; S.e = e; S.ldT = ldT; S.nc = 0;
+  S.Q = take((size_t)nz * nz); S.Qi = take((size_t)nz * nz);
+  S.G = take((size_t)m * nz); S.scr = take((size_t)m * nz);
+  S.A = take((size_t)e * nz); S.GA = take((size_t)m * e); S.S11i = take((size_t)e * e);
+  S.T = t_in_lds ? take((size_t)m * ldT) : T_ws;
+  S.mu_c = take(m);
+  S.p = take(nz); S.x = take(nz); S.rx = take(nz); S.ax = take(nz); S.cx = take(nz); S.bx = take(nz);
+  S.v = take(nz); S.g1 = take(nz);
+  S.h = take(m); S.s = take(m); S.z = take(m); S.d = take(m); S.rs = take(m); S.rz = take(m);
+  S.as = take(m); S.az = take(m); S.cs = take(m); S.cz = take(m); S.bs = take(m); S.bz = take(m);
+  S.hz = take(m); S.tmp = take(m);
+  S.b = take(e); S.y = take(e); S.ry = take(e); S.ay = take(e); S.cy = take(e); S.by = take(e);
+  S.hy = take(e); S.t = take(e); S.u = take(e);
+  S.red = take(2 * NW);
+  S.perm = reinterpret_cast<int*>(q);
+  S.flag = S.perm + m;
+  size_t bytes = (size_t)(reinterpret_cast<unsigned char*>(S.flag + 4) - smem);
+  return (bytes + 15) & ~(size_t)15;
+}
+
+inline size_t lds_bytes_for(int nz, int m, int e, int ldT, bool t_in_lds, int csize) {
+  if (csize == 8) { Scene<double> S; return carve<double>(S, nullptr, nz, m, e, ldT, t_in_lds, nullptr); }
+  Scene<float> S; return carve<float>(S, nullptr, nz, m, e, ldT, t_in_lds, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// F: dense (HBM, I/O precision) or structured (fused path: engines.py:69-73)
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TC>
+struct FDense {
+  const TI* F;   // [m,m] of this scene
+  int m;
+  __device__ TC at(int i, int j) const { return (TC)F[(size_t)i * m + j]; }
+  // out[i] -= (F z)[i]  for all rows (workgroup-cooperative: one wave per row, coalesced)
+  __device__ void sub_Fz(const TC* z, TC* out) const {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int i = w; i < m; i += NW) {
+      TC acc = 0;
+      for (int j = l; j < m; j += 64) acc += (TC)F[(size_t)i * m + j] * z[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += shfl_xor_t(acc, off);
+      if (l == 0) out[i] -= acc;
+    }
+  }
+};
+
+template <typename TC>
+struct FContact {
+  const TC* mu;  // [nc] in LDS
+  int nc;
+  __device__ TC at(int i, int j) const {
+    if (i < nc) return (TC)0;
+    if (i < 3 * nc) return (j >= 3 * nc && ((i - nc) >> 1) == (j - 3 * nc)) ? (TC)1 : (TC)0;
+    const int c = i - 3 * nc;
+    if (j < nc) return (j == c) ? mu[c] : (TC)0;
+    if (j < 3 * nc) return (((j - nc) >> 1) == c) ? (TC)-1 : (TC)0;
+    return (TC)0;
+  }
+  __device__ void sub_Fz(const TC* z, TC* out) const {
+    for (int i = threadIdx.x; i < 4 * nc; i += NT) {
+      TC fz = 0;
+      if (i >= nc && i < 3 * nc) fz = z[3 * nc + ((i - nc) >> 1)];
+      else if (i >= 3 * nc) { const int c = i - 3 * nc; fz = mu[c] * z[c] - (z[nc + 2 * c] + z[nc + 2 * c + 1]); }
+      out[i] -= fz;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// small dense building blocks (workgroup-cooperative, operands in LDS)
+// ------------------------------------------------------------------------------------------
+
+// In-place Gauss-Jordan inverse of an n x n matrix without pivoting (SPD inputs: Q, A Q^-1 A^T).
+// Returns false (to all threads) if a zero / NaN pivot was met.
+template <typename TC>
+__device__ bool gj_inverse(TC* a, int n, int* flag) {
+  if (threadIdx.x == 0) *flag = 0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const TC piv = a[k * n + k];
+    if (!(piv != (TC)0) || piv != piv) { if (threadIdx.x == 0) *flag = 1; }
+    const TC pinv = (TC)1 / piv;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += NT) if (j != k) a[k * n + j] *= pinv;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * n; idx += NT) {
+      const int i = idx / n, j = idx - i * n;
+      if (i != k && j != k) a[idx] -= a[i * n + k] * a[k * n + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) a[i * n + k] = (i == k) ? pinv : -a[i * n + k] * pinv;
+    __syncthreads();
+  }
+  return *flag == 0;
+}
+
+// out[i] = sum_j M[i*ld + j] * v[j]   (rows over threads)
+template <typename TC>
+__device__ __forceinline__ TC row_dot(const TC* Mrow, const TC* v, int n) {
+  TC acc = 0;
+  for (int j = 0; j < n; ++j) acc += Mrow[j] * v[j];
+  return acc;
+}
+// sum_i M[i*ld + col] * v[i]
+template <typename TC>
+__device__ __forceinline__ TC col_dot(const TC* M, int ld, int col, const TC* v, int n) {
+  TC acc = 0;
+  for (int i = 0; i < n; ++i) acc += M[(size_t)i * ld + col] * v[i];
+  return acc;
+}
+
+// pre_factor_kkt (pdipm.py:357-408): Qi = Q^-1, GA = G Qi A^T, S11i = (A Qi A^T)^-1,
+// R = G Qi G^T + F - GA S11i GA^T  (written to the HBM workspace).
+template <typename TC, typename FT>
+__device__ int prefactor(Scene<TC>& S, const FT& F) {
+  const int nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  int status = 0;
+  for (int i = tid; i < nz * nz; i += NT) S.Qi[i] = S.Q[i];
+  __syncthreads();
+  if (!gj_inverse(S.Qi, nz, S.flag)) status |= LCP_ST_SINGULAR_Q;
+  // scr = G Qi   [m, nz]
+  for (int idx = tid; idx < m * nz; idx += NT) {
+    const int i = idx / nz, j = idx - i * nz;
+    S.scr[idx] = col_dot(S.Qi, nz, j, S.G + (size_t)i * nz, nz);
+  }
+  __syncthreads();
+  if (e > 0) {
+    // GA = scr A^T [m, e]
+    for (int idx = tid; idx < m * e; idx += NT) {
+      const int i = idx / e, a = idx - i * e;
+      S.GA[idx] = row_dot(S.scr + (size_t)i * nz, S.A + (size_t)a * nz, nz);
+    }
+    // S11 = A Qi A^T  [e, e]  (t-free: computed straight from Qi)
+    for (int idx = tid; idx < e * e; idx += NT) {
+      const int a = idx / e, c = idx - a * e;
+      TC acc = 0;
+      for (int k = 0; k < nz; ++k) acc += S.A[a * nz + k] * col_dot(S.Qi, nz, k, S.A + (size_t)c * nz, nz);
+      S.S11i[idx] = acc;
+    }
+    __syncthreads();
+    if (!gj_inverse(S.S11i, e, S.flag)) status |= LCP_ST_SINGULAR_S11;
+  }
+  // R = scr G^T + F - (GA S11i) GA^T
+  for (int idx = tid; idx < m * m; idx += NT) {
+    const int i = idx / m, j = idx - i * m;
+    TC acc = row_dot(S.scr + (size_t)i * nz, S.G + (size_t)j * nz, nz) + F.at(i, j);
+    if (e > 0) {
+      TC corr = 0;
+      for (int a = 0; a < e; ++a) {
+        TC ca = 0;
+        for (int c = 0; c < e; ++c) ca += S.GA[i * e + c] * S.S11i[c * e + a];
+        corr += ca * S.GA[j * e + a];
+      }
+      acc -= corr;
+    }
+    S.R[idx] = acc;
+  }
+  __syncthreads();
+  return status;
+}
+
+// factor_kkt (pdipm.py:414-454): T = R + diag(1/d) = R + diag(s/z); LU in place.
+// Returns true when an exact zero pivot was met (the reference's `except` path, :99-102).
+template <typename TC, bool PIVOT>
+__device__ bool factor_T(Scene<TC>& S, const TC* dinv) {
+  const int m = S.m, ld = S.ldT, tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  for (int idx = tid; idx < m * m; idx += NT) {
+    const int i = idx / m, j = idx - i * m;
+    TC val = S.R[idx];
+    if (i == j) val += dinv[i];
+    S.T[(size_t)i * ld + j] = val;
+  }
+  for (int i = tid; i < m; i += NT) S.perm[i] = i;
+  if (tid == 0) *S.flag = 0;
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    if (PIVOT) {
+      // partial pivoting: wave 0 finds argmax_i>=k |T[i][k]| (first max wins), then rows swap
+      if (w == 0) {
+        TC best = -1; int bi = k;
+        for (int i = k + l; i < m; i += 64) {
+          TC a = S.T[(size_t)i * ld + k]; a = a < 0 ? -a : a;
+          if (a > best) { best = a; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          TC ob = shfl_xor_t(best, off); int oi = __shfl_xor(bi, off, 64);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (l == 0) S.flag[1] = bi;
+      }
+      __syncthreads();
+      const int pr = S.flag[1];
+      if (pr != k) {
+        for (int j = tid; j < m; j += NT) {
+          TC a = S.T[(size_t)k * ld + j], b = S.T[(size_t)pr * ld + j];
+          S.T[(size_t)k * ld + j] = b; S.T[(size_t)pr * ld + j] = a;
+        }
+        if (tid == 0) { int a = S.perm[k]; S.perm[k] = S.perm[pr]; S.perm[pr] = a; }
+      }
+      __syncthreads();
+    }
+    const TC piv = S.T[(size_t)k * ld + k];
+    if (piv == (TC)0 && tid == 0) *S.flag = 1;
+    const TC pinv = (TC)1 / piv;
+    for (int i = k + 1 + w; i < m; i += NW) {
+      const TC lik = S.T[(size_t)i * ld + k] * pinv;
+      for (int j = k + 1 + l; j < m; j += 64) S.T[(size_t)i * ld + j] -= lik * S.T[(size_t)k * ld + j];
+      if (l == 0) S.T[(size_t)i * ld + k] = lik;
+    }
+    __syncthreads();
+  }
+  return *S.flag != 0;
+}
+
+// In-place solve T w = rhs with the LU above; rhs / result in S.hz.
+template <typename TC, bool PIVOT>
+__device__ void solve_T(Scene<TC>& S) {
+  const int m = S.m, ld = S.ldT, tid = threadIdx.x;
+  if (m <= 64) {
+    // wave 0, one row per lane, right-hand side in a register, broadcasts by shuffle
+    if (tid < 64) {
+      const int i = tid;
+      TC val = (i < m) ? S.hz[PIVOT ? S.perm[i] : i] : (TC)0;
+      for (int k = 0; k + 1 < m; ++k) {
+        const TC vk = shfl_t(val, k);
+        if (i > k && i < m) val -= S.T[(size_t)i * ld + k] * vk;
+      }
+      for (int k = m - 1; k >= 0; --k) {
+        if (i == k) val = val / S.T[(size_t)k * ld + k];
+        const TC vk = shfl_t(val, k);
+        if (i < k) val -= S.T[(size_t)i * ld + k] * vk;
+      }
+      if (i < m) S.hz[i] = val;
+    }
+    __syncthreads();
+    return;
+  }
+  if (PIVOT) {
+    for (int i = tid; i < m; i += NT) S.tmp[i] = S.hz[S.perm[i]];
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) S.hz[i] = S.tmp[i];
+    __syncthreads();
+  }
+  for (int k = 0; k + 1 < m; ++k) {
+    const TC vk = S.hz[k];
+    for (int i = k + 1 + tid; i < m; i += NT) S.hz[i] -= S.T[(size_t)i * ld + k] * vk;
+    __syncthreads();
+  }
+  for (int k = m - 1; k >= 0; --k) {
+    if (tid == 0) S.hz[k] = S.hz[k] / S.T[(size_t)k * ld + k];
+    __syncthreads();
+    const TC vk = S.hz[k];
+    for (int i = tid; i < k; i += NT) S.hz[i] -= S.T[(size_t)i * ld + k] * vk;
+    __syncthreads();
+  }
+}
+
+// solve_kkt (pdipm.py:325-354).  rhs vectors: rx[nz], rs[m], rz[m], ry[e] (any may be nullptr =
+// zero).  Outputs to ox[nz], os[m], oz[m], oy[e].  d in S.d.
+template <typename TC, bool PIVOT>
+__device__ void solve_kkt(Scene<TC>& S, const TC* rx, const TC* rs, const TC* rz, const TC* ry,
+                          TC* ox, TC* os, TC* oz, TC* oy) {
+  const int nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  // v = Q^-1 rx                                                            (:333)
+  for (int j = tid; j < nz; j += NT) S.v[j] = rx ? row_dot(S.Qi + (size_t)j * nz, rx, nz) : (TC)0;
+  __syncthreads();
+  // hz = G v + rs/d - rz ; hy = A v - ry                                   (:334-340)
+  for (int i = tid; i < m; i += NT) {
+    TC a = rx ? row_dot(S.G + (size_t)i * nz, S.v, nz) : (TC)0;
+    if (rs) a += rs[i] / S.d[i];
+    if (rz) a -= rz[i];
+    S.hz[i] = a;
+  }
+  for (int a = tid; a < e; a += NT) {
+    TC acc = rx ? row_dot(S.A + (size_t)a * nz, S.v, nz) : (TC)0;
+    if (ry) acc -= ry[a];
+    S.hy[a] = acc;
+  }
+  __syncthreads();
+  // w = S^-1 [hy; hz] by block elimination of the equality block           (:342)
+  if (e > 0) {
+    for (int a = tid; a < e; a += NT) S.t[a] = row_dot(S.S11i + (size_t)a * e, S.hy, e);
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) S.hz[i] -= row_dot(S.GA + (size_t)i * e, S.t, e);
+    __syncthreads();
+  }
+  solve_T<TC, PIVOT>(S);                  // hz <- T^-1 hz
+  if (e > 0) {
+    for (int a = tid; a < e; a += NT) S.u[a] = S.hy[a] - col_dot(S.GA, e, a, S.hz, m);
+    __syncthreads();
+    for (int a = tid; a < e; a += NT) oy[a] = -row_dot(S.S11i + (size_t)a * e, S.u, e);   // dy = -wy
+  }
+  for (int i = tid; i < m; i += NT) {
+    const TC dz = -S.hz[i];                                               // dz = w_z = -S^-1 h
+    oz[i] = dz;
+    os[i] = (-(rs ? rs[i] : (TC)0) - dz) / S.d[i];                        // (:347,350)
+  }
+  __syncthreads();
+  // g1 = -rx - G^T dz - A^T dy ; dx = Q^-1 g1                              (:344-349)
+  for (int j = tid; j < nz; j += NT) {
+    TC a = -(rx ? rx[j] : (TC)0) - col_dot(S.G, nz, j, oz, m);
+    if (e > 0) a -= col_dot(S.A, nz, j, oy, e);
+    S.g1[j] = a;
+  }
+  __syncthreads();
+  for (int j = tid; j < nz; j += NT) ox[j] = row_dot(S.Qi + (size_t)j * nz, S.g1, nz);
+  __syncthreads();
+}
+
+// get_step for the pair (z, dz), (s, ds) at once (pdipm.py:182-186, per-scene max):
+// returns min(step(z,dz), step(s,ds)) with NaN propagation.
+template <typename TC>
+__device__ TC step_pair(Scene<TC>& S, const TC* z, const TC* dz, const TC* s, const TC* ds) {
+  const int m = S.m, tid = threadIdx.x;
+  TC mz = -inf_of<TC>(), ms = -inf_of<TC>();
+  for (int i = tid; i < m; i += NT) {
+    mz = pmax(mz, -z[i] / dz[i]);
+    ms = pmax(ms, -s[i] / ds[i]);
+  }
+  block_reduce2(mz, ms, OpMax(), S.red);
+  const TC fz = (mz > (TC)1) ? mz : (TC)1;       // max(1.0, a.max()): NaN -> 1.0
+  const TC fs = (ms > (TC)1) ? ms : (TC)1;
+  TC az = inf_of<TC>(), as = inf_of<TC>();
+  for (int i = tid; i < m; i += NT) {
+    az = pmin(az, (dz[i] > (TC)0) ? fz : (-z[i] / dz[i]));
+    as = pmin(as, (ds[i] > (TC)0) ? fs : (-s[i] / ds[i]));
+  }
+  block_reduce2(az, as, OpMin(), S.red);
+  return pmin(az, as);
+}
+
+// ------------------------------------------------------------------------------------------
+// input stage
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TC>
+__device__ void load_dense(Scene<TC>& S, const FwdArgs& P, int scene) {
+  const int nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  const TI* Q = (const TI*)P.Q + (size_t)scene * nz * nz;
+  const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
+  const TI* p = (const TI*)P.p + (size_t)scene * nz;
+  const TI* h = (const TI*)P.h + (size_t)scene * m;
+  for (int i = tid; i < nz * nz; i += NT) S.Q[i] = (TC)Q[i];
+  for (int i = tid; i < m * nz; i += NT) S.G[i] = (TC)G[i];
+  for (int i = tid; i < nz; i += NT) S.p[i] = (TC)p[i];
+  for (int i = tid; i < m; i += NT) S.h[i] = (TC)h[i];
+  if (e > 0) {
+    const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
+    const TI* b = (const TI*)P.b + (size_t)scene * e;
+    for (int i = tid; i < e * nz; i += NT) S.A[i] = (TC)A[i];
+    for (int i = tid; i < e; i += NT) S.b[i] = (TC)b[i];
+  }
+  __syncthreads();
+}
+
+// engines.py:31-32,50-74 + world.py:144-234: build Q (diag), p = M v + dt f, G = [Jc; Jf; 0],
+// h = [(Jc v) * restitution; 0; 0], mu per contact, A = Je, b = 0 directly in LDS.
+template <typename TI, typename TC>
+__device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene) {
+  const int nb = P.nb, nc = P.nc, nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
+  const TI* vv = (const TI*)P.v + (size_t)scene * nz;
+  const TI* ff = (const TI*)P.f + (size_t)scene * nz;
+  const TI* rest = (const TI*)P.rest + (size_t)scene * nb;
+  const TI* fric = (const TI*)P.fric + (size_t)scene * nb;
+  const TI* cn = (const TI*)P.c_n + (size_t)scene * nc * 2;
+  const TI* c1 = (const TI*)P.c_p1 + (size_t)scene * nc * 2;
+  const TI* c2 = (const TI*)P.c_p2 + (size_t)scene * nc * 2;
+  const int32_t* i1 = P.c_i1 + (size_t)scene * nc;
+  const int32_t* i2 = P.c_i2 + (size_t)scene * nc;
+  S.nc = nc;
+  for (int i = tid; i < nz * nz; i += NT) { const int r = i / nz, c = i - r * nz; S.Q[i] = (r == c) ? (TC)Md[r] : (TC)0; }
+  for (int i = tid; i < m * nz; i += NT) S.G[i] = 0;
+  for (int j = tid; j < nz; j += NT) {
+    S.p[j] = (TC)Md[j] * (TC)vv[j] + (TC)P.dt * (TC)ff[j];               // engines.py:32
+    S.v[j] = (TC)vv[j];
+  }
+  for (int i = tid; i < m; i += NT) S.h[i] = 0;
+  if (e > 0) {
+    const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
+    for (int i = tid; i < e * nz; i += NT) S.A[i] = (TC)Je[i];
+    for (int i = tid; i < e; i += NT) S.b[i] = 0;
+  }
+  __syncthreads();
+  for (int c = tid; c < nc; c += NT) {
+    const TC nx = (TC)cn[2 * c], ny = (TC)cn[2 * c + 1];
+    const TC p1x = (TC)c1[2 * c], p1y = (TC)c1[2 * c + 1], p2x = (TC)c2[2 * c], p2y = (TC)c2[2 * c + 1];
+    const int b1 = i1[c], b2 = i2[c];
+    const TC tx = ny, ty = -nx;                                          // left_orthogonal, utils.py:99-102
+    TC* gn = S.G + (size_t)c * nz;                                       // Jc row            world.py:177-183
+    TC* g0 = S.G + (size_t)(nc + 2 * c) * nz;                            // Jf rows 2c, 2c+1  world.py:196-210
+    TC* g1 = g0 + nz;
+    // body 1 first, body 2 second (plain assignment order of the reference)
+    gn[3 * b1 + 0] = p1x * ny - p1y * nx; gn[3 * b1 + 1] = nx; gn[3 * b1 + 2] = ny;
+    gn[3 * b2 + 0] = -(p2x * ny - p2y * nx); gn[3 * b2 + 1] = -nx; gn[3 * b2 + 2] = -ny;
+    const TC a1 = p1x * ty - p1y * tx, a2 = p2x * ty - p2y * tx;
+    g0[3 * b1 + 0] = a1;  g0[3 * b1 + 1] = tx;  g0[3 * b1 + 2] = ty;
+    g1[3 * b1 + 0] = -a1; g1[3 * b1 + 1] = -tx; g1[3 * b1 + 2] = -ty;
+    g0[3 * b2 + 0] = -a2; g0[3 * b2 + 1] = -tx; g0[3 * b2 + 2] = -ty;
+    g1[3 * b2 + 0] = a2;  g1[3 * b2 + 1] = tx;  g1[3 * b2 + 2] = ty;
+    S.mu_c[c] = (TC)0.5 * ((TC)fric[b1] + (TC)fric[b2]);                 // world.py:213-224
+    const TC r = (TC)0.5 * ((TC)rest[b1] + (TC)rest[b2]);                // world.py:144-151
+    S.h[c] = row_dot(gn, S.v, nz) * r;                                   // engines.py:53
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// the PDIPM loop (pdipm.py:49-179), shared by the dense and the fused kernels
+// ------------------------------------------------------------------------------------------
+template <typename TC, bool PIVOT, typename FT>
+__device__ void pdipm_loop(Scene<TC>& S, const FT& F, TC eps, int max_iter, int lim, int& iters_out,
+                           int& status, double* trace) {
+  const int nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  // init: d = 1, factor, solve with (p, 0, -h, -b)                          (:57-63)
+  for (int i = tid; i < m; i += NT) { S.d[i] = 1; S.rs[i] = 1; S.rz[i] = -S.h[i]; }
+  for (int a = tid; a < e; a += NT) S.ry[a] = -S.b[a];
+  __syncthreads();
+  factor_T<TC, PIVOT>(S, S.rs);
+  solve_kkt<TC, PIVOT>(S, S.p, (const TC*)nullptr, S.rz, e > 0 ? S.ry : (const TC*)nullptr, S.x, S.s, S.z, S.y);
+  {
+    TC smin = inf_of<TC>(), zmin = inf_of<TC>();
+    for (int i = tid; i < m; i += NT) { smin = pmin(smin, S.s[i]); zmin = pmin(zmin, S.z[i]); }
+    block_reduce2(smin, zmin, OpMin(), S.red);
+    for (int i = tid; i < m; i += NT) {                                   // (:66-75)
+      if (smin <= (TC)0) S.s[i] = S.s[i] - smin + (TC)1;
+      if (zmin <= (TC)0) S.z[i] = S.z[i] - zmin + (TC)1;
+    }
+    __syncthreads();
+  }
+  TC best_resid = inf_of<TC>();
+  bool have_best = false;
+  int n_not = 0, iters = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    // residuals                                                             (:82-96)
+    for (int j = tid; j < nz; j += NT) {
+      TC a = col_dot(S.G, nz, j, S.z, m) + row_dot(S.Q + (size_t)j * nz, S.x, nz) + S.p[j];
+      if (e > 0) a += col_dot(S.A, nz, j, S.y, e);
+      S.rx[j] = a;
+    }
+    for (int i = tid; i < m; i += NT) S.rz[i] = row_dot(S.G + (size_t)i * nz, S.x, nz) + S.s[i] - S.h[i];
+    for (int a = tid; a < e; a += NT) S.ry[a] = row_dot(S.A + (size_t)a * nz, S.x, nz) - S.b[a];
+    __syncthreads();
+    F.sub_Fz(S.z, S.rz);
+    __syncthreads();
+    TC n_rx = 0, n_rz = 0, n_ry = 0, sz = 0;
+    for (int j = tid; j < nz; j += NT) n_rx += S.rx[j] * S.rx[j];
+    for (int i = tid; i < m; i += NT) { n_rz += S.rz[i] * S.rz[i]; sz += S.s[i] * S.z[i]; }
+    for (int a = tid; a < e; a += NT) n_ry += S.ry[a] * S.ry[a];
+    block_reduce2(n_rx, n_rz, OpSum(), S.red);
+    block_reduce2(n_ry, sz, OpSum(), S.red);
+    TC mu = sz / (TC)m; mu = mu < 0 ? -mu : mu;                            // (:91)
+    const TC resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + (TC)m * mu;    // (:92-96)
+    // d = z / s ; factor                                                    (:98-100)
+    for (int i = tid; i < m; i += NT) { const TC dd = S.z[i] / S.s[i]; S.d[i] = dd; S.rs[i] = (TC)1 / dd; }
+    __syncthreads();
+    const bool singular = factor_T<TC, PIVOT>(S, S.rs);
+    ++iters;
+    if (trace) { if (tid == 0) { trace[4 * it + 0] = (double)resid; trace[4 * it + 1] = (double)mu; } }
+    if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; break; }       // except: return best (:99-102)
+    // best-iterate bookkeeping                                              (:107-132)
+    const bool improved = !have_best || (resid < best_resid);
+    if (improved) {
+      best_resid = resid; n_not = 0; have_best = true;
+      for (int j = tid; j < nz; j += NT) S.bx[j] = S.x[j];
+      for (int i = tid; i < m; i += NT) { S.bs[i] = S.s[i]; S.bz[i] = S.z[i]; }
+      for (int a = tid; a < e; a += NT) S.by[a] = S.y[a];
+    } else {
+      ++n_not;
+    }
+    if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) break;                  // (:133)
+    // affine direction                                                      (:138-139)
+    for (int i = tid; i < m; i += NT) S.rs[i] = S.z[i];
+    __syncthreads();
+    solve_kkt<TC, PIVOT>(S, S.rx, S.rs, S.rz, e > 0 ? S.ry : (const TC*)nullptr, S.ax, S.as, S.az, S.ay);
+    TC alpha = pmin(step_pair(S, S.z, S.az, S.s, S.as), (TC)1);          // (:142-144)
+    TC t3 = 0, t4 = 0;
+    for (int i = tid; i < m; i += NT) {
+      t3 += (S.s[i] + alpha * S.as[i]) * (S.z[i] + alpha * S.az[i]);
+      t4 += S.s[i] * S.z[i];
+    }
+    block_reduce2(t3, t4, OpSum(), S.red);
+    const TC r3 = t3 / t4, sig = r3 * r3 * r3;                             // (:146-150)
+    for (int i = tid; i < m; i += NT) S.rs[i] = (-mu * sig + S.as[i] * S.az[i]) / S.s[i];   // (:153)
+    __syncthreads();
+    solve_kkt<TC, PIVOT>(S, (const TC*)nullptr, S.rs, (const TC*)nullptr, (const TC*)nullptr, S.cx, S.cs, S.cz, S.cy);
+    for (int j = tid; j < nz; j += NT) S.cx[j] += S.ax[j];                 // (:160-163)
+    for (int i = tid; i < m; i += NT) { S.cs[i] += S.as[i]; S.cz[i] += S.az[i]; }
+    for (int a = tid; a < e; a += NT) S.cy[a] += S.ay[a];
+    __syncthreads();
+    alpha = pmin((TC)0.999 * step_pair(S, S.z, S.cz, S.s, S.cs), (TC)1);  // (:164-166)
+    if (trace) { if (tid == 0) { trace[4 * it + 2] = (double)sig; trace[4 * it + 3] = (double)alpha; } }
+    for (int j = tid; j < nz; j += NT) S.x[j] += alpha * S.cx[j];         // (:171-174)
+    for (int i = tid; i < m; i += NT) { S.s[i] += alpha * S.cs[i]; S.z[i] += alpha * S.cz[i]; }
+    for (int a = tid; a < e; a += NT) S.y[a] += alpha * S.cy[a];
+    __syncthreads();
+  }
+  __syncthreads();
+  iters_out = iters;
+}
+
+// workspace layout per scene (TC elements): R[m*m] Qi[nz*nz] GA[m*e] S11i[e*e] x[nz] s[m] z[m] y[e] (T[m*ldT])
+template <typename TC>
+__host__ __device__ inline size_t ws_elems(int nz, int m, int e, int ldT, bool t_in_ws) {
+  size_t n = (size_t)m * m + (size_t)nz * nz + (size_t)m * e + (size_t)e * e + nz + 2 * (size_t)m + e;
+  if (t_in_ws) n += (size_t)m * ldT;
+  return (n + 31) & ~(size_t)31;
+}
+
+template <typename TC>
+struct WsView {
+  TC *R, *Qi, *GA, *S11i, *x, *s, *z, *y, *T;
+  __device__ WsView(void* ws, size_t stride_elems, int scene, int nz, int m, int e) {
+    TC* q = reinterpret_cast<TC*>(ws) + stride_elems * (size_t)scene;
+    R = q; q += (size_t)m * m; Qi = q; q += (size_t)nz * nz; GA = q; q += (size_t)m * e;
+    S11i = q; q += (size_t)e * e; x = q; q += nz; s = q; q += m; z = q; q += m; y = q; q += e; T = q;
+  }
+};
+
+template <typename TI, typename TC>
+__device__ void store_solution(Scene<TC>& S, WsView<TC>& W, TI* x, TI* y, TI* z, TI* s, int& status) {
+  const int nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+  int bad = 0;
+  for (int j = tid; j < nz; j += NT) { const TC a = S.bx[j]; W.x[j] = a; if (x) x[j] = (TI)a; bad |= (a != a); }
+  for (int i = tid; i < m; i += NT) {
+    const TC a = S.bz[i], c = S.bs[i];
+    W.z[i] = a; W.s[i] = c; if (z) z[i] = (TI)a; if (s) s[i] = (TI)c; bad |= (a != a) | (c != c);
+  }
+  for (int a = tid; a < e; a += NT) { const TC yy = S.by[a]; W.y[a] = yy; if (y) y[a] = (TI)yy; }
+  for (int i = tid; i < nz * nz; i += NT) W.Qi[i] = S.Qi[i];
+  for (int i = tid; i < m * e; i += NT) W.GA[i] = S.GA[i];
+  for (int i = tid; i < e * e; i += NT) W.S11i[i] = S.S11i[i];
+  if (__syncthreads_or(bad)) status |= LCP_ST_NAN;
+}
+
+template <typename TI, typename TC, bool PIVOT>
+__global__ void __launch_bounds__(NT) lcp_fwd_kernel(FwdArgs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x;
+  const int nz = P.nz, m = P.m, e = P.e;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
+  Scene<TC> S;
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  S.R = W.R;
+  load_dense<TI, TC>(S, P, scene);
+  FDense<TI, TC> F{(const TI*)P.F + (size_t)scene * m * m, m};
+  int status = prefactor(S, F);
+  int iters = 0;
+  double* trace = P.trace ? P.trace + (size_t)scene * 4 * P.max_iter : nullptr;
+  pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, trace);
+  TI* x = (TI*)P.x + (size_t)scene * nz;
+  TI* z = (TI*)P.z + (size_t)scene * m;
+  TI* s = (TI*)P.s + (size_t)scene * m;
+  TI* y = (e > 0 && P.y) ? (TI*)P.y + (size_t)scene * e : nullptr;
+  store_solution<TI, TC>(S, W, x, y, z, s, status);
+  if (threadIdx.x == 0) {
+    if (P.iters) P.iters[scene] = iters;
+    if (P.status) P.status[scene] = status;
+  }
+}
+
+// Fused simulation step: assembly + solve + new_v = -x + p <- p + new_v dt (bodies.py:80-82).
+template <typename TI, typename TC, bool PIVOT>
+__global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x;
+  const int nz = 3 * P.nb, m = 4 * P.nc, e = P.e;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
+  Scene<TC> S;
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  S.R = W.R;
+  assemble_scene<TI, TC>(S, P, scene);
+  FContact<TC> F{S.mu_c, P.nc};
+  int status = prefactor(S, F);
+  int iters = 0;
+  pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);
+  TI* z = P.z ? (TI*)P.z + (size_t)scene * m : nullptr;
+  TI* s = P.s ? (TI*)P.s + (size_t)scene * m : nullptr;
+  TI* y = (e > 0 && P.y) ? (TI*)P.y + (size_t)scene * e : nullptr;
+  store_solution<TI, TC>(S, W, (TI*)nullptr, y, z, s, status);
+  const TI* pos = (const TI*)P.pos + (size_t)scene * nz;
+  TI* vn = (TI*)P.v_new + (size_t)scene * nz;
+  TI* pn = (TI*)P.p_new + (size_t)scene * nz;
+  for (int j = threadIdx.x; j < nz; j += NT) {
+    const TC nv = -S.bx[j];                                               // engines.py:76-77
+    vn[j] = (TI)nv;
+    pn[j] = (TI)((TC)pos[j] + nv * (TC)P.dt);                             // bodies.py:81
+  }
+  if (threadIdx.x == 0) {
+    if (P.iters) P.iters[scene] = iters;
+    if (P.status) P.status[scene] = status;
+  }
+}
+
+// Stand-alone assembly to dense tensors (for LCPFunction users / parity of the assembly itself).
+template <typename TI>
+__global__ void __launch_bounds__(NT) lcp_assemble_kernel(StepArgs P, TI* Q, TI* p, TI* G, TI* h, TI* A, TI* b, TI* Fo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x;
+  const int nz = 3 * P.nb, nc = P.nc, m = 4 * nc, e = P.e, tid = threadIdx.x;
+  Scene<TI> S;
+  carve(S, smem, nz, m, e, m, false, (TI*)nullptr);
+  assemble_scene<TI, TI>(S, P, scene);
+  FContact<TI> F{S.mu_c, nc};
+  for (int i = tid; i < nz * nz; i += NT) Q[(size_t)scene * nz * nz + i] = S.Q[i];
+  for (int i = tid; i < nz; i += NT) p[(size_t)scene * nz + i] = S.p[i];
+  for (int i = tid; i < m * nz; i += NT) G[(size_t)scene * m * nz + i] = S.G[i];
+  for (int i = tid; i < m; i += NT) h[(size_t)scene * m + i] = S.h[i];
+  if (e > 0) {
+    for (int i = tid; i < e * nz; i += NT) A[(size_t)scene * e * nz + i] = S.A[i];
+    for (int i = tid; i < e; i += NT) b[(size_t)scene * e + i] = S.b[i];
+  }
+  for (int idx = tid; idx < m * m; idx += NT) Fo[(size_t)scene * m * m + idx] = F.at(idx / m, idx % m);
+}
+
+// LCPFunction.backward (lcp.py:37-64).
+template <typename TI, typename TC, bool PIVOT>
+__global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x, tid = threadIdx.x;
+  const int nz = P.nz, m = P.m, e = P.e;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
+  Scene<TC> S;
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  S.R = W.R;
+  const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
+  for (int i = tid; i < m * nz; i += NT) S.G[i] = (TC)G[i];
+  for (int i = tid; i < nz * nz; i += NT) S.Qi[i] = W.Qi[i];
+  if (e > 0) {
+    const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
+    for (int i = tid; i < e * nz; i += NT) S.A[i] = (TC)A[i];
+    for (int i = tid; i < m * e; i += NT) S.GA[i] = W.GA[i];
+    for (int i = tid; i < e * e; i += NT) S.S11i[i] = W.S11i[i];
+    for (int a = tid; a < e; a += NT) S.y[a] = W.y[a];
+  }
+  const TI* g = (const TI*)P.dl_dx + (size_t)scene * nz;
+  for (int j = tid; j < nz; j += NT) { S.x[j] = W.x[j]; S.rx[j] = (TC)g[j]; }
+  for (int i = tid; i < m; i += NT) {
+    const TC zz = W.z[i], ss = W.s[i];
+    S.z[i] = zz; S.s[i] = ss;
+    const TC dd = zz / ss;                                                 // lcp.py:44
+    S.d[i] = dd; S.rs[i] = (TC)1 / dd;
+  }
+  __syncthreads();
+  factor_T<TC, PIVOT>(S, S.rs);                                           // lcp.py:46
+  solve_kkt<TC, PIVOT>(S, S.rx, (const TC*)nullptr, (const TC*)nullptr, (const TC*)nullptr,
+                       S.cx, S.cs, S.cz, S.cy);                           // lcp.py:47-50
+  // outer products (lcp.py:52-61); dx = cx, dlam = cz, dnu = cy
+  if (P.dp) { TI* o = (TI*)P.dp + (size_t)scene * nz; for (int j = tid; j < nz; j += NT) o[j] = (TI)S.cx[j]; }
+  if (P.dh) { TI* o = (TI*)P.dh + (size_t)scene * m; for (int i = tid; i < m; i += NT) o[i] = (TI)(-S.cz[i]); }
+  if (P.db && e > 0) { TI* o = (TI*)P.db + (size_t)scene * e; for (int a = tid; a < e; a += NT) o[a] = (TI)(-S.cy[a]); }
+  if (P.dQ) {
+    TI* o = (TI*)P.dQ + (size_t)scene * nz * nz;
+    for (int idx = tid; idx < nz * nz; idx += NT) {
+      const int i = idx / nz, j = idx - i * nz;
+      o[idx] = (TI)((TC)0.5 * (S.cx[i] * S.x[j] + S.x[i] * S.cx[j]));
+    }
+  }
+  if (P.dG) {
+    TI* o = (TI*)P.dG + (size_t)scene * m * nz;
+    for (int idx = tid; idx < m * nz; idx += NT) {
+      const int i = idx / nz, j = idx - i * nz;
+      o[idx] = (TI)(S.cz[i] * S.x[j] + S.z[i] * S.cx[j]);
+    }
+  }
+  if (P.dA && e > 0) {
+    TI* o = (TI*)P.dA + (size_t)scene * e * nz;
+    for (int idx = tid; idx < e * nz; idx += NT) {
+      const int a = idx / nz, j = idx - a * nz;
+      o[idx] = (TI)(S.cy[a] * S.x[j] + S.y[a] * S.cx[j]);
+    }
+  }
+  if (P.dF) {
+    TI* o = (TI*)P.dF + (size_t)scene * m * m;
+    for (int idx = tid; idx < m * m; idx += NT) {
+      const int i = idx / m, j = idx - i * m;
+      o[idx] = (TI)(-S.cz[i] * S.z[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch helpers (called from lcp_api.cpp)
+// ------------------------------------------------------------------------------------------
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+Plan make_plan(int nz, int m, int e, int csize) {
+  Plan pl;
+  pl.ldT = m | 1;                      // odd leading dimension: conflict-free column walks
+  pl.t_in_lds = 1;
+  pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, true, csize);
+  if (pl.lds_bytes > LDS_LIMIT) {
+    pl.t_in_lds = 0;
+    pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, false, csize);
+  }
+  pl.ok = pl.lds_bytes <= LDS_LIMIT;
+  pl.ws_stride = (csize == 8) ? ws_elems<double>(nz, m, e, pl.ldT, !pl.t_in_lds)
+                              : ws_elems<float>(nz, m, e, pl.ldT, !pl.t_in_lds);
+  return pl;
+}
+
+// Raise the dynamic-LDS cap of a kernel once per (kernel, size) - gfx950 allows 160 KiB.
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  static size_t granted = 64 * 1024;       // one instance per kernel type K... per instantiation of set_lds
+  if (bytes > granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) return LCP_E_LAUNCH;
+    granted = bytes;
+  }
+  return 0;
+}
+
+template <typename TI, typename TC, bool PIVOT>
+static int launch_fwd_t(const FwdArgs& P, size_t lds, hipStream_t st) {
+  auto k = lcp_fwd_kernel<TI, TC, PIVOT>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+template <typename TI, typename TC, bool PIVOT>
+static int launch_bwd_t(const BwdArgs& P, size_t lds, hipStream_t st) {
+  auto k = lcp_bwd_kernel<TI, TC, PIVOT>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+template <typename TI, typename TC, bool PIVOT>
+static int launch_step_t(const StepArgs& P, size_t lds, hipStream_t st) {
+  auto k = lcp_step_kernel<TI, TC, PIVOT>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (io_f64) return launch_fwd_t<double, double, false>(P, lds, st);
+  if (compute == LCP_COMPUTE_F64) return launch_fwd_t<float, double, false>(P, lds, st);
+  return launch_fwd_t<float, float, true>(P, lds, st);
+}
+int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (io_f64) return launch_bwd_t<double, double, false>(P, lds, st);
+  if (compute == LCP_COMPUTE_F64) return launch_bwd_t<float, double, false>(P, lds, st);
+  return launch_bwd_t<float, float, true>(P, lds, st);
+}
+int generic_step(const StepArgs& P, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (compute == LCP_COMPUTE_F64) return launch_step_t<float, double, false>(P, lds, st);
+  return launch_step_t<float, float, true>(P, lds, st);
+}
+int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b, float* F,
+                     void* stream) {
+  const int nz = 3 * P.nb, m = 4 * P.nc;
+  size_t lds = lds_bytes_for(nz, m, P.e, m, false, 4);
+  if (lds > LDS_LIMIT) return LCP_E_TOOLARGE;
+  auto k = lcp_assemble_kernel<float>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, (hipStream_t)stream, P, Q, p, G, h, A, b, F);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+}  // namespace lcp

@@ -1,0 +1,66 @@
+// lcp_kernels.h - internal launch-argument structs shared by the kernel translation units and
+// the C-ABI layer (lcp_api.cpp).  Plain C++: no HIP types, no torch types.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/lcp_hip.h"
+
+namespace lcp {
+
+struct Plan {
+  int ok;            // fits the LDS budget
+  int ldT;           // leading dimension of T
+  int t_in_lds;      // T = R + diag(s/z) lives in LDS (else in the workspace)
+  size_t lds_bytes;  // dynamic LDS per workgroup
+  size_t ws_stride;  // workspace elements (compute precision) per scene
+};
+
+struct FwdArgs {
+  int B, nz, m, e;
+  const void *Q, *p, *G, *h, *A, *b, *F;
+  void *x, *y, *z, *s;
+  int32_t* iters;
+  int32_t* status;
+  void* ws;
+  size_t ws_stride;
+  double eps;
+  int max_iter, lim;
+  int ldT, t_in_lds;
+  double* trace;     // optional [B, max_iter, 4] (resid, mu, sigma, alpha) - debugging aid
+};
+
+struct BwdArgs {
+  int B, nz, m, e;
+  const void *G, *A, *dl_dx;
+  void *dQ, *dp, *dG, *dh, *dA, *db, *dF;
+  void* ws;
+  size_t ws_stride;
+  int ldT, t_in_lds;
+};
+
+struct StepArgs {
+  int B, nb, nc, e;
+  const void *pos, *Mdiag, *v, *f, *rest, *fric, *c_n, *c_p1, *c_p2;
+  const int32_t *c_i1, *c_i2;
+  const void* Je;
+  double dt;
+  double eps;
+  int max_iter, lim;
+  void *v_new, *p_new, *z, *s, *y;
+  int32_t* iters;
+  int32_t* status;
+  void* ws;
+  size_t ws_stride;
+  int ldT, t_in_lds;
+};
+
+// generic (any size) path - lcp_generic.hip
+Plan make_plan(int nz, int m, int e, int csize);
+int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
+int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
+int generic_step(const StepArgs& P, int compute, size_t lds, void* stream);
+int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b,
+                     float* F, void* stream);
+
+}  // namespace lcp

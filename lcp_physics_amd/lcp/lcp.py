@@ -1,0 +1,191 @@
+"""`LCPFunction`: the differentiable LCP op, MI355X-native.
+
+Host-side mirror of the reference's `lcp_physics/lcp/lcp.py:8-64` - same constructor
+keywords (`eps, verbose, not_improved_lim, max_iter`), same call signature
+`instance(Q, p, G, h, A, b, F) -> zhats[B, nz]`, same attributes after the call
+(`.nus, .lams, .slacks, .neq, .nineq, .nz`), same 7 gradients in input order, same error
+for a singular Q (`lcp/solvers/pdipm.py:361-368`).  Modern torch rejects the reference's
+legacy instance-style `autograd.Function`, so the class dispatches to a new-style Function.
+
+All arithmetic happens in the HIP kernels behind the C ABI (`include/lcp_hip.h`); this file
+only moves pointers.  There is no CPU fallback: without a GPU or without the built library
+the call raises.
+"""
+import torch
+
+from .. import _lib
+
+SINGULAR_Q_MESSAGE = """
+lcp Error: Cannot perform LU factorization on Q.
+Please make sure that your Q matrix is PSD and has
+a non-zero diagonal.
+"""
+
+_COMPUTE = {"f32": _lib.COMPUTE_F32, "f64": _lib.COMPUTE_F64, "fp32": _lib.COMPUTE_F32,
+            "fp64": _lib.COMPUTE_F64, torch.float32: _lib.COMPUTE_F32, torch.float64: _lib.COMPUTE_F64}
+
+
+def _pick_device(tensors):
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("lcp_physics_amd needs a GPU (MI355X); no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _prep(t, B, ndim, device, dtype):
+    """Batch-expand (lcp/util.py:49-55 `expandParam`), move and make contiguous."""
+    if t is None or t.numel() == 0 and t.dim() <= 1:
+        return None
+    t = t.detach()
+    if t.dim() == ndim - 1:
+        t = t.unsqueeze(0).expand(B, *t.shape)
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class LCPSolution:
+    """Result of one batched solve; keeps the workspace the backward kernel needs."""
+    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype")
+
+
+def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64",
+              ws=None, out=None):
+    """Forward solve on GPU tensors (no autograd).  Q,p,G,h,A,b,F: contiguous CUDA tensors of
+    one dtype (float32 or float64), batched; A, b may be None.  Returns an `LCPSolution`."""
+    lib = _lib.load()
+    dtype = G.dtype
+    dev = G.device
+    B, m, nz = G.shape
+    e = A.shape[1] if A is not None else 0
+    for name, t in (("Q", Q), ("p", p), ("G", G), ("h", h), ("F", F)):
+        _lib.require_gpu_tensor(t, name, dtype)
+    if e:
+        _lib.require_gpu_tensor(A, "A", dtype)
+        _lib.require_gpu_tensor(b, "b", dtype)
+    assert Q.shape == (B, nz, nz) and p.shape == (B, nz) and h.shape == (B, m) and F.shape == (B, m, m)
+    comp = _lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]
+    need = _lib.workspace_bytes(B, nz, m, e, comp)
+    if need == 0:
+        raise RuntimeError("invalid LCP sizes B=%d nz=%d nineq=%d neq=%d" % (B, nz, m, e))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    sol = out if out is not None else LCPSolution()
+    if out is None:
+        sol.x = torch.empty(B, nz, dtype=dtype, device=dev)
+        sol.z = torch.empty(B, m, dtype=dtype, device=dev)
+        sol.s = torch.empty(B, m, dtype=dtype, device=dev)
+        sol.y = torch.empty(B, e, dtype=dtype, device=dev) if e else None
+        sol.iters = torch.empty(B, dtype=torch.int32, device=dev)
+        sol.status = torch.empty(B, dtype=torch.int32, device=dev)
+    sol.ws, sol.G, sol.A, sol.sizes, sol.compute, sol.dtype = ws, G, A, (B, nz, m, e), comp, dtype
+    P = _lib.ptr
+    st = _lib.stream_ptr(dev)
+    with torch.cuda.device(dev):
+        if dtype == torch.float64:
+            rc = lib.lcp_pdipm_forward_f64(B, nz, m, e, P(Q), P(p), P(G), P(h), P(A), P(b), P(F),
+                                           float(eps), int(max_iter), int(not_improved_lim),
+                                           P(sol.x), P(sol.y), P(sol.z), P(sol.s), P(sol.iters),
+                                           P(sol.status), P(ws), st)
+        else:
+            rc = lib.lcp_pdipm_forward_f32(B, nz, m, e, P(Q), P(p), P(G), P(h), P(A), P(b), P(F),
+                                           float(eps), int(max_iter), int(not_improved_lim), comp,
+                                           P(sol.x), P(sol.y), P(sol.z), P(sol.s), P(sol.iters),
+                                           P(sol.status), P(ws), st)
+    _lib.check(rc, "lcp_pdipm_forward")
+    return sol
+
+
+def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
+    """Implicit-differentiation backward for a previous `lcp_solve` (lcp.py:37-64).
+    Returns [dQ, dp, dG, dh, dA, db, dF] (None where not needed / no equalities)."""
+    lib = _lib.load()
+    B, nz, m, e = sol.sizes
+    dev, dtype = sol.G.device, sol.dtype
+    dl_dx = _lib.require_gpu_tensor(dl_dx.to(dtype).contiguous(), "dl_dx", dtype)
+    shapes = [(B, nz, nz), (B, nz), (B, m, nz), (B, m), (B, e, nz), (B, e), (B, m, m)]
+    if out is None:
+        out = [torch.empty(sh, dtype=dtype, device=dev) if (nd and (e or i not in (4, 5))) else None
+               for i, (sh, nd) in enumerate(zip(shapes, need))]
+    P = _lib.ptr
+    st = _lib.stream_ptr(dev)
+    with torch.cuda.device(dev):
+        if dtype == torch.float64:
+            rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
+                                            *[P(o) for o in out], P(sol.ws), st)
+        else:
+            rc = lib.lcp_pdipm_backward_f32(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute,
+                                            *[P(o) for o in out], P(sol.ws), st)
+    _lib.check(rc, "lcp_pdipm_backward")
+    return out
+
+
+class _LCPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, p, G, h, A, b, F, holder):
+        ins = (Q, p, G, h, A, b, F)
+        if G.dim() != 3:
+            raise RuntimeError("G must be [batch, nineq, nz] (lcp/lcp.py:23)")
+        B, nineq, nz = G.shape
+        neq = A.size(1) if A.dim() > 1 else 0                      # lcp.py:24
+        assert neq > 0 or nineq > 0                                  # lcp.py:25
+        dev = _pick_device(ins)
+        dtype = G.dtype if G.dtype in (torch.float32, torch.float64) else torch.float32
+        dims = (3, 2, 3, 2, 3, 2, 3)
+        dQ, dp_, dG, dh_, dA, db_, dF = [_prep(t, B, nd, dev, dtype) for t, nd in zip(ins, dims)]
+        if neq == 0:
+            dA, db_ = None, None
+        sol = lcp_solve(dQ, dp_, dG, dh_, dA, db_, dF, eps=holder.eps,
+                        not_improved_lim=holder.not_improved_lim, max_iter=holder.max_iter,
+                        compute=holder.compute)
+        if holder.check:
+            st = sol.status.cpu()
+            if bool((st & _lib.ST_SINGULAR_Q).any()):
+                raise RuntimeError(SINGULAR_Q_MESSAGE)                # pdipm.py:361-368
+        back = lambda t: None if t is None else t.to(device=G.device, dtype=G.dtype)
+        holder.nus, holder.lams, holder.slacks = back(sol.y), back(sol.z), back(sol.s)   # lcp.py:29
+        holder.neq, holder.nineq, holder.nz = neq, nineq, nz
+        holder.iters, holder.status, holder.solution = sol.iters, sol.status, sol
+        ctx.sol = sol
+        ctx.meta = [(t.device, t.dtype, tuple(t.shape)) for t in ins]
+        ctx.neq = neq
+        return back(sol.x)
+
+    @staticmethod
+    def backward(ctx, dl_dzhat):
+        sol = ctx.sol
+        need = list(ctx.needs_input_grad[:7])
+        g = dl_dzhat.to(device=sol.G.device, dtype=sol.dtype).contiguous()
+        grads = lcp_backward(sol, g, need=need)
+        out = []
+        for i, (gr, (dev, dt, shape)) in enumerate(zip(grads, ctx.meta)):
+            if gr is None or not need[i]:
+                out.append(None)
+                continue
+            gr = gr.to(device=dev, dtype=dt)
+            if gr.dim() == len(shape) + 1:                            # un-batched parameter: sum over batch
+                gr = gr.sum(0)
+            out.append(gr)
+        return tuple(out) + (None,)
+
+
+class LCPFunction:
+    """A differentiable LCP solver (primal-dual interior point), drop-in for the reference class.
+
+    Extra keywords (not in the reference): `compute` - arithmetic used inside the kernels for
+    float32 inputs ("f64" = parity path, "f32" = all-fp32 fast path); `check` - read the status
+    word back (one host sync) and raise on a singular Q like the reference does.
+    """
+
+    def __init__(self, eps=1e-12, verbose=-1, not_improved_lim=3, max_iter=10, compute="f64", check=True):
+        self.eps = eps
+        self.verbose = verbose
+        self.not_improved_lim = not_improved_lim
+        self.max_iter = max_iter
+        self.compute = compute
+        self.check = check
+        self.Q_LU = self.S_LU = self.R = None       # kept on the device workspace instead
+        self.nus = self.lams = self.slacks = None
+
+    def __call__(self, Q, p, G, h, A, b, F):
+        return _LCPFn.apply(Q, p, G, h, A, b, F, self)

@@ -1,0 +1,147 @@
+"""Batched scene container and the fused simulation step.
+
+The reference's physics layer is un-batched (`World` steps ONE scene and calls the solver with
+batch 1, `physics/engines.py:54-76`).  `BatchedWorld` is the new batched surface:
+B independent scenes stored structure-of-arrays in HBM (`scenes.SceneBatch`), advanced by one
+HIP launch per step - contact-Jacobian assembly (`world.py:144-234`), `u = M v + dt f`
+(`engines.py:31-32`), the PDIPM LCP solve (`lcp/solvers/pdipm.py`), `new_v = -x`
+(`engines.py:76-77`) and the semi-implicit integrator `p += v dt` (`bodies.py:80-82`).
+Its `step()` has the semantics of the reference's `World.step_dt` for a fixed contact list;
+contact detection (`physics/contacts.py`) is SURVEY.md §8(f) row 1 ("next") and is supplied by
+the caller through `contact_fn` until then.
+"""
+import torch
+
+from .. import _lib
+from ..lcp.lcp import _COMPUTE, LCPSolution
+from ..scenes import SceneBatch
+
+
+def scene_from_contacts(p, v, Mdiag, f, rest, fric, contacts, Je, dt):
+    """Build a 1-scene `SceneBatch` from a reference-style contact list
+    `[((normal, p1, p2, penetration), i1, i2), ...]` (`physics/contacts.py:203-204`)."""
+    st = lambda k: torch.stack([c[0][k].detach().reshape(2) for c in contacts]).unsqueeze(0)
+    idx = lambda k: torch.tensor([[int(c[k]) for c in contacts]], dtype=torch.int32)
+    nb = v.shape[0]
+    u = lambda t: t.detach().unsqueeze(0)
+    Je_b = Je.detach().unsqueeze(0) if Je is not None else torch.zeros(1, 0, 3 * nb, dtype=v.dtype)
+    return SceneBatch(p=u(p), v=u(v), Mdiag=u(Mdiag), f=u(f), rest=u(rest), fric=u(fric),
+                      c_n=st(0), c_p1=st(1), c_p2=st(2), c_i1=idx(1), c_i2=idx(2), Je=Je_b, dt=dt)
+
+
+def _check_scene(sc):
+    for name in ("p", "v", "Mdiag", "f", "rest", "fric", "c_n", "c_p1", "c_p2"):
+        _lib.require_gpu_tensor(getattr(sc, name), name, torch.float32)
+    _lib.require_gpu_tensor(sc.c_i1, "c_i1", torch.int32)
+    _lib.require_gpu_tensor(sc.c_i2, "c_i2", torch.int32)
+    e = sc.Je.shape[1] if sc.Je is not None and sc.Je.numel() else 0
+    if e:
+        _lib.require_gpu_tensor(sc.Je, "Je", torch.float32)
+    return e
+
+
+def assemble_contacts(sc):
+    """Dense (Q, p, G, h, A, b, F) of `engines.py:50-74` for every scene, built by the HIP
+    assembly kernel.  Returns float32 CUDA tensors (A, b are None without joints)."""
+    lib = _lib.load()
+    e = _check_scene(sc)
+    B, nb, nc = sc.B, sc.nb, sc.nc
+    nz, m = 3 * nb, 4 * nc
+    dev = sc.v.device
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    Q, p, G, h, F = new(B, nz, nz), new(B, nz), new(B, m, nz), new(B, m), new(B, m, m)
+    A, b = (new(B, e, nz), new(B, e)) if e else (None, None)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_assemble_contacts_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest),
+                                           P(sc.fric), P(sc.c_n), P(sc.c_p1), P(sc.c_p2), P(sc.c_i1),
+                                           P(sc.c_i2), P(sc.Je) if e else None, float(sc.dt),
+                                           P(Q), P(p), P(G), P(h), P(A), P(b), P(F), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_assemble_contacts_f32")
+    return Q, p, G, h, A, b, F
+
+
+def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None):
+    """One fused simulation step for every scene of `sc` (float32 CUDA `SceneBatch`).
+
+    Returns a dict with v_new, p_new [B,nb,3], z, s [B,4nc], y [B,e], iters, status [B] and the
+    workspace `ws` (re-usable; it also feeds `lcp_backward`)."""
+    lib = _lib.load()
+    e = _check_scene(sc)
+    B, nb, nc = sc.B, sc.nb, sc.nc
+    nz, m = 3 * nb, 4 * nc
+    dev = sc.v.device
+    comp = _COMPUTE[compute]
+    need = _lib.workspace_bytes(B, nz, m, e, comp)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {"v_new": new(B, nb, 3), "p_new": new(B, nb, 3), "z": new(B, m), "s": new(B, m),
+               "y": new(B, e) if e else None,
+               "iters": torch.empty(B, dtype=torch.int32, device=dev),
+               "status": torch.empty(B, dtype=torch.int32, device=dev)}
+    out["ws"] = ws
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_step_fused_f32(B, nb, nc, e, P(sc.p), P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest),
+                                    P(sc.fric), P(sc.c_n), P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2),
+                                    P(sc.Je) if e else None, float(sc.dt), float(eps), int(max_iter),
+                                    int(not_improved_lim), comp, P(out["v_new"]), P(out["p_new"]),
+                                    P(out["z"]), P(out["s"]), P(out["y"]), P(out["iters"]),
+                                    P(out["status"]), P(ws), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_step_fused_f32")
+    return out
+
+
+def solution_of_step(sc, out, G, A, compute="f64"):
+    """Wrap a fused step's workspace as an `LCPSolution` so `lcp.lcp_backward` can follow
+    (G, A from `assemble_contacts`)."""
+    sol = LCPSolution()
+    B, nb, nc = sc.B, sc.nb, sc.nc
+    e = A.shape[1] if A is not None else 0
+    sol.x = -out["v_new"].reshape(B, 3 * nb)
+    sol.y, sol.z, sol.s = out["y"], out["z"], out["s"]
+    sol.iters, sol.status, sol.ws = out["iters"], out["status"], out["ws"]
+    sol.G, sol.A, sol.sizes, sol.compute, sol.dtype = G, A, (B, 3 * nb, 4 * nc, e), _COMPUTE[compute], torch.float32
+    return sol
+
+
+class BatchedWorld:
+    """B independent scenes advanced together on one GPU.
+
+    world = BatchedWorld(scene_batch.to("cuda"), contact_fn=None)
+    world.step()            # one fused HIP launch; updates world.scene.p / .v, world.t
+
+    `contact_fn(world) -> (c_n, c_p1, c_p2, c_i1, c_i2)` may refresh the contact list after the
+    integrator moved the bodies (the role of `World.find_contacts`, `world.py:139-142`)."""
+
+    def __init__(self, scene, contact_fn=None, max_iter=10, compute="f64", eps=1e-12, not_improved_lim=3):
+        self.scene = scene
+        self.contact_fn = contact_fn
+        self.max_iter, self.compute, self.eps, self.lim = max_iter, compute, eps, not_improved_lim
+        self.t = 0.0
+        self.dt = scene.dt
+        self._ws = None
+        self._out = None
+        self.last = None
+
+    def step(self):
+        out = fused_step(self.scene, eps=self.eps, not_improved_lim=self.lim, max_iter=self.max_iter,
+                         compute=self.compute, ws=self._ws, out=self._out)
+        self._ws, self._out, self.last = out["ws"], out, out
+        # double-buffer swap: new state becomes the scene state (world.py:87-90)
+        self.scene.v, out["v_new"] = out["v_new"], self.scene.v
+        self.scene.p, out["p_new"] = out["p_new"], self.scene.p
+        if self.contact_fn is not None:
+            c_n, c_p1, c_p2, c_i1, c_i2 = self.contact_fn(self)
+            self.scene.c_n, self.scene.c_p1, self.scene.c_p2 = c_n, c_p1, c_p2
+            self.scene.c_i1, self.scene.c_i2 = c_i1, c_i2
+        self.t += self.dt
+        return out
+
+    def get_v(self):
+        return self.scene.v
+
+    def get_p(self):
+        return self.scene.p

@@ -1,0 +1,224 @@
+"""Seeded synthetic batched scenes (workload generators for bench.py and the tests).
+
+The reference cannot produce a batch of scenes itself (its physics layer is un-batched,
+SURVEY.md §0.2), so the BASELINE.json workloads are synthesised here following
+SURVEY.md §8(d): a fixed floor plus a stack (or pyramid) of 60x60 boxes, per-scene
+jitter, contacts in the format the reference's contact handler emits
+(`physics/contacts.py:203-204`: ((normal, p1, p2, penetration), i1, i2), p1/p2 relative
+to the body centres, screen coordinates with +y = down = gravity).
+
+Everything here is host-side torch on the CPU; `SceneBatch.to()` moves a batch to a GPU.
+"""
+from dataclasses import dataclass, fields
+
+import torch
+
+FLOOR_DIMS = (900.0, 10.0)
+BOX = 60.0
+GRAVITY = 100.0
+DT = 1.0 / 30.0          # physics/utils.py:27-28
+GAP = 0.05               # inside the eps = 0.1 detection margin (physics/utils.py:16)
+
+
+@dataclass
+class SceneBatch:
+    """Structure-of-arrays description of B independent 2-D rigid-body scenes.
+
+    p, v, Mdiag, f : [B, nb, 3]  (rot, x, y) pose / velocity / diagonal mass matrix / force
+    rest, fric     : [B, nb]     per-body restitution and friction coefficient
+    c_n, c_p1, c_p2: [B, nc, 2]  contact normal and arms;  c_i1, c_i2: [B, nc] int32
+    Je             : [B, e, 3nb] equality (joint) Jacobian;  dt: float
+    """
+    p: torch.Tensor
+    v: torch.Tensor
+    Mdiag: torch.Tensor
+    f: torch.Tensor
+    rest: torch.Tensor
+    fric: torch.Tensor
+    c_n: torch.Tensor
+    c_p1: torch.Tensor
+    c_p2: torch.Tensor
+    c_i1: torch.Tensor
+    c_i2: torch.Tensor
+    Je: torch.Tensor
+    dt: float = DT
+
+    @property
+    def B(self):
+        return self.v.shape[0]
+
+    @property
+    def nb(self):
+        return self.v.shape[1]
+
+    @property
+    def nc(self):
+        return self.c_n.shape[1]
+
+    def to(self, device=None, dtype=None):
+        kw = {}
+        for fl in fields(self):
+            t = getattr(self, fl.name)
+            if isinstance(t, torch.Tensor):
+                if t.is_floating_point():
+                    t = t.to(device=device, dtype=dtype)
+                else:
+                    t = t.to(device=device)
+                t = t.contiguous()
+            kw[fl.name] = t
+        return SceneBatch(**kw)
+
+    def slice(self, lo, hi):
+        kw = {}
+        for fl in fields(self):
+            t = getattr(self, fl.name)
+            kw[fl.name] = t[lo:hi] if isinstance(t, torch.Tensor) else t
+        return SceneBatch(**kw)
+
+    def assembly_args(self):
+        """Argument tuple of oracle.pdipm_oracle.assemble_lcp / solve_dynamics."""
+        return (self.Mdiag, self.v, self.f, self.dt, self.c_n, self.c_p1, self.c_p2,
+                self.c_i1, self.c_i2, self.rest, self.fric, self.Je)
+
+    def phys_dict(self):
+        d = {k: getattr(self, k) for k in ("Mdiag", "v", "f", "c_n", "c_p1", "c_p2", "rest", "fric")}
+        d["c_i1"], d["c_i2"], d["Je"] = self.c_i1, self.c_i2, self.Je
+        return d
+
+
+def _rect_mdiag(mass, w, h):
+    """bodies.py:269-270 (Rect inertia) and :44-47 (M = diag(I, m, m))."""
+    inertia = mass * (w * w + h * h) / 12.0
+    return torch.stack([inertia, mass, mass], dim=-1)
+
+
+def _interface_contacts(xl, hl, xu, hu, wl, wu, pts, gap):
+    """Contact points of one horizontal interface (lower body l, upper body u).
+
+    Returns p1 [B,pts,2] (relative to the lower centre, on its top face) and p2 [B,pts,2]
+    (relative to the upper centre).  The reference puts 2 points at the ends of the overlap
+    segment (`contacts.py:170-204`); the 4-point variant adds two interior points."""
+    lo = torch.maximum(xl - wl / 2, xu - wu / 2)
+    hi = torch.minimum(xl + wl / 2, xu + wu / 2)
+    ctr, ov = 0.5 * (lo + hi), hi - lo
+    if pts == 2:
+        fr = torch.tensor([0.5, -0.5], dtype=xl.dtype)
+    elif pts == 4:
+        fr = torch.tensor([0.5, -0.5, 1.0 / 6.0, -1.0 / 6.0], dtype=xl.dtype)
+    else:
+        fr = torch.linspace(0.5, -0.5, pts, dtype=xl.dtype)
+    xc = ctr.unsqueeze(1) + ov.unsqueeze(1) * fr.unsqueeze(0)            # [B,pts]
+    p1 = torch.stack([xc - xl.unsqueeze(1), torch.full_like(xc, -hl / 2)], dim=-1)
+    p2 = torch.stack([xc - xu.unsqueeze(1), torch.full_like(xc, hu / 2 + gap)], dim=-1)
+    return p1, p2
+
+
+def _finish(B, nb, centres, interfaces, pts, g, dtype, rest_hi=0.5, ang_sigma=0.05,
+            lin_sigma=1.0, gap=GAP):
+    """Common tail: per-scene jitter of mass / friction / restitution / velocity, contacts."""
+    rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    mass = torch.ones(B, nb, dtype=torch.float64)
+    mass[:, 1:] = 0.5 + 1.5 * rnd(B, nb - 1)
+    fric = 0.2 + 0.8 * rnd(B, nb)
+    rest = rest_hi * rnd(B, nb)
+    dims = torch.tensor([[FLOOR_DIMS[0], FLOOR_DIMS[1]]] + [[BOX, BOX]] * (nb - 1), dtype=torch.float64)
+    Mdiag = _rect_mdiag(mass, dims[:, 0].unsqueeze(0), dims[:, 1].unsqueeze(0))
+    v = torch.randn(B, nb, 3, generator=g, dtype=torch.float64)
+    v[:, :, 0] *= ang_sigma
+    v[:, :, 1:] *= lin_sigma
+    v[:, 0] = 0.0                                            # the floor is pinned
+    f = torch.zeros(B, nb, 3, dtype=torch.float64)
+    f[:, 1:, 2] = GRAVITY * mass[:, 1:]                      # forces.py:51-67 (Gravity)
+    p = torch.zeros(B, nb, 3, dtype=torch.float64)
+    p[:, :, 1:] = centres
+    nI = len(interfaces)
+    nc = nI * pts
+    c_p1 = torch.zeros(B, nc, 2, dtype=torch.float64)
+    c_p2 = torch.zeros(B, nc, 2, dtype=torch.float64)
+    c_i1 = torch.zeros(B, nc, dtype=torch.int32)
+    c_i2 = torch.zeros(B, nc, dtype=torch.int32)
+    for k, (lo_b, up_b) in enumerate(interfaces):
+        p1, p2 = _interface_contacts(centres[:, lo_b, 0], float(dims[lo_b, 1]), centres[:, up_b, 0],
+                                     float(dims[up_b, 1]), float(dims[lo_b, 0]), float(dims[up_b, 0]),
+                                     pts, gap)
+        c_p1[:, k * pts:(k + 1) * pts] = p1
+        c_p2[:, k * pts:(k + 1) * pts] = p2
+        c_i1[:, k * pts:(k + 1) * pts] = lo_b
+        c_i2[:, k * pts:(k + 1) * pts] = up_b
+    c_n = torch.zeros(B, nc, 2, dtype=torch.float64)
+    c_n[:, :, 1] = 1.0
+    Je = torch.zeros(B, 3, 3 * nb, dtype=torch.float64)      # TotalConstraint on body 0
+    Je[:, 0, 0] = Je[:, 1, 1] = Je[:, 2, 2] = 1.0            # constraints.py:190-192
+    sb = SceneBatch(p=p, v=v, Mdiag=Mdiag, f=f, rest=rest, fric=fric, c_n=c_n, c_p1=c_p1,
+                    c_p2=c_p2, c_i1=c_i1, c_i2=c_i2, Je=Je, dt=DT)
+    return sb.to(dtype=dtype)
+
+
+def make_stack_scenes(B, nbox, pts_per_interface=4, seed=1234, dtype=torch.float32, **kw):
+    """Floor + `nbox` stacked 60x60 boxes; nc = nbox * pts_per_interface.
+
+    BASELINE configs: nbox=2,pts=4 -> 8 contacts (nineq 32); nbox=4,pts=4 -> 16 (nineq 64);
+    pts=2 gives the scene-faithful 4 / 8 contacts the reference's handler would emit."""
+    g = torch.Generator().manual_seed(seed)
+    nb = nbox + 1
+    centres = torch.zeros(B, nb, 2, dtype=torch.float64)
+    centres[:, 0] = torch.tensor([500.0, 500.0], dtype=torch.float64)
+    top = 500.0 - FLOOR_DIMS[1] / 2
+    for k in range(nbox):
+        off = -10.0 + 20.0 * torch.rand(B, generator=g, dtype=torch.float64)
+        centres[:, k + 1, 0] = 500.0 + off
+        centres[:, k + 1, 1] = top - GAP * (k + 1) - BOX / 2 - BOX * k
+    interfaces = [(k, k + 1) for k in range(nbox)]
+    return _finish(B, nb, centres, interfaces, pts_per_interface, g, dtype, **kw)
+
+
+def make_pile_scenes(B, pts_per_interface=4, seed=1239, dtype=torch.float32, **kw):
+    """Config 5: 10 boxes in a 4-3-2-1 pyramid on the floor, 16 interfaces (64 contacts)."""
+    g = torch.Generator().manual_seed(seed)
+    nb = 11
+    centres = torch.zeros(B, nb, 2, dtype=torch.float64)
+    centres[:, 0] = torch.tensor([500.0, 500.0], dtype=torch.float64)
+    top = 500.0 - FLOOR_DIMS[1] / 2
+    rows = [4, 3, 2, 1]
+    pitch = BOX + 8.0
+    idx = 1
+    row_ids = []
+    for r, n in enumerate(rows):
+        ids = []
+        x0 = 500.0 - pitch * (n - 1) / 2
+        for j in range(n):
+            off = -3.0 + 6.0 * torch.rand(B, generator=g, dtype=torch.float64)
+            centres[:, idx, 0] = x0 + pitch * j + off
+            centres[:, idx, 1] = top - GAP * (r + 1) - BOX / 2 - BOX * r
+            ids.append(idx)
+            idx += 1
+        row_ids.append(ids)
+    interfaces = [(0, b) for b in row_ids[0]]
+    for r in range(1, len(rows)):
+        for j, b in enumerate(row_ids[r]):
+            interfaces.append((row_ids[r - 1][j], b))
+            interfaces.append((row_ids[r - 1][j + 1], b))
+    assert len(interfaces) == 16
+    return _finish(B, nb, centres, interfaces, pts_per_interface, g, dtype, **kw)
+
+
+def make_random_lcp(B, nz, m, e, seed=7, dtype=torch.float32, skew=0.5):
+    """Random-structure dense LCPs (stress inputs, not physics): Q SPD, G/A dense, F = PSD +
+    skew part (monotone LCP, so it is solvable), h > 0 so that x = 0 is strictly feasible."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    L = rn(B, nz, nz)
+    Q = L @ L.transpose(1, 2) / nz + torch.eye(nz, dtype=torch.float64)
+    G = rn(B, m, nz)
+    H = rn(B, m, max(1, m // 4))
+    S = rn(B, m, m)
+    F = 0.1 * (H @ H.transpose(1, 2)) + skew * 0.2 * (S - S.transpose(1, 2))
+    p = rn(B, nz)
+    h = 0.1 + torch.rand(B, m, generator=g, dtype=torch.float64)
+    if e > 0:
+        A = rn(B, e, nz)
+        b = torch.zeros(B, e, dtype=torch.float64)
+    else:
+        A, b = None, None
+    cast = lambda t: None if t is None else t.to(dtype)
+    return tuple(cast(t) for t in (Q, p, G, h, A, b, F))

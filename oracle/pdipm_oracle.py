@@ -52,7 +52,8 @@ def _lu_nopivot(M):
 def lu_factor(M, pivot=True):
     """pdipm.py:15-28 `btrifact_hack`: partial pivoting on CPU, none on GPU."""
     if pivot:
-        return torch.linalg.lu_factor(M)
+        LU, piv, _info = torch.linalg.lu_factor_ex(M)
+        return LU, piv
     return _lu_nopivot(M)
 
 
@@ -129,6 +130,10 @@ def factor_kkt(k, d):
     idx = torch.arange(T.shape[1])
     T[:, idx, idx] += 1.0 / d
     k.T_LU = lu_factor(T, pivot=k.pivot)
+    # exactly singular U (a zero pivot): the reference's bare `except` around factor_kkt
+    # (pdipm.py:99-102) returns the best iterate; report it so the caller can do the same.
+    dg = torch.diagonal(k.T_LU[0], dim1=1, dim2=2)
+    return (dg == 0).any(dim=1)
 
 
 def _solve_S(k, hy, hz):
@@ -211,8 +216,10 @@ def pdipm_forward(Q, p, G, h, A, b, F, k, eps=1e-12, not_improved_lim=3, max_ite
         if neq > 0:
             resid = resid + ry.norm(dim=1)
         d = z / s                                                       # :98
-        factor_kkt(k, d)                                                # :99-102
+        singular = factor_kkt(k, d)                                     # :99-102
         iters = iters + (~done).to(torch.int32)
+        if it > 0:
+            done = done | singular                                      # except: return best
 
         improved = resid < best_r                                       # :115 (NaN -> False)
         first = ~have_best

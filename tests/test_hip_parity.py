@@ -1,0 +1,382 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed
+reference fixtures.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (stated, fp32 I/O): err_x <= 1e-4 (scaled, tests/parity.py), gradients <= 1e-4,
+contact index sets {i: z_i > s_i} identical wherever the oracle's decision is not a tie.
+The fp64-I/O kernel is held to 1e-7 (it follows the reference's native-dtype trajectory).
+"""
+import pytest
+import torch
+
+from oracle import pdipm_oracle as O
+from tests import golden_io, parity
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL_X32 = 1e-4
+TOL_G32 = 1e-4
+
+
+def _gpu(ts, dtype):
+    return [None if t is None else t.to(device=DEV, dtype=dtype).contiguous() for t in ts]
+
+
+def _solve(lcp, dtype, compute="f64", **kw):
+    from lcp_physics_amd.lcp import lcp_solve
+    sol = lcp_solve(*_gpu(lcp, dtype), compute=compute, **kw)
+    torch.cuda.synchronize()
+    return sol
+
+
+def _decisive(z, s, rel=1e-3):
+    """Indices where the oracle's z_i > s_i decision is not a near-tie."""
+    big = torch.maximum(z.abs(), s.abs())
+    return (z - s).abs() > rel * big
+
+
+def _check_forward(sol, ref, Q, p, tol_x, name=""):
+    x = sol.x.double().cpu()
+    ex = parity.err_x(x, ref.x, Q.double(), p.double())
+    assert float(ex.max()) <= tol_x, (name, "err_x", float(ex.max()), int(ex.argmax()))
+    z, s = sol.z.double().cpu(), sol.s.double().cpu()
+    dec = _decisive(ref.z, ref.s)
+    same = (parity.active_sets(z, s) == parity.active_sets(ref.z, ref.s)) | ~dec
+    assert bool(same.all()), (name, "active set", torch.nonzero(~same)[:8].tolist())
+    return ex
+
+
+# ------------------------------------------------------------------ golden fixtures (reference)
+STEPS = list(golden_io.all_steps())
+IDS = [s[0] for s in STEPS]
+
+
+@pytest.mark.parametrize("name,st", STEPS, ids=IDS)
+def test_fp64_kernel_matches_reference_fixture(name, st):
+    lcp = golden_io.lcp_inputs(st)
+    sol = _solve(lcp, torch.float64)
+    Q, p = lcp[0], lcp[1]
+    ex = parity.err_x(sol.x.cpu(), st["x"], Q, p)
+    assert float(ex.max()) < 1e-7, (name, ex)
+    assert float(parity.rel_err(sol.z.cpu(), st["lams"]).max()) < 5e-4
+    z, s = sol.z.cpu(), sol.s.cpu()
+    dec = _decisive(st["lams"], st["slacks"])
+    assert bool(((parity.active_sets(z, s) == parity.active_sets(st["lams"], st["slacks"])) | ~dec).all())
+    assert int(sol.status.cpu().max()) == 0
+
+
+@pytest.mark.parametrize("name,st", STEPS, ids=IDS)
+def test_fp32_io_matches_reference_fixture(name, st):
+    lcp32 = [None if t is None else t.float() for t in golden_io.lcp_inputs(st)]
+    ref = O.lcp_forward(*[None if t is None else t.double() for t in lcp32])
+    sol = _solve(lcp32, torch.float32)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name)
+    # and against the reference's own fp64 answer on the un-rounded inputs
+    Q, p = golden_io.lcp_inputs(st)[:2]
+    ex = parity.err_x(sol.x.double().cpu(), st["x"], Q, p)
+    assert float(ex.max()) <= TOL_X32, (name, float(ex.max()))
+
+
+def _phys(st):
+    ph = {k: st[k][None] for k in parity.PHYS_KEYS}
+    ph["c_i1"], ph["c_i2"] = st["c_i1"][None], st["c_i2"][None]
+    ph["Je"] = st["Je"].unsqueeze(0) if st["Je"].numel() else None
+    return ph
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32io"])
+@pytest.mark.parametrize("name,st", STEPS, ids=IDS)
+def test_backward_matches_reference_fixture(name, st, dtype):
+    from lcp_physics_amd.lcp import lcp_backward
+    lcp = golden_io.lcp_inputs(st)
+    Q, p, G, h, A, b, F = lcp
+    sol = _solve(lcp, dtype)
+    grads = lcp_backward(sol, st["cot"].to(device=DEV, dtype=dtype))
+    torch.cuda.synchronize()
+    grads = {k: (None if g is None else g.double().cpu()) for k, g in zip("QpGhAbF", grads)}
+    ref = golden_io.ref_grads(st)
+    tol = 1e-6 if dtype == torch.float64 else TOL_G32
+    fl = parity.grad_floors(Q, p, st["cot"], st["x"], st["lams"], st.get("nus"))
+    errs = parity.err_grads({k: grads[k] for k in "QpAb"}, {k: ref[k] for k in "QpAb"}, fl)
+    worst = max(float(e.max()) for e in errs.values())
+    assert worst < tol, (name, {k: float(v.max()) for k, v in errs.items()})
+    res = parity.kkt_backward_residual(Q, G, A, F, sol.z.double().cpu(), sol.s.double().cpu(), st["cot"],
+                                       grads["p"], -grads["h"], None if A is None else -grads["b"])
+    assert max(float(v.max()) for v in res.values()) < (1e-7 if dtype == torch.float64 else 1e-5), (name, res)
+    ph = _phys(st)
+    pg = parity.physical_grads(ph, st["dt"], grads, O)
+    pg_ref = parity.physical_grads(ph, st["dt"], ref, O)
+    sc = parity.free_scales(Q, p, st["cot"])
+    floor = parity._n(st["cot"]) * torch.maximum(sc["x_free"], parity._n(st["x"]))
+    ep = parity.err_physical(pg, pg_ref, ph, floor)
+    assert float(ep.max()) < tol, (name, float(ep.max()))
+
+
+# ------------------------------------------------------------------ synthetic BASELINE configs
+CONFIGS = [("cfg2_stack2x4", 2, 4, 256), ("cfg3_stack4x4", 4, 4, 256), ("faithful_stack4x2", 4, 2, 128)]
+
+
+@pytest.mark.parametrize("name,nbox,pts,B", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_stack_scenes_forward_parity(name, nbox, pts, B):
+    from lcp_physics_amd import scenes
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=1234 + nbox, dtype=torch.float32)
+    lcp32 = O.assemble_lcp(*sc.assembly_args())
+    ref = O.lcp_forward(*[None if t is None else t.double() for t in lcp32])   # identical inputs, fp64
+    sol = _solve(lcp32, torch.float32)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name)
+    assert torch.equal(sol.iters.cpu(), ref.iters), (name, "iteration counts differ")
+
+
+@pytest.mark.parametrize("name,nbox,pts,B", CONFIGS[:2], ids=[c[0] for c in CONFIGS[:2]])
+def test_stack_scenes_backward_parity(name, nbox, pts, B):
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    B = 64
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=99 + nbox, dtype=torch.float32)
+    lcp32 = O.assemble_lcp(*sc.assembly_args())
+    lcp64 = [None if t is None else t.double() for t in lcp32]
+    ref = O.lcp_forward(*lcp64)
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(B, lcp32[0].shape[1], generator=g, dtype=torch.float32)
+    gref = O.lcp_backward(ref, *lcp64, cot.double())
+    gref = {k: gref["d" + k] for k in "QpGhAbF"}
+    sol = _solve(lcp32, torch.float32)
+    grads = lcp_backward(sol, cot.to(DEV))
+    torch.cuda.synchronize()
+    grads = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", grads)}
+    Q, p = lcp64[0], lcp64[1]
+    fl = parity.grad_floors(Q, p, cot.double(), ref.x, ref.z, ref.y)
+    errs = parity.err_grads({k: grads[k] for k in "QpAb"}, {k: gref[k] for k in "QpAb"}, fl)
+    worst = max(float(e.max()) for e in errs.values())
+    assert worst < TOL_G32, (name, {k: float(v.max()) for k, v in errs.items()})
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    pg = parity.physical_grads(ph, sc.dt, grads, O)
+    pg_ref = parity.physical_grads(ph, sc.dt, gref, O)
+    scl = parity.free_scales(Q, p, cot.double())
+    floor = parity._n(cot) * torch.maximum(scl["x_free"], parity._n(ref.x))
+    ep = parity.err_physical(pg, pg_ref, ph, floor)
+    assert float(ep.max()) < TOL_G32, (name, float(ep.max()), int(ep.argmax()))
+
+
+RANDOM = [("m4", 6, 4, 3), ("m24_noeq", 7, 24, 0), ("m64", 15, 64, 3), ("m96_generic", 20, 96, 2),
+          ("m130_ws", 12, 130, 1)]
+
+
+@pytest.mark.parametrize("name,nz,m,e", RANDOM, ids=[r[0] for r in RANDOM])
+def test_random_dense_lcp_forward_backward(name, nz, m, e):
+    """Non-physics dense LCPs (non-degenerate): all 7 gradients are well-posed here."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    B = 24
+    lcp32 = scenes.make_random_lcp(B, nz, m, e, seed=nz * 100 + m, dtype=torch.float32)
+    lcp64 = [None if t is None else t.double() for t in lcp32]
+    kw = dict(max_iter=20, not_improved_lim=3)
+    ref = O.lcp_forward(*lcp64, **kw)
+    sol = _solve(lcp32, torch.float32, **kw)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name)
+    assert float(parity.rel_err(sol.z.double().cpu(), ref.z).max()) < 1e-4
+    g = torch.Generator().manual_seed(1)
+    cot = torch.randn(B, nz, generator=g, dtype=torch.float32)
+    gref = O.lcp_backward(ref, *lcp64, cot.double())
+    grads = lcp_backward(sol, cot.to(DEV))
+    torch.cuda.synchronize()
+    for k, gt in zip("QpGhAbF", grads):
+        r = gref["d" + k]
+        if r is None:
+            assert gt is None
+            continue
+        err = parity.rel_err(gt.double().cpu(), r, floor=1e-30)
+        assert float(err.max()) < TOL_G32, (name, k, float(err.max()))
+
+
+def test_fp64_io_random_lcp_tight():
+    from lcp_physics_amd import scenes
+    lcp64 = scenes.make_random_lcp(16, 9, 32, 3, seed=4, dtype=torch.float64)
+    ref = O.lcp_forward(*lcp64)
+    sol = _solve(lcp64, torch.float64)
+    assert float(parity.rel_err(sol.x.cpu(), ref.x).max()) < 1e-8
+    assert float(parity.rel_err(sol.z.cpu(), ref.z).max()) < 1e-7
+    assert torch.equal(sol.iters.cpu(), ref.iters)
+
+
+def test_pure_fp32_compute_mode_is_looser_but_sane():
+    """compute='f32' (all-fp32 arithmetic, partial pivoting) is the optional fast mode: it is held
+    to the accuracy the reference's own fp32 run reaches (median ~1e-6, tail to 1e-2)."""
+    from lcp_physics_amd import scenes
+    sc = scenes.make_stack_scenes(B=256, nbox=4, pts_per_interface=4, seed=77, dtype=torch.float32)
+    lcp32 = O.assemble_lcp(*sc.assembly_args())
+    ref = O.lcp_forward(*[None if t is None else t.double() for t in lcp32])
+    sol = _solve(lcp32, torch.float32, compute="f32")
+    ex = parity.err_x(sol.x.double().cpu(), ref.x, lcp32[0].double(), lcp32[1].double())
+    assert float(ex.median()) < 1e-4 and float(torch.quantile(ex, 0.9)) < 5e-3, (float(ex.median()), float(ex.max()))
+
+
+# ------------------------------------------------------------------ assembly + fused step
+@pytest.mark.parametrize("nbox,pts", [(2, 4), (4, 4), (4, 2)])
+def test_assembly_kernel_matches_oracle(nbox, pts):
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import assemble_contacts
+    sc = scenes.make_stack_scenes(B=32, nbox=nbox, pts_per_interface=pts, seed=3, dtype=torch.float32)
+    ref = O.assemble_lcp(*sc.assembly_args())
+    got = assemble_contacts(sc.to(device=DEV))
+    torch.cuda.synchronize()
+    for nm, a, r in zip("QpGhAbF", got, ref):
+        assert torch.allclose(a.cpu(), r, rtol=1e-6, atol=1e-6 * float(r.abs().max())), nm
+
+
+def test_assembly_kernel_matches_reference_fixtures():
+    from lcp_physics_amd.physics import assemble_contacts
+    from lcp_physics_amd.scenes import SceneBatch
+    for name, st in STEPS:
+        nb = st["v"].shape[0]
+        Je = st["Je"][None] if st["Je"].numel() else torch.zeros(1, 0, 3 * nb, dtype=torch.float64)
+        sc = SceneBatch(p=st["p"][None], v=st["v"][None], Mdiag=st["Mdiag"][None], f=st["f"][None],
+                        rest=st["rest"][None], fric=st["fric"][None], c_n=st["c_n"][None],
+                        c_p1=st["c_p1"][None], c_p2=st["c_p2"][None], c_i1=st["c_i1"][None],
+                        c_i2=st["c_i2"][None], Je=Je, dt=st["dt"]).to(device=DEV, dtype=torch.float32)
+        got = assemble_contacts(sc)
+        for nm, a, r in zip("QpGhAbF", got, golden_io.lcp_inputs(st)):
+            if r is None:
+                assert a is None
+            else:
+                assert torch.allclose(a.double().cpu(), r, rtol=1e-5, atol=1e-6 * max(1.0, float(r.abs().max()))), (name, nm)
+
+
+@pytest.mark.parametrize("nbox,pts,B", [(2, 4, 128), (4, 4, 128)])
+def test_fused_step_matches_oracle_step(nbox, pts, B):
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import fused_step
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=21, dtype=torch.float32)
+    sc64 = sc.to(dtype=torch.float64)
+    new_v, ref, lcp = O.solve_dynamics(*sc64.assembly_args())
+    out = fused_step(sc.to(device=DEV))
+    torch.cuda.synchronize()
+    Q, p = lcp[0], lcp[1]
+    ex = parity.err_x(-out["v_new"].double().cpu().reshape(B, -1), ref.x, Q, p)
+    assert float(ex.max()) <= TOL_X32, float(ex.max())
+    p_ref = O.integrate(sc64.p, new_v, sc64.dt)
+    assert torch.allclose(out["p_new"].double().cpu(), p_ref, rtol=1e-5, atol=1e-3)
+    dec = _decisive(ref.z, ref.s)
+    z, s = out["z"].double().cpu(), out["s"].double().cpu()
+    assert bool(((parity.active_sets(z, s) == parity.active_sets(ref.z, ref.s)) | ~dec).all())
+
+
+# ------------------------------------------------------------------ full BASELINE size: properties
+def test_full_size_config3_properties():
+    """B = 4096 x 16 contacts (nineq 64): size-independent properties + sampled oracle parity."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import assemble_contacts
+    B = 4096
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32)
+    lcp = assemble_contacts(sc.to(device=DEV))
+    from lcp_physics_amd.lcp import lcp_solve
+    sol = lcp_solve(*lcp)
+    sol2 = lcp_solve(*lcp)
+    torch.cuda.synchronize()
+    assert torch.equal(sol.x, sol2.x) and torch.equal(sol.z, sol2.z)          # deterministic / idempotent
+    x, z, s = sol.x.double(), sol.z.double(), sol.s.double()
+    Q, p, G, h, A, b, F = [t.double() for t in lcp]
+    assert bool((z > 0).all()) and bool((s > 0).all())                        # interior iterates
+    mv = lambda M, v: torch.bmm(M, v.unsqueeze(-1)).squeeze(-1)
+    rz = mv(G, x) + s - h - mv(F, z)
+    scale = torch.linalg.solve(Q, p.unsqueeze(-1)).squeeze(-1).norm(dim=1)
+    assert float((rz.norm(dim=1) / (G.norm(dim=(1, 2)) * scale)).max()) < 1e-4   # primal feasibility
+    assert float((mv(A, x).norm(dim=1) / scale).max()) < 1e-5                  # pinned floor
+    comp = (s * z).sum(1) / (64 * (z.norm(dim=1) * scale + 1e-30))
+    assert float(comp.median()) < 1e-6
+    assert int(sol.status.max()) == 0
+    idx = torch.arange(0, B, 37)
+    sub = [t[idx].cpu() for t in (Q, p, G, h, A, b, F)]
+    ref = O.lcp_forward(*sub)
+    ex = parity.err_x(sol.x[idx].double().cpu(), ref.x, sub[0], sub[1])
+    assert float(ex.max()) <= TOL_X32
+
+
+def test_pile_config5_generic_path_runs_small_batch():
+    """Config 5 shape (nineq 256, nz 33): exercises the workspace-resident T path."""
+    from lcp_physics_amd import scenes
+    sc = scenes.make_pile_scenes(B=8, seed=5, dtype=torch.float32)
+    lcp32 = O.assemble_lcp(*sc.assembly_args())
+    ref = O.lcp_forward(*[None if t is None else t.double() for t in lcp32])
+    sol = _solve(lcp32, torch.float32)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, "pile")
+
+
+# ------------------------------------------------------------------ the autograd op and the engine
+def test_lcpfunction_autograd_surface():
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import LCPFunction
+    lcp = scenes.make_random_lcp(4, 6, 12, 2, seed=9, dtype=torch.float64)
+    ins = [t.clone().requires_grad_(True) for t in lcp]            # CPU float64 like the reference
+    fn = LCPFunction(max_iter=20)
+    x = fn(*ins)
+    assert x.shape == (4, 6) and x.dtype == torch.float64 and not x.is_cuda
+    assert fn.lams.shape == (4, 12) and fn.slacks.shape == (4, 12) and fn.nus.shape == (4, 2)
+    assert (fn.neq, fn.nineq, fn.nz) == (2, 12, 6)
+    g = torch.Generator().manual_seed(2)
+    cot = torch.randn(4, 6, generator=g, dtype=torch.float64)
+    x.backward(cot)
+    ref = O.lcp_forward(*lcp, max_iter=20)
+    gref = O.lcp_backward(ref, *lcp, cot)
+    assert float(parity.rel_err(x.detach(), ref.x).max()) < 1e-8
+    for k, t in zip("QpGhAbF", ins):
+        assert float(parity.rel_err(t.grad, gref["d" + k]).max()) < 1e-6, k
+    # no-equality form: A = b = torch.tensor([])  (engines.py:59-60)
+    x2 = LCPFunction()(lcp[0], lcp[1], lcp[2], lcp[3], torch.tensor([]), torch.tensor([]), lcp[6])
+    ref2 = O.lcp_forward(lcp[0], lcp[1], lcp[2], lcp[3], None, None, lcp[6])
+    assert float(parity.rel_err(x2, ref2.x).max()) < 1e-8
+
+
+def test_singular_Q_raises_like_reference():
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import LCPFunction
+    Q, p, G, h, A, b, F = scenes.make_random_lcp(2, 5, 8, 0, seed=1, dtype=torch.float64)
+    Q = torch.zeros_like(Q)
+    with pytest.raises(RuntimeError, match="Cannot perform LU factorization on Q"):
+        LCPFunction()(Q, p, G, h, torch.tensor([]), torch.tensor([]), F)
+
+
+class _FakeWorld:
+    """Just the attributes `Engine.solve_dynamics` reads from the reference's World
+    (`physics/world.py:124-234`), filled from a golden fixture."""
+
+    def __init__(self, st):
+        self.st, self.t, self.vec_len = st, 0.0, 3
+        nb = st["v"].shape[0]
+        self.bodies = [None] * nb
+        self.contacts = [((st["c_n"][i], st["c_p1"][i], st["c_p2"][i], st["c_pen"][i]),
+                          int(st["c_i1"][i]), int(st["c_i2"][i])) for i in range(st["c_n"].shape[0])]
+        self.static_inverse = True
+        lcp = golden_io.lcp_inputs(st)
+        self._lcp = lcp
+        nc = len(self.contacts)
+        self._G = lcp[2][0]
+        self._nc = nc
+
+    def M(self): return self._lcp[0][0]
+    def get_v(self): return self.st["v"].reshape(-1)
+    def apply_forces(self, t): return self.st["f"].reshape(-1)
+    def Je(self): return self.st["Je"]
+    def Jc(self): return self._G[:self._nc]
+    def Jf(self): return self._G[self._nc:3 * self._nc]
+    def restitutions(self):
+        r = self.st["rest"]
+        return torch.stack([0.5 * (r[c[1]] + r[c[2]]) for c in self.contacts])
+    def mu(self):
+        f = self.st["fric"]
+        return torch.diag(torch.stack([0.5 * (f[c[1]] + f[c[2]]) for c in self.contacts]))
+    def E(self):
+        E = torch.zeros(2 * self._nc, self._nc, dtype=torch.float64)
+        for i in range(self._nc):
+            E[2 * i:2 * i + 2, i] = 1
+        return E
+
+
+@pytest.mark.parametrize("name,st", STEPS[::4], ids=IDS[::4])
+def test_engine_plugin_reproduces_reference_new_v(name, st):
+    from lcp_physics_amd.physics import HipPdipmEngine
+    eng = HipPdipmEngine()                      # zero-arg construction, as world.py:26 does
+    new_v = eng.solve_dynamics(_FakeWorld(st), st["dt"])
+    lcp = golden_io.lcp_inputs(st)
+    ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
+    assert float(ev.max()) < 1e-7, (name, float(ev.max()))
