@@ -46,23 +46,30 @@ def parse():
     ap.add_argument("--compute", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default="dense", choices=["dense", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     return ap.parse_args()
 
 
-def cpu_baseline(sc_cpu, sample, cot):
-    """Oracle (port of the reference algorithm) on the host cores: forward + backward."""
+def cpu_baseline(sc_cpu, cot, budget_s=15.0):
+    """Oracle (port of the reference algorithm, vectorised torch fp64) on the host cores: forward +
+    backward on a bounded sample of the same scenes (sized from a calibration pass to ~budget_s)."""
     from oracle import pdipm_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    sub = sc_cpu.slice(0, sample).to(dtype=torch.float64)
-    lcp = O.assemble_lcp(*sub.assembly_args())
-    warm = [None if t is None else t[:64] for t in lcp]
-    O.lcp_backward(O.lcp_forward(*warm), *warm, cot[:64].double())
-    t0 = time.perf_counter()
-    sol = O.lcp_forward(*lcp)
-    O.lcp_backward(sol, *lcp, cot[:sample].double())
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "sim steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    threads = max(1, min(os.cpu_count() or 1, 16))      # tiny batched ops: more threads only add overhead
+    torch.set_num_threads(threads)
+
+    def run(n):
+        sub = sc_cpu.slice(0, n).to(dtype=torch.float64)
+        lcp = O.assemble_lcp(*sub.assembly_args())
+        t0 = time.perf_counter()
+        sol = O.lcp_forward(*lcp)
+        O.lcp_backward(sol, *lcp, cot[:n].double())
+        return time.perf_counter() - t0
+
+    run(32)                                             # warm-up
+    cal = run(128)
+    sample = int(max(128, min(sc_cpu.B, 128 * budget_s / max(cal, 1e-3))))
+    dt = run(sample)
+    return {"value": sample / dt, "unit": "sim steps/s", "cores": threads, "kind": "port",
             "sample": "%d of the same scenes, 1 pass fwd+bwd, vectorised torch fp64 oracle, %.2f s" % (sample, dt)}
 
 
@@ -162,7 +169,7 @@ def main():
                      "hbm_frac_algorithmic": flops.bytes_forward(nz, m, e) * B / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sc_cpu, min(args.cpu_sample, B), cot_cpu)
+        out["cpu_baseline"] = cpu_baseline(sc_cpu, cot_cpu, args.cpu_budget)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

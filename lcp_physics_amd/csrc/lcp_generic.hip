@@ -16,48 +16,19 @@
 //
 // Numerics: TC is the arithmetic type.  With TC = double the iterates follow the reference's
 // fp64 trajectory (T is numerically singular in fp32 for sticking friction pairs).
-// LU(T) uses no pivoting for TC = double (the reference itself does not pivot on GPUs,
-// pdipm.py:18) and partial pivoting for TC = float.
+// LU(T) uses partial pivoting like the reference's CPU path (pdipm.py:18, `pivot=not x.is_cuda`):
+// at a converged iterate T is numerically singular along each sticking friction pair and a
+// pivot-free elimination turns rounding noise into 1e16 multipliers (measured: the backward
+// solve loses all digits on ~1 % of stack scenes without it).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "lcp_kernels.h"
+#include "lcp_device.h"
 
 namespace lcp {
 
 constexpr int NT = 256;          // threads per workgroup (4 waves)
 constexpr int NW = NT / 64;
-
-template <typename T> __device__ __forceinline__ T nan_of();
-template <> __device__ __forceinline__ float nan_of<float>() { return __builtin_nanf(""); }
-template <> __device__ __forceinline__ double nan_of<double>() { return __builtin_nan(""); }
-template <typename T> __device__ __forceinline__ T inf_of();
-template <> __device__ __forceinline__ float inf_of<float>() { return __builtin_huge_valf(); }
-template <> __device__ __forceinline__ double inf_of<double>() { return __builtin_huge_val(); }
-
-// `mu > 1e100` (pdipm.py:133): in fp32 only +inf compares greater than 1e100.
-template <typename T> __device__ __forceinline__ T mu_limit();
-template <> __device__ __forceinline__ float mu_limit<float>() { return 3.402823466e+38f; }
-template <> __device__ __forceinline__ double mu_limit<double>() { return 1e100; }
-
-// NaN-propagating min / max (Tensor.min()/max() and torch.min(a,b) semantics).
-template <typename T> __device__ __forceinline__ T pmin(T a, T b) {
-  return (a != a || b != b) ? nan_of<T>() : (a < b ? a : b);
-}
-template <typename T> __device__ __forceinline__ T pmax(T a, T b) {
-  return (a != a || b != b) ? nan_of<T>() : (a > b ? a : b);
-}
-
-struct OpSum { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
-struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return pmin(a, b); } };
-struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return pmax(a, b); } };
-
-template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off);
-template <> __device__ __forceinline__ float shfl_xor_t<float>(float v, int off) { return __shfl_xor(v, off, 64); }
-template <> __device__ __forceinline__ double shfl_xor_t<double>(double v, int off) { return __shfl_xor(v, off, 64); }
-template <typename T> __device__ __forceinline__ T shfl_t(T v, int src);
-template <> __device__ __forceinline__ float shfl_t<float>(float v, int src) { return __shfl(v, src, 64); }
-template <> __device__ __forceinline__ double shfl_t<double>(double v, int src) { return __shfl(v, src, 64); }
 
 // Workgroup reduction of two values at once (all threads receive the results).
 template <typename T, typename Op>
@@ -102,11 +73,13 @@ struct Scene {
 template <typename TC>
 __host__ __device__ inline size_t carve(Scene<TC>& S, unsigned char* smem, int nz, int m, int e, int ldT,
                                         bool t_in_lds, TC* T_ws) {
+  // t_in_lds == false is the big-problem plan: T and the prefactor scratch (G Q^-1) both live in the
+  // HBM workspace (T_ws points at T, the scratch follows it).
   TC* q = reinterpret_cast<TC*>(smem);
   auto take = [&](size_t n) { TC* r = q; q += n; return r; };
   S.nz = nz; S.m = m; S.e = e; S.ldT = ldT; S.nc = 0;
   S.Q = take((size_t)nz * nz); S.Qi = take((size_t)nz * nz);
-  S.G = take((size_t)m * nz); S.scr = take((size_t)m * nz);
+  S.G = take((size_t)m * nz); S.scr = t_in_lds ? take((size_t)m * nz) : T_ws + (size_t)m * ldT;
   S.A = take((size_t)e * nz); S.GA = take((size_t)m * e); S.S11i = take((size_t)e * e);
   S.T = t_in_lds ? take((size_t)m * ldT) : T_ws;
   S.mu_c = take(m);
@@ -610,7 +583,7 @@ __device__ void pdipm_loop(Scene<TC>& S, const FT& F, TC eps, int max_iter, int 
 template <typename TC>
 __host__ __device__ inline size_t ws_elems(int nz, int m, int e, int ldT, bool t_in_ws) {
   size_t n = (size_t)m * m + (size_t)nz * nz + (size_t)m * e + (size_t)e * e + nz + 2 * (size_t)m + e;
-  if (t_in_ws) n += (size_t)m * ldT;
+  if (t_in_ws) n += (size_t)m * ldT + (size_t)m * nz;   // T and the prefactor scratch
   return (n + 31) & ~(size_t)31;
 }
 
@@ -842,19 +815,19 @@ static int launch_step_t(const StepArgs& P, size_t lds, hipStream_t st) {
 
 int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (io_f64) return launch_fwd_t<double, double, false>(P, lds, st);
-  if (compute == LCP_COMPUTE_F64) return launch_fwd_t<float, double, false>(P, lds, st);
+  if (io_f64) return launch_fwd_t<double, double, true>(P, lds, st);
+  if (compute == LCP_COMPUTE_F64) return launch_fwd_t<float, double, true>(P, lds, st);
   return launch_fwd_t<float, float, true>(P, lds, st);
 }
 int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (io_f64) return launch_bwd_t<double, double, false>(P, lds, st);
-  if (compute == LCP_COMPUTE_F64) return launch_bwd_t<float, double, false>(P, lds, st);
+  if (io_f64) return launch_bwd_t<double, double, true>(P, lds, st);
+  if (compute == LCP_COMPUTE_F64) return launch_bwd_t<float, double, true>(P, lds, st);
   return launch_bwd_t<float, float, true>(P, lds, st);
 }
 int generic_step(const StepArgs& P, int compute, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (compute == LCP_COMPUTE_F64) return launch_step_t<float, double, false>(P, lds, st);
+  if (compute == LCP_COMPUTE_F64) return launch_step_t<float, double, true>(P, lds, st);
   return launch_step_t<float, float, true>(P, lds, st);
 }
 int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b, float* F,
