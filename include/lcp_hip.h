@@ -127,6 +127,14 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
                        float* v_new, float* p_new, float* z, float* s, float* y,
                        int32_t* iters, int32_t* status, void* ws, void* stream);
 
+/* ---- debugging / A-B aids (not part of the drop-in surface) ----
+ * lcp_debug_set_trace: when non-NULL, the dense forward writes trace[B, max_iter, 4] =
+ *   (resid, mu, sigma, alpha) per PDIPM iteration (device pointer to doubles).
+ * lcp_debug_set_path : 0 = automatic kernel selection, 1 = generic (workgroup-per-scene) kernels only,
+ *   2 = wave-per-scene kernels whenever the sizes allow (the default behaviour of 0 today). */
+void lcp_debug_set_trace(double* device_trace);
+void lcp_debug_set_path(int path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lcp_step_fused_f32": (_I, [_I] * 4 + [_P] * 12 + [_c.c_float, _c.c_double, _I, _I, _I] + [_P] * 5
                            + [_P, _P, _P, _P]),
     "lcp_debug_set_trace": (None, [_P]),
+    "lcp_debug_set_path": (None, [_I]),
 }
 
 _lib = None
@@ -84,6 +85,11 @@ def require_gpu_tensor(t, name, dtype=None):
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
     return t
+
+
+def set_path(path):
+    """A/B aid: 'auto' | 'generic' | 'wave64' kernel family."""
+    load().lcp_debug_set_path({"auto": 0, "generic": 1, "wave64": 2}[path])
 
 
 def workspace_bytes(B, nz, m, e, compute):

@@ -8,6 +8,14 @@
 namespace {
 
 double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
+int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels
+
+// Which kernel family serves a problem.  Deterministic in (sizes, io type) so that forward and
+// backward of one op agree on the workspace layout.
+inline bool use_wave64(int io_f64, int nz, int m, int e) {
+  if (io_f64 || g_path == 1) return false;
+  return lcp::wave64_supported(nz, m, e);
+}
 
 inline int csize_of(int io_f64, int compute) { return (io_f64 || compute == LCP_COMPUTE_F64) ? 8 : 4; }
 
@@ -21,8 +29,16 @@ size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
   if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return 0;
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  return (size_t)B * pl.ws_stride * cs;
+  size_t per_scene = pl.ws_stride * cs;
+  if (lcp::wave64_supported(nz, m, e)) {
+    const size_t w = lcp::wave64_ws_bytes(compute);
+    if (w > per_scene) per_scene = w;
+  }
+  return (size_t)B * per_scene;
 }
+
+// Debugging / A-B aid: 0 = automatic kernel selection, 1 = generic kernels only, 2 = wave64 when legal.
+void lcp_debug_set_path(int path) { g_path = path; }
 
 // Debugging aid (not part of the drop-in surface): when set, the dense forward writes
 // trace[B, max_iter, 4] = (resid, mu, sigma, alpha) per PDIPM iteration.  Pass NULL to disable.
@@ -36,8 +52,9 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   if (!Q || !p || !G || !h || !F || !x || !z || !s || !ws) return LCP_E_BADARG;
   if (e > 0 && (!A || !b)) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
+  const bool w64 = use_wave64(io_f64, nz, m, e);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!pl.ok) return LCP_E_TOOLARGE;
+  if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   lcp::FwdArgs P;
   memset(&P, 0, sizeof(P));
   P.B = B; P.nz = nz; P.m = m; P.e = e;
@@ -45,6 +62,7 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   P.x = x; P.y = y; P.z = z; P.s = s; P.iters = iters; P.status = status;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.eps = eps; P.max_iter = max_iter; P.lim = lim;
   P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds; P.trace = g_trace;
+  if (w64) return lcp::wave64_forward(P, compute, stream);
   return lcp::generic_forward(P, io_f64, compute, pl.lds_bytes, stream);
 }
 
@@ -72,13 +90,15 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (!G || !dl_dx || !ws) return LCP_E_BADARG;
   if (e > 0 && !A) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
+  const bool w64 = use_wave64(io_f64, nz, m, e);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!pl.ok) return LCP_E_TOOLARGE;
+  if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   lcp::BwdArgs P;
   memset(&P, 0, sizeof(P));
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  if (w64) return lcp::wave64_backward(P, compute, stream);
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
 }
 
@@ -136,11 +156,13 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   if (!pos || !v_new || !p_new || !ws || max_iter < 0) return LCP_E_BADARG;
   const int nz = 3 * nb, m = 4 * nc;
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  const bool w64 = use_wave64(0, nz, m, e);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!pl.ok) return LCP_E_TOOLARGE;
+  if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = p_new; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  if (w64) return lcp::wave64_step(P, compute, stream);
   return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 

@@ -38,4 +38,28 @@ template <typename T> __device__ __forceinline__ T shfl_t(T v, int src);
 template <> __device__ __forceinline__ float shfl_t<float>(float v, int src) { return __shfl(v, src, 64); }
 template <> __device__ __forceinline__ double shfl_t<double>(double v, int src) { return __shfl(v, src, 64); }
 
+// In-place Gauss-Jordan inverse of an n x n matrix without pivoting (SPD inputs: Q, A Q^-1 A^T).
+// Returns false (to all threads) if a zero / NaN pivot was met.
+template <int NT, typename TC>
+__device__ bool gj_inverse(TC* a, int n, int* flag) {
+  if (threadIdx.x == 0) *flag = 0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const TC piv = a[k * n + k];
+    if (!(piv != (TC)0) || piv != piv) { if (threadIdx.x == 0) *flag = 1; }
+    const TC pinv = (TC)1 / piv;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += NT) if (j != k) a[k * n + j] *= pinv;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * n; idx += NT) {
+      const int i = idx / n, j = idx - i * n;
+      if (i != k && j != k) a[idx] -= a[i * n + k] * a[k * n + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) a[i * n + k] = (i == k) ? pinv : -a[i * n + k] * pinv;
+    __syncthreads();
+  }
+  return *flag == 0;
+}
+
 }  // namespace lcp

@@ -149,30 +149,6 @@ struct FContact {
 // small dense building blocks (workgroup-cooperative, operands in LDS)
 // ------------------------------------------------------------------------------------------
 
-// In-place Gauss-Jordan inverse of an n x n matrix without pivoting (SPD inputs: Q, A Q^-1 A^T).
-// Returns false (to all threads) if a zero / NaN pivot was met.
-template <typename TC>
-__device__ bool gj_inverse(TC* a, int n, int* flag) {
-  if (threadIdx.x == 0) *flag = 0;
-  __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    const TC piv = a[k * n + k];
-    if (!(piv != (TC)0) || piv != piv) { if (threadIdx.x == 0) *flag = 1; }
-    const TC pinv = (TC)1 / piv;
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += NT) if (j != k) a[k * n + j] *= pinv;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < n * n; idx += NT) {
-      const int i = idx / n, j = idx - i * n;
-      if (i != k && j != k) a[idx] -= a[i * n + k] * a[k * n + j];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += NT) a[i * n + k] = (i == k) ? pinv : -a[i * n + k] * pinv;
-    __syncthreads();
-  }
-  return *flag == 0;
-}
-
 // out[i] = sum_j M[i*ld + j] * v[j]   (rows over threads)
 template <typename TC>
 __device__ __forceinline__ TC row_dot(const TC* Mrow, const TC* v, int n) {
@@ -196,7 +172,7 @@ __device__ int prefactor(Scene<TC>& S, const FT& F) {
   int status = 0;
   for (int i = tid; i < nz * nz; i += NT) S.Qi[i] = S.Q[i];
   __syncthreads();
-  if (!gj_inverse(S.Qi, nz, S.flag)) status |= LCP_ST_SINGULAR_Q;
+  if (!gj_inverse<NT>(S.Qi, nz, S.flag)) status |= LCP_ST_SINGULAR_Q;
   // scr = G Qi   [m, nz]
   for (int idx = tid; idx < m * nz; idx += NT) {
     const int i = idx / nz, j = idx - i * nz;
@@ -217,7 +193,7 @@ __device__ int prefactor(Scene<TC>& S, const FT& F) {
       S.S11i[idx] = acc;
     }
     __syncthreads();
-    if (!gj_inverse(S.S11i, e, S.flag)) status |= LCP_ST_SINGULAR_S11;
+    if (!gj_inverse<NT>(S.S11i, e, S.flag)) status |= LCP_ST_SINGULAR_S11;
   }
   // R = scr G^T + F - (GA S11i) GA^T
   for (int idx = tid; idx < m * m; idx += NT) {

@@ -63,4 +63,11 @@ int generic_step(const StepArgs& P, int compute, size_t lds, void* stream);
 int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b,
                      float* F, void* stream);
 
+// wave-per-scene register-resident path (nz <= 16, nineq <= 64, neq <= 8, fp32 I/O) - lcp_wave64.hip
+bool wave64_supported(int nz, int m, int e);
+size_t wave64_ws_bytes(int compute);
+int wave64_forward(const FwdArgs& P, int compute, void* stream);
+int wave64_backward(const BwdArgs& P, int compute, void* stream);
+int wave64_step(const StepArgs& P, int compute, void* stream);
+
 }  // namespace lcp

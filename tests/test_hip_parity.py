@@ -18,6 +18,16 @@ TOL_X32 = 1e-4
 TOL_G32 = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["wave64", "generic"])
+def kernel_path(request):
+    """Every test runs twice: through the wave-per-scene kernels (where the sizes allow - the library
+    falls back to the generic kernels otherwise) and with the generic kernels forced."""
+    from lcp_physics_amd import _lib
+    _lib.set_path(request.param)
+    yield request.param
+    _lib.set_path("auto")
+
+
 def _gpu(ts, dtype):
     return [None if t is None else t.to(device=DEV, dtype=dtype).contiguous() for t in ts]
 
