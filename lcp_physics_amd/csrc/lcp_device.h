@@ -62,4 +62,50 @@ __device__ bool gj_inverse(TC* a, int n, int* flag) {
   return *flag == 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// One contact -> its rows of Jc / Jf, h entry and friction coefficient (physics/world.py:144-224,
+// physics/engines.py:53), formed in I/O precision with FMA contraction OFF so that every kernel
+// that assembles a scene (the stand-alone assembly kernel and both fused step kernels) produces
+// bit-identical LCP data.
+// ------------------------------------------------------------------------------------------
+template <typename TI>
+struct ContactRows {
+  TI jn[6];   // normal row:   cols 3*b1..3*b1+2 then 3*b2..3*b2+2          (world.py:177-183)
+  TI jf[6];   // friction row for direction 1 (the direction-2 row is its negative, world.py:191-210)
+  TI h;       // (Jc v)_c * restitution_c                                     (engines.py:53, world.py:144-151)
+  TI mu;      // 0.5 (fric_b1 + fric_b2)                                       (world.py:213-224)
+  int b1, b2;
+};
+
+template <typename TI>
+__device__ __forceinline__ ContactRows<TI> make_contact(const TI* cn, const TI* c1, const TI* c2, const int32_t* i1,
+                                                        const int32_t* i2, const TI* rest, const TI* fric,
+                                                        const TI* vv, int c) {
+#pragma clang fp contract(off)
+  ContactRows<TI> r;
+  const TI nx = cn[2 * c], ny = cn[2 * c + 1];
+  const TI p1x = c1[2 * c], p1y = c1[2 * c + 1], p2x = c2[2 * c], p2y = c2[2 * c + 1];
+  r.b1 = i1[c]; r.b2 = i2[c];
+  const TI tx = ny, ty = -nx;                                      // left_orthogonal, utils.py:99-102
+  r.jn[0] = p1x * ny - p1y * nx; r.jn[1] = nx; r.jn[2] = ny;       // cross_2d, utils.py:93-96
+  r.jn[3] = -(p2x * ny - p2y * nx); r.jn[4] = -nx; r.jn[5] = -ny;
+  r.jf[0] = p1x * ty - p1y * tx; r.jf[1] = tx; r.jf[2] = ty;
+  r.jf[3] = -(p2x * ty - p2y * tx); r.jf[4] = -tx; r.jf[5] = -ty;
+  TI acc = (TI)0;                                                  // columns in ascending order
+  const int lo = r.b1 < r.b2 ? 0 : 3, hi = 3 - lo;
+  const int blo = r.b1 < r.b2 ? r.b1 : r.b2, bhi = r.b1 < r.b2 ? r.b2 : r.b1;
+  for (int q = 0; q < 3; ++q) acc = acc + r.jn[lo + q] * vv[3 * blo + q];
+  for (int q = 0; q < 3; ++q) acc = acc + r.jn[hi + q] * vv[3 * bhi + q];
+  r.h = acc * ((TI)0.5 * (rest[r.b1] + rest[r.b2]));
+  r.mu = (TI)0.5 * (fric[r.b1] + fric[r.b2]);
+  return r;
+}
+
+// u = M v + dt f (engines.py:32) in I/O precision, contraction off.
+template <typename TI>
+__device__ __forceinline__ TI momentum_entry(TI md, TI v, TI dt, TI f) {
+#pragma clang fp contract(off)
+  return md * v + dt * f;
+}
+
 }  // namespace lcp

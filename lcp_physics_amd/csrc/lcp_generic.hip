@@ -427,10 +427,7 @@ __device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene) {
   S.nc = nc;
   for (int i = tid; i < nz * nz; i += NT) { const int r = i / nz, c = i - r * nz; S.Q[i] = (r == c) ? (TC)Md[r] : (TC)0; }
   for (int i = tid; i < m * nz; i += NT) S.G[i] = 0;
-  for (int j = tid; j < nz; j += NT) {
-    S.p[j] = (TC)Md[j] * (TC)vv[j] + (TC)P.dt * (TC)ff[j];               // engines.py:32
-    S.v[j] = (TC)vv[j];
-  }
+  for (int j = tid; j < nz; j += NT) S.p[j] = (TC)momentum_entry<TI>(Md[j], vv[j], (TI)P.dt, ff[j]);   // engines.py:32
   for (int i = tid; i < m; i += NT) S.h[i] = 0;
   if (e > 0) {
     const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
@@ -439,24 +436,18 @@ __device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene) {
   }
   __syncthreads();
   for (int c = tid; c < nc; c += NT) {
-    const TC nx = (TC)cn[2 * c], ny = (TC)cn[2 * c + 1];
-    const TC p1x = (TC)c1[2 * c], p1y = (TC)c1[2 * c + 1], p2x = (TC)c2[2 * c], p2y = (TC)c2[2 * c + 1];
-    const int b1 = i1[c], b2 = i2[c];
-    const TC tx = ny, ty = -nx;                                          // left_orthogonal, utils.py:99-102
+    const ContactRows<TI> r = make_contact<TI>(cn, c1, c2, i1, i2, rest, fric, vv, c);
     TC* gn = S.G + (size_t)c * nz;                                       // Jc row            world.py:177-183
     TC* g0 = S.G + (size_t)(nc + 2 * c) * nz;                            // Jf rows 2c, 2c+1  world.py:196-210
     TC* g1 = g0 + nz;
-    // body 1 first, body 2 second (plain assignment order of the reference)
-    gn[3 * b1 + 0] = p1x * ny - p1y * nx; gn[3 * b1 + 1] = nx; gn[3 * b1 + 2] = ny;
-    gn[3 * b2 + 0] = -(p2x * ny - p2y * nx); gn[3 * b2 + 1] = -nx; gn[3 * b2 + 2] = -ny;
-    const TC a1 = p1x * ty - p1y * tx, a2 = p2x * ty - p2y * tx;
-    g0[3 * b1 + 0] = a1;  g0[3 * b1 + 1] = tx;  g0[3 * b1 + 2] = ty;
-    g1[3 * b1 + 0] = -a1; g1[3 * b1 + 1] = -tx; g1[3 * b1 + 2] = -ty;
-    g0[3 * b2 + 0] = -a2; g0[3 * b2 + 1] = -tx; g0[3 * b2 + 2] = -ty;
-    g1[3 * b2 + 0] = a2;  g1[3 * b2 + 1] = tx;  g1[3 * b2 + 2] = ty;
-    S.mu_c[c] = (TC)0.5 * ((TC)fric[b1] + (TC)fric[b2]);                 // world.py:213-224
-    const TC r = (TC)0.5 * ((TC)rest[b1] + (TC)rest[b2]);                // world.py:144-151
-    S.h[c] = row_dot(gn, S.v, nz) * r;                                   // engines.py:53
+    for (int q = 0; q < 3; ++q) {                                        // body 1 first, body 2 second
+      gn[3 * r.b1 + q] = (TC)r.jn[q]; g0[3 * r.b1 + q] = (TC)r.jf[q]; g1[3 * r.b1 + q] = (TC)(-r.jf[q]);
+    }
+    for (int q = 0; q < 3; ++q) {
+      gn[3 * r.b2 + q] = (TC)r.jn[3 + q]; g0[3 * r.b2 + q] = (TC)r.jf[3 + q]; g1[3 * r.b2 + q] = (TC)(-r.jf[3 + q]);
+    }
+    S.mu_c[c] = (TC)r.mu;
+    S.h[c] = (TC)r.h;
   }
   __syncthreads();
 }

@@ -468,38 +468,21 @@ __device__ __forceinline__ void assemble_scene(const Lds<TI, TC>& L, const StepA
   b = (TC)0;
   {
     const int j = lane & 15;
-    const TI pj = (j < nz) ? (TI)(Md[j] * vv[j] + (TI)P.dt * ff[j]) : (TI)0;      // engines.py:32
-    p = (TC)pj;
+    p = (j < nz) ? (TC)momentum_entry<TI>(Md[j], vv[j], (TI)P.dt, ff[j]) : (TC)0;      // engines.py:32
   }
   TI hrow = (TI)0;
   if (lane < nc) {
     const int c = lane;
-    const TI nx = cn[2 * c], ny = cn[2 * c + 1];
-    const TI p1x = c1[2 * c], p1y = c1[2 * c + 1], p2x = c2[2 * c], p2y = c2[2 * c + 1];
-    const int b1 = i1[c], b2 = i2[c];
-    const TI tx = ny, ty = -nx;                                                   // utils.py:99-102
-    TI rowv[6], fr0[6];
-    rowv[0] = p1x * ny - p1y * nx; rowv[1] = nx; rowv[2] = ny;                    // world.py:177-183
-    rowv[3] = -(p2x * ny - p2y * nx); rowv[4] = -nx; rowv[5] = -ny;
-    const TI a1 = p1x * ty - p1y * tx, a2 = p2x * ty - p2y * tx;                  // world.py:196-210
-    fr0[0] = a1; fr0[1] = tx; fr0[2] = ty; fr0[3] = -a2; fr0[4] = -tx; fr0[5] = -ty;
+    const ContactRows<TI> r = make_contact<TI>(cn, c1, c2, i1, i2, rest, fric, vv, c);
     const int rn = c, rf0 = nc + 2 * c, rf1 = nc + 2 * c + 1;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
-      L.Gc[col * MP + rn] = rowv[q];   L.Gr[rn * GRS + col] = rowv[q];
-      L.Gc[col * MP + rf0] = fr0[q];   L.Gr[rf0 * GRS + col] = fr0[q];
-      L.Gc[col * MP + rf1] = -fr0[q];  L.Gr[rf1 * GRS + col] = -fr0[q];
+      const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
+      L.Gc[col * MP + rn] = r.jn[q];    L.Gr[rn * GRS + col] = r.jn[q];
+      L.Gc[col * MP + rf0] = r.jf[q];   L.Gr[rf0 * GRS + col] = r.jf[q];
+      L.Gc[col * MP + rf1] = -r.jf[q];  L.Gr[rf1 * GRS + col] = -r.jf[q];
     }
-    // h_c = (Jc v)_c * restitution, accumulated over the columns in order (engines.py:53)
-    TI acc = (TI)0;
-    for (int col = 0; col < nz; ++col) {
-      TI g = (TI)0;
-      if (col >= 3 * b1 && col < 3 * b1 + 3) g = rowv[col - 3 * b1];
-      if (col >= 3 * b2 && col < 3 * b2 + 3) g = rowv[3 + col - 3 * b2];
-      acc += g * vv[col];
-    }
-    hrow = acc * ((TI)0.5 * (rest[b1] + rest[b2]));                                // world.py:144-151
+    hrow = r.h;
   }
   h = (TC)hrow;
   {
