@@ -145,7 +145,7 @@ def test_stack_scenes_forward_parity(name, nbox, pts, B):
     assert int(di.max()) <= 1 and float((di == 0).float().mean()) >= 0.97, (name, "iteration counts", di.tolist())
 
 
-@pytest.mark.parametrize("name,nbox,pts,B", CONFIGS[:2], ids=[c[0] for c in CONFIGS[:2]])
+@pytest.mark.parametrize("name,nbox,pts,B", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_stack_scenes_backward_parity(name, nbox, pts, B):
     from lcp_physics_amd import scenes
     from lcp_physics_amd.lcp import lcp_backward
@@ -162,17 +162,23 @@ def test_stack_scenes_backward_parity(name, nbox, pts, B):
     grads = lcp_backward(sol, cot.to(DEV))
     torch.cuda.synchronize()
     grads = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", grads)}
-    Q, p = lcp64[0], lcp64[1]
+    Q, p, G, h, A, b, F = lcp64
     fl = parity.grad_floors(Q, p, cot.double(), ref.x, ref.z, ref.y)
     errs = parity.err_grads({k: grads[k] for k in "QpAb"}, {k: gref[k] for k in "QpAb"}, fl)
     worst = max(float(e.max()) for e in errs.values())
     assert worst < TOL_G32, (name, {k: float(v.max()) for k, v in errs.items()})
+    res = parity.kkt_backward_residual(Q, G, A, F, sol.z.double().cpu(), sol.s.double().cpu(), cot.double(),
+                                       grads["p"], -grads["h"], -grads["b"])
+    assert max(float(v.max()) for v in res.values()) < 1e-5, (name, res)
     ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
     pg = parity.physical_grads(ph, sc.dt, grads, O)
     pg_ref = parity.physical_grads(ph, sc.dt, gref, O)
     scl = parity.free_scales(Q, p, cot.double())
     floor = parity._n(cot) * torch.maximum(scl["x_free"], parity._n(ref.x))
-    ep = parity.err_physical(pg, pg_ref, ph, floor)
+    # 2 points per interface: every physical gradient is defined; 4 (redundant) points: only the
+    # parameters entering through Q and p are (see parity.err_physical)
+    keys = None if pts == 2 else ["Mdiag", "v", "f"]
+    ep = parity.err_physical(pg, pg_ref, ph, floor, keys=keys)
     assert float(ep.max()) < TOL_G32, (name, float(ep.max()), int(ep.argmax()))
 
 
@@ -260,23 +266,49 @@ def test_assembly_kernel_matches_reference_fixtures():
                 assert torch.allclose(a.double().cpu(), r, rtol=1e-5, atol=1e-6 * max(1.0, float(r.abs().max()))), (name, nm)
 
 
-@pytest.mark.parametrize("nbox,pts,B", [(2, 4, 128), (4, 4, 128)])
+@pytest.mark.parametrize("nbox,pts,B", [(2, 4, 128), (4, 4, 128), (4, 2, 64)])
 def test_fused_step_matches_oracle_step(nbox, pts, B):
+    """Fused launch (assembly + solve + integrate) vs the oracle solving the SAME LCP: the fp32 LCP data
+    the HIP assembly produces (all assembling kernels share one contraction-free builder).  With
+    redundant contact points the multipliers are non-unique, so identical inputs are what makes the
+    z / s / active-set comparison meaningful."""
     from lcp_physics_amd import scenes
-    from lcp_physics_amd.physics import fused_step
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
     sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=21, dtype=torch.float32)
-    sc64 = sc.to(dtype=torch.float64)
-    new_v, ref, lcp = O.solve_dynamics(*sc64.assembly_args())
-    out = fused_step(sc.to(device=DEV))
+    scg = sc.to(device=DEV)
+    lcp = [None if t is None else t.double().cpu() for t in assemble_contacts(scg)]
+    ref = O.lcp_forward(*lcp)
+    out = fused_step(scg)
     torch.cuda.synchronize()
     Q, p = lcp[0], lcp[1]
     ex = parity.err_x(-out["v_new"].double().cpu().reshape(B, -1), ref.x, Q, p)
     assert float(ex.max()) <= TOL_X32, float(ex.max())
-    p_ref = O.integrate(sc64.p, new_v, sc64.dt)
+    p_ref = O.integrate(sc.p.double(), (-ref.x).reshape(B, -1, 3), sc.dt)
     assert torch.allclose(out["p_new"].double().cpu(), p_ref, rtol=1e-5, atol=1e-3)
     dec = _decisive(ref.z, ref.s)
     z, s = out["z"].double().cpu(), out["s"].double().cpu()
-    assert bool(((parity.active_sets(z, s) == parity.active_sets(ref.z, ref.s)) | ~dec).all())
+    same = (parity.active_sets(z, s) == parity.active_sets(ref.z, ref.s)) | ~dec
+    assert bool(same.all()), torch.nonzero(~same)[:8].tolist()
+    # and against the independent fp64 assembly of the oracle: velocities only
+    new_v, _, lcp_o = O.solve_dynamics(*sc.to(dtype=torch.float64).assembly_args())
+    ev = parity.err_x(out["v_new"].double().cpu().reshape(B, -1), new_v.reshape(B, -1), lcp_o[0], lcp_o[1])
+    assert float(ev.max()) <= TOL_X32, float(ev.max())
+
+
+def test_fused_step_equals_assemble_then_solve(kernel_path):
+    """The fused kernel and assemble -> dense solve see the same LCP data and run the same arithmetic
+    (bit-identical on the wave64 path, where both F operators are exact)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_solve
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    sc = scenes.make_stack_scenes(B=96, nbox=4, pts_per_interface=4, seed=8, dtype=torch.float32).to(device=DEV)
+    lcp = assemble_contacts(sc)
+    sol = lcp_solve(*lcp)
+    out = fused_step(sc)
+    torch.cuda.synchronize()
+    ex = parity.err_x(-out["v_new"].double().cpu().reshape(96, -1), sol.x.double().cpu(), lcp[0].double().cpu(), lcp[1].double().cpu())
+    assert float(ex.max()) < 1e-6, float(ex.max())
+    assert int((out["iters"] - sol.iters).abs().max()) <= 1
 
 
 # ------------------------------------------------------------------ full BASELINE size: properties
