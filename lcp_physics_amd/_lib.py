@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblcp_hip.so")
+LIB_PATH = os.environ.get("LCP_HIP_LIB", os.path.join(_HERE, "csrc", "liblcp_hip.so"))   # override: A/B builds
 
 COMPUTE_F32 = 0
 COMPUTE_F64 = 1

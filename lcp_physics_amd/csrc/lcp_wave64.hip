@@ -28,6 +28,17 @@ constexpr int MP = 64;    // padded nineq (lanes)
 constexpr int NZP = 16;   // padded nz
 constexpr int EP = 8;     // padded neq
 constexpr int GRS = 17;   // row stride of the row-major G copy (bank-conflict-free group reads)
+// Scenes (waves) per workgroup.  The unrolled LU is far larger than the 64 KB instruction cache, so a
+// wave on its own streams its code from L2 every PDIPM iteration (measured: fetch-bound).  Putting WPB
+// waves in one workgroup and re-synchronising them with s_barrier at every elimination step keeps them
+// in the same few cache lines, so the instruction stream is fetched once per workgroup.
+#ifndef LCP_W64_WPB
+#define LCP_W64_WPB 1
+#endif
+constexpr int WPB = LCP_W64_WPB;
+#ifndef LCP_W64_SYNC_EVERY
+#define LCP_W64_SYNC_EVERY 1
+#endif
 
 // Compile-time loops: every index into the register-resident row t[] must be a constant the front end
 // can see (hipcc demotes the array to scratch otherwise - measured), so the unrolling is done with
@@ -118,42 +129,83 @@ __device__ __forceinline__ void store2(double* dst, double a, double b) { *reint
 //   udinv  : 1 / U[mystep][mystep] of this lane's row
 // After the call: for lanes with mystep > k, t[k] holds the multiplier L[.][k]; for the lane with
 // mystep == k, t[k..] is row k of U.  Returns true if an exact zero pivot was met.
+//
+// Code-size-aware blocking (the instruction cache is 64 KB; a fully unrolled 64x64 elimination is
+// ~48 KB of code on its own and ran instruction-fetch-latency bound - measured 21 cycles/instruction):
+//   * the matrix is processed in four 16-column panels;
+//   * a panel is copied to LDS and factorised THERE with rolled loops (LDS addresses may be dynamic,
+//     register names may not), then copied back;
+//   * the trailing columns are updated by a rolled loop over the panel's 16 elimination steps: the
+//     registers it touches do not depend on the step, the pivot lane and the multiplier do, and both
+//     are run-time values (v_readlane lane select / an LDS read).
+// Every v_readlane + FMA pair of the trailing update therefore exists once in the code per panel
+// (96 pairs in total instead of 2016).
+constexpr int PB = 16;          // panel width
+constexpr int PS = PB + 1;      // LDS row stride of the panel (odd: conflict-free column walks)
+
 template <typename TC, bool PIVOT>
-__device__ __forceinline__ bool lu_factor(TC (&t)[MP], int m, int lane, int& mystep, int& porder, TC& udinv) {
+__device__ __forceinline__ bool lu_factor(TC (&t)[MP], TC* pan, int m, int lane, int& mystep, int& porder, TC& udinv) {
   mystep = MP; porder = lane; udinv = (TC)1;
   bool singular = false;
-  static_for<MP>([&](auto K) LCP_INL {
-    constexpr int k = K;
-    if (k < m) {
-      int p = k;
-      if (PIVOT) {
-        const bool cand = (mystep == MP) && (lane < m);
-        const float a = fabsf((float)t[k]);
-        unsigned key = cand ? ((__float_as_uint(a) & ~63u) | (unsigned)lane) : 0u;
-        key = wave_max_u32(key);
-        p = (int)(__builtin_amdgcn_readfirstlane((int)key) & 63);
+  TC* myrow = pan + lane * PS;
+  static_for<MP / PB>([&](auto BK) LCP_INL {
+    constexpr int b = BK;
+    if (PB * b < m) {
+      // 1. panel -> LDS
+      static_for<PB>([&](auto JJ) LCP_INL { myrow[JJ] = t[PB * b + JJ]; });
+      __syncthreads();
+      const int kend = (m - PB * b) < PB ? (m - PB * b) : PB;
+      // 2. factorise the panel in LDS (partial pivoting over the lanes not used yet)
+#pragma unroll 1
+      for (int kk = 0; kk < kend; ++kk) {
+        const int k = PB * b + kk;
+        const TC a = myrow[kk];
+        int p = k;
+        if (PIVOT) {
+          const bool cand = (mystep == MP) && (lane < m);
+          unsigned key = cand ? ((__float_as_uint(fabsf((float)a)) & ~63u) | (unsigned)lane) : 0u;
+          key = wave_max_u32(key);
+          p = (int)(__builtin_amdgcn_readfirstlane((int)key) & 63);
+        }
+        const TC piv = pan[p * PS + kk];
+        singular = singular || (piv == (TC)0);
+        const TC inv = (TC)1 / piv;
+        const bool isp = (lane == p);
+        const bool act = (mystep == MP) && !isp && (lane < m);
+        const TC l = act ? a * inv : (TC)0;
+        if (act) myrow[kk] = l;
+        mystep = isp ? k : mystep;
+        udinv = isp ? inv : udinv;
+        porder = (lane == k) ? p : porder;
+        const TC* prow = pan + p * PS;
+#pragma unroll 1
+        for (int jj = kk + 1; jj < PB; ++jj) myrow[jj] = fma(-l, prow[jj], myrow[jj]);
+        __syncthreads();
       }
-      const TC piv = rdlane(t[k], p);
-      singular = singular || (piv == (TC)0);
-      const TC inv = (TC)1 / piv;
-      const bool isp = (lane == p);
-      const bool act = (mystep == MP) && !isp && (lane < m);
-      const TC l = act ? t[k] * inv : (TC)0;
-      t[k] = act ? l : t[k];
-      mystep = isp ? k : mystep;
-      udinv = isp ? inv : udinv;
-      porder = (lane == k) ? p : porder;
-      static_for<MP / 8>([&](auto C) LCP_INL {
-        constexpr int c = C;
-        if constexpr (c * 8 + 7 > k) {
-          if (c * 8 < m) {
-            static_for<8>([&](auto JJ) LCP_INL {
-              constexpr int j = c * 8 + JJ;
-              if constexpr (j > k) t[j] = fma(-l, rdlane(t[j], p), t[j]);
+      // 3. panel -> registers
+      static_for<PB>([&](auto JJ) LCP_INL { t[PB * b + JJ] = myrow[JJ]; });
+      // 4. trailing columns: rolled over the panel's steps, static over the columns
+      if constexpr (b + 1 < MP / PB) {
+        if (PB * (b + 1) < m) {
+#pragma unroll 1
+          for (int kk = 0; kk < kend; ++kk) {
+            const int k = PB * b + kk;
+            const int p = rdlane_i(porder, k);
+            const TC lraw = myrow[kk];
+            const TC l = (mystep > k && lane < m) ? lraw : (TC)0;
+            static_for<MP / PB - 1 - b>([&](auto CB) LCP_INL {
+              constexpr int cb = b + 1 + CB;
+              if (PB * cb < m) {
+                static_for<PB>([&](auto JJ) LCP_INL {
+                  constexpr int j = PB * cb + JJ;
+                  t[j] = fma(-l, rdlane(t[j], p), t[j]);
+                });
+              }
             });
           }
         }
-      });
+      }
+      __syncthreads();
     }
   });
   return singular;
@@ -163,28 +215,201 @@ __device__ __forceinline__ bool lu_factor(TC (&t)[MP], int m, int lane, int& mys
 // the result has component j in lane j.
 template <typename TC, bool PIVOT>
 __device__ __forceinline__ TC lu_solve(const TC (&t)[MP], TC w, int m, int lane, int mystep, int porder, TC udinv) {
-  static_for<MP>([&](auto K) LCP_INL {                 // L y = P rhs
-    constexpr int k = K;
-    if (k < m) {
-      const int p = PIVOT ? rdlane_i(porder, k) : k;
-      const TC yk = rdlane(w, p);
-      const TC lk = (mystep > k && lane < m) ? t[k] : (TC)0;
-      w = fma(-lk, yk, w);
+  // (steps beyond m inside a partly used 16-block act on the identity padding of T and are harmless)
+  static_for<MP / PB>([&](auto BK) LCP_INL {           // L y = P rhs
+    constexpr int b = BK;
+    if (PB * b < m) {
+      static_for<PB>([&](auto KK) LCP_INL {
+        constexpr int k = PB * b + KK;
+        const int p = PIVOT ? rdlane_i(porder, k) : k;
+        const TC yk = rdlane(w, p);
+        const TC lk = (mystep > k) ? t[k] : (TC)0;
+        w = fma(-lk, yk, w);
+      });
     }
   });
   TC out = (TC)0;
   const TC wu = udinv;
-  static_for<MP>([&](auto JR) LCP_INL {                // U x = y
-    constexpr int j = MP - 1 - JR;
-    if (j < m) {
-      const int p = PIVOT ? rdlane_i(porder, j) : j;
-      const TC xj = rdlane(w * wu, p);
-      const TC uj = (mystep < j) ? t[j] : (TC)0;
-      w = fma(-uj, xj, w);
-      out = (lane == j) ? xj : out;
+  static_for<MP / PB>([&](auto BR) LCP_INL {           // U x = y
+    constexpr int b = MP / PB - 1 - BR;
+    if (PB * b < m) {
+      static_for<PB>([&](auto JR) LCP_INL {
+        constexpr int j = PB * b + PB - 1 - JR;
+        const int p = PIVOT ? rdlane_i(porder, j) : j;
+        const TC xj = rdlane(w * wu, p);
+        const TC uj = (mystep < j) ? t[j] : (TC)0;
+        w = fma(-uj, xj, w);
+        out = (lane == j) ? xj : out;
+      });
     }
   });
   return out;
+}
+
+// ---------------------------------------------------------------- contact-structured reduction
+// For LCPs with the contact structure of physics/engines.py:67-73 (G = [Jc; Jf; 0] with the two friction
+// rows of a contact being negatives of each other, F = [[0,0,0],[0,0,E],[mu,-E^T,0]]) the system
+//     (R + diag(s/z)) dz = r,   dz = (a | b1,b2 per contact | g)
+// is reduced EXACTLY to 2 nc unknowns: with u = b1 - b2, w = b1 + b2 and D = s/z,
+//     rows f1+f2 and gamma of contact c involve only (w_c, g_c, a_c, u_c) and all their couplings are
+//     diagonal, so (w_c, g_c) is eliminated per contact by a 2x2 solve:
+//        Sp w + 2 g = (r1 + r2) - Sm u ,   -w + Dg g = rg - mu a ,   Sp = (D1+D2)/2, Sm = (D1-D2)/2
+//     rows n and (f1 - f2)/2 then read
+//        [ Wnn + Dn            Wnt                    ] [a]   [ rn                       ]
+//        [ Wtn + Sm wa / 2     Wtt + (Sp + Sm wu) / 2 ] [u] = [ (r1 - r2)/2 - Sm w0 / 2  ]
+//     with W = J P J^T for J = [Jc; Jt] (the rows n and f1 of R) and w = w0 + wa a + wu u.
+// The reduced matrix is W plus positive diagonal terms (quasi-definite): elimination WITHOUT pivoting is
+// backward stable at every PDIPM iterate (checked against the oracle: normwise backward error <= 1e-17
+// up to cond(T) = 6e19, tests/test_reduction_algebra.py), because the +/- duplicated friction rows that
+// make T numerically singular are removed analytically.  One eighth of the flops of the 4 nc system.
+constexpr int NR = 32;          // reduced size (2 nc <= 32)
+
+template <typename TC>
+__device__ __forceinline__ bool lu32_factor(TC (&t)[MP], int nr, int lane, TC& udinv) {
+  udinv = (TC)1;
+  bool singular = false;
+  static_for<NR / 8>([&](auto B8) LCP_INL {
+    if (8 * B8 < nr) {
+      static_for<8>([&](auto KK) LCP_INL {
+        constexpr int k = 8 * B8 + KK;
+        const TC piv = rdlane(t[k], k);
+        singular = singular || (piv == (TC)0);
+        const TC inv = (TC)1 / piv;
+        const TC l = (lane > k) ? t[k] * inv : (TC)0;
+        t[k] = (lane > k) ? l : t[k];
+        udinv = (lane == k) ? inv : udinv;
+        static_for<NR / 8>([&](auto C) LCP_INL {
+          constexpr int c = C;
+          if constexpr (c * 8 + 7 > k) {
+            if (c * 8 < nr) {
+              // broadcasts first, FMAs second: v_readlane has ~8 cycles of latency before a dependent VALU
+              // can use the SGPR; batching hides it (measured 29 -> 21 cycles per pair)
+              TC sv[8];
+              static_for<8>([&](auto JJ) LCP_INL { constexpr int j = c * 8 + JJ; if constexpr (j > k) sv[JJ] = rdlane(t[j], k); });
+              __builtin_amdgcn_sched_barrier(0);
+              static_for<8>([&](auto JJ) LCP_INL { constexpr int j = c * 8 + JJ; if constexpr (j > k) t[j] = fma(-l, sv[JJ], t[j]); });
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        });
+      });
+    }
+  });
+  return singular;
+}
+
+template <typename TC>
+__device__ __forceinline__ TC lu32_solve(const TC (&t)[MP], TC w, int nr, int lane, TC udinv) {
+  static_for<NR / 8>([&](auto B8) LCP_INL {
+    if (8 * B8 < nr) {
+      static_for<8>([&](auto KK) LCP_INL {
+        constexpr int k = 8 * B8 + KK;
+        const TC yk = rdlane(w, k);
+        const TC lk = (lane > k) ? t[k] : (TC)0;
+        w = fma(-lk, yk, w);
+      });
+    }
+  });
+  static_for<NR / 8>([&](auto BR) LCP_INL {
+    constexpr int b8 = NR / 8 - 1 - BR;
+    if (8 * b8 < nr) {
+      static_for<8>([&](auto JR) LCP_INL {
+        constexpr int j = 8 * b8 + 7 - JR;
+        const TC xj = rdlane(w * udinv, j);
+        const TC uj = (lane < j) ? t[j] : (TC)0;
+        w = fma(-uj, xj, w);
+      });
+    }
+  });
+  return w * udinv;
+}
+
+// Per-scene bookkeeping of the reduction.  Reduced lane r: r < nc -> a_r (normal), nc <= r < 2 nc -> u_{r-nc}.
+template <typename TC>
+struct Red {
+  int nc, nr;
+  bool isa, isu;
+  int cu;                 // contact of this u-lane
+  int i1, i2, ig;         // m-space lanes of f1, f2, gamma of contact cu (u-lanes)
+  int back_src;           // m-space lane i takes its dz from this reduced lane
+  int back_kind;          // 0: a (own lane)  1: b1  2: b2  3: g   4: padding
+  TC mu;                  // friction coefficient of contact cu (u-lanes)
+  // per factorisation (functions of D = s/z)
+  TC Sp, Sm, Dg, idet, wa, wu;
+  __device__ __forceinline__ void init(int nc_, int lane, int m) {
+    nc = nc_; nr = 2 * nc_;
+    isa = lane < nc; isu = (lane >= nc) && (lane < 2 * nc);
+    cu = isu ? lane - nc : 0;
+    i1 = nc + 2 * cu; i2 = i1 + 1; ig = 3 * nc + cu;
+    if (lane < nc) { back_src = lane; back_kind = 0; }
+    else if (lane < 3 * nc) { back_src = nc + ((lane - nc) >> 1); back_kind = 1 + ((lane - nc) & 1); }
+    else if (lane < 4 * nc) { back_src = nc + (lane - 3 * nc); back_kind = 3; }
+    else { back_src = lane; back_kind = 4; }
+    mu = 0; Sp = Sm = Dg = idet = wa = wu = 0;
+  }
+  // D = s/z of this m-space lane
+  __device__ __forceinline__ void prepare(TC D) {
+    const TC D1 = shfl_t(D, i1), D2 = shfl_t(D, i2);
+    Dg = shfl_t(D, ig);
+    Sp = (TC)0.5 * (D1 + D2); Sm = (TC)0.5 * (D1 - D2);
+    idet = (TC)1 / (Sp * Dg + (TC)2);
+    wa = (TC)2 * mu * idet; wu = -Dg * Sm * idet;
+  }
+  // reduced matrix row of this lane from W (workspace) and the diagonal terms
+  template <typename TI>
+  __device__ __forceinline__ void build(TC (&t)[MP], const TC* W2, TC D, int lane) const {
+    const TC addA = isa ? D : (isu ? (TC)0.5 * (Sp + Sm * wu) : (TC)1);
+    const TC addB = isu ? (TC)0.5 * Sm * wa : (TC)0;
+    const int colB = isu ? cu : -1;
+    static_for<NR / 8>([&](auto B8) LCP_INL {
+      if (8 * B8 < nr) {
+        static_for<4>([&](auto JJ) LCP_INL {
+          constexpr int j = 8 * B8 + 2 * JJ;
+          TC a, c;
+          load2(W2 + ((size_t)(j >> 1) * MP + lane) * 2, a, c);
+          t[j] = a + ((lane == j) ? addA : (TC)0) + ((colB == j) ? addB : (TC)0);
+          t[j + 1] = c + ((lane == j + 1) ? addA : (TC)0) + ((colB == j + 1) ? addB : (TC)0);
+        });
+      }
+    });
+  }
+  // T^-1 hz through the reduced system (hz, result: m-space lanes)
+  __device__ __forceinline__ TC solve(const TC (&t)[MP], TC hz, int lane, TC udinv) const {
+    const TC r1 = shfl_t(hz, i1), r2 = shfl_t(hz, i2), rg = shfl_t(hz, ig);
+    const TC w0 = (Dg * (r1 + r2) - (TC)2 * rg) * idet;
+    const TC rhs = isa ? hz : (isu ? (TC)0.5 * (r1 - r2) - (TC)0.5 * Sm * w0 : (TC)0);
+    const TC sol = lu32_solve<TC>(t, rhs, nr, lane, udinv);
+    const TC ac = shfl_t(sol, cu);                       // a of this u-lane's contact
+    const TC w = w0 + wa * ac + wu * sol;
+    const TC gg = ((r1 + r2) - Sm * sol + Sp * (rg - mu * ac)) * idet;
+    const TC b1 = (TC)0.5 * (w + sol), b2 = (TC)0.5 * (w - sol);
+    const TC g1 = shfl_t(b1, back_src), g2 = shfl_t(b2, back_src), g3 = shfl_t(gg, back_src);
+    return back_kind == 0 ? sol : (back_kind == 1 ? g1 : (back_kind == 2 ? g2 : (back_kind == 3 ? g3 : (TC)0)));
+  }
+};
+
+// Gauss-Jordan inverse by one wave (same algorithm as gj_inverse<NT>, lane-indexed so that several waves
+// of a workgroup can each invert their own matrix; the barriers are workgroup-wide and executed by all).
+template <typename TC>
+__device__ bool gj_inverse_wave(TC* a, int n, int* flag, int lane) {
+  if (lane == 0) *flag = 0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const TC piv = a[k * n + k];
+    if (!(piv != (TC)0) || piv != piv) { if (lane == 0) *flag = 1; }
+    const TC pinv = (TC)1 / piv;
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) if (j != k) a[k * n + j] *= pinv;
+    __syncthreads();
+    for (int idx = lane; idx < n * n; idx += 64) {
+      const int i = idx / n, j = idx - i * n;
+      if (i != k && j != k) a[idx] -= a[i * n + k] * a[k * n + j];
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) a[i * n + k] = (i == k) ? pinv : -a[i * n + k] * pinv;
+    __syncthreads();
+  }
+  return *flag == 0;
 }
 
 // ---------------------------------------------------------------- per-scene LDS block
@@ -195,7 +420,8 @@ struct Lds {
   TI* Qt;    // [NZP][NZP]  Qt[k*NZP + j] = Q[j][k]
   TI* At;    // [EP][NZP]   At[a*NZP + k] = A[a][k]
   TC* Qit;   // [NZP][NZP]  Qit[k*NZP + j] = Qinv[j][k]
-  TC* Qrm;   // [nz][nz]    row-major Q^-1 (Gauss-Jordan work area, stride nz)
+  TC* pan;   // [MP][PS]    LU panel work area (lu_factor)
+  TC* Qrm;   // [nz][nz]    row-major Q^-1 (Gauss-Jordan work area, stride nz) - aliases `pan`
   TC* GAc;   // [EP][MP]    GAc[a*MP + i] = (G Q^-1 A^T)[i][a]
   TC* S11i;  // [e][e]      (A Q^-1 A^T)^-1, stride e
   TC* wbuf;  // [MP]
@@ -207,7 +433,8 @@ __host__ __device__ inline size_t carve(Lds<TI, TC>& L, unsigned char* smem) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
   L.Qit = (TC*)take(sizeof(TC) * NZP * NZP);
-  L.Qrm = (TC*)take(sizeof(TC) * NZP * NZP);
+  L.pan = (TC*)take(sizeof(TC) * MP * (16 + 1));
+  L.Qrm = L.pan;
   L.GAc = (TC*)take(sizeof(TC) * EP * MP);
   L.S11i = (TC*)take(sizeof(TC) * EP * EP);
   L.wbuf = (TC*)take(sizeof(TC) * MP);
@@ -227,13 +454,13 @@ template <typename TI, typename TC> __host__ __device__ inline size_t ws_bytes()
 
 template <typename TI, typename TC>
 struct Ws {
-  TC *R2, *Qit, *GAc, *S11i, *x, *s, *z, *y;
+  TC *R2, *Qit, *GAc, *S11i, *x, *s, *z, *y, *meta;     // meta[0] = structured flag, meta[1 + c] = mu of contact c
   TI* Ft;
   __device__ Ws(void* ws, int scene) {
     unsigned char* base = (unsigned char*)ws + (size_t)scene * ws_bytes<TI, TC>();
     TC* q = (TC*)base;
     R2 = q; q += MP * MP; Qit = q; q += NZP * NZP; GAc = q; q += EP * MP; S11i = q; q += EP * EP;
-    x = q; q += NZP; s = q; q += MP; z = q; q += MP; y = q;
+    x = q; q += NZP; s = q; q += MP; z = q; q += MP; y = q; q += EP; meta = q;   // 5080 + 17 <= WS_TC
     Ft = (TI*)(base + WS_TC * sizeof(TC));
   }
 };
@@ -248,17 +475,16 @@ struct FDenseW {
   // (F z)_lane  using the lane-major copy (coalesced 16 B per lane)
   __device__ __forceinline__ TC Fz(TC z, int lane) const {
     TC acc = 0;
-#pragma unroll
-    for (int jj = 0; jj < MP / 4; ++jj) {
-      if (jj * 4 < m) {
-        const TI* src = Ft + ((size_t)jj * MP + lane) * 4;
-        TI f0, f1, f2, f3;
-        load4(src, f0, f1, f2, f3);
-        acc = fma((TC)f0, rdlane(z, jj * 4 + 0), acc);
-        acc = fma((TC)f1, rdlane(z, jj * 4 + 1), acc);
-        acc = fma((TC)f2, rdlane(z, jj * 4 + 2), acc);
-        acc = fma((TC)f3, rdlane(z, jj * 4 + 3), acc);
-      }
+    const int nq = (m + 3) >> 2;
+#pragma unroll 1
+    for (int jj = 0; jj < nq; ++jj) {
+      const TI* src = Ft + ((size_t)jj * MP + lane) * 4;
+      TI f0, f1, f2, f3;
+      load4(src, f0, f1, f2, f3);
+      acc = fma((TC)f0, rdlane(z, jj * 4 + 0), acc);
+      acc = fma((TC)f1, rdlane(z, jj * 4 + 1), acc);
+      acc = fma((TC)f2, rdlane(z, jj * 4 + 2), acc);
+      acc = fma((TC)f3, rdlane(z, jj * 4 + 3), acc);
     }
     return acc;
   }
@@ -298,11 +524,13 @@ template <typename TI, typename TC>
 struct Ops {
   Lds<TI, TC> L;
   int nz, m, e, lane;
+  // All loops below are ROLLED on purpose (run-time trip counts, v_readlane with a run-time lane select):
+  // these products are small next to the LU, and compact code is what keeps the kernel in the I-cache.
   // m-space <- x-space : (G v)_i
   __device__ __forceinline__ TC Gv(TC v) const {
     TC acc = 0;
-#pragma unroll
-    for (int j = 0; j < NZP; ++j) if (j < nz) acc = fma((TC)L.Gc[j * MP + lane], rdlane(v, j), acc);
+#pragma unroll 1
+    for (int j = 0; j < nz; ++j) acc = fma((TC)L.Gc[j * MP + lane], rdlane(v, j), acc);
     return acc;
   }
   // x-space <- m-space : (G^T w)_j, j = lane & 15 (replicated in the four lane groups)
@@ -312,8 +540,10 @@ struct Ops {
     __syncthreads();
     const int j = lane & 15, q = lane >> 4;
     TC acc = 0;
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) acc = fma((TC)L.Gr[(q * 16 + ii) * GRS + j], L.wbuf[q * 16 + ii], acc);
+    const TI* g = L.Gr + (q * 16) * GRS + j;
+    const TC* wb = L.wbuf + q * 16;
+#pragma unroll 4
+    for (int ii = 0; ii < 16; ++ii) acc = fma((TC)g[ii * GRS], wb[ii], acc);
     acc += shfl_xor_t(acc, 16);
     acc += shfl_xor_t(acc, 32);
     return acc;
@@ -321,58 +551,56 @@ struct Ops {
   __device__ __forceinline__ TC Qiv(TC v) const {
     const int j = lane & 15;
     TC acc = 0;
-#pragma unroll
-    for (int k = 0; k < NZP; ++k) if (k < nz) acc = fma(L.Qit[k * NZP + j], rdlane(v, k), acc);
+#pragma unroll 1
+    for (int k = 0; k < nz; ++k) acc = fma(L.Qit[k * NZP + j], rdlane(v, k), acc);
     return acc;
   }
   __device__ __forceinline__ TC Qv(TC v) const {
     const int j = lane & 15;
     TC acc = 0;
-#pragma unroll
-    for (int k = 0; k < NZP; ++k) if (k < nz) acc = fma((TC)L.Qt[k * NZP + j], rdlane(v, k), acc);
+#pragma unroll 1
+    for (int k = 0; k < nz; ++k) acc = fma((TC)L.Qt[k * NZP + j], rdlane(v, k), acc);
     return acc;
   }
   // e-space <- x-space : (A v)_a, a = lane & 7
   __device__ __forceinline__ TC Av(TC v) const {
     const int a = lane & 7;
     TC acc = 0;
-#pragma unroll
-    for (int k = 0; k < NZP; ++k) if (k < nz) acc = fma((TC)L.At[a * NZP + k], rdlane(v, k), acc);
+#pragma unroll 1
+    for (int k = 0; k < nz; ++k) acc = fma((TC)L.At[a * NZP + k], rdlane(v, k), acc);
     return acc;
   }
   // x-space <- e-space : (A^T y)_j
   __device__ __forceinline__ TC Aty(TC y) const {
     const int j = lane & 15;
     TC acc = 0;
-#pragma unroll
-    for (int a = 0; a < EP; ++a) if (a < e) acc = fma((TC)L.At[a * NZP + j], rdlane(y, a), acc);
+#pragma unroll 1
+    for (int a = 0; a < e; ++a) acc = fma((TC)L.At[a * NZP + j], rdlane(y, a), acc);
     return acc;
   }
   // m-space <- e-space : (GA t)_i
   __device__ __forceinline__ TC GAt(TC t) const {
     TC acc = 0;
-#pragma unroll
-    for (int a = 0; a < EP; ++a) if (a < e) acc = fma(L.GAc[a * MP + lane], rdlane(t, a), acc);
+#pragma unroll 1
+    for (int a = 0; a < e; ++a) acc = fma(L.GAc[a * MP + lane], rdlane(t, a), acc);
     return acc;
   }
   // e-space <- m-space : (GA^T w)_a
   __device__ __forceinline__ TC GAtw(TC w) const {
     TC out = 0;
     const TC wm = (lane < m) ? w : (TC)0;
-#pragma unroll
-    for (int a = 0; a < EP; ++a) {
-      if (a < e) {
-        const TC sm = wave_sum(L.GAc[a * MP + lane] * wm);
-        if ((lane & 7) == a) out = sm;
-      }
+#pragma unroll 1
+    for (int a = 0; a < e; ++a) {
+      const TC sm = wave_sum(L.GAc[a * MP + lane] * wm);
+      if ((lane & 7) == a) out = sm;
     }
     return out;
   }
   __device__ __forceinline__ TC S11v(TC v) const {
     const int a = lane & 7;
     TC acc = 0;
-#pragma unroll
-    for (int c = 0; c < EP; ++c) if (c < e) acc = fma((a < e) ? L.S11i[a * e + c] : (TC)0, rdlane(v, c), acc);
+#pragma unroll 1
+    for (int c = 0; c < e; ++c) acc = fma((a < e) ? L.S11i[a * e + c] : (TC)0, rdlane(v, c), acc);
     return acc;
   }
 };
@@ -492,38 +720,93 @@ __device__ __forceinline__ void assemble_scene(const Lds<TI, TC>& L, const StepA
   __syncthreads();
 }
 
-// pre_factor_kkt (pdipm.py:357-408): Q^-1, G Q^-1 A^T, (A Q^-1 A^T)^-1 into LDS, R (and the lane-major F)
-// into the workspace.
-template <typename TI, typename TC, typename FT>
-__device__ __forceinline__ int prefactor(const Lds<TI, TC>& L, const Ws<TI, TC>& W, const FT& F, int nz, int m, int e, int lane) {
-  int status = 0;
-  if (!gj_inverse<64>(L.Qrm, nz, L.flag)) status |= LCP_ST_SINGULAR_Q;
-  for (int idx = lane; idx < nz * nz; idx += 64) { const int r = idx / nz, c = idx - r * nz; L.Qit[c * NZP + r] = L.Qrm[idx]; }
-  __syncthreads();
-  // gq = row `lane` of G Q^-1
-  TC gq[NZP];
-#pragma unroll
-  for (int k = 0; k < NZP; ++k) {
-    TC acc = 0;
-    if (k < nz) for (int j = 0; j < nz; ++j) acc = fma((TC)L.Gr[lane * GRS + j], L.Qrm[j * nz + k], acc);
-    gq[k] = acc;
+// Does the dense LCP have the contact structure of engines.py:67-73 ?  (wave-uniform answer)
+//   G rows >= 3 nc are zero, friction rows come in +/- pairs, F = [[0,0,0],[0,0,E],[mu,-E^T,0]].
+// mu_g: friction coefficient for this lane if it is a gamma row.
+template <typename TI, typename TC>
+__device__ __forceinline__ bool detect_structure(const Lds<TI, TC>& L, const TI* F, int nz, int m, int lane, TC& mu_g) {
+  mu_g = 0;
+  if ((m & 3) != 0 || m > 4 * (NR / 2)) return false;
+  const int nc = m >> 2;
+  bool ok = true;
+  if (lane < m) {
+    const int i = lane;
+    const TI* g = L.Gr + i * GRS;
+    if (i >= 3 * nc) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == (TI)0); }
+    else if (i >= nc && ((i - nc) & 1)) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == -g[j - GRS]); }
+    const TI* f = F + (size_t)i * m;
+    const int cf = (i - nc) >> 1, cg = i - 3 * nc;
+    for (int j = 0; j < m; ++j) {
+      const TI v = f[j];
+      TI want = (TI)0;
+      if (i >= nc && i < 3 * nc) want = (j == 3 * nc + cf) ? (TI)1 : (TI)0;
+      else if (i >= 3 * nc) {
+        if (j == cg) { want = v; mu_g = (TC)v; }
+        else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = (TI)-1;
+      }
+      ok = ok && (v == want);
+    }
   }
-  TC cc[EP];
+  return __all(ok);
+}
+
+// row `row` of G times Q^-1 (gq) and of (G Q^-1 A^T) S11^-1 (cc); ga_out (optional) receives G Q^-1 A^T of that row
+template <typename TI, typename TC>
+__device__ __forceinline__ void row_products(const Lds<TI, TC>& L, int row, bool valid, int nz, int e, bool have_s11,
+                                             TC (&gq)[NZP], TC (&cc)[EP], TC (&ga)[EP]) {
 #pragma unroll
-  for (int a = 0; a < EP; ++a) cc[a] = 0;
+  for (int k = 0; k < NZP; ++k) gq[k] = 0;
+#pragma unroll
+  for (int a = 0; a < EP; ++a) { cc[a] = 0; ga[a] = 0; }
+  if (!valid) return;
+  const TI* g = L.Gr + row * GRS;
+#pragma unroll 1
+  for (int j = 0; j < nz; ++j) {
+    const TC gj = (TC)g[j];
+    const TC* qrow = L.Qrm + j * nz;
+#pragma unroll
+    for (int k = 0; k < NZP; ++k) gq[k] = fma(gj, (k < nz) ? qrow[k] : (TC)0, gq[k]);
+  }
   if (e > 0) {
-    // GA = (G Q^-1) A^T
 #pragma unroll
     for (int a = 0; a < EP; ++a) {
       if (a < e) {
         TC acc = 0;
 #pragma unroll
         for (int k = 0; k < NZP; ++k) acc = fma(gq[k], (TC)L.At[a * NZP + k], acc);
-        L.GAc[a * MP + lane] = (lane < m) ? acc : (TC)0;
+        ga[a] = acc;
       }
     }
-    // S11 = A Q^-1 A^T, one entry per lane (a = lane / e, c = lane % e)
-    if (lane < e * e) {
+    if (have_s11) {
+#pragma unroll
+      for (int a = 0; a < EP; ++a) {
+        if (a < e) {
+          TC acc = 0;
+#pragma unroll
+          for (int c = 0; c < EP; ++c) if (c < e) acc = fma(ga[c], L.S11i[c * e + a], acc);
+          cc[a] = acc;
+        }
+      }
+    }
+  }
+}
+
+// pre_factor_kkt (pdipm.py:357-408): Q^-1, G Q^-1 A^T, (A Q^-1 A^T)^-1 into LDS; then either the dense
+// R = G Q^-1 G^T + F - GA S11^-1 GA^T (+ the lane-major copy of F) or, for contact-structured problems,
+// only W = J P J^T (rows / columns n and f1 of R) - both into the HBM workspace, two columns per lane-store.
+template <typename TI, typename TC, typename FT>
+__device__ __forceinline__ int prefactor(const Lds<TI, TC>& L, const Ws<TI, TC>& W, const FT& F, int nz, int m, int e,
+                                         int lane, bool structured) {
+  int status = 0;
+  if (!gj_inverse_wave(L.Qrm, nz, L.flag, lane)) status |= LCP_ST_SINGULAR_Q;
+  for (int idx = lane; idx < nz * nz; idx += 64) { const int r = idx / nz, c = idx - r * nz; L.Qit[c * NZP + r] = L.Qrm[idx]; }
+  __syncthreads();
+  TC gq[NZP], cc[EP], ga[EP];
+  row_products<TI, TC>(L, lane, lane < m, nz, e, false, gq, cc, ga);
+  if (e > 0) {
+#pragma unroll
+    for (int a = 0; a < EP; ++a) if (a < e) L.GAc[a * MP + lane] = ga[a];
+    if (lane < e * e) {                               // S11 = A Q^-1 A^T, one entry per lane
       const int a = lane / e, c = lane - a * e;
       TC acc = 0;
       for (int k = 0; k < nz; ++k) {
@@ -534,44 +817,41 @@ __device__ __forceinline__ int prefactor(const Lds<TI, TC>& L, const Ws<TI, TC>&
       L.S11i[lane] = acc;
     }
     __syncthreads();
-    if (!gj_inverse<64>(L.S11i, e, L.flag)) status |= LCP_ST_SINGULAR_S11;
-    // cc = row `lane` of GA S11^-1
-#pragma unroll
-    for (int a = 0; a < EP; ++a) {
-      if (a < e) {
-        TC acc = 0;
-        for (int c = 0; c < e; ++c) acc = fma(L.GAc[c * MP + lane], L.S11i[c * e + a], acc);
-        cc[a] = acc;
-      }
-    }
+    if (!gj_inverse_wave(L.S11i, e, L.flag, lane)) status |= LCP_ST_SINGULAR_S11;
   }
-  // R[i][j] = gq . G[j,:] + F[i][j] - cc . GA[j,:]   (two columns per trip, 16 B stores per lane)
-  for (int j0 = 0; j0 < MP; j0 += 2) {
+  const int nc = m >> 2;
+  // which full row does this lane produce ?  dense: its own; structured: reduced lane r -> n_r or f1_{r-nc}
+  const int nrows = structured ? 2 * nc : m;
+  const int myrow = structured ? ((lane < nc) ? lane : nc + 2 * (lane - nc)) : lane;
+  row_products<TI, TC>(L, myrow, lane < nrows, nz, e, true, gq, cc, ga);
+  const int ncols = structured ? NR : MP;
+#pragma unroll 1
+  for (int j0 = 0; j0 < ncols; j0 += 2) {
     TC r2[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = j0 + jj;
+      const int col = structured ? ((j < nc) ? j : nc + 2 * (j - nc)) : j;      // full column index
       TC val = 0;
-      if (lane < m && j < m) {
+      if (lane < nrows && j < nrows) {
+        const TI* gcol = L.Gr + col * GRS;
 #pragma unroll
-        for (int k = 0; k < NZP; ++k) val = fma(gq[k], (TC)L.Gr[j * GRS + k], val);
-        const TC f = F.at(lane, j);
-        F.keep(lane, j, (TI)f);
-        val += f;
+        for (int k = 0; k < NZP; ++k) val = fma(gq[k], (TC)gcol[k], val);
 #pragma unroll
-        for (int a = 0; a < EP; ++a) if (a < e) val = fma(-cc[a], L.GAc[a * MP + j], val);
-      } else if (lane < MP && j < MP) {
+        for (int a = 0; a < EP; ++a) if (a < e) val = fma(-cc[a], L.GAc[a * MP + col], val);
+        if (!structured) { const TC f = F.at(lane, j); F.keep(lane, j, (TI)f); val += f; }
+      } else if (!structured) {
         F.keep(lane, j, (TI)0);
       }
       r2[jj] = val;
     }
-    TC* dst = W.R2 + ((size_t)(j0 >> 1) * MP + lane) * 2;
-    store2(dst, r2[0], r2[1]);
+    store2(W.R2 + ((size_t)(j0 >> 1) * MP + lane) * 2, r2[0], r2[1]);
   }
   // things the backward kernel needs
   for (int i = lane; i < NZP * NZP; i += 64) W.Qit[i] = L.Qit[i];
   for (int i = lane; i < EP * MP; i += 64) W.GAc[i] = L.GAc[i];
   for (int i = lane; i < EP * EP; i += 64) W.S11i[i] = L.S11i[i];
+  if (lane == 0) W.meta[0] = structured ? (TC)1 : (TC)0;
   __threadfence_block();
   __syncthreads();
   return status;
@@ -580,24 +860,28 @@ __device__ __forceinline__ int prefactor(const Lds<TI, TC>& L, const Ws<TI, TC>&
 // T = R + diag(1/d) from the workspace into registers (pdipm.py:427-429)
 template <typename TI, typename TC>
 __device__ __forceinline__ void load_T(TC (&t)[MP], const Ws<TI, TC>& W, TC dinv, int m, int lane) {
-  static_for<MP / 2>([&](auto JJ) LCP_INL {
-    constexpr int jj = JJ;
-    if (jj * 2 < m) {
-      const TC* src = W.R2 + ((size_t)jj * MP + lane) * 2;
-      TC a, b;
-      load2(src, a, b);
-      t[2 * jj] = a + ((lane == 2 * jj) ? dinv : (TC)0);
-      t[2 * jj + 1] = b + ((lane == 2 * jj + 1) ? dinv : (TC)0);
+  static_for<MP / PB>([&](auto BK) LCP_INL {
+    constexpr int b = BK;
+    if (PB * b < m) {
+      static_for<PB / 2>([&](auto JJ) LCP_INL {
+        constexpr int j = PB * b + 2 * JJ;
+        const TC* src = W.R2 + ((size_t)(j >> 1) * MP + lane) * 2;      // zero beyond m (prefactor pads)
+        TC a, c;
+        load2(src, a, c);
+        t[j] = a + ((lane == j) ? dinv : (TC)0);
+        t[j + 1] = c + ((lane == j + 1) ? dinv : (TC)0);
+      });
     } else {
-      t[2 * jj] = (lane == 2 * jj) ? dinv : (TC)0;
-      t[2 * jj + 1] = (lane == 2 * jj + 1) ? dinv : (TC)0;
+      static_for<PB>([&](auto JJ) LCP_INL { constexpr int j = PB * b + JJ; t[j] = (lane == j) ? dinv : (TC)0; });
     }
   });
 }
 
-// solve_kkt (pdipm.py:325-354) at wave level.  rs_over_d = rs / d (m-space).
-template <typename TI, typename TC, bool PIVOT>
+// solve_kkt (pdipm.py:325-354) at wave level.  The T-solve goes through the reduced system when the
+// scene is contact-structured, through the pivoted 64x64 factorisation otherwise.
+template <typename TI, typename TC, bool PIVOT, bool ALWAYS_STRUCT>
 __device__ __forceinline__ void solve_kkt(const Ops<TI, TC>& O, const TC (&t)[MP], int mystep, int porder, TC udinv,
+                                          const Red<TC>& RD, bool structured,
                                           TC d, TC rx, TC rs, TC rz, TC ry, TC& ox, TC& os, TC& oz, TC& oy) {
   const int m = O.m, e = O.e, lane = O.lane;
   const TC v = O.Qiv(rx);                                                  // :333
@@ -608,7 +892,13 @@ __device__ __forceinline__ void solve_kkt(const Ops<TI, TC>& O, const TC (&t)[MP
     hz -= O.GAt(O.S11v(hy));
     if (lane >= m) hz = 0;
   }
-  const TC wz = lu_solve<TC, PIVOT>(t, hz, m, lane, mystep, porder, udinv);   // T^-1 (...)
+  TC wz;                                                                   // T^-1 (...)
+  if (ALWAYS_STRUCT) {
+    wz = RD.solve(t, hz, lane, udinv);
+  } else {
+    if (structured) wz = RD.solve(t, hz, lane, udinv);
+    else wz = lu_solve<TC, PIVOT>(t, hz, m, lane, mystep, porder, udinv);
+  }
   TC dy = 0;
   if (e > 0) dy = -O.S11v(hy - O.GAtw(wz));                                // dy = -wy
   const TC dz = (lane < m) ? -wz : (TC)0;                                  // :342
@@ -619,11 +909,32 @@ __device__ __forceinline__ void solve_kkt(const Ops<TI, TC>& O, const TC (&t)[MP
   ox = O.Qiv(g1);                                                          // :349
 }
 
+// Build + factor T (or its reduction) for D^-1 = dinv.  Returns "exact zero pivot".
+template <typename TI, typename TC, bool PIVOT, bool ALWAYS_STRUCT>
+__device__ __forceinline__ bool factor(TC (&t)[MP], const Ops<TI, TC>& O, const Ws<TI, TC>& W, Red<TC>& RD, bool structured,
+                                       TC dinv, int& mystep, int& porder, TC& udinv) {
+  const int m = O.m, lane = O.lane;
+  if (ALWAYS_STRUCT || structured) {
+    RD.prepare(dinv);
+    RD.template build<TI>(t, W.R2, dinv, lane);
+    mystep = 0; porder = lane;
+    return lu32_factor<TC>(t, RD.nr, lane, udinv);
+  }
+  if (!ALWAYS_STRUCT) {
+    load_T<TI, TC>(t, W, dinv, m, lane);
+    return lu_factor<TC, PIVOT>(t, O.L.pan, m, lane, mystep, porder, udinv);
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------- the forward kernel
 template <typename TI, typename TC, bool PIVOT, bool FUSED>
-__global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int scene = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int scene = blockIdx.x * WPB + wave;
+  if (scene >= (FUSED ? SP.B : P.B)) return;            // whole wave leaves; s_barrier ignores terminated waves
+  unsigned char* smem = smem_all + (size_t)wave * lds_per_wave;
   const int nz = FUSED ? 3 * SP.nb : P.nz, m = FUSED ? 4 * SP.nc : P.m, e = FUSED ? SP.e : P.e;
   const int max_iter = FUSED ? SP.max_iter : P.max_iter, lim = FUSED ? SP.lim : P.lim;
   const TC eps = (TC)(FUSED ? SP.eps : P.eps);
@@ -634,17 +945,24 @@ __global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
   const bool vm = lane < m;
   TC p, h, b, mu_lane = 0;
   int status;
-  TC fz_dummy = 0; (void)fz_dummy;
   FDenseW<TI, TC> Fd{FUSED ? nullptr : (const TI*)P.F + (size_t)scene * m * m, W.Ft, m};
+  bool structured = FUSED;
+  const int nc = m >> 2;
+  Red<TC> RD;
+  RD.init(nc, lane, m);
   if (FUSED) {
     assemble_scene<TI, TC>(O.L, SP, scene, lane, p, h, b, mu_lane);
-    FContactW<TC> Fc{SP.nc, mu_lane};
-    status = prefactor<TI, TC>(O.L, W, Fc, nz, m, e, lane);
   } else {
     load_dense<TI, TC>(O.L, P, scene, lane, p, h, b);
-    status = prefactor<TI, TC>(O.L, W, Fd, nz, m, e, lane);
+    structured = detect_structure<TI, TC>(O.L, Fd.F, nz, m, lane, mu_lane);
   }
-  FContactW<TC> Fc{FUSED ? SP.nc : 0, mu_lane};
+  // friction coefficient of this lane's contact when it is a u-lane: it sits in the gamma lane 3 nc + cu
+  RD.mu = shfl_t(mu_lane, RD.isu ? RD.ig : 0);
+  if (!RD.isu) RD.mu = 0;
+  if (structured && RD.isu) W.meta[1 + RD.cu] = RD.mu;
+  FContactW<TC> Fc{nc, mu_lane};
+  if (FUSED) status = prefactor<TI, TC>(O.L, W, Fc, nz, m, e, lane, true);
+  else status = prefactor<TI, TC>(O.L, W, Fd, nz, m, e, lane, structured);
 
   TC t[MP];
   int mystep, porder;
@@ -665,7 +983,9 @@ __global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
       rx = O.Gtw(z) + O.Qv(x) + p;
       if (e > 0) rx += O.Aty(y);
       rs = z;
-      const TC fz = FUSED ? Fc.Fz(z, lane) : Fd.Fz(z, lane);
+      TC fz;
+      if (FUSED) fz = Fc.Fz(z, lane);
+      else fz = structured ? Fc.Fz(z, lane) : Fd.Fz(z, lane);
       rz = vm ? (O.Gv(x) + s - h - fz) : (TC)0;
       ry = (e > 0) ? (O.Av(x) - b) : (TC)0;
       TC n_rx = (lane < nz) ? rx * rx : (TC)0, n_rz = rz * rz;
@@ -676,8 +996,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + (TC)m * mu;
       d = vm ? z / s : (TC)1;                                               // (:98)
     }
-    load_T<TI, TC>(t, W, vm ? (TC)1 / d : (TC)1, m, lane);
-    const bool singular = lu_factor<TC, PIVOT>(t, m, lane, mystep, porder, udinv);   // (:99-100)
+    const bool singular = factor<TI, TC, PIVOT, FUSED>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1,
+                                                       mystep, porder, udinv);                // (:99-100)
     if (it >= 0) {
       ++iters;
       if (trace && lane == 0) { trace[4 * it] = (double)resid; trace[4 * it + 1] = (double)mu; }
@@ -687,29 +1007,37 @@ __global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
       else ++n_not;
       if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) break;  // (:133)
     }
-    TC ax, as_, az, ay;
-    solve_kkt<TI, TC, PIVOT>(O, t, mystep, porder, udinv, d, rx, rs, rz, ry, ax, as_, az, ay);
-    if (it < 0) {
-      x = ax; s = as_; z = az; y = ay;                                      // (:60-63)
-      TC smin = vm ? s : inf_of<TC>(), zmin = vm ? z : inf_of<TC>();
-      wave_pmin2(smin, zmin);
-      if (smin <= (TC)0) s = s - smin + (TC)1;                              // (:66-75)
-      if (zmin <= (TC)0) z = z - zmin + (TC)1;
-      if (!vm) { s = 1; z = 1; }
-      continue;
+    // one call site for the KKT solve (code size): pass 0 = init / affine, pass 1 = corrector
+    TC ax = 0, as_ = 0, az = 0, ay = 0;
+    const int npass = (it < 0) ? 1 : 2;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      TC ox, os, oz, oy;
+      solve_kkt<TI, TC, PIVOT, FUSED>(O, t, mystep, porder, udinv, RD, structured, d, rx, rs, rz, ry, ox, os, oz, oy);
+      if (it < 0) {
+        x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
+        TC smin = vm ? s : inf_of<TC>(), zmin = vm ? z : inf_of<TC>();
+        wave_pmin2(smin, zmin);
+        if (smin <= (TC)0) s = s - smin + (TC)1;                            // (:66-75)
+        if (zmin <= (TC)0) z = z - zmin + (TC)1;
+        if (!vm) { s = 1; z = 1; }
+      } else if (pass == 0) {
+        ax = ox; as_ = os; az = oz; ay = oy;                                // affine direction (:138-139)
+        const TC alpha = pmin(step_pair(z, az, s, as_, vm), (TC)1);        // (:142-144)
+        TC t3 = vm ? (s + alpha * as_) * (z + alpha * az) : (TC)0, t4 = vm ? s * z : (TC)0;
+        wave_sum2(t3, t4);
+        const TC r3 = t3 / t4, sig = r3 * r3 * r3;                          // (:146-150)
+        if (trace && lane == 0) trace[4 * it + 2] = (double)sig;
+        rx = 0; rz = 0; ry = 0;
+        rs = vm ? (-mu * sig + as_ * az) / s : (TC)0;                       // (:153)
+      } else {
+        const TC cx = ox + ax, cs = os + as_, cz = oz + az, cy = oy + ay;   // (:160-163)
+        const TC alpha = pmin((TC)0.999 * step_pair(z, cz, s, cs, vm), (TC)1);   // (:164-166)
+        if (trace && lane == 0) trace[4 * it + 3] = (double)alpha;
+        x += alpha * cx; y += alpha * cy;                                   // (:171-174)
+        if (vm) { s += alpha * cs; z += alpha * cz; }
+      }
     }
-    TC alpha = pmin(step_pair(z, az, s, as_, vm), (TC)1);                  // (:142-144)
-    TC t3 = vm ? (s + alpha * as_) * (z + alpha * az) : (TC)0, t4 = vm ? s * z : (TC)0;
-    wave_sum2(t3, t4);
-    const TC r3 = t3 / t4, sig = r3 * r3 * r3;                              // (:146-150)
-    const TC rsc = vm ? (-mu * sig + as_ * az) / s : (TC)0;                 // (:153)
-    TC cx, cs, cz, cy;
-    solve_kkt<TI, TC, PIVOT>(O, t, mystep, porder, udinv, d, (TC)0, rsc, (TC)0, (TC)0, cx, cs, cz, cy);
-    cx += ax; cs += as_; cz += az; cy += ay;                                // (:160-163)
-    alpha = pmin((TC)0.999 * step_pair(z, cz, s, cs, vm), (TC)1);          // (:164-166)
-    if (trace && lane == 0) { trace[4 * it + 2] = (double)sig; trace[4 * it + 3] = (double)alpha; }
-    x += alpha * cx; y += alpha * cy;                                       // (:171-174)
-    if (vm) { s += alpha * cs; z += alpha * cz; }
   }
 
   // outputs: best iterate (x-space lanes < nz, m-space lanes < m, e-space lanes < e)
@@ -739,9 +1067,12 @@ __global__ void __launch_bounds__(64) lcp_fwd_wave(FwdArgs P, StepArgs SP) {
 
 // ---------------------------------------------------------------- the backward kernel (lcp.py:37-64)
 template <typename TI, typename TC, bool PIVOT>
-__global__ void __launch_bounds__(64) lcp_bwd_wave(BwdArgs P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int scene = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int scene = blockIdx.x * WPB + wave;
+  if (scene >= P.B) return;
+  unsigned char* smem = smem_all + (size_t)wave * lds_per_wave;
   const int nz = P.nz, m = P.m, e = P.e;
   Ops<TI, TC> O;
   carve(O.L, smem);
@@ -773,10 +1104,14 @@ __global__ void __launch_bounds__(64) lcp_bwd_wave(BwdArgs P) {
   TC t[MP];
   int mystep, porder;
   TC udinv;
-  load_T<TI, TC>(t, W, vm ? (TC)1 / d : (TC)1, m, lane);
-  lu_factor<TC, PIVOT>(t, m, lane, mystep, porder, udinv);                  // lcp.py:46
+  const bool structured = W.meta[0] != (TC)0;
+  Red<TC> RD;
+  RD.init(m >> 2, lane, m);
+  if (structured && RD.isu) RD.mu = W.meta[1 + RD.cu];
+  factor<TI, TC, PIVOT, false>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1, mystep, porder, udinv);   // lcp.py:46
   TC dx, ds, dlam, dnu;
-  solve_kkt<TI, TC, PIVOT>(O, t, mystep, porder, udinv, d, g, (TC)0, (TC)0, (TC)0, dx, ds, dlam, dnu);   // lcp.py:47-50
+  solve_kkt<TI, TC, PIVOT, false>(O, t, mystep, porder, udinv, RD, structured, d, g, (TC)0, (TC)0, (TC)0,
+                                  dx, ds, dlam, dnu);                                                    // lcp.py:47-50
   // outer products (lcp.py:52-61)
   if (P.dp && lane < nz) ((TI*)P.dp)[(size_t)scene * nz + lane] = (TI)dx;
   if (P.dh && vm) ((TI*)P.dh)[(size_t)scene * m + lane] = (TI)(-dlam);
@@ -823,32 +1158,64 @@ size_t wave64_ws_bytes(int compute) {
 template <typename TC>
 static size_t w64_lds() { w64::Lds<float, TC> L; return w64::carve<float, TC>(L, nullptr); }
 
+static inline dim3 w64_grid(int B) { return dim3((B + w64::WPB - 1) / w64::WPB); }
+
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel (gfx950 has 160 KiB per CU)
+template <typename K>
+static int w64_allow_lds(K kernel, size_t bytes) {
+  static size_t granted = 64 * 1024;
+  if (bytes > granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) return LCP_E_LAUNCH;
+    granted = bytes;
+  }
+  return 0;
+}
+#define LCP_W64_LAUNCH(KERNEL, GRID, LW, ...)                                            \
+  do {                                                                                   \
+    auto kfn = KERNEL;                                                                   \
+    if (w64_allow_lds(kfn, (size_t)(LW) * w64::WPB)) return LCP_E_LAUNCH;                \
+    hipLaunchKernelGGL(kfn, GRID, blk, (size_t)(LW) * w64::WPB, st, __VA_ARGS__);        \
+  } while (0)
+
 int wave64_forward(const FwdArgs& P, int compute, void* stream) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
-  if (compute == LCP_COMPUTE_F64)
-    hipLaunchKernelGGL((w64::lcp_fwd_wave<float, double, true, false>), dim3(P.B), dim3(64), w64_lds<double>(), st, P, SP);
-  else
-    hipLaunchKernelGGL((w64::lcp_fwd_wave<float, float, true, false>), dim3(P.B), dim3(64), w64_lds<float>(), st, P, SP);
+  const dim3 blk(64 * w64::WPB);
+  if (compute == LCP_COMPUTE_F64) {
+    const int lw = (int)w64_lds<double>();
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, SP, lw);
+  } else {
+    const int lw = (int)w64_lds<float>();
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, SP, lw);
+  }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
 int wave64_step(const StepArgs& SP, int compute, void* stream) {
   FwdArgs P = {};
   hipStream_t st = (hipStream_t)stream;
-  if (compute == LCP_COMPUTE_F64)
-    hipLaunchKernelGGL((w64::lcp_fwd_wave<float, double, true, true>), dim3(SP.B), dim3(64), w64_lds<double>(), st, P, SP);
-  else
-    hipLaunchKernelGGL((w64::lcp_fwd_wave<float, float, true, true>), dim3(SP.B), dim3(64), w64_lds<float>(), st, P, SP);
+  const dim3 blk(64 * w64::WPB);
+  if (compute == LCP_COMPUTE_F64) {
+    const int lw = (int)w64_lds<double>();
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+  } else {
+    const int lw = (int)w64_lds<float>();
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+  }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
 int wave64_backward(const BwdArgs& P, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (compute == LCP_COMPUTE_F64)
-    hipLaunchKernelGGL((w64::lcp_bwd_wave<float, double, true>), dim3(P.B), dim3(64), w64_lds<double>(), st, P);
-  else
-    hipLaunchKernelGGL((w64::lcp_bwd_wave<float, float, true>), dim3(P.B), dim3(64), w64_lds<float>(), st, P);
+  const dim3 blk(64 * w64::WPB);
+  if (compute == LCP_COMPUTE_F64) {
+    const int lw = (int)w64_lds<double>();
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true>), w64_grid(P.B), lw, P, lw);
+  } else {
+    const int lw = (int)w64_lds<float>();
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true>), w64_grid(P.B), lw, P, lw);
+  }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
