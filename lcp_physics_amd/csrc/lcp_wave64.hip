@@ -36,6 +36,9 @@ constexpr int GRS = 17;   // row stride of the row-major G copy (bank-conflict-f
 #define LCP_W64_WPB 1
 #endif
 constexpr int WPB = LCP_W64_WPB;
+#ifndef LCP_W64_OCC
+#define LCP_W64_OCC 1     // waves per SIMD the structured forward kernel is compiled for
+#endif
 #ifndef LCP_W64_SYNC_EVERY
 #define LCP_W64_SYNC_EVERY 1
 #endif
@@ -893,12 +896,8 @@ __device__ __forceinline__ void solve_kkt(const Ops<TI, TC>& O, const TC (&t)[MP
     if (lane >= m) hz = 0;
   }
   TC wz;                                                                   // T^-1 (...)
-  if (ALWAYS_STRUCT) {
-    wz = RD.solve(t, hz, lane, udinv);
-  } else {
-    if (structured) wz = RD.solve(t, hz, lane, udinv);
-    else wz = lu_solve<TC, PIVOT>(t, hz, m, lane, mystep, porder, udinv);
-  }
+  if constexpr (ALWAYS_STRUCT) wz = RD.solve(t, hz, lane, udinv);
+  else wz = lu_solve<TC, PIVOT>(t, hz, m, lane, mystep, porder, udinv);
   TC dy = 0;
   if (e > 0) dy = -O.S11v(hy - O.GAtw(wz));                                // dy = -wy
   const TC dz = (lane < m) ? -wz : (TC)0;                                  // :342
@@ -910,26 +909,62 @@ __device__ __forceinline__ void solve_kkt(const Ops<TI, TC>& O, const TC (&t)[MP
 }
 
 // Build + factor T (or its reduction) for D^-1 = dinv.  Returns "exact zero pivot".
-template <typename TI, typename TC, bool PIVOT, bool ALWAYS_STRUCT>
-__device__ __forceinline__ bool factor(TC (&t)[MP], const Ops<TI, TC>& O, const Ws<TI, TC>& W, Red<TC>& RD, bool structured,
+template <typename TI, typename TC, bool PIVOT, bool STRUCT>
+__device__ __forceinline__ bool factor(TC (&t)[MP], const Ops<TI, TC>& O, const Ws<TI, TC>& W, Red<TC>& RD, bool,
                                        TC dinv, int& mystep, int& porder, TC& udinv) {
   const int m = O.m, lane = O.lane;
-  if (ALWAYS_STRUCT || structured) {
+  if constexpr (STRUCT) {
     RD.prepare(dinv);
     RD.template build<TI>(t, W.R2, dinv, lane);
     mystep = 0; porder = lane;
     return lu32_factor<TC>(t, RD.nr, lane, udinv);
-  }
-  if (!ALWAYS_STRUCT) {
+  } else {
     load_T<TI, TC>(t, W, dinv, m, lane);
     return lu_factor<TC, PIVOT>(t, O.L.pan, m, lane, mystep, porder, udinv);
   }
-  return false;
+}
+
+// ---------------------------------------------------------------- structure classification
+// One wave per scene: does the dense LCP have the contact structure of engines.py:67-73 ?  Writes
+// meta[0] = 1/0 and the per-contact friction coefficients meta[1 + c] into the scene's workspace; the
+// single-path solver kernels below read the flag first and leave immediately when it is not theirs.
+template <typename TI, typename TC>
+__global__ void __launch_bounds__(64) lcp_classify_wave(FwdArgs P) {
+  const int scene = blockIdx.x, lane = threadIdx.x;
+  const int nz = P.nz, m = P.m;
+  Ws<TI, TC> W(P.ws, scene);
+  bool ok = ((m & 3) == 0) && (m <= 4 * (NR / 2));
+  const int nc = m >> 2;
+  TC mu = 0;
+  if (ok && lane < m) {
+    const int i = lane;
+    const TI* g = (const TI*)P.G + ((size_t)scene * m + i) * nz;
+    if (i >= 3 * nc) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == (TI)0); }
+    else if (i >= nc && ((i - nc) & 1)) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == -g[j - nz]); }
+    const TI* f = (const TI*)P.F + ((size_t)scene * m + i) * m;
+    const int cf = (i - nc) >> 1, cg = i - 3 * nc;
+    for (int j = 0; j < m; ++j) {
+      const TI v = f[j];
+      TI want = (TI)0;
+      if (i >= nc && i < 3 * nc) want = (j == 3 * nc + cf) ? (TI)1 : (TI)0;
+      else if (i >= 3 * nc) {
+        if (j == cg) { want = v; mu = (TC)v; }
+        else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = (TI)-1;
+      }
+      ok = ok && (v == want);
+    }
+  }
+  const bool all_ok = __all(ok);
+  if (lane == 0) W.meta[0] = all_ok ? (TC)1 : (TC)0;
+  if (all_ok && lane >= 3 * nc && lane < m) W.meta[1 + lane - 3 * nc] = mu;
 }
 
 // ---------------------------------------------------------------- the forward kernel
-template <typename TI, typename TC, bool PIVOT, bool FUSED>
-__global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave) {
+// STRUCT = contact-structured path (reduced 2 nc system); FUSED implies STRUCT.  For dense inputs both
+// instantiations are launched and each scene is served by the one its classification flag selects.
+template <typename TI, typename TC, bool PIVOT, bool FUSED, bool STRUCT>
+__global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave) {
+  static_assert(STRUCT || !FUSED, "the fused step is always contact-structured");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int scene = blockIdx.x * WPB + wave;
@@ -946,23 +981,26 @@ __global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP,
   TC p, h, b, mu_lane = 0;
   int status;
   FDenseW<TI, TC> Fd{FUSED ? nullptr : (const TI*)P.F + (size_t)scene * m * m, W.Ft, m};
-  bool structured = FUSED;
+  constexpr bool structured = STRUCT;
+  if (!FUSED) { if ((W.meta[0] != (TC)0) != STRUCT) return; }     // not this kernel's scene
   const int nc = m >> 2;
   Red<TC> RD;
   RD.init(nc, lane, m);
   if (FUSED) {
     assemble_scene<TI, TC>(O.L, SP, scene, lane, p, h, b, mu_lane);
+    RD.mu = shfl_t(mu_lane, RD.isu ? RD.ig : 0);                    // mu of a u-lane's contact sits in its gamma lane
+    if (!RD.isu) RD.mu = 0;
+    if (RD.isu) W.meta[1 + RD.cu] = RD.mu;
   } else {
     load_dense<TI, TC>(O.L, P, scene, lane, p, h, b);
-    structured = detect_structure<TI, TC>(O.L, Fd.F, nz, m, lane, mu_lane);
+    if (STRUCT) {
+      mu_lane = (lane >= 3 * nc && lane < m) ? W.meta[1 + lane - 3 * nc] : (TC)0;
+      RD.mu = RD.isu ? W.meta[1 + RD.cu] : (TC)0;
+    }
   }
-  // friction coefficient of this lane's contact when it is a u-lane: it sits in the gamma lane 3 nc + cu
-  RD.mu = shfl_t(mu_lane, RD.isu ? RD.ig : 0);
-  if (!RD.isu) RD.mu = 0;
-  if (structured && RD.isu) W.meta[1 + RD.cu] = RD.mu;
   FContactW<TC> Fc{nc, mu_lane};
-  if (FUSED) status = prefactor<TI, TC>(O.L, W, Fc, nz, m, e, lane, true);
-  else status = prefactor<TI, TC>(O.L, W, Fd, nz, m, e, lane, structured);
+  if (STRUCT) status = prefactor<TI, TC>(O.L, W, Fc, nz, m, e, lane, true);
+  else status = prefactor<TI, TC>(O.L, W, Fd, nz, m, e, lane, false);
 
   TC t[MP];
   int mystep, porder;
@@ -984,8 +1022,8 @@ __global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP,
       if (e > 0) rx += O.Aty(y);
       rs = z;
       TC fz;
-      if (FUSED) fz = Fc.Fz(z, lane);
-      else fz = structured ? Fc.Fz(z, lane) : Fd.Fz(z, lane);
+      if (STRUCT) fz = Fc.Fz(z, lane);
+      else fz = Fd.Fz(z, lane);
       rz = vm ? (O.Gv(x) + s - h - fz) : (TC)0;
       ry = (e > 0) ? (O.Av(x) - b) : (TC)0;
       TC n_rx = (lane < nz) ? rx * rx : (TC)0, n_rz = rz * rz;
@@ -996,7 +1034,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP,
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + (TC)m * mu;
       d = vm ? z / s : (TC)1;                                               // (:98)
     }
-    const bool singular = factor<TI, TC, PIVOT, FUSED>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1,
+    const bool singular = factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1,
                                                        mystep, porder, udinv);                // (:99-100)
     if (it >= 0) {
       ++iters;
@@ -1013,7 +1051,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP,
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
       TC ox, os, oz, oy;
-      solve_kkt<TI, TC, PIVOT, FUSED>(O, t, mystep, porder, udinv, RD, structured, d, rx, rs, rz, ry, ox, os, oz, oy);
+      solve_kkt<TI, TC, PIVOT, STRUCT>(O, t, mystep, porder, udinv, RD, structured, d, rx, rs, rz, ry, ox, os, oz, oy);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
         TC smin = vm ? s : inf_of<TC>(), zmin = vm ? z : inf_of<TC>();
@@ -1066,7 +1104,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave(FwdArgs P, StepArgs SP,
 }
 
 // ---------------------------------------------------------------- the backward kernel (lcp.py:37-64)
-template <typename TI, typename TC, bool PIVOT>
+template <typename TI, typename TC, bool PIVOT, bool STRUCT>
 __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1078,6 +1116,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   carve(O.L, smem);
   O.nz = nz; O.m = m; O.e = e; O.lane = lane;
   Ws<TI, TC> W(P.ws, scene);
+  if ((W.meta[0] != (TC)0) != STRUCT) return;                     // served by the other instantiation
   const bool vm = lane < m;
   zero_lds_inputs(O.L, lane);
   __syncthreads();
@@ -1104,13 +1143,13 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   TC t[MP];
   int mystep, porder;
   TC udinv;
-  const bool structured = W.meta[0] != (TC)0;
+  constexpr bool structured = STRUCT;
   Red<TC> RD;
   RD.init(m >> 2, lane, m);
-  if (structured && RD.isu) RD.mu = W.meta[1 + RD.cu];
-  factor<TI, TC, PIVOT, false>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1, mystep, porder, udinv);   // lcp.py:46
+  if (STRUCT && RD.isu) RD.mu = W.meta[1 + RD.cu];
+  factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1, mystep, porder, udinv);   // lcp.py:46
   TC dx, ds, dlam, dnu;
-  solve_kkt<TI, TC, PIVOT, false>(O, t, mystep, porder, udinv, RD, structured, d, g, (TC)0, (TC)0, (TC)0,
+  solve_kkt<TI, TC, PIVOT, STRUCT>(O, t, mystep, porder, udinv, RD, structured, d, g, (TC)0, (TC)0, (TC)0,
                                   dx, ds, dlam, dnu);                                                    // lcp.py:47-50
   // outer products (lcp.py:52-61)
   if (P.dp && lane < nz) ((TI*)P.dp)[(size_t)scene * nz + lane] = (TI)dx;
@@ -1182,12 +1221,17 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
+  // classify, then the structured and the general solver (each scene is picked up by exactly one)
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>();
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, SP, lw);
+    hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3(P.B), dim3(64), 0, st, P);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
   } else {
     const int lw = (int)w64_lds<float>();
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, SP, lw);
+    hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3(P.B), dim3(64), 0, st, P);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1198,10 +1242,10 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   const dim3 blk(64 * w64::WPB);
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>();
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
   } else {
     const int lw = (int)w64_lds<float>();
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1211,10 +1255,12 @@ int wave64_backward(const BwdArgs& P, int compute, void* stream) {
   const dim3 blk(64 * w64::WPB);
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>();
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw);
   } else {
     const int lw = (int)w64_lds<float>();
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
