@@ -431,12 +431,14 @@ struct Lds {
   int* flag;
 };
 
+// `with_panel`: the 8.7 KB LU panel is only needed by the general (pivoted 64x64) path; without it a
+// scene needs 19 KB of LDS, i.e. 8 waves per CU instead of 6.
 template <typename TI, typename TC>
-__host__ __device__ inline size_t carve(Lds<TI, TC>& L, unsigned char* smem) {
+__host__ __device__ inline size_t carve(Lds<TI, TC>& L, unsigned char* smem, bool with_panel = true) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
   L.Qit = (TC*)take(sizeof(TC) * NZP * NZP);
-  L.pan = (TC*)take(sizeof(TC) * MP * (16 + 1));
+  L.pan = (TC*)take(with_panel ? sizeof(TC) * MP * (16 + 1) : sizeof(TC) * NZP * NZP);
   L.Qrm = L.pan;
   L.GAc = (TC*)take(sizeof(TC) * EP * MP);
   L.S11i = (TC*)take(sizeof(TC) * EP * EP);
@@ -929,34 +931,40 @@ __device__ __forceinline__ bool factor(TC (&t)[MP], const Ops<TI, TC>& O, const 
 // meta[0] = 1/0 and the per-contact friction coefficients meta[1 + c] into the scene's workspace; the
 // single-path solver kernels below read the flag first and leave immediately when it is not theirs.
 template <typename TI, typename TC>
-__global__ void __launch_bounds__(64) lcp_classify_wave(FwdArgs P) {
-  const int scene = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
+  const int scene = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (scene >= P.B) return;
   const int nz = P.nz, m = P.m;
   Ws<TI, TC> W(P.ws, scene);
   bool ok = ((m & 3) == 0) && (m <= 4 * (NR / 2));
   const int nc = m >> 2;
-  TC mu = 0;
-  if (ok && lane < m) {
-    const int i = lane;
-    const TI* g = (const TI*)P.G + ((size_t)scene * m + i) * nz;
-    if (i >= 3 * nc) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == (TI)0); }
-    else if (i >= nc && ((i - nc) & 1)) { for (int j = 0; j < nz; ++j) ok = ok && (g[j] == -g[j - nz]); }
-    const TI* f = (const TI*)P.F + ((size_t)scene * m + i) * m;
-    const int cf = (i - nc) >> 1, cg = i - 3 * nc;
-    for (int j = 0; j < m; ++j) {
-      const TI v = f[j];
-      TI want = (TI)0;
-      if (i >= nc && i < 3 * nc) want = (j == 3 * nc + cf) ? (TI)1 : (TI)0;
-      else if (i >= 3 * nc) {
-        if (j == cg) { want = v; mu = (TC)v; }
-        else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = (TI)-1;
+  if (ok) {
+    // G: lanes over columns, loop over rows (coalesced)
+    const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
+    if (lane < nz) {
+      for (int i = nc; i < 3 * nc; i += 2) ok = ok && (G[(i + 1) * nz + lane] == -G[i * nz + lane]);
+      for (int i = 3 * nc; i < m; ++i) ok = ok && (G[i * nz + lane] == (TI)0);
+    }
+    // F: lane j holds column j of every row in turn (one coalesced 4 m-byte read per row)
+    const TI* F = (const TI*)P.F + (size_t)scene * m * m;
+    if (lane < m) {
+      const int j = lane;
+      for (int i = 0; i < m; ++i) {
+        const TI v = F[(size_t)i * m + j];
+        TI want = (TI)0;
+        if (i >= nc && i < 3 * nc) want = (j == 3 * nc + ((i - nc) >> 1)) ? (TI)1 : (TI)0;
+        else if (i >= 3 * nc) {
+          const int cg = i - 3 * nc;
+          if (j == cg) want = v;
+          else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = (TI)-1;
+        }
+        ok = ok && (v == want);
       }
-      ok = ok && (v == want);
     }
   }
   const bool all_ok = __all(ok);
   if (lane == 0) W.meta[0] = all_ok ? (TC)1 : (TC)0;
-  if (all_ok && lane >= 3 * nc && lane < m) W.meta[1 + lane - 3 * nc] = mu;
+  if (all_ok && lane < nc) W.meta[1 + lane] = (TC)((const TI*)P.F)[(size_t)scene * m * m + (size_t)(3 * nc + lane) * m + lane];
 }
 
 // ---------------------------------------------------------------- the forward kernel
@@ -974,7 +982,7 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   const int max_iter = FUSED ? SP.max_iter : P.max_iter, lim = FUSED ? SP.lim : P.lim;
   const TC eps = (TC)(FUSED ? SP.eps : P.eps);
   Ops<TI, TC> O;
-  carve(O.L, smem);
+  carve(O.L, smem, !STRUCT);
   O.nz = nz; O.m = m; O.e = e; O.lane = lane;
   Ws<TI, TC> W(FUSED ? SP.ws : P.ws, scene);
   const bool vm = lane < m;
@@ -1113,7 +1121,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   unsigned char* smem = smem_all + (size_t)wave * lds_per_wave;
   const int nz = P.nz, m = P.m, e = P.e;
   Ops<TI, TC> O;
-  carve(O.L, smem);
+  carve(O.L, smem, !STRUCT);
   O.nz = nz; O.m = m; O.e = e; O.lane = lane;
   Ws<TI, TC> W(P.ws, scene);
   if ((W.meta[0] != (TC)0) != STRUCT) return;                     // served by the other instantiation
@@ -1195,7 +1203,7 @@ size_t wave64_ws_bytes(int compute) {
 }
 
 template <typename TC>
-static size_t w64_lds() { w64::Lds<float, TC> L; return w64::carve<float, TC>(L, nullptr); }
+static size_t w64_lds(bool with_panel = true) { w64::Lds<float, TC> L; return w64::carve<float, TC>(L, nullptr, with_panel); }
 
 static inline dim3 w64_grid(int B) { return dim3((B + w64::WPB - 1) / w64::WPB); }
 
@@ -1223,14 +1231,14 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream) {
   const dim3 blk(64 * w64::WPB);
   // classify, then the structured and the general solver (each scene is picked up by exactly one)
   if (compute == LCP_COMPUTE_F64) {
-    const int lw = (int)w64_lds<double>();
-    hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3(P.B), dim3(64), 0, st, P);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), lw, P, SP, lw);
+    const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
+    hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls);
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
   } else {
-    const int lw = (int)w64_lds<float>();
-    hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3(P.B), dim3(64), 0, st, P);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), lw, P, SP, lw);
+    const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
+    hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), ls, P, SP, ls);
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
@@ -1241,10 +1249,10 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   if (compute == LCP_COMPUTE_F64) {
-    const int lw = (int)w64_lds<double>();
+    const int lw = (int)w64_lds<double>(false);
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
   } else {
-    const int lw = (int)w64_lds<float>();
+    const int lw = (int)w64_lds<float>(false);
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
@@ -1254,12 +1262,12 @@ int wave64_backward(const BwdArgs& P, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   if (compute == LCP_COMPUTE_F64) {
-    const int lw = (int)w64_lds<double>();
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), lw, P, lw);
+    const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw);
   } else {
-    const int lw = (int)w64_lds<float>();
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), lw, P, lw);
+    const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), ls, P, ls);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, lw);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
