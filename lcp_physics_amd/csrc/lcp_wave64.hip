@@ -68,34 +68,44 @@ template <> __device__ __forceinline__ double rdlane<double>(double v, int src) 
 }
 __device__ __forceinline__ int rdlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += shfl_xor_t(v, off);
-  return v;
+// Wavefront reductions with DPP row operations (quad_perm / row_half_mirror / row_mirror: a few cycles each)
+// plus four v_readlane for the cross-row step - the ds_bpermute butterfly they replace was ~100 cycles of
+// latency per step (micro-benchmark: ds_bpermute ~22 cycles issue, ~60+ latency).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-template <typename T> __device__ __forceinline__ void wave_sum2(T& a, T& b) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { a += shfl_xor_t(a, off); b += shfl_xor_t(b, off); }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
-// NaN-propagating max / min over the wave (Tensor.max()/min() semantics): plain IEEE max, then
-// force NaN if any lane held one.
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <typename T, typename Op> __device__ __forceinline__ T wave_reduce(T v, Op op) {
+  v = op(v, dpp_mov<DPP_XOR1>(v));
+  v = op(v, dpp_mov<DPP_XOR2>(v));
+  v = op(v, dpp_mov<DPP_HALF_MIRROR>(v));
+  v = op(v, dpp_mov<DPP_ROW_MIRROR>(v));                 // every lane now holds its 16-lane row's result
+  const T r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
+struct RSum { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct RMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct RMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? a : b; } };
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_reduce(v, RSum()); }
+template <typename T> __device__ __forceinline__ void wave_sum2(T& a, T& b) { a = wave_reduce(a, RSum()); b = wave_reduce(b, RSum()); }
+// NaN-propagating max / min over the wave (Tensor.max()/min() semantics): plain max, then force NaN if any
+// lane held one.
 template <typename T> __device__ __forceinline__ void wave_pmax2(T& a, T& b) {
   const bool na = __any(a != a), nb = __any(b != b);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const T oa = shfl_xor_t(a, off), ob = shfl_xor_t(b, off);
-    a = a > oa ? a : oa; b = b > ob ? b : ob;
-  }
+  a = wave_reduce(a, RMax()); b = wave_reduce(b, RMax());
   if (na) a = nan_of<T>();
   if (nb) b = nan_of<T>();
 }
 template <typename T> __device__ __forceinline__ void wave_pmin2(T& a, T& b) {
   const bool na = __any(a != a), nb = __any(b != b);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const T oa = shfl_xor_t(a, off), ob = shfl_xor_t(b, off);
-    a = a < oa ? a : oa; b = b < ob ? b : ob;
-  }
+  a = wave_reduce(a, RMin()); b = wave_reduce(b, RMin());
   if (na) a = nan_of<T>();
   if (nb) b = nan_of<T>();
 }
@@ -106,6 +116,20 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = v > o ? v : o;
   }
   return v;
+}
+
+// 1/x by v_rcp + Newton steps (the IEEE division sequence is ~12 dependent instructions and sat on the
+// critical path of every elimination step).  Two steps for fp64 (v_rcp_f64 is ~26 bits), one for fp32.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  r = fmaf(fmaf(-x, r, 1.0f), r, r);
+  return r;
 }
 
 // 16-byte / 8-byte vector loads (the pointers are 16 B aligned by construction of the workspace)
@@ -277,7 +301,7 @@ __device__ __forceinline__ bool lu32_factor(TC (&t)[MP], int nr, int lane, TC& u
         constexpr int k = 8 * B8 + KK;
         const TC piv = rdlane(t[k], k);
         singular = singular || (piv == (TC)0);
-        const TC inv = (TC)1 / piv;
+        const TC inv = fast_rcp(piv);
         const TC l = (lane > k) ? t[k] * inv : (TC)0;
         t[k] = (lane > k) ? l : t[k];
         udinv = (lane == k) ? inv : udinv;
@@ -465,7 +489,7 @@ struct Ws {
     unsigned char* base = (unsigned char*)ws + (size_t)scene * ws_bytes<TI, TC>();
     TC* q = (TC*)base;
     R2 = q; q += MP * MP; Qit = q; q += NZP * NZP; GAc = q; q += EP * MP; S11i = q; q += EP * EP;
-    x = q; q += NZP; s = q; q += MP; z = q; q += MP; y = q; q += EP; meta = q;   // 5080 + 17 <= WS_TC
+    x = q; q += NZP; s = q; q += MP; z = q; q += MP; y = q; q += EP; meta = q;   // 5080 + 19 <= WS_TC   (meta[18] = Q-is-diagonal flag)
     Ft = (TI*)(base + WS_TC * sizeof(TC));
   }
 };
@@ -529,13 +553,20 @@ template <typename TI, typename TC>
 struct Ops {
   Lds<TI, TC> L;
   int nz, m, e, lane;
+  bool diagq;          // Q is diagonal (always true for assembled contact scenes): Q v and Q^-1 v are one multiply
+  TC qd, qid;          // Q[j][j], Qinv[j][j] for j = lane & 15
+  TI grow[NZP];        // row `lane` of G, register-resident (G v without LDS traffic)
+  __device__ __forceinline__ void cache_rows() {
+    static_for<NZP>([&](auto J) LCP_INL { grow[J] = L.Gc[J * MP + lane]; });
+    const int j = lane & 15;
+    qd = (TC)L.Qt[j * NZP + j]; qid = L.Qit[j * NZP + j];
+  }
   // All loops below are ROLLED on purpose (run-time trip counts, v_readlane with a run-time lane select):
   // these products are small next to the LU, and compact code is what keeps the kernel in the I-cache.
   // m-space <- x-space : (G v)_i
   __device__ __forceinline__ TC Gv(TC v) const {
-    TC acc = 0;
-#pragma unroll 1
-    for (int j = 0; j < nz; ++j) acc = fma((TC)L.Gc[j * MP + lane], rdlane(v, j), acc);
+    TC acc = 0;                                        // columns >= nz are zero in grow and in v
+    static_for<NZP>([&](auto J) LCP_INL { acc = fma((TC)grow[J], rdlane(v, J), acc); });
     return acc;
   }
   // x-space <- m-space : (G^T w)_j, j = lane & 15 (replicated in the four lane groups)
@@ -554,6 +585,7 @@ struct Ops {
     return acc;
   }
   __device__ __forceinline__ TC Qiv(TC v) const {
+    if (diagq) return qid * v;
     const int j = lane & 15;
     TC acc = 0;
 #pragma unroll 1
@@ -561,6 +593,7 @@ struct Ops {
     return acc;
   }
   __device__ __forceinline__ TC Qv(TC v) const {
+    if (diagq) return qd * v;
     const int j = lane & 15;
     TC acc = 0;
 #pragma unroll 1
@@ -962,8 +995,14 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
       }
     }
   }
+  bool qdiag = true;
+  {
+    const TI* Q = (const TI*)P.Q + (size_t)scene * nz * nz;
+    for (int idx = lane; idx < nz * nz; idx += 64) { const int r = idx / nz, c = idx - r * nz; if (r != c) qdiag = qdiag && (Q[idx] == (TI)0); }
+  }
+  qdiag = __all(qdiag);
   const bool all_ok = __all(ok);
-  if (lane == 0) W.meta[0] = all_ok ? (TC)1 : (TC)0;
+  if (lane == 0) { W.meta[0] = all_ok ? (TC)1 : (TC)0; W.meta[18] = qdiag ? (TC)1 : (TC)0; }
   if (all_ok && lane < nc) W.meta[1 + lane] = (TC)((const TI*)P.F)[(size_t)scene * m * m + (size_t)(3 * nc + lane) * m + lane];
 }
 
@@ -1009,6 +1048,8 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   FContactW<TC> Fc{nc, mu_lane};
   if (STRUCT) status = prefactor<TI, TC>(O.L, W, Fc, nz, m, e, lane, true);
   else status = prefactor<TI, TC>(O.L, W, Fd, nz, m, e, lane, false);
+  O.diagq = FUSED ? true : (W.meta[18] != (TC)0);
+  O.cache_rows();
 
   TC t[MP];
   int mystep, porder;
@@ -1142,6 +1183,8 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
     for (int i = lane; i < EP * EP; i += 64) O.L.S11i[i] = W.S11i[i];
   }
   __syncthreads();
+  O.diagq = false;                                     // backward keeps the general Q^-1 product (one solve only)
+  O.cache_rows();
   const int jx = lane & 15, ae = lane & 7;
   const TC x = (jx < nz) ? W.x[jx] : (TC)0;
   const TC z = vm ? W.z[lane] : (TC)1, s = vm ? W.s[lane] : (TC)1;
