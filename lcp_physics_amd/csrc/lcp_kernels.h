@@ -70,4 +70,11 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream);
 int wave64_backward(const BwdArgs& P, int compute, void* stream);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
+// four-scenes-per-wave contact-structured path (nc <= 16, nz <= 16, neq <= 4, diagonal Q) - lcp_quad.hip
+// `accept`: classification flag value (workspace meta[0]) the launch serves
+bool quad_supported(int nz, int m, int e);
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream);
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
+int quad_step(const StepArgs& P, int compute, void* stream);
+
 }  // namespace lcp

@@ -1,0 +1,770 @@
+// lcp_quad.hip - contact-structured PDIPM kernels, FOUR SCENES PER WAVEFRONT (16 lanes per scene).
+//
+// The fastest path: contact-structured LCPs (engines.py:67-73) with diagonal Q, nc <= 16 contacts,
+// nz <= 16, neq <= 4, fp32 I/O.  Mapping (CDNA4-first):
+//   * one 16-lane DPP row = one scene, lane c = contact c.  The lane holds everything that belongs to its
+//     contact: the four inequality components (normal, friction +, friction -, gamma) of every m-space
+//     vector, its rows of Jc and Jt, and BOTH of its rows of the reduced 2nc x 2nc system (a_c and u_c,
+//     see lcp_wave64.hip `Red` for the algebra).  The per-contact 2x2 elimination, F z, the reduction's
+//     right-hand side and back-substitution are therefore lane-local - no cross-lane traffic at all.
+//   * x-space vectors (nz <= 16) live one entry per lane of the row, e-space (neq <= 4) likewise.
+//   * every cross-lane move is a DPP row operation: `row_newbcast:k` broadcasts lane k of each row to its row
+//     (pivot rows in the LU, vector entries in the products), quad_perm / row_mirror give row-local
+//     reductions.  Micro-benchmark (tools/microbench/pair_cost.hip): 8.8 cycles per fp64 FMA fed this way
+//     versus 21-29 through v_readlane, and one instruction serves four scenes.
+//   * the pivot-free LU runs over the 2 x 32 register-resident row entries of each lane.
+// Scenes of a wave advance in lock-step; a scene that terminates (pdipm.py:133) freezes its state and waits.
+// Same algorithm and the same reference lines as lcp_wave64.hip / lcp_generic.hip.
+#include "lcp_wave_common.h"
+
+namespace lcp {
+namespace q16 {
+
+using namespace w64;
+
+constexpr int NCQ = 16;   // contacts (lanes) per scene
+constexpr int EQ = 4;     // padded neq
+
+// ---------------------------------------------------------------- DPP row primitives
+template <int K> __device__ __forceinline__ float bc(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, true));
+}
+template <int K> __device__ __forceinline__ double bc(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dppx(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dppx(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// reductions over the 16 lanes of a row; every lane of the row receives the result
+template <typename T> __device__ __forceinline__ T row_sum(T v) {
+  v += dppx<0xB1>(v); v += dppx<0x4E>(v); v += dppx<0x141>(v); v += dppx<0x140>(v);
+  return v;
+}
+template <typename T> __device__ __forceinline__ T row_max(T v) {
+  T o;
+  o = dppx<0xB1>(v); v = v > o ? v : o;
+  o = dppx<0x4E>(v); v = v > o ? v : o;
+  o = dppx<0x141>(v); v = v > o ? v : o;
+  o = dppx<0x140>(v); v = v > o ? v : o;
+  return v;
+}
+template <typename T> __device__ __forceinline__ T row_min(T v) {
+  T o;
+  o = dppx<0xB1>(v); v = v < o ? v : o;
+  o = dppx<0x4E>(v); v = v < o ? v : o;
+  o = dppx<0x141>(v); v = v < o ? v : o;
+  o = dppx<0x140>(v); v = v < o ? v : o;
+  return v;
+}
+__device__ __forceinline__ bool row_any(bool p) { return row_max(p ? 1.0f : 0.0f) > 0.0f; }
+// NaN-propagating (Tensor.max()/min() semantics)
+template <typename T> __device__ __forceinline__ T row_pmax(T v) { const bool n = row_any(v != v); v = row_max(v); return n ? nan_of<T>() : v; }
+template <typename T> __device__ __forceinline__ T row_pmin(T v) { const bool n = row_any(v != v); v = row_min(v); return n ? nan_of<T>() : v; }
+
+template <typename TC> struct M4 { TC n, f1, f2, g; };       // the four inequality rows of one contact
+template <typename TC> __device__ __forceinline__ M4<TC> m4(TC a, TC b, TC c, TC d) { M4<TC> r; r.n = a; r.f1 = b; r.f2 = c; r.g = d; return r; }
+template <typename TC> __device__ __forceinline__ TC sum4(const M4<TC>& a) { return (a.n + a.f1) + (a.f2 + a.g); }
+
+// ---------------------------------------------------------------- per-scene LDS block
+template <typename TI, typename TC>
+struct LdsQ {
+  TI* GL;    // [16][16]  Jc rows: GL[c*16 + j]
+  TI* GTL;   // [16][16]  Jt rows
+  TI* AtL;   // [EQ][16]  A rows
+  TC* GAL;   // [16][2][EQ]  (J Q^-1 A^T) of the n / t row of every contact
+  TC* S11;   // [EQ][EQ]     (A Q^-1 A^T)^-1
+};
+template <typename TI, typename TC>
+__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem) {
+  unsigned char* q = smem;
+  auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
+  L.GAL = (TC*)take(sizeof(TC) * NCQ * 2 * EQ);
+  L.S11 = (TC*)take(sizeof(TC) * EQ * EQ);
+  L.GL = (TI*)take(sizeof(TI) * NCQ * 16);
+  L.GTL = (TI*)take(sizeof(TI) * NCQ * 16);
+  L.AtL = (TI*)take(sizeof(TI) * EQ * 16);
+  return (size_t)(q - smem);
+}
+
+// ---------------------------------------------------------------- per-lane scene data and products
+template <typename TI, typename TC>
+struct SceneQ {
+  LdsQ<TI, TC> L;
+  int nz, nc, e, l16;
+  TI jc[16], jt[16];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
+  TI arow[16];            // row l16 of A (lanes < e)
+  TC gan[EQ], gat[EQ];    // (J Q^-1 A^T) rows of this contact
+  TC s11row[EQ];          // row l16 of (A Q^-1 A^T)^-1
+  TC qd, qid;             // Q[j][j], 1 / Q[j][j] for j = l16
+  TC mu;                  // friction coefficient of this contact
+
+  // m-space <- x-space:  (Jc v)_c and (Jt v)_c
+  __device__ __forceinline__ void Gv(TC v, TC& gn, TC& gt) const {
+    gn = 0; gt = 0;
+    static_for<16>([&](auto J) LCP_INL { const TC vb = bc<J>(v); gn = fma((TC)jc[J], vb, gn); gt = fma((TC)jt[J], vb, gt); });
+  }
+  // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
+  __device__ __forceinline__ TC Gtw(TC wn, TC wt) const {
+    TC acc = 0;
+    static_for<16>([&](auto C) LCP_INL {
+      acc = fma((TC)L.GL[C * 16 + l16], bc<C>(wn), acc);
+      acc = fma((TC)L.GTL[C * 16 + l16], bc<C>(wt), acc);
+    });
+    return acc;
+  }
+  __device__ __forceinline__ TC Av(TC v) const {        // e-space <- x-space
+    TC acc = 0;
+    static_for<16>([&](auto K) LCP_INL { acc = fma((TC)arow[K], bc<K>(v), acc); });
+    return acc;
+  }
+  __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
+    TC acc = 0;
+    static_for<EQ>([&](auto A) LCP_INL { acc = fma((TC)L.AtL[A * 16 + l16], bc<A>(y), acc); });
+    return acc;
+  }
+  __device__ __forceinline__ void GAt(TC t, TC& gn, TC& gt) const {     // m-space <- e-space
+    gn = 0; gt = 0;
+    static_for<EQ>([&](auto A) LCP_INL { const TC tb = bc<A>(t); gn = fma(gan[A], tb, gn); gt = fma(gat[A], tb, gt); });
+  }
+  __device__ __forceinline__ TC GAtw(TC wn, TC wt) const {              // e-space <- m-space
+    TC out = 0;
+    static_for<EQ>([&](auto A) LCP_INL { const TC sm = row_sum(gan[A] * wn + gat[A] * wt); if (l16 == A) out = sm; });
+    return out;
+  }
+  __device__ __forceinline__ TC S11v(TC v) const {
+    TC acc = 0;
+    static_for<EQ>([&](auto C) LCP_INL { acc = fma(s11row[C], bc<C>(v), acc); });
+    return acc;
+  }
+};
+
+// ---------------------------------------------------------------- reduced system in registers
+// Lane c holds row a_c (index c) in ta[] and row u_c (index 16 + c) in tu[]; columns 0..15 <-> a, 16..31 <-> u.
+template <typename TC>
+struct RedQ {
+  TC Sp, Sm, Dg, idet, wa, wu;        // per factorisation (functions of D = s/z), see lcp_wave64.hip `Red`
+  TC ua, uu;                          // 1 / U[c][c], 1 / U[16+c][16+c]
+};
+
+template <typename TI, typename TC>
+__device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC>& S, const TC* W2q,
+                                         const M4<TC>& D, bool valid) {
+  const int l16 = S.l16, nc = S.nc;
+  R.Dg = D.g;
+  R.Sp = (TC)0.5 * (D.f1 + D.f2); R.Sm = (TC)0.5 * (D.f1 - D.f2);
+  R.idet = fast_rcp(R.Sp * R.Dg + (TC)2);
+  R.wa = (TC)2 * S.mu * R.idet; R.wu = -R.Dg * R.Sm * R.idet;
+  const TC addA = valid ? D.n : (TC)1;                                           // on column c of row a_c
+  const TC addB = valid ? (TC)0.5 * R.Sm * R.wa : (TC)0;                         // on column c of row u_c
+  const TC addU = valid ? (TC)0.5 * (R.Sp + R.Sm * R.wu) : (TC)1;                // on column 16 + c of row u_c
+  static_for<16>([&](auto P) LCP_INL {
+    constexpr int q = 2 * P;
+    load2(W2q + (((size_t)P * 2 + 0) * 16 + l16) * 2, ta[q], ta[q + 1]);
+    load2(W2q + (((size_t)P * 2 + 1) * 16 + l16) * 2, tu[q], tu[q + 1]);
+  });
+  static_for<16>([&](auto Q) LCP_INL {
+    ta[Q] += (l16 == Q) ? addA : (TC)0;
+    tu[Q] += (l16 == Q) ? addB : (TC)0;
+    tu[16 + Q] += (l16 == Q) ? addU : (TC)0;
+  });
+  bool singular = false;
+  R.ua = 1; R.uu = 1;
+  static_for<16>([&](auto K) LCP_INL {                                           // pivots a_0 .. a_15
+    constexpr int k = K;
+    if (k < nc) {
+      const TC piv = bc<k>(ta[k]);
+      singular = singular || (piv == (TC)0);
+      const TC inv = fast_rcp(piv);
+      const TC la = (l16 > k) ? ta[k] * inv : (TC)0;
+      const TC lu = tu[k] * inv;
+      ta[k] = (l16 > k) ? la : ta[k];
+      tu[k] = lu;
+      R.ua = (l16 == k) ? inv : R.ua;
+      static_for<31 - k>([&](auto JJ) LCP_INL {
+        constexpr int j = k + 1 + JJ;
+        const TC sj = bc<k>(ta[j]);
+        ta[j] = fma(-la, sj, ta[j]);
+        tu[j] = fma(-lu, sj, tu[j]);
+      });
+    }
+  });
+  static_for<16>([&](auto K) LCP_INL {                                           // pivots u_0 .. u_15
+    constexpr int kk = K, k = 16 + K;
+    if (kk < nc) {
+      const TC piv = bc<kk>(tu[k]);
+      singular = singular || (piv == (TC)0);
+      const TC inv = fast_rcp(piv);
+      const TC lu = (l16 > kk) ? tu[k] * inv : (TC)0;
+      tu[k] = (l16 > kk) ? lu : tu[k];
+      R.uu = (l16 == kk) ? inv : R.uu;
+      static_for<15 - kk>([&](auto JJ) LCP_INL {
+        constexpr int j = k + 1 + JJ;
+        tu[j] = fma(-lu, bc<kk>(tu[j]), tu[j]);
+      });
+    }
+  });
+  return singular;
+}
+
+// T^-1 hz through the reduced system; everything except the two triangular sweeps is lane-local.
+template <typename TI, typename TC>
+__device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R, const SceneQ<TI, TC>& S,
+                                           const M4<TC>& hz) {
+  const int l16 = S.l16, nc = S.nc;
+  const TC r12 = hz.f1 + hz.f2;
+  const TC w0 = (R.Dg * r12 - (TC)2 * hz.g) * R.idet;
+  TC ra = hz.n, ru = (TC)0.5 * (hz.f1 - hz.f2) - (TC)0.5 * R.Sm * w0;
+  static_for<16>([&](auto K) LCP_INL {                     // L y = rhs
+    constexpr int k = K;
+    if (k < nc) {
+      const TC yk = bc<k>(ra);
+      ra = fma(-((l16 > k) ? ta[k] : (TC)0), yk, ra);
+      ru = fma(-tu[k], yk, ru);
+    }
+  });
+  static_for<16>([&](auto K) LCP_INL {
+    constexpr int kk = K, k = 16 + K;
+    if (kk < nc) {
+      const TC yk = bc<kk>(ru);
+      ru = fma(-((l16 > kk) ? tu[k] : (TC)0), yk, ru);
+    }
+  });
+  static_for<16>([&](auto KR) LCP_INL {                    // U x = y
+    constexpr int kk = 15 - KR, k = 16 + kk;
+    if (kk < nc) {
+      const TC xk = bc<kk>(ru * R.uu);
+      ru = fma(-((l16 < kk) ? tu[k] : (TC)0), xk, ru);
+      ra = fma(-ta[k], xk, ra);
+    }
+  });
+  static_for<16>([&](auto KR) LCP_INL {
+    constexpr int k = 15 - KR;
+    if (k < nc) {
+      const TC xk = bc<k>(ra * R.ua);
+      ra = fma(-((l16 < k) ? ta[k] : (TC)0), xk, ra);
+    }
+  });
+  const TC a = ra * R.ua, u = ru * R.uu;
+  const TC w = w0 + R.wa * a + R.wu * u;
+  M4<TC> dz;
+  dz.n = a; dz.f1 = (TC)0.5 * (w + u); dz.f2 = (TC)0.5 * (w - u);
+  dz.g = (r12 - R.Sm * u + R.Sp * (hz.g - S.mu * a)) * R.idet;
+  return dz;
+}
+
+// solve_kkt (pdipm.py:325-354).  rs, rz given per contact (M4), rx in x-space, ry in e-space.
+template <typename TI, typename TC>
+__device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R,
+                                            const M4<TC>& d, bool valid, TC rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
+                                            TC& ox, M4<TC>& os, M4<TC>& oz, TC& oy) {
+  const TC v = S.qid * rx;                                                 // :333 (diagonal Q)
+  TC gn, gt;
+  S.Gv(v, gn, gt);
+  M4<TC> hz = m4<TC>(gn + rs.n / d.n - rz.n, gt + rs.f1 / d.f1 - rz.f1, -gt + rs.f2 / d.f2 - rz.f2, rs.g / d.g - rz.g);   // :334-340
+  TC hy = 0;
+  if (S.e > 0) {
+    hy = S.Av(v) - ry;
+    TC an, at;
+    S.GAt(S.S11v(hy), an, at);
+    hz.n -= an; hz.f1 -= at; hz.f2 += at;
+  }
+  if (!valid) hz = m4<TC>(0, 0, 0, 0);
+  const M4<TC> wz = tsolve_q<TI, TC>(ta, tu, R, S, hz);
+  TC dy = 0;
+  if (S.e > 0) dy = -S.S11v(hy - S.GAtw(valid ? wz.n : (TC)0, valid ? wz.f1 - wz.f2 : (TC)0));    // dy = -wy
+  oz = m4<TC>(-wz.n, -wz.f1, -wz.f2, -wz.g);                               // :342
+  if (!valid) oz = m4<TC>(0, 0, 0, 0);
+  os = m4<TC>((-rs.n - oz.n) / d.n, (-rs.f1 - oz.f1) / d.f1, (-rs.f2 - oz.f2) / d.f2, (-rs.g - oz.g) / d.g);   // :347,350
+  if (!valid) os = m4<TC>(0, 0, 0, 0);
+  oy = dy;
+  TC g1 = -rx - S.Gtw(oz.n, oz.f1 - oz.f2);                                // :344-346
+  if (S.e > 0) g1 -= S.Aty(dy);
+  ox = S.qid * g1;                                                         // :349
+}
+
+// get_step for (z,dz),(s,ds) of one scene (pdipm.py:182-186): min(step(z,dz), step(s,ds)), NaN semantics kept
+template <typename TC>
+__device__ __forceinline__ TC step_pair_q(const M4<TC>& z, const M4<TC>& dz, const M4<TC>& s, const M4<TC>& ds, bool valid) {
+  const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
+  const M4<TC> az = m4<TC>(-z.n / dz.n, -z.f1 / dz.f1, -z.f2 / dz.f2, -z.g / dz.g);
+  const M4<TC> as = m4<TC>(-s.n / ds.n, -s.f1 / ds.f1, -s.f2 / ds.f2, -s.g / ds.g);
+  TC mz = valid ? pmax(pmax(az.n, az.f1), pmax(az.f2, az.g)) : ninf;
+  TC ms = valid ? pmax(pmax(as.n, as.f1), pmax(as.f2, as.g)) : ninf;
+  mz = row_pmax(mz); ms = row_pmax(ms);
+  const TC fz = (mz > (TC)1) ? mz : (TC)1, fs = (ms > (TC)1) ? ms : (TC)1;
+  auto pick = [&](TC dv, TC a, TC fill) { return (dv > (TC)0) ? fill : a; };
+  TC lz = valid ? pmin(pmin(pick(dz.n, az.n, fz), pick(dz.f1, az.f1, fz)), pmin(pick(dz.f2, az.f2, fz), pick(dz.g, az.g, fz))) : pinf;
+  TC ls = valid ? pmin(pmin(pick(ds.n, as.n, fs), pick(ds.f1, as.f1, fs)), pmin(pick(ds.f2, as.f2, fs), pick(ds.g, as.g, fs))) : pinf;
+  lz = row_pmin(lz); ls = row_pmin(ls);
+  return pmin(lz, ls);
+}
+
+// workspace view of the quad path: W (8 KB) in the R2 region, the rest in the w64 fields
+//   W2q[((p*2 + slot)*16 + lane)*2 + (q&1)], p = q>>1, slot 0 = row a_lane, 1 = row u_lane
+template <typename TI, typename TC>
+__device__ __forceinline__ void store_scene_ws(const Ws<TI, TC>& W, const SceneQ<TI, TC>& S) {
+  const int l16 = S.l16;
+  static_for<EQ>([&](auto A) LCP_INL { W.GAc[(l16 * 2 + 0) * EQ + A] = S.gan[A]; W.GAc[(l16 * 2 + 1) * EQ + A] = S.gat[A]; });
+  static_for<EQ>([&](auto C) LCP_INL { if (l16 < EQ) W.S11i[l16 * EQ + C] = S.s11row[C]; });
+  W.Qit[l16] = S.qid;
+}
+
+// ---------------------------------------------------------------- inputs
+// dense contact-structured LCP -> per-lane rows (+ LDS copies for the transposed products)
+template <typename TI, typename TC>
+__device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P, const Ws<TI, TC>& W, int scene,
+                                             TC& p, TC& hn, TC& b) {
+  const int nz = S.nz, nc = S.nc, e = S.e, l16 = S.l16, m = 4 * nc;
+  const bool vc = l16 < nc;
+  const TI* Grow_n = (const TI*)P.G + ((size_t)scene * m + (vc ? l16 : 0)) * nz;
+  const TI* Grow_t = (const TI*)P.G + ((size_t)scene * m + nc + 2 * (vc ? l16 : 0)) * nz;
+  static_for<16>([&](auto J) LCP_INL {
+    S.jc[J] = (vc && J < nz) ? Grow_n[J] : (TI)0;
+    S.jt[J] = (vc && J < nz) ? Grow_t[J] : (TI)0;
+    S.L.GL[l16 * 16 + J] = S.jc[J];
+    S.L.GTL[l16 * 16 + J] = S.jt[J];
+  });
+  const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
+  static_for<16>([&](auto K) LCP_INL {
+    S.arow[K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
+    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+  });
+  const TI q = (l16 < nz) ? ((const TI*)P.Q)[(size_t)scene * nz * nz + l16 * nz + l16] : (TI)1;
+  S.qd = (l16 < nz) ? (TC)q : (TC)0;
+  S.qid = (l16 < nz) ? (TC)1 / (TC)q : (TC)0;
+  S.mu = vc ? W.meta[1 + l16] : (TC)0;
+  p = (l16 < nz) ? (TC)((const TI*)P.p)[(size_t)scene * nz + l16] : (TC)0;
+  hn = vc ? (TC)((const TI*)P.h)[(size_t)scene * m + l16] : (TC)0;
+  b = (l16 < e) ? (TC)((const TI*)P.b)[(size_t)scene * e + l16] : (TC)0;
+}
+
+// contact list -> per-lane rows (physics/engines.py:31-32,50-74; physics/world.py:144-234)
+template <typename TI, typename TC>
+__device__ __forceinline__ void assemble_q(SceneQ<TI, TC>& S, const StepArgs& P, int scene, TC& p, TC& hn, TC& b) {
+  const int nb = P.nb, nc = S.nc, nz = S.nz, e = S.e, l16 = S.l16;
+  const bool vc = l16 < nc;
+  const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
+  const TI* vv = (const TI*)P.v + (size_t)scene * nz;
+  const TI* ff = (const TI*)P.f + (size_t)scene * nz;
+  static_for<16>([&](auto J) LCP_INL { S.L.GL[l16 * 16 + J] = (TI)0; S.L.GTL[l16 * 16 + J] = (TI)0; });
+  TI hrow = (TI)0, mu = (TI)0;
+  if (vc) {
+    const ContactRows<TI> r = make_contact<TI>((const TI*)P.c_n + (size_t)scene * nc * 2, (const TI*)P.c_p1 + (size_t)scene * nc * 2,
+                                               (const TI*)P.c_p2 + (size_t)scene * nc * 2, P.c_i1 + (size_t)scene * nc,
+                                               P.c_i2 + (size_t)scene * nc, (const TI*)P.rest + (size_t)scene * nb,
+                                               (const TI*)P.fric + (size_t)scene * nb, vv, l16);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
+      S.L.GL[l16 * 16 + col] = r.jn[q];
+      S.L.GTL[l16 * 16 + col] = r.jf[q];
+    }
+    hrow = r.h; mu = r.mu;
+  }
+  static_for<16>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * 16 + J]; S.jt[J] = S.L.GTL[l16 * 16 + J]; });   // own row only
+  const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
+  static_for<16>([&](auto K) LCP_INL {
+    S.arow[K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
+    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+  });
+  const TI q = (l16 < nz) ? Md[l16] : (TI)1;
+  S.qd = (l16 < nz) ? (TC)q : (TC)0;
+  S.qid = (l16 < nz) ? (TC)1 / (TC)q : (TC)0;
+  S.mu = (TC)mu;
+  p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16], vv[l16], (TI)P.dt, ff[l16]) : (TC)0;     // engines.py:32
+  hn = (TC)hrow;
+  b = (TC)0;
+}
+
+// pre_factor_kkt for diagonal Q: G Q^-1 A^T rows, (A Q^-1 A^T)^-1, W = J P J^T into the workspace
+template <typename TI, typename TC>
+__device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& W, bool live) {
+  const int nc = S.nc, e = S.e, l16 = S.l16, nz = S.nz;
+  int status = 0;
+  if (row_any(l16 < nz && !(S.qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
+  TC gqn[16], gqt[16];
+  static_for<16>([&](auto K) LCP_INL { const TC qi = bc<K>(S.qid); gqn[K] = (TC)S.jc[K] * qi; gqt[K] = (TC)S.jt[K] * qi; });
+  TC ccn[EQ], cct[EQ];
+  static_for<EQ>([&](auto A) LCP_INL { S.gan[A] = 0; S.gat[A] = 0; S.s11row[A] = 0; ccn[A] = 0; cct[A] = 0; });
+  __syncthreads();                                   // LDS rows written by the loaders
+  if (e > 0) {
+    static_for<EQ>([&](auto A) LCP_INL {
+      TC an = 0, at = 0;
+      static_for<16>([&](auto K) LCP_INL { const TC aak = (TC)S.L.AtL[A * 16 + K]; an = fma(gqn[K], aak, an); at = fma(gqt[K], aak, at); });
+      S.gan[A] = an; S.gat[A] = at;
+      S.L.GAL[(l16 * 2 + 0) * EQ + A] = an; S.L.GAL[(l16 * 2 + 1) * EQ + A] = at;
+    });
+    {                                                 // S11 = A Q^-1 A^T, entry (a, c') in lane a*EQ + c'
+      const int a = l16 >> 2, c = l16 & 3;
+      TC acc = 0;
+      static_for<16>([&](auto K) LCP_INL { acc = fma((TC)S.L.AtL[a * 16 + K] * bc<K>(S.qid), (TC)S.L.AtL[c * 16 + K], acc); });
+      S.L.S11[l16] = acc;
+    }
+    __syncthreads();
+    if (l16 == 0) {                                   // tiny e x e Gauss-Jordan, one lane per scene
+      TC* a = S.L.S11;
+      bool bad = false;
+      for (int k = 0; k < e; ++k) {
+        const TC piv = a[k * EQ + k];
+        bad = bad || !(piv != (TC)0) || (piv != piv);
+        const TC pinv = (TC)1 / piv;
+        for (int j = 0; j < e; ++j) if (j != k) a[k * EQ + j] *= pinv;
+        for (int i = 0; i < e; ++i) if (i != k) { const TC f = a[i * EQ + k]; for (int j = 0; j < e; ++j) if (j != k) a[i * EQ + j] -= f * a[k * EQ + j]; a[i * EQ + k] = -f * pinv; }
+        a[k * EQ + k] = pinv;
+      }
+      for (int i = 0; i < EQ; ++i) for (int j = 0; j < EQ; ++j) if (i >= e || j >= e) a[i * EQ + j] = 0;
+      a[0] = bad ? nan_of<TC>() : a[0];
+    }
+    __syncthreads();
+    if (S.L.S11[0] != S.L.S11[0]) status |= LCP_ST_SINGULAR_S11;
+    static_for<EQ>([&](auto C) LCP_INL { S.s11row[C] = (l16 < EQ) ? S.L.S11[l16 * EQ + C] : (TC)0; });
+    static_for<EQ>([&](auto A) LCP_INL {
+      TC an = 0, at = 0;
+      static_for<EQ>([&](auto C) LCP_INL { const TC sca = S.L.S11[C * EQ + A]; an = fma(S.gan[C], sca, an); at = fma(S.gat[C], sca, at); });
+      ccn[A] = an; cct[A] = at;
+    });
+  }
+  const bool vr = l16 < nc;
+#pragma unroll 1
+  for (int q0 = 0; q0 < 32; q0 += 2) {
+    TC va[2], vu[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int q = q0 + h2, cq = q & 15, kind = q >> 4;
+      const TI* jrow = (kind ? S.L.GTL : S.L.GL) + cq * 16;
+      const TC* garow = S.L.GAL + (cq * 2 + kind) * EQ;
+      TC a = 0, u = 0;
+      static_for<16>([&](auto K) LCP_INL { const TC jk = (TC)jrow[K]; a = fma(gqn[K], jk, a); u = fma(gqt[K], jk, u); });
+      if (e > 0) static_for<EQ>([&](auto A) LCP_INL { const TC g = garow[A]; a = fma(-ccn[A], g, a); u = fma(-cct[A], g, u); });
+      const bool ok = vr && (cq < nc);
+      va[h2] = ok ? a : (TC)0; vu[h2] = ok ? u : (TC)0;
+    }
+    if (live) {
+      store2(W.R2 + (((size_t)(q0 >> 1) * 2 + 0) * 16 + l16) * 2, va[0], va[1]);
+      store2(W.R2 + (((size_t)(q0 >> 1) * 2 + 1) * 16 + l16) * 2, vu[0], vu[1]);
+    }
+  }
+  if (live) store_scene_ws<TI, TC>(W, S);
+  __threadfence_block();
+  __syncthreads();
+  return status;
+}
+
+// ---------------------------------------------------------------- forward kernel
+// `accept`: value of the classification flag (meta[0]) this kernel serves for dense inputs.
+template <typename TI, typename TC, bool FUSED>
+__global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
+  const int Btot = FUSED ? SP.B : P.B;
+  const int scene_raw = blockIdx.x * 4 + row;
+  const int scene = scene_raw < Btot ? scene_raw : Btot - 1;           // tail rows shadow the last scene (never stored)
+  const int nz = FUSED ? 3 * SP.nb : P.nz, nc = FUSED ? SP.nc : (P.m >> 2), e = FUSED ? SP.e : P.e;
+  const int m = 4 * nc;
+  const int max_iter = FUSED ? SP.max_iter : P.max_iter, lim = FUSED ? SP.lim : P.lim;
+  const TC eps = (TC)(FUSED ? SP.eps : P.eps);
+  Ws<TI, TC> W(FUSED ? SP.ws : P.ws, scene);
+  bool live = scene_raw < Btot;
+  if (!FUSED) live = live && ((int)W.meta[0] == accept);
+  if (!__any(live)) return;
+  SceneQ<TI, TC> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
+  S.nz = nz; S.nc = nc; S.e = e; S.l16 = l16;
+  const bool vc = l16 < nc;                                              // this lane owns a contact
+  TC p, hn, b;
+  if (FUSED) {
+    assemble_q<TI, TC>(S, SP, scene, p, hn, b);
+    if (live && vc) W.meta[1 + l16] = S.mu;
+    if (live && l16 == 0) { W.meta[0] = (TC)2; W.meta[18] = (TC)1; }
+  } else {
+    load_dense_q<TI, TC>(S, P, W, scene, p, hn, b);
+  }
+  int status = prefactor_q<TI, TC>(S, W, live);
+
+  TC ta[32], tu[32];
+  RedQ<TC> R;
+  TC x = 0, y = 0;
+  M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), d = m4<TC>(1, 1, 1, 1);
+  TC bx = 0, by = 0;
+  M4<TC> bs = s, bz = z;
+  TC best_resid = inf_of<TC>();
+  bool have_best = false, done = !live;
+  int n_not = 0, iters = 0;
+  const TC mf = (TC)m;
+
+#pragma unroll 1
+  for (int it = -1; it < max_iter; ++it) {
+    if (!__any(!done)) break;
+    TC rx, ry, mu = 0, resid = 0;
+    M4<TC> rs, rz;
+    if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63)
+      rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); d = m4<TC>(1, 1, 1, 1);
+    } else {                                                               // residuals (:82-96)
+      rx = S.Gtw(z.n, z.f1 - z.f2) + S.qd * x + p;
+      if (e > 0) rx += S.Aty(y);
+      rs = z;
+      TC gn, gt;
+      S.Gv(x, gn, gt);
+      // F z is lane-local for the contact structure (engines.py:69-73)
+      rz = m4<TC>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (S.mu * z.n - (z.f1 + z.f2)));
+      if (!vc) rz = m4<TC>(0, 0, 0, 0);
+      ry = (e > 0) ? (S.Av(x) - b) : (TC)0;
+      const TC n_rx = row_sum((l16 < nz) ? rx * rx : (TC)0);
+      const TC n_rz = row_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
+      const TC n_ry = row_sum((l16 < e) ? ry * ry : (TC)0);
+      const TC sz = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
+      mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
+      resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
+      d = vc ? m4<TC>(z.n / s.n, z.f1 / s.f1, z.f2 / s.f2, z.g / s.g) : m4<TC>(1, 1, 1, 1);   // (:98)
+    }
+    const M4<TC> dinv = m4<TC>((TC)1 / d.n, (TC)1 / d.f1, (TC)1 / d.f2, (TC)1 / d.g);
+    const bool singular = row_any(factor_q<TI, TC>(ta, tu, R, S, W.R2, dinv, vc));           // (:99-100)
+    if (it >= 0 && !done) {
+      ++iters;
+      if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
+      else {
+        const bool improved = !have_best || (resid < best_resid);             // (:107-132)
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; bs = s; bz = z; by = y; }
+        else ++n_not;
+        if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
+      }
+    }
+    if (!__any(!done)) break;
+    TC ax = 0, ay = 0;
+    M4<TC> as_ = m4<TC>(0, 0, 0, 0), az = as_;
+    const int npass = (it < 0) ? 1 : 2;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      TC ox, oy;
+      M4<TC> os, oz;
+      solve_kkt_q<TI, TC>(S, ta, tu, R, d, vc, rx, rs, rz, ry, ox, os, oz, oy);
+      if (it < 0) {
+        x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
+        const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());
+        const TC zmin = row_pmin(vc ? pmin(pmin(z.n, z.f1), pmin(z.f2, z.g)) : inf_of<TC>());
+        if (smin <= (TC)0) { const TC sh = (TC)1 - smin; s = m4<TC>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
+        if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
+        if (!vc) { s = m4<TC>(1, 1, 1, 1); z = s; }
+      } else if (pass == 0) {
+        ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
+        const TC alpha = pmin(step_pair_q(z, az, s, as_, vc), (TC)1);        // (:142-144)
+        auto sc = [&](TC sv, TC dsv, TC zv, TC dzv) { return (sv + alpha * dsv) * (zv + alpha * dzv); };
+        const TC t3 = row_sum(vc ? (sc(s.n, as_.n, z.n, az.n) + sc(s.f1, as_.f1, z.f1, az.f1)) + (sc(s.f2, as_.f2, z.f2, az.f2) + sc(s.g, as_.g, z.g, az.g)) : (TC)0);
+        const TC t4 = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
+        const TC r3 = t3 / t4, sig = r3 * r3 * r3;                            // (:146-150)
+        const TC ms = -mu * sig;
+        rx = 0; ry = 0; rz = m4<TC>(0, 0, 0, 0);
+        rs = vc ? m4<TC>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
+                : m4<TC>(0, 0, 0, 0);                                         // (:153)
+      } else {
+        const TC cx = ox + ax, cy = oy + ay;                                  // (:160-163)
+        const M4<TC> cs = m4<TC>(os.n + as_.n, os.f1 + as_.f1, os.f2 + as_.f2, os.g + as_.g);
+        const M4<TC> cz = m4<TC>(oz.n + az.n, oz.f1 + az.f1, oz.f2 + az.f2, oz.g + az.g);
+        const TC alpha = pmin((TC)0.999 * step_pair_q(z, cz, s, cs, vc), (TC)1);   // (:164-166)
+        if (!done) {
+          x += alpha * cx; y += alpha * cy;                                   // (:171-174)
+          if (vc) {
+            s = m4<TC>(s.n + alpha * cs.n, s.f1 + alpha * cs.f1, s.f2 + alpha * cs.f2, s.g + alpha * cs.g);
+            z = m4<TC>(z.n + alpha * cz.n, z.f1 + alpha * cz.f1, z.f2 + alpha * cz.f2, z.g + alpha * cz.g);
+          }
+        }
+      }
+    }
+  }
+
+  // outputs (natural m-space order: n rows, friction pairs, gamma rows)
+  if (!live) return;
+  bool bad = (l16 < nz) && (bx != bx);
+  if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
+                (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
+  if (row_any(bad)) status |= LCP_ST_NAN;
+  if (l16 < nz) W.x[l16] = bx;
+  if (l16 < e) W.y[l16] = by;
+  if (vc) {
+    W.z[l16] = bz.n; W.z[nc + 2 * l16] = bz.f1; W.z[nc + 2 * l16 + 1] = bz.f2; W.z[3 * nc + l16] = bz.g;
+    W.s[l16] = bs.n; W.s[nc + 2 * l16] = bs.f1; W.s[nc + 2 * l16 + 1] = bs.f2; W.s[3 * nc + l16] = bs.g;
+  }
+  TI* zo = (TI*)(FUSED ? SP.z : P.z);
+  TI* so = (TI*)(FUSED ? SP.s : P.s);
+  TI* yo = (TI*)(FUSED ? SP.y : P.y);
+  if (vc && zo) {
+    TI* o = zo + (size_t)scene * m;
+    o[l16] = (TI)bz.n; o[nc + 2 * l16] = (TI)bz.f1; o[nc + 2 * l16 + 1] = (TI)bz.f2; o[3 * nc + l16] = (TI)bz.g;
+  }
+  if (vc && so) {
+    TI* o = so + (size_t)scene * m;
+    o[l16] = (TI)bs.n; o[nc + 2 * l16] = (TI)bs.f1; o[nc + 2 * l16 + 1] = (TI)bs.f2; o[3 * nc + l16] = (TI)bs.g;
+  }
+  if (l16 < e && yo) yo[(size_t)scene * e + l16] = (TI)by;
+  if (FUSED) {
+    if (l16 < nz) {
+      const TC nv = -bx;                                                      // engines.py:76-77
+      ((TI*)SP.v_new)[(size_t)scene * nz + l16] = (TI)nv;
+      ((TI*)SP.p_new)[(size_t)scene * nz + l16] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + l16] + nv * (TC)SP.dt);   // bodies.py:81
+    }
+    if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+  } else {
+    if (l16 < nz) ((TI*)P.x)[(size_t)scene * nz + l16] = (TI)bx;
+    if (l16 == 0) { if (P.iters) P.iters[scene] = iters; if (P.status) P.status[scene] = status; }
+  }
+}
+
+// ---------------------------------------------------------------- backward kernel (lcp.py:37-64)
+template <typename TI, typename TC>
+__global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene, int accept) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
+  const int scene_raw = blockIdx.x * 4 + row;
+  const int scene = scene_raw < P.B ? scene_raw : P.B - 1;
+  const int nz = P.nz, nc = P.m >> 2, e = P.e, m = P.m;
+  Ws<TI, TC> W(P.ws, scene);
+  const bool live = (scene_raw < P.B) && ((int)W.meta[0] == accept);
+  if (!__any(live)) return;
+  SceneQ<TI, TC> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
+  S.nz = nz; S.nc = nc; S.e = e; S.l16 = l16;
+  const bool vc = l16 < nc;
+  {
+    const TI* Grow_n = (const TI*)P.G + ((size_t)scene * m + (vc ? l16 : 0)) * nz;
+    const TI* Grow_t = (const TI*)P.G + ((size_t)scene * m + nc + 2 * (vc ? l16 : 0)) * nz;
+    static_for<16>([&](auto J) LCP_INL {
+      S.jc[J] = (vc && J < nz) ? Grow_n[J] : (TI)0;
+      S.jt[J] = (vc && J < nz) ? Grow_t[J] : (TI)0;
+      S.L.GL[l16 * 16 + J] = S.jc[J]; S.L.GTL[l16 * 16 + J] = S.jt[J];
+    });
+    const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
+    static_for<16>([&](auto K) LCP_INL {
+      S.arow[K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
+      if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+    });
+    static_for<EQ>([&](auto A_) LCP_INL {
+      S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
+      S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
+    });
+    S.qid = W.Qit[l16]; S.qd = 0;
+    S.mu = vc ? W.meta[1 + l16] : (TC)0;
+  }
+  __syncthreads();
+  const TC x = (l16 < nz) ? W.x[l16] : (TC)0, y = (l16 < e) ? W.y[l16] : (TC)0;
+  const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  const TC g = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
+  const M4<TC> d = m4<TC>(z.n / s.n, z.f1 / s.f1, z.f2 / s.f2, z.g / s.g);               // lcp.py:44
+  const M4<TC> dinv = m4<TC>((TC)1 / d.n, (TC)1 / d.f1, (TC)1 / d.f2, (TC)1 / d.g);
+  TC ta[32], tu[32];
+  RedQ<TC> R;
+  factor_q<TI, TC>(ta, tu, R, S, W.R2, dinv, vc);                                      // lcp.py:46
+  TC dx, dnu;
+  M4<TC> ds, dl;
+  const M4<TC> zero = m4<TC>(0, 0, 0, 0);
+  solve_kkt_q<TI, TC>(S, ta, tu, R, d, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu);     // lcp.py:47-50
+  if (!live) return;
+  // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
+  if (P.dp && l16 < nz) ((TI*)P.dp)[(size_t)scene * nz + l16] = (TI)dx;
+  if (P.db && l16 < e) ((TI*)P.db)[(size_t)scene * e + l16] = (TI)(-dnu);
+  if (P.dh && vc) {
+    TI* o = (TI*)P.dh + (size_t)scene * m;
+    o[l16] = (TI)(-dl.n); o[nc + 2 * l16] = (TI)(-dl.f1); o[nc + 2 * l16 + 1] = (TI)(-dl.f2); o[3 * nc + l16] = (TI)(-dl.g);
+  }
+  if (P.dQ) {
+    TI* o = (TI*)P.dQ + (size_t)scene * nz * nz;
+    static_for<16>([&](auto Rr) LCP_INL {
+      if (Rr < nz) { const TC dxr = bc<Rr>(dx), xr = bc<Rr>(x); if (l16 < nz) o[Rr * nz + l16] = (TI)((TC)0.5 * (dxr * x + xr * dx)); }
+    });
+  }
+  if (P.dA && e > 0) {
+    TI* o = (TI*)P.dA + (size_t)scene * e * nz;
+    static_for<EQ>([&](auto Rr) LCP_INL {
+      if (Rr < e) { const TC dn = bc<Rr>(dnu), yr = bc<Rr>(y); if (l16 < nz) o[Rr * nz + l16] = (TI)(dn * x + yr * dx); }
+    });
+  }
+  if (P.dG) {
+    TI* o = (TI*)P.dG + (size_t)scene * m * nz;
+    static_for<16>([&](auto C) LCP_INL {
+      if (C < nc) {
+        const TC a0 = bc<C>(dl.n), a1 = bc<C>(dl.f1), a2 = bc<C>(dl.f2), a3 = bc<C>(dl.g);
+        const TC b0 = bc<C>(z.n), b1 = bc<C>(z.f1), b2 = bc<C>(z.f2), b3 = bc<C>(z.g);
+        if (l16 < nz) {
+          o[(size_t)C * nz + l16] = (TI)(a0 * x + b0 * dx);
+          o[(size_t)(nc + 2 * C) * nz + l16] = (TI)(a1 * x + b1 * dx);
+          o[(size_t)(nc + 2 * C + 1) * nz + l16] = (TI)(a2 * x + b2 * dx);
+          o[(size_t)(3 * nc + C) * nz + l16] = (TI)(a3 * x + b3 * dx);
+        }
+      }
+    });
+  }
+  if (P.dF) {
+    TI* o = (TI*)P.dF + (size_t)scene * m * m;
+    // dF[i][j] = -dlam_i lam_j ; lane c' writes the four columns of its contact for every row i
+    static_for<16>([&](auto C) LCP_INL {
+      if (C < nc) {
+        const TC a0 = bc<C>(dl.n), a1 = bc<C>(dl.f1), a2 = bc<C>(dl.f2), a3 = bc<C>(dl.g);
+        if (vc) {
+          auto wr = [&](int i, TC dli) {
+            TI* r = o + (size_t)i * m;
+            r[l16] = (TI)(-dli * z.n); r[nc + 2 * l16] = (TI)(-dli * z.f1); r[nc + 2 * l16 + 1] = (TI)(-dli * z.f2); r[3 * nc + l16] = (TI)(-dli * z.g);
+          };
+          wr(C, a0); wr(nc + 2 * C, a1); wr(nc + 2 * C + 1, a2); wr(3 * nc + C, a3);
+        }
+      }
+    });
+  }
+}
+
+}  // namespace q16
+
+// ---------------------------------------------------------------- host-side launchers
+bool quad_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
+
+template <typename TC>
+static size_t q16_lds() { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr); }
+
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
+  StepArgs SP = {};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((P.B + 3) / 4), blk(64);
+  if (compute == LCP_COMPUTE_F64) {
+    const int ls = (int)q16_lds<double>();
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+  } else {
+    const int ls = (int)q16_lds<float>();
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+int quad_step(const StepArgs& SP, int compute, void* stream) {
+  FwdArgs P = {};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((SP.B + 3) / 4), blk(64);
+  if (compute == LCP_COMPUTE_F64) {
+    const int ls = (int)q16_lds<double>();
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+  } else {
+    const int ls = (int)q16_lds<float>();
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((P.B + 3) / 4), blk(64);
+  if (compute == LCP_COMPUTE_F64) {
+    const int ls = (int)q16_lds<double>();
+    hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double>), grid, blk, 4 * ls, st, P, ls, accept);
+  } else {
+    const int ls = (int)q16_lds<float>();
+    hipLaunchKernelGGL((q16::lcp_bwd_quad<float, float>), grid, blk, 4 * ls, st, P, ls, accept);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+}  // namespace lcp

@@ -17,16 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <utility>
-
-#include "lcp_device.h"
+#include "lcp_wave_common.h"
 
 namespace lcp {
 namespace w64 {
 
-constexpr int MP = 64;    // padded nineq (lanes)
-constexpr int NZP = 16;   // padded nz
-constexpr int EP = 8;     // padded neq
 constexpr int GRS = 17;   // row stride of the row-major G copy (bank-conflict-free group reads)
 // Scenes (waves) per workgroup.  The unrolled LU is far larger than the 64 KB instruction cache, so a
 // wave on its own streams its code from L2 every PDIPM iteration (measured: fetch-bound).  Putting WPB
@@ -42,19 +37,6 @@ constexpr int WPB = LCP_W64_WPB;
 #ifndef LCP_W64_SYNC_EVERY
 #define LCP_W64_SYNC_EVERY 1
 #endif
-
-// Compile-time loops: every index into the register-resident row t[] must be a constant the front end
-// can see (hipcc demotes the array to scratch otherwise - measured), so the unrolling is done with
-// templates rather than `#pragma unroll`.
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
-#define LCP_INL __attribute__((always_inline))
 
 // ---------------------------------------------------------------- lane primitives
 template <typename T> __device__ __forceinline__ T rdlane(T v, int src);
@@ -117,37 +99,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   }
   return v;
 }
-
-// 1/x by v_rcp + Newton steps (the IEEE division sequence is ~12 dependent instructions and sat on the
-// critical path of every elimination step).  Two steps for fp64 (v_rcp_f64 is ~26 bits), one for fp32.
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ float fast_rcp(float x) {
-  float r = __builtin_amdgcn_rcpf(x);
-  r = fmaf(fmaf(-x, r, 1.0f), r, r);
-  return r;
-}
-
-// 16-byte / 8-byte vector loads (the pointers are 16 B aligned by construction of the workspace)
-__device__ __forceinline__ void load4(const float* src, float& a, float& b, float& c, float& d) {
-  const float4 v = *reinterpret_cast<const float4*>(src); a = v.x; b = v.y; c = v.z; d = v.w;
-}
-__device__ __forceinline__ void load4(const double* src, double& a, double& b, double& c, double& d) {
-  const double2 u = *reinterpret_cast<const double2*>(src), v = *reinterpret_cast<const double2*>(src + 2);
-  a = u.x; b = u.y; c = v.x; d = v.y;
-}
-__device__ __forceinline__ void load2(const float* src, float& a, float& b) {
-  const float2 v = *reinterpret_cast<const float2*>(src); a = v.x; b = v.y;
-}
-__device__ __forceinline__ void load2(const double* src, double& a, double& b) {
-  const double2 v = *reinterpret_cast<const double2*>(src); a = v.x; b = v.y;
-}
-__device__ __forceinline__ void store2(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
-__device__ __forceinline__ void store2(double* dst, double a, double b) { *reinterpret_cast<double2*>(dst) = make_double2(a, b); }
 
 // ---------------------------------------------------------------- LU of T in registers
 // t[j] of lane i = T[i][j].  Rows never move: step k eliminates with pivot lane p_k.
@@ -289,7 +240,6 @@ __device__ __forceinline__ TC lu_solve(const TC (&t)[MP], TC w, int m, int lane,
 // backward stable at every PDIPM iterate (checked against the oracle: normwise backward error <= 1e-17
 // up to cond(T) = 6e19, tests/test_reduction_algebra.py), because the +/- duplicated friction rows that
 // make T numerically singular are removed analytically.  One eighth of the flops of the 4 nc system.
-constexpr int NR = 32;          // reduced size (2 nc <= 32)
 
 template <typename TC>
 __device__ __forceinline__ bool lu32_factor(TC (&t)[MP], int nr, int lane, TC& udinv) {
@@ -474,25 +424,6 @@ __host__ __device__ inline size_t carve(Lds<TI, TC>& L, unsigned char* smem, boo
   L.flag = (int*)take(16);
   return (size_t)(q - smem);
 }
-
-// workspace per scene:  [TC] R2[MP*MP] Qit[256] GAc[512] S11i[64] x[16] s[64] z[64] y[8] pad -> 5120 TC
-//                       [TI] Ft[MP*MP]   (lane-major copy of F: Ft[((j>>2)*MP + i)*4 + (j&3)] = F[i][j])
-constexpr size_t WS_TC = 5120;
-constexpr size_t WS_TI = MP * MP;
-template <typename TI, typename TC> __host__ __device__ inline size_t ws_bytes() { return WS_TC * sizeof(TC) + WS_TI * sizeof(TI); }
-
-template <typename TI, typename TC>
-struct Ws {
-  TC *R2, *Qit, *GAc, *S11i, *x, *s, *z, *y, *meta;     // meta[0] = structured flag, meta[1 + c] = mu of contact c
-  TI* Ft;
-  __device__ Ws(void* ws, int scene) {
-    unsigned char* base = (unsigned char*)ws + (size_t)scene * ws_bytes<TI, TC>();
-    TC* q = (TC*)base;
-    R2 = q; q += MP * MP; Qit = q; q += NZP * NZP; GAc = q; q += EP * MP; S11i = q; q += EP * EP;
-    x = q; q += NZP; s = q; q += MP; z = q; q += MP; y = q; q += EP; meta = q;   // 5080 + 19 <= WS_TC   (meta[18] = Q-is-diagonal flag)
-    Ft = (TI*)(base + WS_TC * sizeof(TC));
-  }
-};
 
 // ---------------------------------------------------------------- F operators (wave level)
 template <typename TI, typename TC>
@@ -889,7 +820,7 @@ __device__ __forceinline__ int prefactor(const Lds<TI, TC>& L, const Ws<TI, TC>&
   for (int i = lane; i < NZP * NZP; i += 64) W.Qit[i] = L.Qit[i];
   for (int i = lane; i < EP * MP; i += 64) W.GAc[i] = L.GAc[i];
   for (int i = lane; i < EP * EP; i += 64) W.S11i[i] = L.S11i[i];
-  if (lane == 0) W.meta[0] = structured ? (TC)1 : (TC)0;
+  if (lane == 0 && structured && W.meta[0] == (TC)0) W.meta[0] = (TC)1;   // (fused input: no classification ran)
   __threadfence_block();
   __syncthreads();
   return status;
@@ -1002,7 +933,8 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
   }
   qdiag = __all(qdiag);
   const bool all_ok = __all(ok);
-  if (lane == 0) { W.meta[0] = all_ok ? (TC)1 : (TC)0; W.meta[18] = qdiag ? (TC)1 : (TC)0; }
+  // meta[0]: 0 = general, 1 = contact-structured, 2 = contact-structured with diagonal Q (quad-kernel eligible)
+  if (lane == 0) { W.meta[0] = all_ok ? (qdiag ? (TC)2 : (TC)1) : (TC)0; W.meta[18] = qdiag ? (TC)1 : (TC)0; }
   if (all_ok && lane < nc) W.meta[1 + lane] = (TC)((const TI*)P.F)[(size_t)scene * m * m + (size_t)(3 * nc + lane) * m + lane];
 }
 
@@ -1010,7 +942,7 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
 // STRUCT = contact-structured path (reduced 2 nc system); FUSED implies STRUCT.  For dense inputs both
 // instantiations are launched and each scene is served by the one its classification flag selects.
 template <typename TI, typename TC, bool PIVOT, bool FUSED, bool STRUCT>
-__global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave) {
+__global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave, int skip2) {
   static_assert(STRUCT || !FUSED, "the fused step is always contact-structured");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1029,7 +961,10 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   int status;
   FDenseW<TI, TC> Fd{FUSED ? nullptr : (const TI*)P.F + (size_t)scene * m * m, W.Ft, m};
   constexpr bool structured = STRUCT;
-  if (!FUSED) { if ((W.meta[0] != (TC)0) != STRUCT) return; }     // not this kernel's scene
+  if (!FUSED) {                                                    // not this kernel's scene ?
+    if ((W.meta[0] != (TC)0) != STRUCT) return;
+    if (STRUCT && skip2 && W.meta[0] == (TC)2) return;               // served by the quad kernel
+  }
   const int nc = m >> 2;
   Red<TC> RD;
   RD.init(nc, lane, m);
@@ -1061,6 +996,13 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   int n_not = 0, iters = 0;
   double* trace = (!FUSED && P.trace) ? P.trace + (size_t)scene * 4 * max_iter : nullptr;
 
+#ifdef LCP_W64_PROFILE
+  long long pc_res = 0, pc_fac = 0, pc_sol = 0, pc_mid = 0;
+#define LCP_TICK(var) { const long long now_ = clock64(); var += now_ - tick_; tick_ = now_; }
+  long long tick_ = clock64();
+#else
+#define LCP_TICK(var)
+#endif
 #pragma unroll 1
   for (int it = -1; it < max_iter; ++it) {
     TC rx, rs, rz, ry, mu = 0, resid = 0;
@@ -1083,8 +1025,10 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + (TC)m * mu;
       d = vm ? z / s : (TC)1;                                               // (:98)
     }
+    LCP_TICK(pc_res)
     const bool singular = factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1,
                                                        mystep, porder, udinv);                // (:99-100)
+    LCP_TICK(pc_fac)
     if (it >= 0) {
       ++iters;
       if (trace && lane == 0) { trace[4 * it] = (double)resid; trace[4 * it + 1] = (double)mu; }
@@ -1100,7 +1044,9 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
       TC ox, os, oz, oy;
+      LCP_TICK(pc_mid)
       solve_kkt<TI, TC, PIVOT, STRUCT>(O, t, mystep, porder, udinv, RD, structured, d, rx, rs, rz, ry, ox, os, oz, oy);
+      LCP_TICK(pc_sol)
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
         TC smin = vm ? s : inf_of<TC>(), zmin = vm ? z : inf_of<TC>();
@@ -1127,6 +1073,9 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
     }
   }
 
+#ifdef LCP_W64_PROFILE
+  if (trace && lane == 0) { trace[0] = (double)pc_res; trace[1] = (double)pc_fac; trace[2] = (double)pc_sol; trace[3] = (double)pc_mid; trace[4] = (double)iters; }
+#endif
   // outputs: best iterate (x-space lanes < nz, m-space lanes < m, e-space lanes < e)
   int bad = 0;
   if (lane < nz) { W.x[lane] = bx; bad |= (bx != bx); }
@@ -1154,7 +1103,7 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
 
 // ---------------------------------------------------------------- the backward kernel (lcp.py:37-64)
 template <typename TI, typename TC, bool PIVOT, bool STRUCT>
-__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave) {
+__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave, int skip2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int scene = blockIdx.x * WPB + wave;
@@ -1166,6 +1115,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   O.nz = nz; O.m = m; O.e = e; O.lane = lane;
   Ws<TI, TC> W(P.ws, scene);
   if ((W.meta[0] != (TC)0) != STRUCT) return;                     // served by the other instantiation
+  if (STRUCT && skip2 && W.meta[0] == (TC)2) return;              // served by the quad kernel
   const bool vm = lane < m;
   zero_lds_inputs(O.L, lane);
   __syncthreads();
@@ -1272,17 +1222,21 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
-  // classify, then the structured and the general solver (each scene is picked up by exactly one)
+  const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
+  // classify, then: quad kernel (structured + diagonal Q), wave64 structured kernel, general kernel -
+  // every scene is picked up by exactly one of them.
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
+    if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
   } else {
     const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), ls, P, SP, ls);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, false>), w64_grid(P.B), lw, P, SP, lw);
+    if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1291,12 +1245,13 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   FwdArgs P = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
+  if (quad_supported(3 * SP.nb, 4 * SP.nc, SP.e)) return quad_step(SP, compute, stream);
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(false);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, true, true>), w64_grid(SP.B), lw, P, SP, lw, 0);
   } else {
     const int lw = (int)w64_lds<float>(false);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true, true>), w64_grid(SP.B), lw, P, SP, lw);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, true, true>), w64_grid(SP.B), lw, P, SP, lw, 0);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1304,14 +1259,16 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
 int wave64_backward(const BwdArgs& P, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
+  const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
+  if (quad) { int rc = quad_backward(P, compute, 2, stream); if (rc) return rc; }
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw, 0);
   } else {
     const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), ls, P, ls);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, lw);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), ls, P, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, lw, 0);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(64) k(T* out, long long* cyc, int reps, int pl
   const int lane = threadIdx.x;
   T t[NP];
   sfor<NP>([&](auto J) INL { t[J] = (T)(lane + J) * (T)1e-3; });
-  T l = (T)1e-9 * lane;
+  T l = (T)1e-9 * lane, l2 = (T)2e-9 * lane;
   long long t0 = clock64();
   for (int r = 0; r < reps; ++r) {
     const int p = (pl + r) & 63;
@@ -27,6 +27,20 @@ __global__ void __launch_bounds__(64) k(T* out, long long* cyc, int reps, int pl
       sfor<NP>([&](auto J) INL { t[J] = fma(-l, rdl(t[J], p), t[J]); });
     } else if (MODE == 6) {          // broadcast through ds_bpermute (VGPR result, no SGPR hazard)
       sfor<NP>([&](auto J) INL { t[J] = fma(-l, __shfl(t[J], p, 64), t[J]); });
+    } else if (MODE == 10) {         // DPP row_newbcast (lane (r&15) of every 16-lane row -> that row) + 2 FMAs
+      sfor<NP / 2>([&](auto J) INL {
+        constexpr int ctrl = 0x150 + (J % 16);
+        T sj;
+        if constexpr (sizeof(T) == 8) {
+          const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(t[J]), ctrl, 0xf, 0xf, true);
+          const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(t[J]), ctrl, 0xf, 0xf, true);
+          sj = __hiloint2double(hi, lo);
+        } else {
+          sj = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t[J]), ctrl, 0xf, 0xf, true));
+        }
+        t[J] = fma(-l, sj, t[J]);
+        t[J + NP / 2] = fma(-l2, sj, t[J + NP / 2]);
+      });
     } else if (MODE == 7 || MODE == 8 || MODE == 9) {   // batched: G readlane pairs first, then G fmas
       constexpr int G = (MODE == 7) ? 4 : (MODE == 8) ? 8 : 16;
       sfor<NP / G>([&](auto B) INL {
@@ -117,6 +131,8 @@ int main() {
     run("pair f64 batched 8", k<double, 8, 48>, blocks, reps, 48, o);
     run("pair f64 batched 16", k<double, 9, 48>, blocks, reps, 48, o);
     run("pair f32 batched 16", k<float, 9, 48>, blocks, reps, 48, of);
+    run("dpp newbcast f64: 24 bcast + 48 fma", k<double, 10, 48>, blocks, reps, 48, o);
+    run("dpp newbcast f32: 24 bcast + 48 fma", k<float, 10, 48>, blocks, reps, 48, of);
     run("fma f64 only x48", k<double, 2, 48>, blocks, reps, 48, o);
     run("fma f32 only x48", k<float, 3, 48>, blocks, reps, 48, of);
     run2("mfma f64 16x16x4 x4", kmfma<1>, blocks, reps, 4, o);
