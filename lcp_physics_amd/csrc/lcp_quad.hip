@@ -68,6 +68,12 @@ __device__ __forceinline__ bool row_any(bool p) { return row_max(p ? 1.0f : 0.0f
 template <typename T> __device__ __forceinline__ T row_pmax(T v) { const bool n = row_any(v != v); v = row_max(v); return n ? nan_of<T>() : v; }
 template <typename T> __device__ __forceinline__ T row_pmin(T v) { const bool n = row_any(v != v); v = row_min(v); return n ? nan_of<T>() : v; }
 
+// Opaque pass-through: stops LICM from hoisting loop-invariant LDS loads / float->double conversions of the
+// Jacobian rows out of the PDIPM loop (it did, and the ~200 extra live registers spilled to scratch).
+template <typename T> __device__ __forceinline__ T* launder(T* p) { asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ float launder(float f) { asm volatile("" : "+v"(f)); return f; }
+__device__ __forceinline__ double launder(double f) { asm volatile("" : "+v"(f)); return f; }
+
 template <typename TC> struct M4 { TC n, f1, f2, g; };       // the four inequality rows of one contact
 template <typename TC> __device__ __forceinline__ M4<TC> m4(TC a, TC b, TC c, TC d) { M4<TC> r; r.n = a; r.f1 = b; r.f2 = c; r.g = d; return r; }
 template <typename TC> __device__ __forceinline__ TC sum4(const M4<TC>& a) { return (a.n + a.f1) + (a.f2 + a.g); }
@@ -99,7 +105,6 @@ struct SceneQ {
   LdsQ<TI, TC> L;
   int nz, nc, e, l16;
   TI jc[16], jt[16];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
-  TI arow[16];            // row l16 of A (lanes < e)
   TC gan[EQ], gat[EQ];    // (J Q^-1 A^T) rows of this contact
   TC s11row[EQ];          // row l16 of (A Q^-1 A^T)^-1
   TC qd, qid;             // Q[j][j], 1 / Q[j][j] for j = l16
@@ -108,25 +113,29 @@ struct SceneQ {
   // m-space <- x-space:  (Jc v)_c and (Jt v)_c
   __device__ __forceinline__ void Gv(TC v, TC& gn, TC& gt) const {
     gn = 0; gt = 0;
-    static_for<16>([&](auto J) LCP_INL { const TC vb = bc<J>(v); gn = fma((TC)jc[J], vb, gn); gt = fma((TC)jt[J], vb, gt); });
+    static_for<16>([&](auto J) LCP_INL { const TC vb = bc<J>(v); gn = fma((TC)launder(jc[J]), vb, gn); gt = fma((TC)launder(jt[J]), vb, gt); });
   }
   // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
   __device__ __forceinline__ TC Gtw(TC wn, TC wt) const {
     TC acc = 0;
+    const TI* gl = launder(L.GL) + l16;
+    const TI* gtl = launder(L.GTL) + l16;
     static_for<16>([&](auto C) LCP_INL {
-      acc = fma((TC)L.GL[C * 16 + l16], bc<C>(wn), acc);
-      acc = fma((TC)L.GTL[C * 16 + l16], bc<C>(wt), acc);
+      acc = fma((TC)gl[C * 16], bc<C>(wn), acc);
+      acc = fma((TC)gtl[C * 16], bc<C>(wt), acc);
     });
     return acc;
   }
   __device__ __forceinline__ TC Av(TC v) const {        // e-space <- x-space
     TC acc = 0;
-    static_for<16>([&](auto K) LCP_INL { acc = fma((TC)arow[K], bc<K>(v), acc); });
-    return acc;
+    const TI* ar = launder(L.AtL) + (l16 & (EQ - 1)) * 16;       // row l16 of A (rows >= e are zero; lanes >= EQ unused)
+    static_for<16>([&](auto K) LCP_INL { acc = fma((TC)ar[K], bc<K>(v), acc); });
+    return (l16 < EQ) ? acc : (TC)0;
   }
   __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
     TC acc = 0;
-    static_for<EQ>([&](auto A) LCP_INL { acc = fma((TC)L.AtL[A * 16 + l16], bc<A>(y), acc); });
+    const TI* at = launder(L.AtL) + l16;
+    static_for<EQ>([&](auto A) LCP_INL { acc = fma((TC)at[A * 16], bc<A>(y), acc); });
     return acc;
   }
   __device__ __forceinline__ void GAt(TC t, TC& gn, TC& gt) const {     // m-space <- e-space
@@ -333,8 +342,7 @@ __device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P
   });
   const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
   static_for<16>([&](auto K) LCP_INL {
-    S.arow[K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
-    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
   });
   const TI q = (l16 < nz) ? ((const TI*)P.Q)[(size_t)scene * nz * nz + l16 * nz + l16] : (TI)1;
   S.qd = (l16 < nz) ? (TC)q : (TC)0;
@@ -371,8 +379,7 @@ __device__ __forceinline__ void assemble_q(SceneQ<TI, TC>& S, const StepArgs& P,
   static_for<16>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * 16 + J]; S.jt[J] = S.L.GTL[l16 * 16 + J]; });   // own row only
   const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
   static_for<16>([&](auto K) LCP_INL {
-    S.arow[K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
-    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
   });
   const TI q = (l16 < nz) ? Md[l16] : (TI)1;
   S.qd = (l16 < nz) ? (TC)q : (TC)0;
@@ -492,8 +499,6 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   RedQ<TC> R;
   TC x = 0, y = 0;
   M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), d = m4<TC>(1, 1, 1, 1);
-  TC bx = 0, by = 0;
-  M4<TC> bs = s, bz = z;
   TC best_resid = inf_of<TC>();
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
@@ -531,8 +536,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
       else {
         const bool improved = !have_best || (resid < best_resid);             // (:107-132)
-        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; bs = s; bz = z; by = y; }
-        else ++n_not;
+        if (improved) {                                                       // best iterate -> workspace
+          best_resid = resid; n_not = 0; have_best = true;
+          if (l16 < nz) W.x[l16] = x;
+          if (l16 < e) W.y[l16] = y;
+          if (vc) {
+            W.z[l16] = z.n; W.z[nc + 2 * l16] = z.f1; W.z[nc + 2 * l16 + 1] = z.f2; W.z[3 * nc + l16] = z.g;
+            W.s[l16] = s.n; W.s[nc + 2 * l16] = s.f1; W.s[nc + 2 * l16 + 1] = s.f2; W.s[3 * nc + l16] = s.g;
+          }
+        } else ++n_not;
         if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
       }
     }
@@ -579,18 +591,16 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     }
   }
 
-  // outputs (natural m-space order: n rows, friction pairs, gamma rows)
+  // outputs (natural m-space order: n rows, friction pairs, gamma rows): read the best iterate back
   if (!live) return;
+  __threadfence_block();
+  const TC bx = (l16 < nz) ? W.x[l16] : (TC)0, by = (l16 < e) ? W.y[l16] : (TC)0;
+  const M4<TC> bz = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  const M4<TC> bs = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   bool bad = (l16 < nz) && (bx != bx);
   if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
                 (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
   if (row_any(bad)) status |= LCP_ST_NAN;
-  if (l16 < nz) W.x[l16] = bx;
-  if (l16 < e) W.y[l16] = by;
-  if (vc) {
-    W.z[l16] = bz.n; W.z[nc + 2 * l16] = bz.f1; W.z[nc + 2 * l16 + 1] = bz.f2; W.z[3 * nc + l16] = bz.g;
-    W.s[l16] = bs.n; W.s[nc + 2 * l16] = bs.f1; W.s[nc + 2 * l16 + 1] = bs.f2; W.s[3 * nc + l16] = bs.g;
-  }
   TI* zo = (TI*)(FUSED ? SP.z : P.z);
   TI* so = (TI*)(FUSED ? SP.s : P.s);
   TI* yo = (TI*)(FUSED ? SP.y : P.y);
@@ -641,8 +651,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
     });
     const TI* A = (const TI*)P.A + (size_t)scene * e * nz;
     static_for<16>([&](auto K) LCP_INL {
-      S.arow[K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
-      if (l16 < EQ) S.L.AtL[l16 * 16 + K] = S.arow[K];
+      if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
     });
     static_for<EQ>([&](auto A_) LCP_INL {
       S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
