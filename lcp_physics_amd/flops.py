@@ -32,3 +32,8 @@ def bytes_backward(nz, m, e, word=4):
     rd = word * (nz * nz + m * nz + e * nz + m * m) + word * (nz + 2 * m + e) + word * nz
     wr = word * (nz * nz + nz + m * nz + m + e * nz + e + m * m)
     return rd + wr
+
+
+def bytes_fused_step(nb, nc, word=4):
+    """Fused boundary: contact list + body state in, new velocity + pose out."""
+    return word * (14 * nb + 7 * nc) + 8 * nc + word * 6 * nb

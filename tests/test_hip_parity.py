@@ -326,6 +326,57 @@ def test_fused_step_equals_assemble_then_solve(kernel_path):
     assert int((out["iters"] - sol.iters).abs().max()) <= 1
 
 
+def test_mixed_batch_every_scene_served_by_the_right_kernel(kernel_path):
+    """One batch holding all three classes: contact-structured + diagonal Q (quad kernel), contact-structured
+    with a dense SPD Q (wave64 structured kernel) and unstructured dense LCPs (general kernel).  B = 13 also
+    exercises the partially filled last wavefront of the 4-scenes-per-wave kernel."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    B = 13
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=31, dtype=torch.float32)
+    Q, p, G, h, A, b, F = [t.clone() for t in O.assemble_lcp(*sc.assembly_args())]
+    nz, m = Q.shape[1], G.shape[1]
+    g = torch.Generator().manual_seed(3)
+    for i in range(4, 8):                                   # dense SPD Q, structure of G / F untouched
+        L = torch.randn(nz, nz, generator=g)
+        Q[i] = Q[i] + 0.05 * (L @ L.t()) * Q[i].diagonal().min()
+    rq, rp, rG, rh, rA, rb, rF = scenes.make_random_lcp(5, nz, m, 3, seed=77, dtype=torch.float32)
+    Q[8:], p[8:], G[8:], h[8:], A[8:], b[8:], F[8:] = rq, rp, rG, rh, rA, rb, rF      # unstructured
+    lcp32 = [Q, p, G, h, A, b, F]
+    lcp64 = [t.double() for t in lcp32]
+    ref = O.lcp_forward(*lcp64)
+    sol = _solve(lcp32, torch.float32)
+    _check_forward(sol, ref, Q, p, TOL_X32, "mixed")
+    if kernel_path == "wave64":
+        from lcp_physics_amd import _lib
+        import ctypes
+        # classification flags live in the workspace: meta[0] of each scene (see lcp_wave_common.h `Ws`)
+        stride = _lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) // B
+        flags = sol.ws.view(torch.float64).reshape(B, stride // 8)[:, 5080].cpu()
+        assert flags.tolist() == [2.0] * 4 + [1.0] * 4 + [0.0] * 5
+    cot = torch.randn(B, nz, generator=g, dtype=torch.float32)
+    gref = O.lcp_backward(ref, *lcp64, cot.double())
+    grads = lcp_backward(sol, cot.to(DEV))
+    torch.cuda.synchronize()
+    fl = parity.grad_floors(lcp64[0], lcp64[1], cot.double(), ref.x, ref.z, ref.y)
+    errs = parity.err_grads({"p": grads[1].double().cpu(), "Q": grads[0].double().cpu()}, {"p": gref["dp"], "Q": gref["dQ"]}, fl)
+    assert max(float(e.max()) for e in errs.values()) < TOL_G32, {k: float(v.max()) for k, v in errs.items()}
+
+
+@pytest.mark.parametrize("B", [1, 3, 6])
+def test_fused_step_partial_wavefronts(B):
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    sc = scenes.make_stack_scenes(B=B, nbox=2, pts_per_interface=2, seed=40 + B, dtype=torch.float32).to(device=DEV)
+    lcp = [None if t is None else t.double().cpu() for t in assemble_contacts(sc)]
+    ref = O.lcp_forward(*lcp)
+    out = fused_step(sc)
+    torch.cuda.synchronize()
+    ex = parity.err_x(-out["v_new"].double().cpu().reshape(B, -1), ref.x, lcp[0], lcp[1])
+    assert float(ex.max()) <= TOL_X32
+    assert torch.equal(out["iters"].cpu(), ref.iters)
+
+
 # ------------------------------------------------------------------ full BASELINE size: properties
 def test_full_size_config3_properties():
     """B = 4096 x 16 contacts (nineq 64): size-independent properties + sampled oracle parity."""
