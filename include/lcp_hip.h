@@ -127,6 +127,36 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
                        float* v_new, float* p_new, float* z, float* s, float* y,
                        int32_t* iters, int32_t* status, void* ws, void* stream);
 
+/* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the
+ * contact generation it calls, for B independent scenes in one launch:
+ *   Body.move (physics/bodies.py:80-82)         p_try = p_start + v dt
+ *   World.find_contacts (world.py:139-142)      all body pairs i < j (the reference delegates the
+ *                                               broadphase to ODE; `no_contact[B,nb,nb]` != 0 skips a pair)
+ *   DiffContactHandler.__call__ (physics/contacts.py:57-205) circle/circle, circle/hull (GJK + SAT),
+ *                                               hull/hull (SAT, incident edge, clipping), with its helpers
+ *                                               (contacts.py:207-352) and rotate_verts (bodies.py:211-214)
+ *   the penetration test and dt halving (world.py:95-101): while any contact penetrates by more than
+ *   `tol`, dt <- dt / 2 and retry from p_start; `strict` = strict_no_penetration, `dt_floor` = world.dt / 4
+ *   (non-strict worlds accept once dt < dt_floor).  The loop is per scene and runs on the device;
+ *   `max_trials` bounds it (the reference would spin forever on a pose that penetrates at dt -> 0).
+ * Geometry and poses are fp64 (tol = 1e-6 against coordinates of several hundred cannot be resolved in
+ * fp32); the contact frame handed to the LCP kernels is fp32.
+ *   in : kind[B,nb] (0 circle, 1 hull)  radius[B,nb]  verts_local[B,nb,8,2] (body frame, CCW as the
+ *        reference's Hull.verts)  nverts[B,nb]  p_start[B,nb,3] (rot,x,y)  v[B,nb,3] (NULL: detect at p_start)
+ *   out: p_out[B,nb,3]  c_n/c_p1/c_p2[B,maxc,2]  c_pen[B,maxc]  c_i1/c_i2[B,maxc]  count[B] (contacts found,
+ *        in the reference's order; > maxc means the list was truncated)  max_pen[B]  dt_used[B]
+ *        t[B] (+= dt_used)  trials[B]   (c_pen, max_pen, dt_used, t, trials, p_out may be NULL)
+ * nb <= 16, hulls of <= 8 vertices. */
+int lcp_move_find_contacts_f64(int B, int nb, int maxc,
+                               const int32_t* kind, const double* radius, const double* verts_local,
+                               const int32_t* nverts, const uint8_t* no_contact,
+                               const double* p_start, const float* v,
+                               double dt, double dt_floor, int strict, int max_trials,
+                               double eps, double tol,
+                               double* p_out, float* c_n, float* c_p1, float* c_p2, double* c_pen,
+                               int32_t* c_i1, int32_t* c_i2, int32_t* count, double* max_pen,
+                               double* dt_used, double* t, int32_t* trials, void* stream);
+
 /* ---- debugging / A-B aids (not part of the drop-in surface) ----
  * lcp_debug_set_trace: when non-NULL, the dense forward writes trace[B, max_iter, 4] =
  *   (resid, mu, sigma, alpha) per PDIPM iteration (device pointer to doubles).

@@ -166,4 +166,23 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
+int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,
+                               const double* verts_local, const int32_t* nverts, const uint8_t* no_contact,
+                               const double* p_start, const float* v, double dt, double dt_floor, int strict,
+                               int max_trials, double eps, double tol, double* p_out, float* c_n, float* c_p1,
+                               float* c_p2, double* c_pen, int32_t* c_i1, int32_t* c_i2, int32_t* count,
+                               double* max_pen, double* dt_used, double* t, int32_t* trials, void* stream) {
+  if (B <= 0 || nb <= 0 || maxc <= 0 || max_trials <= 0) return LCP_E_BADARG;
+  if (!kind || !radius || !verts_local || !nverts || !p_start) return LCP_E_BADARG;
+  if (!c_n || !c_p1 || !c_p2 || !c_i1 || !c_i2 || !count) return LCP_E_BADARG;
+  lcp::ContactArgs P;
+  memset(&P, 0, sizeof(P));
+  P.B = B; P.nb = nb; P.maxc = maxc; P.kind = kind; P.nverts = nverts; P.radius = radius;
+  P.verts_local = verts_local; P.no_contact = no_contact; P.p_start = p_start; P.v = v;
+  P.dt = dt; P.dt_floor = dt_floor; P.eps = eps; P.tol = tol; P.strict = strict; P.max_trials = max_trials;
+  P.p_out = p_out; P.c_n = c_n; P.c_p1 = c_p1; P.c_p2 = c_p2; P.c_pen = c_pen; P.c_i1 = c_i1; P.c_i2 = c_i2;
+  P.count = count; P.max_pen = max_pen; P.dt_used = dt_used; P.t = t; P.trials = trials;
+  return lcp::contacts_launch(P, stream);
+}
+
 }  // extern "C"

@@ -55,6 +55,23 @@ struct StepArgs {
   int ldT, t_in_lds;
 };
 
+struct ContactArgs {
+  int B, nb, maxc;
+  const int32_t *kind, *nverts;         // [B, nb]  0 = circle, 1 = hull ; vertex count of a hull
+  const double *radius, *verts_local;   // [B, nb], [B, nb, 8, 2] (body frame)
+  const uint8_t* no_contact;            // [B, nb, nb] pairs to skip, or NULL
+  const double* p_start;                // [B, nb, 3] (rot, x, y)
+  const float* v;                       // [B, nb, 3] or NULL (detect at p_start)
+  double dt, dt_floor, eps, tol;
+  int strict, max_trials;
+  double* p_out;
+  float *c_n, *c_p1, *c_p2;
+  double* c_pen;
+  int32_t *c_i1, *c_i2, *count;
+  double *max_pen, *dt_used, *t;
+  int32_t* trials;
+};
+
 // generic (any size) path - lcp_generic.hip
 Plan make_plan(int nz, int m, int e, int csize);
 int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
@@ -76,5 +93,8 @@ bool quad_supported(int nz, int m, int e);
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream);
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
 int quad_step(const StepArgs& P, int compute, void* stream);
+
+// narrow-phase contact generation + position update - lcp_contacts.hip
+int contacts_launch(const ContactArgs& P, void* stream);
 
 }  // namespace lcp

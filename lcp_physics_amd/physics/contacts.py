@@ -1,0 +1,127 @@
+"""Batched narrow-phase contact generation on the GPU.
+
+Host-side mirror of the reference's contact pipeline for B independent scenes:
+`World.find_contacts` (`physics/world.py:139-142`) + `DiffContactHandler.__call__`
+(`physics/contacts.py:57-205`) + the move / penetration-check / dt-halving loop of `World.step_dt`
+(`world.py:88-101`), all inside ONE launch of `lcp_move_find_contacts_f64` (include/lcp_hip.h).
+The contact record has the reference's format `((normal, p1, p2, penetration), i1, i2)`
+(`contacts.py:203-204`), stored structure-of-arrays and padded to `maxc` contacts per scene with a
+per-scene `count`.  No CPU fallback.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+CIRCLE, HULL = 0, 1
+NV = 8                   # vertex capacity of a hull (lcp_contacts.hip)
+EPSILON = 0.1            # physics/utils.py:16  (contact detection margin)
+TOL = 1e-6               # physics/utils.py:17  (allowed penetration)
+
+
+@dataclass
+class GeometryBatch:
+    """Collision geometry of the bodies of B scenes (constant over a simulation).
+
+    kind [B,nb] int32 (0 circle, 1 hull), radius [B,nb] f64, verts_local [B,nb,8,2] f64 (body frame, the
+    order of the reference's `Hull.verts`), nverts [B,nb] int32, no_contact [B,nb,nb] uint8 or None
+    (the pairs `World` excludes through `add_no_contact`, bodies.py:117-118)."""
+    kind: torch.Tensor
+    radius: torch.Tensor
+    verts_local: torch.Tensor
+    nverts: torch.Tensor
+    no_contact: torch.Tensor = None
+
+    @property
+    def B(self):
+        return self.kind.shape[0]
+
+    @property
+    def nb(self):
+        return self.kind.shape[1]
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device).contiguous()
+        return GeometryBatch(mv(self.kind), mv(self.radius), mv(self.verts_local), mv(self.nverts), mv(self.no_contact))
+
+    @staticmethod
+    def from_shapes(shapes, B=1):
+        """`shapes`: per body ('circle', rad) or ('rect', (w, h)) or ('hull', verts[nv,2]); replicated B times."""
+        nb = len(shapes)
+        kind = torch.zeros(nb, dtype=torch.int32)
+        radius = torch.zeros(nb, dtype=torch.float64)
+        verts = torch.zeros(nb, NV, 2, dtype=torch.float64)
+        nverts = torch.zeros(nb, dtype=torch.int32)
+        for i, (k, a) in enumerate(shapes):
+            if k == "circle":
+                kind[i], radius[i] = CIRCLE, float(a)
+            else:
+                if k == "rect":                      # bodies.py:261-264: [half, half * (-1, 1), -half, -half * (-1, 1)]
+                    hw, hh = float(a[0]) / 2, float(a[1]) / 2
+                    vs = [[hw, hh], [-hw, hh], [-hw, -hh], [hw, -hh]]
+                else:
+                    vs = np.asarray(a, dtype=np.float64).tolist()
+                if len(vs) > NV:
+                    raise ValueError("hulls are limited to %d vertices" % NV)
+                kind[i], nverts[i] = HULL, len(vs)
+                verts[i, :len(vs)] = torch.tensor(vs, dtype=torch.float64)
+        rep = lambda t: t.unsqueeze(0).repeat(B, *([1] * t.dim())).contiguous()
+        return GeometryBatch(rep(kind), rep(radius), rep(verts), rep(nverts), None)
+
+
+class ContactBuffers:
+    """Device buffers the contact kernel fills (allocated once, re-used every step)."""
+
+    def __init__(self, B, nb, maxc, device):
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        f64 = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        self.maxc = maxc
+        self.p_out = f64(B, nb, 3)
+        self.c_n, self.c_p1, self.c_p2 = f32(B, maxc, 2), f32(B, maxc, 2), f32(B, maxc, 2)
+        self.c_pen = f64(B, maxc)
+        self.c_i1, self.c_i2 = i32(B, maxc), i32(B, maxc)
+        self.count, self.trials = i32(B), i32(B)
+        self.max_pen, self.dt_used = f64(B), f64(B)
+
+
+def move_and_find_contacts(geom, p_start, v, dt, maxc=16, eps=EPSILON, tol=TOL, strict=True, dt_floor=None,
+                           max_trials=64, t=None, out=None):
+    """`p <- p_start + v dt`, contacts at the new pose, dt halving while a contact penetrates by more than `tol`
+    (`world.py:88-101`) for every scene.  `v=None` detects at `p_start` (the `find_contacts()` of
+    `World.__init__`, `world.py:65-66`).  Returns the `ContactBuffers` (p_out = accepted pose)."""
+    lib = _lib.load()
+    B, nb = geom.B, geom.nb
+    _lib.require_gpu_tensor(geom.kind, "kind", torch.int32)
+    _lib.require_gpu_tensor(geom.nverts, "nverts", torch.int32)
+    _lib.require_gpu_tensor(geom.radius, "radius", torch.float64)
+    _lib.require_gpu_tensor(geom.verts_local, "verts_local", torch.float64)
+    _lib.require_gpu_tensor(p_start, "p_start", torch.float64)
+    if tuple(p_start.shape) != (B, nb, 3) or tuple(geom.verts_local.shape) != (B, nb, NV, 2):
+        raise RuntimeError("p_start must be [B,nb,3] and verts_local [B,nb,%d,2]" % NV)
+    if v is not None:
+        _lib.require_gpu_tensor(v, "v", torch.float32)
+    if geom.no_contact is not None:
+        _lib.require_gpu_tensor(geom.no_contact, "no_contact", torch.uint8)
+    if t is not None:
+        _lib.require_gpu_tensor(t, "t", torch.float64)
+    dev = p_start.device
+    if out is None:
+        out = ContactBuffers(B, nb, maxc, dev)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_move_find_contacts_f64(
+            B, nb, out.maxc, P(geom.kind), P(geom.radius), P(geom.verts_local), P(geom.nverts), P(geom.no_contact),
+            P(p_start), P(v), float(dt), float(dt / 4 if dt_floor is None else dt_floor), int(bool(strict)),
+            int(max_trials), float(eps), float(tol), P(out.p_out), P(out.c_n), P(out.c_p1), P(out.c_p2),
+            P(out.c_pen), P(out.c_i1), P(out.c_i2), P(out.count), P(out.max_pen), P(out.dt_used), P(t),
+            P(out.trials), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_move_find_contacts_f64")
+    return out
+
+
+def find_contacts(geom, p, maxc=16, eps=EPSILON, out=None):
+    """`World.find_contacts` (`world.py:139-142`) for every scene at pose `p` [B,nb,3] (float64)."""
+    return move_and_find_contacts(geom, p, None, 0.0, maxc=maxc, eps=eps, out=out, max_trials=1)

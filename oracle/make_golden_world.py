@@ -1,0 +1,116 @@
+"""Generate tests/golden/world_traj.npz: trajectories of the UNMODIFIED reference `World` (physics/world.py,
+through oracle/ref_shim.py) for small scenes that exercise contact creation, the penetration check with dt
+halving (world.py:88-101) and the no-contact branch of the engine (engines.py:36-50).
+TEST INFRASTRUCTURE ONLY; needs /root/reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_world.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _scenes():
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import TotalConstraint
+    from lcp_physics.physics.forces import Gravity
+
+    def floor():
+        r = Rect([500, 500], [900, 10])
+        return r, TotalConstraint(r)
+
+    def ball_floor():
+        fl, j = floor()
+        c = Circle([500, 420], 30, restitution=0.6)
+        c.add_force(Gravity(g=100))
+        return [fl, c], [j], 45, True
+
+    def stack3():
+        fl, j = floor()
+        bodies = [fl]
+        y = 495.0
+        for i, dx in enumerate((0.0, 7.0, -5.0)):
+            y -= 20.0
+            b = Rect([500 + dx, y - 0.5 - 2.0 * i], [40, 40], mass=1.0 + 0.5 * i, fric_coeff=0.4 + 0.1 * i,
+                     restitution=0.2 + 0.1 * i)
+            y -= 20.0
+            b.add_force(Gravity(g=100))
+            bodies.append(b)
+        return bodies, [j], 30, True
+
+    def mixed(strict):
+        def make():
+            fl, j = floor()
+            a = Rect([470, 470], [50, 50], vel=[0, 30, 0], fric_coeff=0.3)
+            b = Circle([560, 440], 20, vel=[0, -60, 0], restitution=0.3)
+            c = Rect([0.3, 520, 380], [30, 20], mass=0.5)
+            for x in (a, b, c):
+                x.add_force(Gravity(g=100))
+            return [fl, a, b, c], [j], 40, strict
+        return make
+
+    def tumble():
+        fl, j = floor()
+        a = Rect([0.4, 500, 440], [60, 30], vel=[1.0, 20, 0], restitution=0.3)
+        a.add_force(Gravity(g=100))
+        return [fl, a], [j], 45, True
+
+    return dict(ball_floor=ball_floor, stack3=stack3, mixed=mixed(True), mixed_nonstrict=mixed(False), tumble=tumble)
+
+
+def record(name, make):
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.world import World
+    random.seed(0)
+    bodies, joints, nsteps, strict = make()
+    world = World(bodies, joints, dt=1.0 / 30, strict_no_penetration=strict)
+    nb = len(bodies)
+    kind = np.array([0 if isinstance(b, Circle) else 1 for b in bodies])
+    size = np.array([[float(b.rad), 0.0] if isinstance(b, Circle) else b.dims.numpy().tolist() for b in bodies])
+    rec = dict(kind=kind, size=size, dt=np.float64(world.dt), strict=np.int64(strict), eps=np.float64(float(world.eps)),
+               tol=np.float64(float(world.tol)),
+               Mdiag=torch.diagonal(world.M()).reshape(nb, 3).numpy().copy(),
+               f=world.apply_forces(0).reshape(nb, 3).numpy().copy(),
+               rest=np.array([float(b.restitution) for b in bodies]),
+               fric=np.array([float(b.fric_coeff) for b in bodies]),
+               Je=world.Je().numpy().copy())
+    P, V, T, NC = [], [], [], []
+    snap = lambda: (torch.stack([b.p for b in bodies]).numpy().copy(), world.get_v().reshape(nb, 3).numpy().copy())
+    p, v = snap()
+    P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
+    for _ in range(nsteps):
+        world.step()
+        p, v = snap()
+        P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
+    rec.update(p=np.stack(P), v=np.stack(V), t=np.array(T), ncontacts=np.array(NC))
+    return rec
+
+
+def main():
+    ref_shim.load_reference()
+    torch.set_default_dtype(torch.float64)
+    flat = {}
+    names = []
+    for name, make in _scenes().items():
+        rec = record(name, make)
+        names.append(name)
+        for k, v in rec.items():
+            flat["%s__%s" % (name, k)] = v
+        dts = np.diff(rec["t"])
+        print(name, "steps", len(dts), "contacts", rec["ncontacts"].tolist(), "\n   halved steps:", int((dts < rec["dt"] * 0.99).sum()),
+              "min dt", dts.min())
+    flat["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "world_traj.npz"), **flat)
+
+
+if __name__ == "__main__":
+    main()
