@@ -127,6 +127,24 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
                        float* v_new, float* p_new, float* z, float* s, float* y,
                        int32_t* iters, int32_t* status, void* ws, void* stream);
 
+/* Replaces PdipmEngine.solve_dynamics (physics/engines.py:26-78) for B scenes whose contact lists have
+ * DIFFERENT lengths (what contact detection produces): scene k uses the first c_count[k] <= maxc records of
+ * its padded contact list and solves the mixed LCP of exactly that size (nineq = 4 c_count[k], engines.py:51-76);
+ * a scene without contacts takes the direct KKT solve of engines.py:36-50.  One launch, no position update
+ * (that is lcp_move_find_contacts_f64).  Arguments as lcp_step_fused_f32; z, s use the row layout of a
+ * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
+ * The workspace it leaves feeds lcp_pdipm_backward_f32 with m = 4 maxc (padded slots get zero gradients).
+ * Served by the four-scenes-per-wave kernel: 3 nb <= 16, maxc <= 16, e <= 4 (else LCP_E_TOOLARGE).
+ *   out: v_new[B,nb,3]  z[B,4 maxc]  s[B,4 maxc]  y[B,e]  iters[B]  status[B] */
+int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
+                           const float* Mdiag, const float* v, const float* f,
+                           const float* rest, const float* fric,
+                           const float* c_n, const float* c_p1, const float* c_p2,
+                           const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                           double eps, int max_iter, int not_improved_lim, int compute,
+                           float* v_new, float* z, float* s, float* y,
+                           int32_t* iters, int32_t* status, void* ws, void* stream);
+
 /* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the
  * contact generation it calls, for B independent scenes in one launch:
  *   Body.move (physics/bodies.py:80-82)         p_try = p_start + v dt

@@ -166,6 +166,26 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
+int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
+                           const float* v, const float* f, const float* rest, const float* fric,
+                           const float* c_n, const float* c_p1, const float* c_p2, const int32_t* c_i1,
+                           const int32_t* c_i2, const float* Je, float dt, double eps, int max_iter,
+                           int not_improved_lim, int compute, float* v_new, float* z, float* s, float* y,
+                           int32_t* iters, int32_t* status, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  lcp::StepArgs P;
+  int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
+  if (rc) return rc;
+  if (!c_count || !v_new || !ws || max_iter < 0) return LCP_E_BADARG;
+  const int nz = 3 * nb, m = 4 * maxc;
+  if (!lcp::quad_supported(nz, m, e)) return LCP_E_TOOLARGE;
+  P.c_count = c_count;
+  P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
+  P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
+  P.ws = ws;
+  return lcp::quad_step(P, compute, stream);
+}
+
 int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,
                                const double* verts_local, const int32_t* nverts, const uint8_t* no_contact,
                                const double* p_start, const float* v, double dt, double dt_floor, int strict,

@@ -43,6 +43,7 @@ struct StepArgs {
   int B, nb, nc, e;
   const void *pos, *Mdiag, *v, *f, *rest, *fric, *c_n, *c_p1, *c_p2;
   const int32_t *c_i1, *c_i2;
+  const int32_t* c_count;   // per-scene live contacts (<= nc) or NULL = nc everywhere
   const void* Je;
   double dt;
   double eps;

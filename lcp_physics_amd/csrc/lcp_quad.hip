@@ -103,7 +103,8 @@ __host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem) 
 template <typename TI, typename TC>
 struct SceneQ {
   LdsQ<TI, TC> L;
-  int nz, nc, e, l16;
+  int nz, nc, e, l16;      // nc: live contacts of THIS scene (row-uniform)
+  int ncw, ncap;          // ncw: max nc over the scenes of the wave (loop bound); ncap: contact capacity (array strides)
   TI jc[16], jt[16];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
   TC gan[EQ], gat[EQ];    // (J Q^-1 A^T) rows of this contact
   TC s11row[EQ];          // row l16 of (A Q^-1 A^T)^-1
@@ -165,7 +166,7 @@ struct RedQ {
 template <typename TI, typename TC>
 __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC>& S, const TC* W2q,
                                          const M4<TC>& D, bool valid) {
-  const int l16 = S.l16, nc = S.nc;
+  const int l16 = S.l16, nc = S.ncw;
   R.Dg = D.g;
   R.Sp = (TC)0.5 * (D.f1 + D.f2); R.Sm = (TC)0.5 * (D.f1 - D.f2);
   R.idet = fast_rcp(R.Sp * R.Dg + (TC)2);
@@ -226,7 +227,7 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
 template <typename TI, typename TC>
 __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R, const SceneQ<TI, TC>& S,
                                            const M4<TC>& hz) {
-  const int l16 = S.l16, nc = S.nc;
+  const int l16 = S.l16, nc = S.ncw;
   const TC r12 = hz.f1 + hz.f2;
   const TC w0 = (R.Dg * r12 - (TC)2 * hz.g) * R.idet;
   TC ra = hz.n, ru = (TC)0.5 * (hz.f1 - hz.f2) - (TC)0.5 * R.Sm * w0;
@@ -330,8 +331,8 @@ __device__ __forceinline__ void store_scene_ws(const Ws<TI, TC>& W, const SceneQ
 template <typename TI, typename TC>
 __device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P, const Ws<TI, TC>& W, int scene,
                                              TC& p, TC& hn, TC& b) {
-  const int nz = S.nz, nc = S.nc, e = S.e, l16 = S.l16, m = 4 * nc;
-  const bool vc = l16 < nc;
+  const int nz = S.nz, nc = S.ncap, e = S.e, l16 = S.l16, m = 4 * nc;
+  const bool vc = l16 < S.nc;
   const TI* Grow_n = (const TI*)P.G + ((size_t)scene * m + (vc ? l16 : 0)) * nz;
   const TI* Grow_t = (const TI*)P.G + ((size_t)scene * m + nc + 2 * (vc ? l16 : 0)) * nz;
   static_for<16>([&](auto J) LCP_INL {
@@ -356,8 +357,8 @@ __device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P
 // contact list -> per-lane rows (physics/engines.py:31-32,50-74; physics/world.py:144-234)
 template <typename TI, typename TC>
 __device__ __forceinline__ void assemble_q(SceneQ<TI, TC>& S, const StepArgs& P, int scene, TC& p, TC& hn, TC& b) {
-  const int nb = P.nb, nc = S.nc, nz = S.nz, e = S.e, l16 = S.l16;
-  const bool vc = l16 < nc;
+  const int nb = P.nb, nc = S.ncap, nz = S.nz, e = S.e, l16 = S.l16;
+  const bool vc = l16 < S.nc;
   const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
   const TI* vv = (const TI*)P.v + (size_t)scene * nz;
   const TI* ff = (const TI*)P.f + (size_t)scene * nz;
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   const int scene_raw = blockIdx.x * 4 + row;
   const int scene = scene_raw < Btot ? scene_raw : Btot - 1;           // tail rows shadow the last scene (never stored)
   const int nz = FUSED ? 3 * SP.nb : P.nz, nc = FUSED ? SP.nc : (P.m >> 2), e = FUSED ? SP.e : P.e;
-  const int m = 4 * nc;
+  const int m = 4 * nc;                                                  // capacity: strides and output layout
   const int max_iter = FUSED ? SP.max_iter : P.max_iter, lim = FUSED ? SP.lim : P.lim;
   const TC eps = (TC)(FUSED ? SP.eps : P.eps);
   Ws<TI, TC> W(FUSED ? SP.ws : P.ws, scene);
@@ -483,8 +484,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   if (!__any(live)) return;
   SceneQ<TI, TC> S;
   carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
-  S.nz = nz; S.nc = nc; S.e = e; S.l16 = l16;
-  const bool vc = l16 < nc;                                              // this lane owns a contact
+  // per-scene contact count (solve_dynamics with detection); a scene without contacts takes the
+  // direct KKT solve of engines.py:36-50, which is what the initialisation solve computes
+  int ncs = nc;
+  if (FUSED && SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; }
+  int ncw = ncs;
+  ncw = max(ncw, __shfl_xor(ncw, 16, 64)); ncw = max(ncw, __shfl_xor(ncw, 32, 64));
+  ncw = __builtin_amdgcn_readfirstlane(ncw);
+  S.nz = nz; S.nc = ncs; S.ncw = ncw; S.ncap = nc; S.e = e; S.l16 = l16;
+  const bool vc = l16 < ncs;                                             // this lane owns a contact
   TC p, hn, b;
   if (FUSED) {
     assemble_q<TI, TC>(S, SP, scene, p, hn, b);
@@ -493,6 +501,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   } else {
     load_dense_q<TI, TC>(S, P, W, scene, p, hn, b);
   }
+  if (live && l16 == 0) W.meta[19] = (TC)ncs;
   int status = prefactor_q<TI, TC>(S, W, live);
 
   TC ta[32], tu[32];
@@ -502,7 +511,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   TC best_resid = inf_of<TC>();
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
-  const TC mf = (TC)m;
+  const TC mf = (TC)(4 * ncs);                                           // nineq of this scene
 
 #pragma unroll 1
   for (int it = -1; it < max_iter; ++it) {
@@ -564,6 +573,11 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         if (smin <= (TC)0) { const TC sh = (TC)1 - smin; s = m4<TC>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
         if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
         if (!vc) { s = m4<TC>(1, 1, 1, 1); z = s; }
+        if (ncs == 0 && !done) {                                              // engines.py:36-50: x = P^-1 u, no LCP
+          if (l16 < nz) W.x[l16] = x;
+          if (l16 < e) W.y[l16] = y;
+          done = true;
+        }
       } else if (pass == 0) {
         ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
         const TC alpha = pmin(step_pair_q(z, az, s, as_, vc), (TC)1);        // (:142-144)
@@ -604,20 +618,23 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   TI* zo = (TI*)(FUSED ? SP.z : P.z);
   TI* so = (TI*)(FUSED ? SP.s : P.s);
   TI* yo = (TI*)(FUSED ? SP.y : P.y);
-  if (vc && zo) {
+  const bool vslot = l16 < nc;                                            // slot of the (padded) contact list
+  if (vslot && zo) {
     TI* o = zo + (size_t)scene * m;
-    o[l16] = (TI)bz.n; o[nc + 2 * l16] = (TI)bz.f1; o[nc + 2 * l16 + 1] = (TI)bz.f2; o[3 * nc + l16] = (TI)bz.g;
+    const TI k = vc ? (TI)1 : (TI)0;                                      // padded slots report 0
+    o[l16] = k * (TI)bz.n; o[nc + 2 * l16] = k * (TI)bz.f1; o[nc + 2 * l16 + 1] = k * (TI)bz.f2; o[3 * nc + l16] = k * (TI)bz.g;
   }
-  if (vc && so) {
+  if (vslot && so) {
     TI* o = so + (size_t)scene * m;
-    o[l16] = (TI)bs.n; o[nc + 2 * l16] = (TI)bs.f1; o[nc + 2 * l16 + 1] = (TI)bs.f2; o[3 * nc + l16] = (TI)bs.g;
+    const TI k = vc ? (TI)1 : (TI)0;
+    o[l16] = k * (TI)bs.n; o[nc + 2 * l16] = k * (TI)bs.f1; o[nc + 2 * l16 + 1] = k * (TI)bs.f2; o[3 * nc + l16] = k * (TI)bs.g;
   }
   if (l16 < e && yo) yo[(size_t)scene * e + l16] = (TI)by;
   if (FUSED) {
     if (l16 < nz) {
       const TC nv = -bx;                                                      // engines.py:76-77
       ((TI*)SP.v_new)[(size_t)scene * nz + l16] = (TI)nv;
-      ((TI*)SP.p_new)[(size_t)scene * nz + l16] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + l16] + nv * (TC)SP.dt);   // bodies.py:81
+      if (SP.p_new) ((TI*)SP.p_new)[(size_t)scene * nz + l16] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + l16] + nv * (TC)SP.dt);   // bodies.py:81
     }
     if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
   } else {
@@ -639,8 +656,13 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   if (!__any(live)) return;
   SceneQ<TI, TC> S;
   carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
-  S.nz = nz; S.nc = nc; S.e = e; S.l16 = l16;
-  const bool vc = l16 < nc;
+  int ncs = live ? (int)W.meta[19] : 0;                                  // live contacts of the scene (set by the forward)
+  ncs = ncs < 0 ? 0 : (ncs > nc ? nc : ncs);
+  int ncw = ncs;
+  ncw = max(ncw, __shfl_xor(ncw, 16, 64)); ncw = max(ncw, __shfl_xor(ncw, 32, 64));
+  ncw = __builtin_amdgcn_readfirstlane(ncw);
+  S.nz = nz; S.nc = ncs; S.ncw = ncw; S.ncap = nc; S.e = e; S.l16 = l16;
+  const bool vc = l16 < ncs;
   {
     const TI* Grow_n = (const TI*)P.G + ((size_t)scene * m + (vc ? l16 : 0)) * nz;
     const TI* Grow_t = (const TI*)P.G + ((size_t)scene * m + nc + 2 * (vc ? l16 : 0)) * nz;
@@ -678,7 +700,9 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
   if (P.dp && l16 < nz) ((TI*)P.dp)[(size_t)scene * nz + l16] = (TI)dx;
   if (P.db && l16 < e) ((TI*)P.db)[(size_t)scene * e + l16] = (TI)(-dnu);
-  if (P.dh && vc) {
+  const bool vslot = l16 < nc;                                            // padded contact slots get zero gradients
+  const M4<TC> zq = vc ? z : m4<TC>(0, 0, 0, 0);
+  if (P.dh && vslot) {
     TI* o = (TI*)P.dh + (size_t)scene * m;
     o[l16] = (TI)(-dl.n); o[nc + 2 * l16] = (TI)(-dl.f1); o[nc + 2 * l16 + 1] = (TI)(-dl.f2); o[3 * nc + l16] = (TI)(-dl.g);
   }
@@ -699,7 +723,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
     static_for<16>([&](auto C) LCP_INL {
       if (C < nc) {
         const TC a0 = bc<C>(dl.n), a1 = bc<C>(dl.f1), a2 = bc<C>(dl.f2), a3 = bc<C>(dl.g);
-        const TC b0 = bc<C>(z.n), b1 = bc<C>(z.f1), b2 = bc<C>(z.f2), b3 = bc<C>(z.g);
+        const TC b0 = bc<C>(zq.n), b1 = bc<C>(zq.f1), b2 = bc<C>(zq.f2), b3 = bc<C>(zq.g);
         if (l16 < nz) {
           o[(size_t)C * nz + l16] = (TI)(a0 * x + b0 * dx);
           o[(size_t)(nc + 2 * C) * nz + l16] = (TI)(a1 * x + b1 * dx);
@@ -715,10 +739,10 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
     static_for<16>([&](auto C) LCP_INL {
       if (C < nc) {
         const TC a0 = bc<C>(dl.n), a1 = bc<C>(dl.f1), a2 = bc<C>(dl.f2), a3 = bc<C>(dl.g);
-        if (vc) {
+        if (vslot) {
           auto wr = [&](int i, TC dli) {
             TI* r = o + (size_t)i * m;
-            r[l16] = (TI)(-dli * z.n); r[nc + 2 * l16] = (TI)(-dli * z.f1); r[nc + 2 * l16 + 1] = (TI)(-dli * z.f2); r[3 * nc + l16] = (TI)(-dli * z.g);
+            r[l16] = (TI)(-dli * zq.n); r[nc + 2 * l16] = (TI)(-dli * zq.f1); r[nc + 2 * l16 + 1] = (TI)(-dli * zq.f2); r[3 * nc + l16] = (TI)(-dli * zq.g);
           };
           wr(C, a0); wr(nc + 2 * C, a1); wr(nc + 2 * C + 1, a2); wr(3 * nc + C, a3);
         }

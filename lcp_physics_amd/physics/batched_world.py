@@ -145,3 +145,100 @@ class BatchedWorld:
 
     def get_p(self):
         return self.scene.p
+
+
+def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, eps=1e-12, not_improved_lim=3,
+                   max_iter=10, compute="f64", ws=None, out=None):
+    """`PdipmEngine.solve_dynamics` (`engines.py:26-78`) for B scenes with per-scene contact counts
+    (`count` [B] int32, contact records in `cb`, a `contacts.ContactBuffers`): one launch of
+    `lcp_solve_dynamics_f32`.  Returns dict(v_new, z, s, y, iters, status, ws)."""
+    lib = _lib.load()
+    dev = v.device
+    comp = _COMPUTE[compute]
+    nz, m = 3 * nb, 4 * maxc
+    need = _lib.workspace_bytes(B, nz, m, e, comp)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {"v_new": new(B, nb, 3), "z": new(B, m), "s": new(B, m), "y": new(B, e) if e else None,
+               "iters": torch.empty(B, dtype=torch.int32, device=dev),
+               "status": torch.empty(B, dtype=torch.int32, device=dev)}
+    out["ws"] = ws
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_solve_dynamics_f32(B, nb, maxc, e, P(count), P(Mdiag), P(v), P(f), P(rest), P(fric),
+                                        P(cb.c_n), P(cb.c_p1), P(cb.c_p2), P(cb.c_i1), P(cb.c_i2),
+                                        P(Je) if e else None, float(dt), float(eps), int(max_iter),
+                                        int(not_improved_lim), comp, P(out["v_new"]), P(out["z"]), P(out["s"]),
+                                        P(out["y"]), P(out["iters"]), P(out["status"]), P(ws), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_solve_dynamics_f32")
+    return out
+
+
+class ContactWorld:
+    """B independent scenes WITH contact detection, advanced together on one GPU: the batched counterpart of
+    the reference's `World` (`physics/world.py:17-122`) with its default `DiffContactHandler` and `PdipmEngine`.
+
+        world = ContactWorld(geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1/30)
+        world.step()        # two launches, no host synchronisation:
+                            #   lcp_solve_dynamics_f32      new_v            (engines.py:26-78)
+                            #   lcp_move_find_contacts_f64  p, contacts, t   (world.py:88-101,122,139-142; contacts.py)
+
+    State: `p` [B,nb,3] float64 (rot, x, y), `v` [B,nb,3] float32, `t` [B] float64 (scenes advance by their own
+    accepted dt, world.py:122), `contacts` (`contacts.ContactBuffers`: padded records + `count`).
+    Restrictions: forces are constant (gravity-like), joints have a constant Jacobian `Je` (Total/X/Y/Rot
+    constraints), post-stabilisation (off by default in the reference, utils.py:30) is not implemented;
+    3 nb <= 16, maxc <= 16, e <= 4 (the four-scenes-per-wave solver).
+    """
+
+    def __init__(self, geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1.0 / 30, eps=0.1, tol=1e-6,
+                 strict_no_penetration=True, maxc=16, max_iter=10, compute="f64", solver_eps=1e-12,
+                 not_improved_lim=3, max_trials=64, check=True):
+        from . import contacts as _contacts
+        self._contacts_mod = _contacts
+        self.geom = geom
+        dev = p.device
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        self.p = p.to(dtype=torch.float64).contiguous()
+        self.v, self.Mdiag, self.f, self.rest, self.fric = f32(v), f32(Mdiag), f32(f), f32(rest), f32(fric)
+        self.B, self.nb = self.p.shape[0], self.p.shape[1]
+        self.e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+        self.Je = f32(Je) if self.e else None
+        self.dt, self.eps, self.tol, self.strict = float(dt), float(eps), float(tol), bool(strict_no_penetration)
+        self.maxc, self.max_iter, self.compute = int(maxc), int(max_iter), compute
+        self.solver_eps, self.lim, self.max_trials = solver_eps, not_improved_lim, max_trials
+        self.t = torch.zeros(self.B, dtype=torch.float64, device=dev)
+        self._ws = self._out = None
+        # world.py:65-66: contacts of the initial pose; :67-70: refuse interpenetration at start
+        self.contacts = _contacts.find_contacts(geom, self.p, maxc=self.maxc, eps=self.eps)
+        if check:
+            self.check_capacity()
+            if self.strict and bool((self.contacts.max_pen > self.tol).any()):
+                raise AssertionError("Interpenetration at start (world.py:68-70)")
+
+    def check_capacity(self):
+        """Host check (synchronises): no scene produced more than `maxc` contacts."""
+        worst = int(self.contacts.count.max())
+        if worst > self.maxc:
+            raise RuntimeError("a scene has %d contacts but maxc = %d" % (worst, self.maxc))
+
+    def step(self):
+        """`World.step()` = `step_dt(self.dt)` (`world.py:72-122`) for every scene."""
+        cb = self.contacts
+        out = solve_dynamics(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, self.f, self.rest,
+                             self.fric, cb, self.Je, self.dt, eps=self.solver_eps, not_improved_lim=self.lim,
+                             max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
+        self._ws, self._out = out["ws"], out
+        self.v, out["v_new"] = out["v_new"], self.v                      # world.py:87 set_v(new_v)
+        self._contacts_mod.move_and_find_contacts(self.geom, self.p, self.v, self.dt, eps=self.eps, tol=self.tol,
+                                                  strict=self.strict, dt_floor=self.dt / 4,
+                                                  max_trials=self.max_trials, t=self.t, out=cb)
+        self.p, cb.p_out = cb.p_out, self.p                              # accepted pose becomes the state (double buffer)
+        return out
+
+    def get_v(self):
+        return self.v
+
+    def get_p(self):
+        return self.p

@@ -1,0 +1,298 @@
+"""GPU parity tests of the contact-generation / position-update kernel (`lcp_move_find_contacts_f64`), the
+variable-contact-count engine solve (`lcp_solve_dynamics_f32`) and the batched `ContactWorld`, through the C ABI,
+against the reference fixtures (tests/golden/contacts_*.npz, world_traj.npz) and the CPU oracles.
+
+Tolerances: contact index lists, counts, trial counts: exact.  Penetration (fp64 end to end): 1e-9.
+Contact frame (normal, arms): the kernel computes them in fp64 and rounds to fp32 for the LCP kernels, so they
+are compared at fp32 resolution of their magnitude (|arm| <= ~500 -> 1e-4 absolute; normals 1e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import contacts_oracle as C
+from oracle import world_oracle as W
+from tests.world_io import load_world_traj, shapes_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ATOL_ARM, ATOL_N, ATOL_PEN = 1e-4, 1e-6, 1e-9
+
+
+def _geom(shape_lists):
+    """GeometryBatch for a list (one per scene) of shape lists of equal length."""
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    gs = [GeometryBatch.from_shapes(sh, 1) for sh in shape_lists]
+    cat = lambda k: torch.cat([getattr(g, k) for g in gs])
+    return GeometryBatch(cat("kind"), cat("radius"), cat("verts_local"), cat("nverts"), None).to(DEV)
+
+
+def _shape(kind, size):
+    return ("circle", float(size[0])) if int(kind) == 0 else ("rect", (float(size[0]), float(size[1])))
+
+
+def _compare_lists(cb, k, ref, what):
+    """Contact list of scene k in the device buffers against a reference-format list."""
+    n = int(cb.count[k])
+    assert n == len(ref), (what, "count", n, len(ref))
+    if n == 0:
+        return
+    i1, i2 = cb.c_i1[k, :n].cpu().tolist(), cb.c_i2[k, :n].cpu().tolist()
+    assert i1 == [c[1] for c in ref] and i2 == [c[2] for c in ref], (what, "body indices")
+    g = lambda t: t[k, :n].double().cpu().numpy()
+    rn, r1, r2 = (np.stack([c[0][q] for c in ref]) for q in range(3))
+    rp = np.array([c[0][3] for c in ref])
+    assert np.abs(g(cb.c_n) - rn).max() <= ATOL_N, (what, "normal", np.abs(g(cb.c_n) - rn).max())
+    assert np.abs(g(cb.c_p1) - r1).max() <= ATOL_ARM, (what, "p1", np.abs(g(cb.c_p1) - r1).max())
+    assert np.abs(g(cb.c_p2) - r2).max() <= ATOL_ARM, (what, "p2", np.abs(g(cb.c_p2) - r2).max())
+    assert np.abs(g(cb.c_pen) - rp).max() <= ATOL_PEN, (what, "penetration", np.abs(g(cb.c_pen) - rp).max())
+
+
+def test_pairs_match_reference_fixture():
+    """600 reference DiffContactHandler outputs (contacts.py:57-205), one pair per scene."""
+    from lcp_physics_amd.physics.contacts import find_contacts
+    from tests.test_contacts_oracle import GOLD
+    import os
+    d = np.load(os.path.join(GOLD, "contacts_pairs.npz"))
+    n = len(d["count"])
+    geom = _geom([[_shape(d["kind"][i, 0], d["size"][i, 0]), _shape(d["kind"][i, 1], d["size"][i, 1])] for i in range(n)])
+    p = torch.tensor(d["pos"], dtype=torch.float64, device=DEV)
+    cb = find_contacts(geom, p, maxc=4)
+    torch.cuda.synchronize()
+    assert cb.count.cpu().tolist() == d["count"].tolist()
+    for i in range(n):
+        ref = [((d["normal"][i, k], d["p1"][i, k], d["p2"][i, k], d["pen"][i, k]), 0, 1) for k in range(int(d["count"][i]))]
+        _compare_lists(cb, i, ref, "pair %d" % i)
+    # padded slots are zeroed
+    pad = torch.arange(4, device=DEV).unsqueeze(0) >= cb.count.unsqueeze(1)
+    assert float(cb.c_n[pad].abs().max()) == 0.0 and int(cb.c_i2[pad].abs().max()) == 0
+
+
+def test_scene_lists_match_reference_fixture():
+    """60 multi-body scenes: the order of the contact list is the reference's (pair order i < j)."""
+    from lcp_physics_amd.physics.contacts import find_contacts
+    from tests.test_contacts_oracle import GOLD
+    import os
+    d = np.load(os.path.join(GOLD, "contacts_scenes.npz"))
+    by_nb = {}
+    for s in range(int(d["n"])):
+        by_nb.setdefault(len(d["s%d_kind" % s]), []).append(s)
+    for nb, ids in by_nb.items():
+        g = lambda s, k: d["s%d_%s" % (s, k)]
+        geom = _geom([[_shape(k, z) for k, z in zip(g(s, "kind"), g(s, "size"))] for s in ids])
+        p = torch.tensor(np.stack([g(s, "pos") for s in ids]), dtype=torch.float64, device=DEV)
+        cb = find_contacts(geom, p, maxc=16)
+        torch.cuda.synchronize()
+        for k, s in enumerate(ids):
+            ref = [((g(s, "normal")[q], g(s, "p1")[q], g(s, "p2")[q], g(s, "pen")[q]), int(g(s, "i1")[q]), int(g(s, "i2")[q]))
+                   for q in range(len(g(s, "pen")))]
+            _compare_lists(cb, k, ref, "scene %d" % s)
+
+
+def _random_scene(rng, nb, hulls=True, rotate=True):
+    """Floor + bodies dropped near each other; returns (shapes, pose[nb,3])."""
+    shapes, pose = [("rect", (500.0, 10.0))], [[0.0, 300.0, 400.0]]
+    y = 395.0
+    for _ in range(nb - 1):
+        r = rng.random()
+        sz = rng.uniform(15, 30, size=2)
+        if r < 0.35:
+            shapes.append(("circle", float(sz[0]))); hh = sz[0]
+        elif r < 0.8 or not hulls:
+            shapes.append(("rect", (float(sz[0]), float(sz[1])))); hh = sz[1] / 2
+        else:                                                   # convex polygon with 3..6 vertices (a Hull, bodies.py:135)
+            nv = int(rng.integers(3, 7))
+            # counter-clockwise like the reference's Rect (bodies.py:261-264): left_orthogonal(edge) points outwards
+            ang = (np.arange(nv) + rng.uniform(-0.3, 0.3, nv)) * (2 * np.pi / nv) + rng.uniform(0, 2 * np.pi)
+            rad = float(sz[0])
+            shapes.append(("hull", np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1))); hh = rad * 0.8
+        y -= hh
+        rot = 0.0 if (rng.random() < 0.5 or not rotate) else float(rng.uniform(-0.4, 0.4))
+        pose.append([rot, 300.0 + float(rng.uniform(-15, 15)), y + float(rng.uniform(-0.3, 0.1))])
+        y -= hh
+    return shapes, np.array(pose)
+
+
+def test_random_scenes_match_oracle():
+    """Circles, rects and general convex hulls (3-6 vertices), 3-6 bodies, against oracle/contacts_oracle.py."""
+    from lcp_physics_amd.physics.contacts import find_contacts
+    rng = np.random.default_rng(7)
+    total = 0
+    for nb in (3, 4, 6):
+        scenes = [_random_scene(rng, nb) for _ in range(96)]
+        geom = _geom([s[0] for s in scenes])
+        p = torch.tensor(np.stack([s[1] for s in scenes]), dtype=torch.float64, device=DEV)
+        cb = find_contacts(geom, p, maxc=24)
+        torch.cuda.synchronize()
+        for k, (shapes, pose) in enumerate(scenes):
+            try:
+                ref = C.find_contacts(W.bodies_at(shapes, pose), eps=0.1)
+            except ValueError:          # get_closest raises on a degenerate simplex (contacts.py:330) - no reference answer
+                continue
+            _compare_lists(cb, k, ref, "nb%d scene %d" % (nb, k))
+            total += len(ref)
+    assert total > 400
+
+
+def test_no_contact_mask_and_capacity_report():
+    from lcp_physics_amd.physics.contacts import find_contacts
+    rng = np.random.default_rng(3)
+    shapes, pose = _random_scene(rng, 5, hulls=False)
+    geom = _geom([shapes, shapes])
+    ref0 = C.find_contacts(W.bodies_at(shapes, pose), eps=0.1)
+    a, b = ref0[0][1], ref0[0][2]
+    mask = torch.zeros(2, 5, 5, dtype=torch.uint8)
+    mask[1, a, b] = 1                                            # scene 1 ignores one touching pair (bodies.py:117-118)
+    geom.no_contact = mask.to(DEV)
+    p = torch.tensor(np.stack([pose, pose]), dtype=torch.float64, device=DEV)
+    cb = find_contacts(geom, p, maxc=16)
+    ref1 = C.find_contacts(W.bodies_at(shapes, pose), eps=0.1, no_contact=[(a, b)])
+    assert len(ref1) < len(ref0)
+    _compare_lists(cb, 0, ref0, "unmasked")
+    _compare_lists(cb, 1, ref1, "masked")
+    # a list longer than the capacity is reported through `count` (and truncated, not overrun)
+    small = find_contacts(geom, p, maxc=2)
+    assert int(small.count[0]) == len(ref0) > 2
+    assert small.c_n.shape[1] == 2
+
+
+def test_move_and_halve_matches_oracle():
+    """world.py:88-101: accepted dt, number of trials, pose and contact list per scene."""
+    from lcp_physics_amd.physics.contacts import move_and_find_contacts
+    rng = np.random.default_rng(11)
+    nb, B = 4, 128
+    scenes = [_random_scene(rng, nb, hulls=False, rotate=False) for _ in range(B)]
+    # lift the bodies clear of each other and throw them down: most scenes penetrate at the full dt
+    p0 = np.stack([s[1] for s in scenes])
+    p0[:, 1:, 2] -= rng.uniform(0.5, 3.0, size=(B, nb - 1)).cumsum(axis=1)
+    v = np.zeros((B, nb, 3))
+    v[:, 1:, 2] = rng.uniform(20, 120, size=(B, nb - 1))
+    v[:, 1:, 1] = rng.uniform(-20, 20, size=(B, nb - 1))
+    v[:, 1:, 0] = rng.uniform(-0.5, 0.5, size=(B, nb - 1))
+    v32 = torch.tensor(v, dtype=torch.float32)
+    geom = _geom([s[0] for s in scenes])
+    dt = 1.0 / 30
+    for strict in (True, False):
+        t = torch.zeros(B, dtype=torch.float64, device=DEV)
+        cb = move_and_find_contacts(geom, torch.tensor(p0, dtype=torch.float64, device=DEV), v32.to(DEV), dt,
+                                    maxc=16, strict=strict, t=t)
+        torch.cuda.synchronize()
+        halved = 0
+        for k in range(B):
+            p_ref, ref, dt_ref, trials = W.move_and_find(scenes[k][0], p0[k], v32[k].double().numpy(), dt, strict=strict)
+            assert int(cb.trials[k]) == trials, (strict, k, int(cb.trials[k]), trials)
+            assert float(cb.dt_used[k]) == dt_ref and abs(float(t[k]) - dt_ref) < 1e-15
+            assert np.abs(cb.p_out[k].cpu().numpy() - p_ref).max() < 1e-10
+            _compare_lists(cb, k, ref, "strict=%s scene %d" % (strict, k))
+            halved += trials > 1
+        assert halved > B // 4
+
+
+def _variable_count_batch(rng, B, nb, maxc):
+    """Random scenes with their oracle contact lists (0 .. maxc contacts)."""
+    scenes, lists = [], []
+    while len(scenes) < B:
+        shapes, pose = _random_scene(rng, nb, hulls=False)
+        if rng.random() < 0.2:
+            pose[1:, 2] -= 40.0                                  # lifted clear of the floor: fewer / no contacts
+        if rng.random() < 0.1:
+            pose[1:, 2] -= 400.0 * np.arange(1, nb)              # everything apart: no contact at all
+        try:
+            cs = C.find_contacts(W.bodies_at(shapes, pose), eps=0.1)
+        except ValueError:
+            continue
+        if len(cs) <= maxc:
+            scenes.append((shapes, pose)); lists.append(cs)
+    return scenes, lists
+
+
+@pytest.mark.parametrize("with_joint", [True, False])
+def test_solve_dynamics_variable_counts_match_oracle(with_joint):
+    """engines.py:26-78 with per-scene contact counts (incl. the no-contact branch :36-50): new_v within 1e-4
+    (scaled by the velocity scale of the scene) of the fp64 oracle."""
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
+    from lcp_physics_amd.physics.contacts import find_contacts
+    rng = np.random.default_rng(5)
+    B, nb, maxc = 192, 4, 12
+    scenes, lists = _variable_count_batch(rng, B, nb, maxc)
+    counts = [len(c) for c in lists]
+    assert min(counts) == 0 and max(counts) >= 5 and len(set(counts)) >= 4
+    geom = _geom([s[0] for s in scenes])
+    p = torch.tensor(np.stack([s[1] for s in scenes]), dtype=torch.float64, device=DEV)
+    cb = find_contacts(geom, p, maxc=maxc)
+    mass = rng.uniform(0.5, 2.0, size=(B, nb))
+    Mdiag = np.stack([mass * rng.uniform(50, 200, size=(B, nb)), mass, mass], axis=-1)
+    v = rng.normal(0, 5.0, size=(B, nb, 3)); v[:, :, 0] *= 0.05
+    f = np.zeros((B, nb, 3)); f[:, :, 2] = mass * 100.0
+    rest, fric = rng.uniform(0.1, 0.6, size=(B, nb)), rng.uniform(0.2, 0.8, size=(B, nb))
+    if with_joint:
+        Je = np.zeros((B, 3, 3 * nb)); Je[:, :, :3] = np.eye(3)       # TotalConstraint on the floor (constraints.py:176-192)
+        v[:, 0] = 0
+    else:
+        Je = None
+        Mdiag[:, 0] *= 1e4; f[:, 0] = 0; v[:, 0] = 0                  # a heavy free floor
+    g32 = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV).contiguous()
+    Mg, vg, fg, rg, cg = g32(Mdiag), g32(v), g32(f), g32(rest), g32(fric)
+    Jg = g32(Je) if with_joint else None
+    dt = 1.0 / 30
+    out = solve_dynamics(B, nb, maxc, 3 if with_joint else 0, cb.count, Mg, vg, fg, rg, cg, cb, Jg, dt)
+    torch.cuda.synchronize()
+    got = out["v_new"].double().cpu().numpy()
+    d64 = lambda t: t.double().cpu().numpy()
+    worst = 0.0
+    for k in range(B):
+        n = counts[k]
+        # the oracle sees the same fp32-rounded inputs and the same (fp32-rounded) contact frame as the kernel
+        cs = [((d64(cb.c_n[k, q]), d64(cb.c_p1[k, q]), d64(cb.c_p2[k, q]), 0.0), int(cb.c_i1[k, q]), int(cb.c_i2[k, q])) for q in range(n)]
+        ref = W.solve_dynamics(d64(Mg[k]), d64(vg[k]), d64(fg[k]), dt, cs, d64(rg[k]), d64(cg[k]),
+                               d64(Jg[k]) if with_joint else None)
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got[k] - ref).max() / scale
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, n, err)
+        assert int(out["status"][k]) & 8 == 0
+        # padded slots of z / s are reported as 0
+        z = out["z"][k].cpu().numpy().reshape(-1)
+        slots = np.concatenate([np.arange(n, maxc), maxc + np.arange(2 * n, 2 * maxc), 3 * maxc + np.arange(n, maxc)])
+        assert np.all(z[slots] == 0)
+    print("worst scaled new_v error", worst)
+
+
+@pytest.mark.parametrize("name", sorted(load_world_traj()))
+def test_contact_world_follows_reference_trajectory(name):
+    """ContactWorld.step() against trajectories of the unmodified reference World (world.py:72-122).
+    Velocities are carried in fp32 between the two kernels, so poses (coordinates of ~500) and velocities
+    (~100) are held to 2e-4 absolute over the whole run (measured: 4e-5); accepted step times (to 1e-12) and
+    contact counts must agree exactly, i.e. every dt-halving decision of the reference is reproduced."""
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    rec = load_world_traj()[name]
+    shapes = shapes_of(rec)
+    B = 5                                                        # replicas (a wave holds 4 scenes: exercises the tail too)
+    geom = _geom([shapes] * B)
+    rep = lambda a, dt_: torch.tensor(np.broadcast_to(a, (B,) + a.shape).copy(), dtype=dt_, device=DEV)
+    world = ContactWorld(geom, rep(rec["p"][0], torch.float64), rep(rec["v"][0], torch.float32),
+                         rep(rec["Mdiag"], torch.float32), rep(rec["f"], torch.float32), rep(rec["rest"], torch.float32),
+                         rep(rec["fric"], torch.float32), Je=rep(rec["Je"], torch.float32), dt=float(rec["dt"]),
+                         eps=float(rec["eps"]), tol=float(rec["tol"]), strict_no_penetration=bool(rec["strict"]), maxc=8)
+    assert world.contacts.count.cpu().tolist() == [int(rec["ncontacts"][0])] * B
+    worst_p = worst_v = 0.0
+    for k in range(1, len(rec["t"])):
+        world.step()
+        t = world.t.cpu().numpy()
+        assert np.abs(t - rec["t"][k]).max() < 1e-12, (name, k, "t", t, rec["t"][k])
+        assert world.contacts.count.cpu().tolist() == [int(rec["ncontacts"][k])] * B, (name, k, "contact count")
+        ep = np.abs(world.p.cpu().numpy() - rec["p"][k]).max()
+        ev = np.abs(world.v.double().cpu().numpy() - rec["v"][k]).max()
+        worst_p, worst_v = max(worst_p, ep), max(worst_v, ev)
+        assert ep <= 2e-4 and ev <= 2e-4, (name, k, ep, ev)
+    print(name, "worst |dp|", worst_p, "worst |dv|", worst_v)
+
+
+def test_contact_world_refuses_initial_penetration():
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    shapes = [("rect", (500.0, 10.0)), ("rect", (40.0, 40.0))]
+    geom = _geom([shapes])
+    p = torch.tensor([[[0.0, 300.0, 400.0], [0.0, 300.0, 376.0]]], dtype=torch.float64, device=DEV)   # 1 px inside
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with pytest.raises(AssertionError):
+        ContactWorld(geom, p, z(1, 2, 3), torch.ones(1, 2, 3, device=DEV), z(1, 2, 3), z(1, 2), z(1, 2))
