@@ -30,10 +30,55 @@ template <int K> __device__ __forceinline__ float bc(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, true));
 }
 template <int K> __device__ __forceinline__ double bc(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);     // one v_mov_b64_dpp (64-bit DPP: row_newbcast only)
 }
+// acc (+/-)= (lane K of the row's `src`) * mult with the broadcast folded into the FMA.  The fp64 ALU of gfx950
+// takes a 64-bit DPP operand (row_newbcast only) at full rate: 4.7 cycles per FMA against 8.8 for mov + FMA, and a
+// dependent chain (the triangular sweeps) runs at 8.5 instead of 16.4 (tools/microbench/pair_cost.hip).  The
+// hardware interlocks the DPP read-after-write of the DP ALU (tools/microbench/dpp_hazard.hip), no s_nop needed.
+template <int K> __device__ __forceinline__ void fmac_bc(double& acc, double src, double mult) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fnmac_bc(double& acc, double src, double mult) {
+  asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
+}
+// LCP_Q_LDSW = 1 keeps a packed symmetric copy of W in LDS and rebuilds T from it instead of re-reading the workspace
+// (cuts the L2-miss traffic of the 11 factorisations).  Measured on MI355X, B = 4096 x 16 contacts: forward 0.260 ms
+// against 0.227 ms with the plain 16-byte global loads (64 ds_read_b64 + address selects per lane cost more than 32
+// L2/MALL-served dwordx4 loads), so it is off.
+#ifndef LCP_Q_LDSW
+#define LCP_Q_LDSW 0
+#endif
+#ifndef LCP_Q_ASM_PROD
+#define LCP_Q_ASM_PROD 0
+#endif
+#ifndef LCP_Q_ASM_LU
+#define LCP_Q_ASM_LU 0
+#endif
+#ifndef LCP_Q_ASM_TS
+#define LCP_Q_ASM_TS 0
+#endif
+template <int K, int ASM> __device__ __forceinline__ void fmac_sel(double& acc, double src, double mult) {
+  if (ASM) fmac_bc<K>(acc, src, mult); else acc = fma(bc<K>(src), mult, acc);
+}
+template <int K, int ASM> __device__ __forceinline__ void fnmac_sel(double& acc, double src, double mult) {
+  if (ASM) fnmac_bc<K>(acc, src, mult); else acc = fma(bc<K>(src), -mult, acc);
+}
+template <int K, int ASM> __device__ __forceinline__ void fmac_sel(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), mult, acc); }
+template <int K, int ASM> __device__ __forceinline__ void fnmac_sel(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), -mult, acc); }
+template <int K> __device__ __forceinline__ void fmac_bc(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), mult, acc); }
+template <int K> __device__ __forceinline__ void fnmac_bc(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), -mult, acc); }
+// v where keep, else (numerically) zero: clears the high dword only - what is left is below 2^-1042, which vanishes
+// in every accumulation it enters.  One v_cndmask instead of two for the masked triangular-solve multipliers.
+__device__ __forceinline__ double keep_if(double v, bool keep) { return __hiloint2double(keep ? __double2hiint(v) : 0, __double2loint(v)); }
+__device__ __forceinline__ float keep_if(float v, bool keep) { return keep ? v : 0.0f; }
+// the same with the condition taken from bit K of a per-lane bit mask: v_bfe_i32 + v_and, no compare, no VCC hazard
+// (the bit-field extract is opaque asm: written with the builtin, instcombine turns it back into compare + select)
+template <int K> __device__ __forceinline__ int bit_to_word(int mask) { int m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(mask), "n"(K)); return m; }
+template <int K> __device__ __forceinline__ double keep_bit(double v, int mask) {
+  return __hiloint2double(__double2hiint(v) & bit_to_word<K>(mask), __double2loint(v));
+}
+template <int K> __device__ __forceinline__ float keep_bit(float v, int mask) { return __int_as_float(__float_as_int(v) & bit_to_word<K>(mask)); }
 template <int CTRL> __device__ __forceinline__ float dppx(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
@@ -63,16 +108,59 @@ template <typename T> __device__ __forceinline__ T row_min(T v) {
   o = dppx<0x140>(v); v = v < o ? v : o;
   return v;
 }
-__device__ __forceinline__ bool row_any(bool p) { return row_max(p ? 1.0f : 0.0f) > 0.0f; }
+// NaN handling without compare + select chains (on gfx950 every v_cmp -> v_cndmask pair costs an extra 2 wait states):
+// the value reductions use v_max / v_min (which skip NaNs) and NaN-ness travels separately as the "key" = the value's
+// high word without the sign bit, reduced with an unsigned max; only a NaN has a key above the infinity pattern.
+__device__ __forceinline__ uint32_t nan_key(double v) { return (uint32_t)__double2hiint(v) & 0x7fffffffu; }
+__device__ __forceinline__ uint32_t nan_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+template <typename T> __device__ __forceinline__ bool key_is_nan(uint32_t k);
+template <> __device__ __forceinline__ bool key_is_nan<double>(uint32_t k) { return k > 0x7ff00000u; }
+template <> __device__ __forceinline__ bool key_is_nan<float>(uint32_t k) { return k > 0x7f800000u; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ uint32_t row_umax(uint32_t k) {
+  k = umax(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xf, 0xf, true));
+  k = umax(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xf, 0xf, true));
+  k = umax(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xf, 0xf, true));
+  k = umax(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xf, 0xf, true));
+  return k;
+}
+template <typename T> __device__ __forceinline__ T row_fmax(T v) {
+  v = fmax_(v, dppx<0xB1>(v)); v = fmax_(v, dppx<0x4E>(v)); v = fmax_(v, dppx<0x141>(v)); v = fmax_(v, dppx<0x140>(v));
+  return v;
+}
+template <typename T> __device__ __forceinline__ T row_fmin(T v) {
+  v = fmin_(v, dppx<0xB1>(v)); v = fmin_(v, dppx<0x4E>(v)); v = fmin_(v, dppx<0x141>(v)); v = fmin_(v, dppx<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ bool row_any(bool p) { return row_umax(p ? 1u : 0u) != 0u; }
 // NaN-propagating (Tensor.max()/min() semantics)
-template <typename T> __device__ __forceinline__ T row_pmax(T v) { const bool n = row_any(v != v); v = row_max(v); return n ? nan_of<T>() : v; }
-template <typename T> __device__ __forceinline__ T row_pmin(T v) { const bool n = row_any(v != v); v = row_min(v); return n ? nan_of<T>() : v; }
+template <typename T> __device__ __forceinline__ T row_pmax(T v) { const uint32_t k = row_umax(nan_key(v)); v = row_fmax(v); return key_is_nan<T>(k) ? nan_of<T>() : v; }
+template <typename T> __device__ __forceinline__ T row_pmin(T v) { const uint32_t k = row_umax(nan_key(v)); v = row_fmin(v); return key_is_nan<T>(k) ? nan_of<T>() : v; }
 
 // Opaque pass-through: stops LICM from hoisting loop-invariant LDS loads / float->double conversions of the
 // Jacobian rows out of the PDIPM loop (it did, and the ~200 extra live registers spilled to scratch).
 template <typename T> __device__ __forceinline__ T* launder(T* p) { asm volatile("" : "+v"(p)); return p; }
 __device__ __forceinline__ float launder(float f) { asm volatile("" : "+v"(f)); return f; }
+// the lane-index compares (l16 > k, l16 == k ...) are loop-invariant: hoisted, their 64-bit masks overflow the SGPR file and
+// come back through v_readlane spills; laundering the index per call keeps them local (one v_cmp each instead)
+__device__ __forceinline__ int launder(int i) { asm volatile("" : "+v"(i)); return i; }
 __device__ __forceinline__ double launder(double f) { asm volatile("" : "+v"(f)); return f; }
+
+// Phase timing (build with -DLCP_Q_PROFILE; the dense forward then writes cycle totals to the debug trace buffer)
+#ifdef LCP_Q_PROFILE
+struct Prof { long long t[10]; long long last; };
+#define LCP_QTICK(pr, i) { const long long now_ = clock64(); (pr).t[i] += now_ - (pr).last; (pr).last = now_; }
+#define LCP_QPROF_ARG , Prof& pr
+#define LCP_QPROF_PASS , pr
+#else
+#define LCP_QTICK(pr, i)
+#define LCP_QPROF_ARG
+#define LCP_QPROF_PASS
+#endif
 
 template <typename TC> struct M4 { TC n, f1, f2, g; };       // the four inequality rows of one contact
 template <typename TC> __device__ __forceinline__ M4<TC> m4(TC a, TC b, TC c, TC d) { M4<TC> r; r.n = a; r.f1 = b; r.f2 = c; r.g = d; return r; }
@@ -86,9 +174,14 @@ struct LdsQ {
   TI* AtL;   // [EQ][16]  A rows
   TC* GAL;   // [16][2][EQ]  (J Q^-1 A^T) of the n / t row of every contact
   TC* S11;   // [EQ][EQ]     (A Q^-1 A^T)^-1
+  TC* WL;    // [528]        W = J P J^T of the reduced system, upper triangle packed by rows (forward kernel only):
+             //              the 11 factorisations of a solve rebuild T = W + diag from here instead of re-reading HBM
 };
+constexpr int NRED = 32;                                   // rows of the reduced system: a_0..a_15, u_0..u_15
+__host__ __device__ constexpr int wl_row(int i) { return i * NRED - (i * (i - 1)) / 2 - i; }   // (i, j >= i) lives at wl_row(i) + j
+constexpr int WL_ELEMS = NRED * (NRED + 1) / 2;
 template <typename TI, typename TC>
-__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem) {
+__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, bool with_w) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
   L.GAL = (TC*)take(sizeof(TC) * NCQ * 2 * EQ);
@@ -96,6 +189,7 @@ __host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem) 
   L.GL = (TI*)take(sizeof(TI) * NCQ * 16);
   L.GTL = (TI*)take(sizeof(TI) * NCQ * 16);
   L.AtL = (TI*)take(sizeof(TI) * EQ * 16);
+  L.WL = with_w ? (TC*)take(sizeof(TC) * WL_ELEMS + 16) : nullptr;   // (+16 B: scene blocks do not all start on the same LDS bank)
   return (size_t)(q - smem);
 }
 
@@ -112,36 +206,51 @@ struct SceneQ {
   TC mu;                  // friction coefficient of this contact
 
   // m-space <- x-space:  (Jc v)_c and (Jt v)_c
+  // (the wave is alone on its SIMD: a single accumulator would serialise on the FMA latency, so every product below
+  //  runs two to four independent partial sums)
   __device__ __forceinline__ void Gv(TC v, TC& gn, TC& gt) const {
-    gn = 0; gt = 0;
-    static_for<16>([&](auto J) LCP_INL { const TC vb = bc<J>(v); gn = fma((TC)launder(jc[J]), vb, gn); gt = fma((TC)launder(jt[J]), vb, gt); });
+    TC n0 = 0, n1 = 0, t0 = 0, t1 = 0;
+    static_for<8>([&](auto H) LCP_INL {
+      constexpr int J = 2 * H;
+      fmac_sel<J, LCP_Q_ASM_PROD>(n0, v, (TC)launder(jc[J])); fmac_sel<J, LCP_Q_ASM_PROD>(t0, v, (TC)launder(jt[J]));
+      fmac_sel<J + 1, LCP_Q_ASM_PROD>(n1, v, (TC)launder(jc[J + 1])); fmac_sel<J + 1, LCP_Q_ASM_PROD>(t1, v, (TC)launder(jt[J + 1]));
+    });
+    gn = n0 + n1; gt = t0 + t1;
   }
   // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
   __device__ __forceinline__ TC Gtw(TC wn, TC wt) const {
-    TC acc = 0;
+    TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const TI* gl = launder(L.GL) + l16;
     const TI* gtl = launder(L.GTL) + l16;
-    static_for<16>([&](auto C) LCP_INL {
-      acc = fma((TC)gl[C * 16], bc<C>(wn), acc);
-      acc = fma((TC)gtl[C * 16], bc<C>(wt), acc);
+    static_for<8>([&](auto H) LCP_INL {
+      constexpr int C = 2 * H;
+      fmac_sel<C, LCP_Q_ASM_PROD>(a0, wn, (TC)gl[C * 16]);
+      fmac_sel<C, LCP_Q_ASM_PROD>(a1, wt, (TC)gtl[C * 16]);
+      fmac_sel<C + 1, LCP_Q_ASM_PROD>(a2, wn, (TC)gl[(C + 1) * 16]);
+      fmac_sel<C + 1, LCP_Q_ASM_PROD>(a3, wt, (TC)gtl[(C + 1) * 16]);
     });
-    return acc;
+    return (a0 + a1) + (a2 + a3);
   }
   __device__ __forceinline__ TC Av(TC v) const {        // e-space <- x-space
-    TC acc = 0;
+    TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const TI* ar = launder(L.AtL) + (l16 & (EQ - 1)) * 16;       // row l16 of A (rows >= e are zero; lanes >= EQ unused)
-    static_for<16>([&](auto K) LCP_INL { acc = fma((TC)ar[K], bc<K>(v), acc); });
-    return (l16 < EQ) ? acc : (TC)0;
+    static_for<4>([&](auto H) LCP_INL {
+      constexpr int K = 4 * H;
+      fmac_sel<K, LCP_Q_ASM_PROD>(a0, v, (TC)ar[K]); fmac_sel<K + 1, LCP_Q_ASM_PROD>(a1, v, (TC)ar[K + 1]);
+      fmac_sel<K + 2, LCP_Q_ASM_PROD>(a2, v, (TC)ar[K + 2]); fmac_sel<K + 3, LCP_Q_ASM_PROD>(a3, v, (TC)ar[K + 3]);
+    });
+    return (l16 < EQ) ? (a0 + a1) + (a2 + a3) : (TC)0;
   }
   __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
-    TC acc = 0;
+    TC a0 = 0, a1 = 0;
     const TI* at = launder(L.AtL) + l16;
-    static_for<EQ>([&](auto A) LCP_INL { acc = fma((TC)at[A * 16], bc<A>(y), acc); });
-    return acc;
+    fmac_sel<0, LCP_Q_ASM_PROD>(a0, y, (TC)at[0]); fmac_sel<1, LCP_Q_ASM_PROD>(a1, y, (TC)at[16]);
+    fmac_sel<2, LCP_Q_ASM_PROD>(a0, y, (TC)at[32]); fmac_sel<3, LCP_Q_ASM_PROD>(a1, y, (TC)at[48]);
+    return a0 + a1;
   }
   __device__ __forceinline__ void GAt(TC t, TC& gn, TC& gt) const {     // m-space <- e-space
     gn = 0; gt = 0;
-    static_for<EQ>([&](auto A) LCP_INL { const TC tb = bc<A>(t); gn = fma(gan[A], tb, gn); gt = fma(gat[A], tb, gt); });
+    static_for<EQ>([&](auto A) LCP_INL { fmac_sel<A, LCP_Q_ASM_PROD>(gn, t, gan[A]); fmac_sel<A, LCP_Q_ASM_PROD>(gt, t, gat[A]); });
   }
   __device__ __forceinline__ TC GAtw(TC wn, TC wt) const {              // e-space <- m-space
     TC out = 0;
@@ -149,9 +258,10 @@ struct SceneQ {
     return out;
   }
   __device__ __forceinline__ TC S11v(TC v) const {
-    TC acc = 0;
-    static_for<EQ>([&](auto C) LCP_INL { acc = fma(s11row[C], bc<C>(v), acc); });
-    return acc;
+    TC a0 = 0, a1 = 0;
+    fmac_sel<0, LCP_Q_ASM_PROD>(a0, v, s11row[0]); fmac_sel<1, LCP_Q_ASM_PROD>(a1, v, s11row[1]);
+    fmac_sel<2, LCP_Q_ASM_PROD>(a0, v, s11row[2]); fmac_sel<3, LCP_Q_ASM_PROD>(a1, v, s11row[3]);
+    return a0 + a1;
   }
 };
 
@@ -163,10 +273,10 @@ struct RedQ {
   TC ua, uu;                          // 1 / U[c][c], 1 / U[16+c][16+c]
 };
 
-template <typename TI, typename TC>
+template <typename TI, typename TC, bool LDSW>
 __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC>& S, const TC* W2q,
-                                         const M4<TC>& D, bool valid) {
-  const int l16 = S.l16, nc = S.ncw;
+                                         const M4<TC>& D, bool valid LCP_QPROF_ARG) {
+  const int l16 = launder(S.l16), nc = S.ncw;
   R.Dg = D.g;
   R.Sp = (TC)0.5 * (D.f1 + D.f2); R.Sm = (TC)0.5 * (D.f1 - D.f2);
   R.idet = fast_rcp(R.Sp * R.Dg + (TC)2);
@@ -174,11 +284,24 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
   const TC addA = valid ? D.n : (TC)1;                                           // on column c of row a_c
   const TC addB = valid ? (TC)0.5 * R.Sm * R.wa : (TC)0;                         // on column c of row u_c
   const TC addU = valid ? (TC)0.5 * (R.Sp + R.Sm * R.wu) : (TC)1;                // on column 16 + c of row u_c
-  static_for<16>([&](auto P) LCP_INL {
-    constexpr int q = 2 * P;
-    load2(W2q + (((size_t)P * 2 + 0) * 16 + l16) * 2, ta[q], ta[q + 1]);
-    load2(W2q + (((size_t)P * 2 + 1) * 16 + l16) * 2, tu[q], tu[q + 1]);
-  });
+  if (LDSW) {
+    // symmetric W from LDS: row r of lane (r = l16 for a, 16 + l16 for u), column q: (r, q) if q >= r else (q, r)
+    const TC* wl = launder(S.L.WL);
+    const int ra = wl_row(l16), ru = wl_row(16 + l16);
+    static_for<32>([&](auto Qc) LCP_INL {
+      constexpr int q = Qc;
+      if (q >= 16) ta[q] = wl[ra + q];
+      else ta[q] = wl[(q >= l16) ? (ra + q) : (wl_row(q) + l16)];
+      if (q < 16) tu[q] = wl[wl_row(q) + 16 + l16];
+      else tu[q] = wl[(q >= 16 + l16) ? (ru + q) : (wl_row(q) + 16 + l16)];
+    });
+  } else {
+    static_for<16>([&](auto P) LCP_INL {
+      constexpr int q = 2 * P;
+      load2(W2q + (((size_t)P * 2 + 0) * 16 + l16) * 2, ta[q], ta[q + 1]);
+      load2(W2q + (((size_t)P * 2 + 1) * 16 + l16) * 2, tu[q], tu[q + 1]);
+    });
+  }
   static_for<16>([&](auto Q) LCP_INL {
     ta[Q] += (l16 == Q) ? addA : (TC)0;
     tu[Q] += (l16 == Q) ? addB : (TC)0;
@@ -186,40 +309,52 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
   });
   bool singular = false;
   R.ua = 1; R.uu = 1;
+  LCP_QTICK(pr, 1)                                                               // W load + diagonal
+  // Right-looking LU without pivoting.  The wave is alone on its SIMD (register budget), so nothing hides the
+  // latency of the pivot chain (row broadcast -> v_rcp_f64 -> Newton steps): each step therefore updates the NEXT pivot
+  // column first and launches that pivot's reciprocal before it sweeps the remaining columns.
+  TC pivv = bc<0>(ta[0]);
+  TC inv = fast_rcp(pivv);
   static_for<16>([&](auto K) LCP_INL {                                           // pivots a_0 .. a_15
     constexpr int k = K;
     if (k < nc) {
-      const TC piv = bc<k>(ta[k]);
-      singular = singular || (piv == (TC)0);
-      const TC inv = fast_rcp(piv);
+      singular = singular || (pivv == (TC)0);
       const TC la = (l16 > k) ? ta[k] * inv : (TC)0;
       const TC lu = tu[k] * inv;
       ta[k] = (l16 > k) ? la : ta[k];
       tu[k] = lu;
       R.ua = (l16 == k) ? inv : R.ua;
-      static_for<31 - k>([&](auto JJ) LCP_INL {
-        constexpr int j = k + 1 + JJ;
-        const TC sj = bc<k>(ta[j]);
-        ta[j] = fma(-la, sj, ta[j]);
-        tu[j] = fma(-lu, sj, tu[j]);
+      fnmac_sel<k, LCP_Q_ASM_LU>(tu[k + 1], ta[k + 1], lu);          // (reads row k's ta[j] before it is updated below)
+      fnmac_sel<k, LCP_Q_ASM_LU>(ta[k + 1], ta[k + 1], la);
+      if constexpr (k + 1 < 16) pivv = bc<(k + 1) & 15>(ta[k + 1]); else pivv = bc<0>(tu[16]);
+      inv = fast_rcp(pivv);
+      static_for<30 - k>([&](auto JJ) LCP_INL {
+        constexpr int j = k + 2 + JJ;
+        fnmac_sel<k, LCP_Q_ASM_LU>(tu[j], ta[j], lu);
+        fnmac_sel<k, LCP_Q_ASM_LU>(ta[j], ta[j], la);
       });
     }
   });
+  if (nc < 16) { pivv = bc<0>(tu[16]); inv = fast_rcp(pivv); }                   // (the a sweep stopped early)
   static_for<16>([&](auto K) LCP_INL {                                           // pivots u_0 .. u_15
     constexpr int kk = K, k = 16 + K;
     if (kk < nc) {
-      const TC piv = bc<kk>(tu[k]);
-      singular = singular || (piv == (TC)0);
-      const TC inv = fast_rcp(piv);
+      singular = singular || (pivv == (TC)0);
       const TC lu = (l16 > kk) ? tu[k] * inv : (TC)0;
       tu[k] = (l16 > kk) ? lu : tu[k];
       R.uu = (l16 == kk) ? inv : R.uu;
-      static_for<15 - kk>([&](auto JJ) LCP_INL {
-        constexpr int j = k + 1 + JJ;
-        tu[j] = fma(-lu, bc<kk>(tu[j]), tu[j]);
-      });
+      if constexpr (kk < 15) {
+        fnmac_sel<kk, LCP_Q_ASM_LU>(tu[k + 1], tu[k + 1], lu);
+        pivv = bc<(kk + 1) & 15>(tu[k + 1]);
+        inv = fast_rcp(pivv);
+        static_for<14 - kk>([&](auto JJ) LCP_INL {
+          constexpr int j = k + 2 + JJ;
+          fnmac_sel<kk, LCP_Q_ASM_LU>(tu[j], tu[j], lu);
+        });
+      }
     }
   });
+  LCP_QTICK(pr, 2)                                                               // LU
   return singular;
 }
 
@@ -234,31 +369,27 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
   static_for<16>([&](auto K) LCP_INL {                     // L y = rhs
     constexpr int k = K;
     if (k < nc) {
-      const TC yk = bc<k>(ra);
-      ra = fma(-((l16 > k) ? ta[k] : (TC)0), yk, ra);
-      ru = fma(-tu[k], yk, ru);
+      fnmac_sel<k, LCP_Q_ASM_TS>(ru, ra, tu[k]);
+      fnmac_sel<k, LCP_Q_ASM_TS>(ra, ra, keep_if(ta[k], l16 > k));
     }
   });
   static_for<16>([&](auto K) LCP_INL {
     constexpr int kk = K, k = 16 + K;
-    if (kk < nc) {
-      const TC yk = bc<kk>(ru);
-      ru = fma(-((l16 > kk) ? tu[k] : (TC)0), yk, ru);
-    }
+    if (kk < nc) fnmac_sel<kk, LCP_Q_ASM_TS>(ru, ru, keep_if(tu[k], l16 > kk));
   });
   static_for<16>([&](auto KR) LCP_INL {                    // U x = y
     constexpr int kk = 15 - KR, k = 16 + kk;
     if (kk < nc) {
-      const TC xk = bc<kk>(ru * R.uu);
-      ru = fma(-((l16 < kk) ? tu[k] : (TC)0), xk, ru);
-      ra = fma(-ta[k], xk, ra);
+      const TC xs = ru * R.uu;                             // x_kk lives in lane kk of xs
+      fnmac_sel<kk, LCP_Q_ASM_TS>(ra, xs, ta[k]);
+      fnmac_sel<kk, LCP_Q_ASM_TS>(ru, xs, keep_if(tu[k], l16 < kk));
     }
   });
   static_for<16>([&](auto KR) LCP_INL {
     constexpr int k = 15 - KR;
     if (k < nc) {
-      const TC xk = bc<k>(ra * R.ua);
-      ra = fma(-((l16 < k) ? ta[k] : (TC)0), xk, ra);
+      const TC xs = ra * R.ua;
+      fnmac_sel<k, LCP_Q_ASM_TS>(ra, xs, keep_if(ta[k], l16 < k));
     }
   });
   const TC a = ra * R.ua, u = ru * R.uu;
@@ -272,12 +403,14 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
 // solve_kkt (pdipm.py:325-354).  rs, rz given per contact (M4), rx in x-space, ry in e-space.
 template <typename TI, typename TC>
 __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R,
-                                            const M4<TC>& d, bool valid, TC rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
-                                            TC& ox, M4<TC>& os, M4<TC>& oz, TC& oy) {
+                                            const M4<TC>& di, bool valid, TC rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
+                                            TC& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
   const TC v = S.qid * rx;                                                 // :333 (diagonal Q)
   TC gn, gt;
   S.Gv(v, gn, gt);
-  M4<TC> hz = m4<TC>(gn + rs.n / d.n - rz.n, gt + rs.f1 / d.f1 - rz.f1, -gt + rs.f2 / d.f2 - rz.f2, rs.g / d.g - rz.g);   // :334-340
+  // `di` = 1 / d (already formed for T = R + diag(1/d)): rs / d is taken as rs * di - one rounding more than the
+  // reference's division, 8 fp64 divisions less per solve
+  M4<TC> hz = m4<TC>(gn + rs.n * di.n - rz.n, gt + rs.f1 * di.f1 - rz.f1, -gt + rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);   // :334-340
   TC hy = 0;
   if (S.e > 0) {
     hy = S.Av(v) - ry;
@@ -286,17 +419,20 @@ __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&
     hz.n -= an; hz.f1 -= at; hz.f2 += at;
   }
   if (!valid) hz = m4<TC>(0, 0, 0, 0);
+  LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
   const M4<TC> wz = tsolve_q<TI, TC>(ta, tu, R, S, hz);
+  LCP_QTICK(pr, 4)                                                         // triangular sweeps
   TC dy = 0;
   if (S.e > 0) dy = -S.S11v(hy - S.GAtw(valid ? wz.n : (TC)0, valid ? wz.f1 - wz.f2 : (TC)0));    // dy = -wy
   oz = m4<TC>(-wz.n, -wz.f1, -wz.f2, -wz.g);                               // :342
   if (!valid) oz = m4<TC>(0, 0, 0, 0);
-  os = m4<TC>((-rs.n - oz.n) / d.n, (-rs.f1 - oz.f1) / d.f1, (-rs.f2 - oz.f2) / d.f2, (-rs.g - oz.g) / d.g);   // :347,350
+  os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
   if (!valid) os = m4<TC>(0, 0, 0, 0);
   oy = dy;
   TC g1 = -rx - S.Gtw(oz.n, oz.f1 - oz.f2);                                // :344-346
   if (S.e > 0) g1 -= S.Aty(dy);
   ox = S.qid * g1;                                                         // :349
+  LCP_QTICK(pr, 5)                                                         // solve_kkt: products after
 }
 
 // get_step for (z,dz),(s,ds) of one scene (pdipm.py:182-186): min(step(z,dz), step(s,ds)), NaN semantics kept
@@ -305,15 +441,21 @@ __device__ __forceinline__ TC step_pair_q(const M4<TC>& z, const M4<TC>& dz, con
   const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
   const M4<TC> az = m4<TC>(-z.n / dz.n, -z.f1 / dz.f1, -z.f2 / dz.f2, -z.g / dz.g);
   const M4<TC> as = m4<TC>(-s.n / ds.n, -s.f1 / ds.f1, -s.f2 / ds.f2, -s.g / ds.g);
-  TC mz = valid ? pmax(pmax(az.n, az.f1), pmax(az.f2, az.g)) : ninf;
-  TC ms = valid ? pmax(pmax(as.n, as.f1), pmax(as.f2, as.g)) : ninf;
-  mz = row_pmax(mz); ms = row_pmax(ms);
-  const TC fz = (mz > (TC)1) ? mz : (TC)1, fs = (ms > (TC)1) ? ms : (TC)1;
+  auto key4 = [&](const M4<TC>& a) { return umax(umax(nan_key(a.n), nan_key(a.f1)), umax(nan_key(a.f2), nan_key(a.g))); };
+  // a.max() (NaN if any entry is NaN), then max(1.0, .) which maps NaN to 1.0
+  TC mz = valid ? fmax_(fmax_(az.n, az.f1), fmax_(az.f2, az.g)) : ninf;
+  TC ms = valid ? fmax_(fmax_(as.n, as.f1), fmax_(as.f2, as.g)) : ninf;
+  const uint32_t kmz = row_umax(valid ? key4(az) : 0u), kms = row_umax(valid ? key4(as) : 0u);
+  mz = row_fmax(mz); ms = row_fmax(ms);
+  const TC fz = key_is_nan<TC>(kmz) ? (TC)1 : fmax_(mz, (TC)1), fs = key_is_nan<TC>(kms) ? (TC)1 : fmax_(ms, (TC)1);
+  // a[dv > 0] = fill ; a.min() (NaN if any remaining entry is NaN) ; the two vectors are merged before the row reduction
   auto pick = [&](TC dv, TC a, TC fill) { return (dv > (TC)0) ? fill : a; };
-  TC lz = valid ? pmin(pmin(pick(dz.n, az.n, fz), pick(dz.f1, az.f1, fz)), pmin(pick(dz.f2, az.f2, fz), pick(dz.g, az.g, fz))) : pinf;
-  TC ls = valid ? pmin(pmin(pick(ds.n, as.n, fs), pick(ds.f1, as.f1, fs)), pmin(pick(ds.f2, as.f2, fs), pick(ds.g, as.g, fs))) : pinf;
-  lz = row_pmin(lz); ls = row_pmin(ls);
-  return pmin(lz, ls);
+  const M4<TC> pz = m4<TC>(pick(dz.n, az.n, fz), pick(dz.f1, az.f1, fz), pick(dz.f2, az.f2, fz), pick(dz.g, az.g, fz));
+  const M4<TC> ps = m4<TC>(pick(ds.n, as.n, fs), pick(ds.f1, as.f1, fs), pick(ds.f2, as.f2, fs), pick(ds.g, as.g, fs));
+  TC l = valid ? fmin_(fmin_(fmin_(pz.n, pz.f1), fmin_(pz.f2, pz.g)), fmin_(fmin_(ps.n, ps.f1), fmin_(ps.f2, ps.g))) : pinf;
+  const uint32_t kl = row_umax(valid ? umax(key4(pz), key4(ps)) : 0u);
+  l = row_fmin(l);
+  return key_is_nan<TC>(kl) ? nan_of<TC>() : l;
 }
 
 // workspace view of the quad path: W (8 KB) in the R2 region, the rest in the w64 fields
@@ -458,6 +600,14 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& 
       store2(W.R2 + (((size_t)(q0 >> 1) * 2 + 0) * 16 + l16) * 2, va[0], va[1]);
       store2(W.R2 + (((size_t)(q0 >> 1) * 2 + 1) * 16 + l16) * 2, vu[0], vu[1]);
     }
+    if (S.L.WL) {                                       // upper triangle -> LDS (W is symmetric up to rounding)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int q = q0 + h2;
+        if (q >= l16) S.L.WL[wl_row(l16) + q] = va[h2];
+        if (q >= 16 + l16) S.L.WL[wl_row(16 + l16) + q] = vu[h2];
+      }
+    }
   }
   if (live) store_scene_ws<TI, TC>(W, S);
   __threadfence_block();
@@ -483,7 +633,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   if (!FUSED) live = live && ((int)W.meta[0] == accept);
   if (!__any(live)) return;
   SceneQ<TI, TC> S;
-  carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0);
   // per-scene contact count (solve_dynamics with detection); a scene without contacts takes the
   // direct KKT solve of engines.py:36-50, which is what the initialisation solve computes
   int ncs = nc;
@@ -507,11 +657,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   TC ta[32], tu[32];
   RedQ<TC> R;
   TC x = 0, y = 0;
-  M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), d = m4<TC>(1, 1, 1, 1);
+  M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), dinv = m4<TC>(1, 1, 1, 1);
   TC best_resid = inf_of<TC>();
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
   const TC mf = (TC)(4 * ncs);                                           // nineq of this scene
+#ifdef LCP_Q_PROFILE
+  Prof pr; for (int i = 0; i < 10; ++i) pr.t[i] = 0;
+  pr.last = clock64();
+#endif
 
 #pragma unroll 1
   for (int it = -1; it < max_iter; ++it) {
@@ -519,7 +673,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     TC rx, ry, mu = 0, resid = 0;
     M4<TC> rs, rz;
     if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63)
-      rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); d = m4<TC>(1, 1, 1, 1);
+      rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); dinv = m4<TC>(1, 1, 1, 1);
     } else {                                                               // residuals (:82-96)
       rx = S.Gtw(z.n, z.f1 - z.f2) + S.qd * x + p;
       if (e > 0) rx += S.Aty(y);
@@ -536,10 +690,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       const TC sz = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
       mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
-      d = vc ? m4<TC>(z.n / s.n, z.f1 / s.f1, z.f2 / s.f2, z.g / s.g) : m4<TC>(1, 1, 1, 1);   // (:98)
+      dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
     }
-    const M4<TC> dinv = m4<TC>((TC)1 / d.n, (TC)1 / d.f1, (TC)1 / d.f2, (TC)1 / d.g);
-    const bool singular = row_any(factor_q<TI, TC>(ta, tu, R, S, W.R2, dinv, vc));           // (:99-100)
+    LCP_QTICK(pr, 0)                                                       // residuals, d
+    const bool singular = row_any(factor_q<TI, TC, LCP_Q_LDSW != 0>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS));     // (:99-100)
     if (it >= 0 && !done) {
       ++iters;
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
@@ -558,6 +712,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       }
     }
     if (!__any(!done)) break;
+    LCP_QTICK(pr, 6)                                                       // bookkeeping, best iterate
     TC ax = 0, ay = 0;
     M4<TC> as_ = m4<TC>(0, 0, 0, 0), az = as_;
     const int npass = (it < 0) ? 1 : 2;
@@ -565,10 +720,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     for (int pass = 0; pass < npass; ++pass) {
       TC ox, oy;
       M4<TC> os, oz;
-      solve_kkt_q<TI, TC>(S, ta, tu, R, d, vc, rx, rs, rz, ry, ox, os, oz, oy);
+      solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
-        const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());
+        const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());       // (once per solve)
         const TC zmin = row_pmin(vc ? pmin(pmin(z.n, z.f1), pmin(z.f2, z.g)) : inf_of<TC>());
         if (smin <= (TC)0) { const TC sh = (TC)1 - smin; s = m4<TC>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
         if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
@@ -602,8 +757,12 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
           }
         }
       }
+      LCP_QTICK(pr, 7)                                                     // step lengths, sigma, update
     }
   }
+#ifdef LCP_Q_PROFILE
+  if (!FUSED && P.trace && lane == 0) { double* tr = P.trace + (size_t)scene * 4 * max_iter; for (int i = 0; i < 8; ++i) tr[i] = (double)pr.t[i]; tr[8] = (double)iters; }
+#endif
 
   // outputs (natural m-space order: n rows, friction pairs, gamma rows): read the best iterate back
   if (!live) return;
@@ -655,7 +814,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   const bool live = (scene_raw < P.B) && ((int)W.meta[0] == accept);
   if (!__any(live)) return;
   SceneQ<TI, TC> S;
-  carve_q(S.L, smem_all + (size_t)row * lds_per_scene);
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, false);
   int ncs = live ? (int)W.meta[19] : 0;                                  // live contacts of the scene (set by the forward)
   ncs = ncs < 0 ? 0 : (ncs > nc ? nc : ncs);
   int ncw = ncs;
@@ -687,15 +846,17 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const TC g = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
-  const M4<TC> d = m4<TC>(z.n / s.n, z.f1 / s.f1, z.f2 / s.f2, z.g / s.g);               // lcp.py:44
-  const M4<TC> dinv = m4<TC>((TC)1 / d.n, (TC)1 / d.f1, (TC)1 / d.f2, (TC)1 / d.g);
+  const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);            // 1 / d, d = z / s (lcp.py:44)
   TC ta[32], tu[32];
   RedQ<TC> R;
-  factor_q<TI, TC>(ta, tu, R, S, W.R2, dinv, vc);                                      // lcp.py:46
+#ifdef LCP_Q_PROFILE
+  Prof pr; pr.last = 0;
+#endif
+  factor_q<TI, TC, false>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
   TC dx, dnu;
   M4<TC> ds, dl;
   const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC>(S, ta, tu, R, d, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu);     // lcp.py:47-50
+  solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
   if (!live) return;
   // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
   if (P.dp && l16 < nz) ((TI*)P.dp)[(size_t)scene * nz + l16] = (TI)dx;
@@ -757,17 +918,17 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
 bool quad_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
 
 template <typename TC>
-static size_t q16_lds() { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr); }
+static size_t q16_lds(bool with_w) { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr, with_w); }
 
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
   if (compute == LCP_COMPUTE_F64) {
-    const int ls = (int)q16_lds<double>();
+    const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else {
-    const int ls = (int)q16_lds<float>();
+    const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
@@ -778,10 +939,10 @@ int quad_step(const StepArgs& SP, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
   if (compute == LCP_COMPUTE_F64) {
-    const int ls = (int)q16_lds<double>();
+    const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {
-    const int ls = (int)q16_lds<float>();
+    const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
@@ -791,10 +952,10 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
   if (compute == LCP_COMPUTE_F64) {
-    const int ls = (int)q16_lds<double>();
+    const int ls = (int)q16_lds<double>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double>), grid, blk, 4 * ls, st, P, ls, accept);
   } else {
-    const int ls = (int)q16_lds<float>();
+    const int ls = (int)q16_lds<float>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<float, float>), grid, blk, 4 * ls, st, P, ls, accept);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;

@@ -12,6 +12,18 @@ __device__ __forceinline__ double rdl(double v, int s) {
 }
 __device__ __forceinline__ float rdl(float v, int s) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s)); }
 
+// acc += bcast_K(src) * mult with the broadcast folded into the FMA (64-bit DPP of the DP ALU, row_newbcast only)
+template <int K, bool NOP> __device__ __forceinline__ void fmac_bc(double& acc, double src, double mult) {
+  if (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
+}
+template <int K, bool NOP> __device__ __forceinline__ void fmac_bc_self(double& acc, double mult) {
+  if (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(mult), "n"(K));
+  else asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(mult), "n"(K));
+}
+template <int K, bool NOP> __device__ __forceinline__ void fmac_bc(float&, float, float) {}
+template <int K, bool NOP> __device__ __forceinline__ void fmac_bc_self(float&, float) {}
+
 // MODE 0: pair f64 (2 readlane + fma)   1: pair f32   2: fma f64 only (VGPR operands)   3: fma f32 only
 // MODE 4: 16x16x4 f64 MFMA chain (4 independent accumulators)   5: 16x16x4 f32 MFMA
 template <typename T, int MODE, int NP>
@@ -41,6 +53,54 @@ __global__ void __launch_bounds__(64) k(T* out, long long* cyc, int reps, int pl
         t[J] = fma(-l, sj, t[J]);
         t[J + NP / 2] = fma(-l2, sj, t[J + NP / 2]);
       });
+    } else if (MODE == 11) {         // one v_mov_b64_dpp row_newbcast (64-bit DPP of the DP ALU) + 2 FMAs
+      if constexpr (sizeof(T) == 8) {
+        sfor<NP / 2>([&](auto J) INL {
+          constexpr int ctrl = 0x150 + (J % 16);
+          const T sj = __builtin_amdgcn_update_dpp((T)0, t[J], ctrl, 0xf, 0xf, true);
+          t[J] = fma(-l, sj, t[J]);
+          t[J + NP / 2] = fma(-l2, sj, t[J + NP / 2]);
+        });
+      }
+    } else if (MODE == 12) {         // broadcast folded into the FMA: v_fmac_f64_dpp row_newbcast (no mov at all)
+      if constexpr (sizeof(T) == 8) {
+        const T nl = -l, nl2 = -l2;
+        sfor<NP / 2>([&](auto J) INL {
+          constexpr int K = J % 16;
+          fmac_bc<K, false>(t[J + NP / 2], t[J], nl2);
+          fmac_bc_self<K, false>(t[J], nl);
+        });
+      }
+    } else if (MODE == 13) {         // as 12, with the 2 wait states a freshly written DPP source needs (s_nop 1) in front of each
+      if constexpr (sizeof(T) == 8) {
+        const T nl = -l, nl2 = -l2;
+        sfor<NP / 2>([&](auto J) INL {
+          constexpr int K = J % 16;
+          fmac_bc<K, true>(t[J + NP / 2], t[J], nl2);
+          fmac_bc_self<K, true>(t[J], nl);
+        });
+      }
+    } else if (MODE == 14) {         // dependent chain: x += bcast_k(x) * c   (the triangular-solve pattern), builtin mov + fma
+      if constexpr (sizeof(T) == 8) {
+        sfor<NP>([&](auto J) INL {
+          constexpr int ctrl = 0x150 + (J % 16);
+          const T sj = __builtin_amdgcn_update_dpp((T)0, t[0], ctrl, 0xf, 0xf, true);
+          t[0] = fma(-l, sj, t[0]);
+        });
+      }
+    } else if (MODE == 15) {         // dependent chain with v_fmac_f64_dpp (+ s_nop 1 for the DPP read-after-write hazard)
+      if constexpr (sizeof(T) == 8) {
+        const T nl = -l;
+        sfor<NP>([&](auto J) INL {
+          constexpr int K = J % 16;
+          fmac_bc_self<K, true>(t[0], nl);
+        });
+      }
+    } else if (MODE == 16) {         // dependent chain with v_fmac_f64_dpp, no s_nop
+      if constexpr (sizeof(T) == 8) {
+        const T nl = -l;
+        sfor<NP>([&](auto J) INL { fmac_bc_self<J % 16, false>(t[0], nl); });
+      }
     } else if (MODE == 7 || MODE == 8 || MODE == 9) {   // batched: G readlane pairs first, then G fmas
       constexpr int G = (MODE == 7) ? 4 : (MODE == 8) ? 8 : 16;
       sfor<NP / G>([&](auto B) INL {
@@ -133,6 +193,12 @@ int main() {
     run("pair f32 batched 16", k<float, 9, 48>, blocks, reps, 48, of);
     run("dpp newbcast f64: 24 bcast + 48 fma", k<double, 10, 48>, blocks, reps, 48, o);
     run("dpp newbcast f32: 24 bcast + 48 fma", k<float, 10, 48>, blocks, reps, 48, of);
+    run("dpp b64 mov: 24 bcast + 48 fma", k<double, 11, 48>, blocks, reps, 48, o);
+    run("v_fmac_f64_dpp newbcast x48", k<double, 12, 48>, blocks, reps, 48, o);
+    run("v_fmac_f64_dpp + s_nop 1 x48", k<double, 13, 48>, blocks, reps, 48, o);
+    run("chain: b64 dpp mov + fma x48", k<double, 14, 48>, blocks, reps, 48, o);
+    run("chain: s_nop 1 + v_fmac_f64_dpp x48", k<double, 15, 48>, blocks, reps, 48, o);
+    run("chain: v_fmac_f64_dpp (no nop) x48", k<double, 16, 48>, blocks, reps, 48, o);
     run("fma f64 only x48", k<double, 2, 48>, blocks, reps, 48, o);
     run("fma f32 only x48", k<float, 3, 48>, blocks, reps, 48, of);
     run2("mfma f64 16x16x4 x4", kmfma<1>, blocks, reps, 4, o);
