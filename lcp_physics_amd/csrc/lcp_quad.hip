@@ -53,7 +53,7 @@ template <int K> __device__ __forceinline__ void fnmac_bc(double& acc, double sr
 #define LCP_Q_ASM_PROD 0
 #endif
 #ifndef LCP_Q_ASM_LU
-#define LCP_Q_ASM_LU 0
+#define LCP_Q_ASM_LU 1
 #endif
 #ifndef LCP_Q_ASM_TS
 #define LCP_Q_ASM_TS 0
@@ -273,10 +273,141 @@ struct RedQ {
   TC ua, uu;                          // 1 / U[c][c], 1 / U[16+c][16+c]
 };
 
+
+// ---------------------------------------------------------------- LU column updates as hazard-safe asm blocks
+// The trailing update of an LU step is `row[j] -= bcast_k(row_k[j]) * l` for every remaining column j.  Written with
+// the builtin it costs v_mov_b64_dpp + v_fma_f64 per entry; v_fmac_f64_dpp folds the broadcast into the FMA (4.7 instead
+// of 6.7 cycles per entry, tools/microbench/pair_cost.hip).  clang never forms that instruction itself (its DPP combiner
+// skips FMAC), so it is emitted as inline asm - and inline asm is invisible to the hazard recogniser: gfx950 needs 2 wait
+// states between a VALU write of a VGPR and a DPP read of it (tools/microbench/dpp_hazard2.hip shows stale reads
+// without them).  Every asm statement below therefore starts with `s_nop 1` (covers whatever the compiler put in front:
+// copies, v_accvgpr_read ...) and inside a statement no DPP source is written before it is read; up to 14 column pairs
+// (30 operands) share one s_nop.
+#define LCP_DPP_FULL "row_mask:0xf bank_mask:0xf"
+#define LCP_LUA_COL(A, U)                                                                   \
+  "v_fmac_f64_dpp %[" #U "], %[" #A "], -%[lu] row_newbcast:%[k] " LCP_DPP_FULL "\n\t"      \
+  "v_fmac_f64_dpp %[" #A "], %[" #A "], -%[la] row_newbcast:%[k] " LCP_DPP_FULL "\n\t"
+#define LCP_LUU_COL(U) "v_fmac_f64_dpp %[" #U "], %[" #U "], -%[lu] row_newbcast:%[k] " LCP_DPP_FULL "\n\t"
+#define LCP_LUA_S1 LCP_LUA_COL(a0, u0)
+#define LCP_LUA_S2 LCP_LUA_S1 LCP_LUA_COL(a1, u1)
+#define LCP_LUA_S3 LCP_LUA_S2 LCP_LUA_COL(a2, u2)
+#define LCP_LUA_S4 LCP_LUA_S3 LCP_LUA_COL(a3, u3)
+#define LCP_LUA_S5 LCP_LUA_S4 LCP_LUA_COL(a4, u4)
+#define LCP_LUA_S6 LCP_LUA_S5 LCP_LUA_COL(a5, u5)
+#define LCP_LUA_S7 LCP_LUA_S6 LCP_LUA_COL(a6, u6)
+#define LCP_LUA_S8 LCP_LUA_S7 LCP_LUA_COL(a7, u7)
+#define LCP_LUA_S9 LCP_LUA_S8 LCP_LUA_COL(a8, u8)
+#define LCP_LUA_S10 LCP_LUA_S9 LCP_LUA_COL(a9, u9)
+#define LCP_LUA_S11 LCP_LUA_S10 LCP_LUA_COL(a10, u10)
+#define LCP_LUA_S12 LCP_LUA_S11 LCP_LUA_COL(a11, u11)
+#define LCP_LUA_S13 LCP_LUA_S12 LCP_LUA_COL(a12, u12)
+#define LCP_LUA_S14 LCP_LUA_S13 LCP_LUA_COL(a13, u13)
+#define LCP_LUA_O1 [a0] "+v"(ta[J0 + 0]), [u0] "+v"(tu[J0 + 0])
+#define LCP_LUA_O2 LCP_LUA_O1, [a1] "+v"(ta[J0 + 1]), [u1] "+v"(tu[J0 + 1])
+#define LCP_LUA_O3 LCP_LUA_O2, [a2] "+v"(ta[J0 + 2]), [u2] "+v"(tu[J0 + 2])
+#define LCP_LUA_O4 LCP_LUA_O3, [a3] "+v"(ta[J0 + 3]), [u3] "+v"(tu[J0 + 3])
+#define LCP_LUA_O5 LCP_LUA_O4, [a4] "+v"(ta[J0 + 4]), [u4] "+v"(tu[J0 + 4])
+#define LCP_LUA_O6 LCP_LUA_O5, [a5] "+v"(ta[J0 + 5]), [u5] "+v"(tu[J0 + 5])
+#define LCP_LUA_O7 LCP_LUA_O6, [a6] "+v"(ta[J0 + 6]), [u6] "+v"(tu[J0 + 6])
+#define LCP_LUA_O8 LCP_LUA_O7, [a7] "+v"(ta[J0 + 7]), [u7] "+v"(tu[J0 + 7])
+#define LCP_LUA_O9 LCP_LUA_O8, [a8] "+v"(ta[J0 + 8]), [u8] "+v"(tu[J0 + 8])
+#define LCP_LUA_O10 LCP_LUA_O9, [a9] "+v"(ta[J0 + 9]), [u9] "+v"(tu[J0 + 9])
+#define LCP_LUA_O11 LCP_LUA_O10, [a10] "+v"(ta[J0 + 10]), [u10] "+v"(tu[J0 + 10])
+#define LCP_LUA_O12 LCP_LUA_O11, [a11] "+v"(ta[J0 + 11]), [u11] "+v"(tu[J0 + 11])
+#define LCP_LUA_O13 LCP_LUA_O12, [a12] "+v"(ta[J0 + 12]), [u12] "+v"(tu[J0 + 12])
+#define LCP_LUA_O14 LCP_LUA_O13, [a13] "+v"(ta[J0 + 13]), [u13] "+v"(tu[J0 + 13])
+#define LCP_LUU_S1 LCP_LUU_COL(u0)
+#define LCP_LUU_S2 LCP_LUU_S1 LCP_LUU_COL(u1)
+#define LCP_LUU_S3 LCP_LUU_S2 LCP_LUU_COL(u2)
+#define LCP_LUU_S4 LCP_LUU_S3 LCP_LUU_COL(u3)
+#define LCP_LUU_S5 LCP_LUU_S4 LCP_LUU_COL(u4)
+#define LCP_LUU_S6 LCP_LUU_S5 LCP_LUU_COL(u5)
+#define LCP_LUU_S7 LCP_LUU_S6 LCP_LUU_COL(u6)
+#define LCP_LUU_S8 LCP_LUU_S7 LCP_LUU_COL(u7)
+#define LCP_LUU_S9 LCP_LUU_S8 LCP_LUU_COL(u8)
+#define LCP_LUU_S10 LCP_LUU_S9 LCP_LUU_COL(u9)
+#define LCP_LUU_S11 LCP_LUU_S10 LCP_LUU_COL(u10)
+#define LCP_LUU_S12 LCP_LUU_S11 LCP_LUU_COL(u11)
+#define LCP_LUU_S13 LCP_LUU_S12 LCP_LUU_COL(u12)
+#define LCP_LUU_S14 LCP_LUU_S13 LCP_LUU_COL(u13)
+#define LCP_LUU_S15 LCP_LUU_S14 LCP_LUU_COL(u14)
+#define LCP_LUU_O1 [u0] "+v"(tu[J0 + 0])
+#define LCP_LUU_O2 LCP_LUU_O1 , [u1] "+v"(tu[J0 + 1])
+#define LCP_LUU_O3 LCP_LUU_O2 , [u2] "+v"(tu[J0 + 2])
+#define LCP_LUU_O4 LCP_LUU_O3 , [u3] "+v"(tu[J0 + 3])
+#define LCP_LUU_O5 LCP_LUU_O4 , [u4] "+v"(tu[J0 + 4])
+#define LCP_LUU_O6 LCP_LUU_O5 , [u5] "+v"(tu[J0 + 5])
+#define LCP_LUU_O7 LCP_LUU_O6 , [u6] "+v"(tu[J0 + 6])
+#define LCP_LUU_O8 LCP_LUU_O7 , [u7] "+v"(tu[J0 + 7])
+#define LCP_LUU_O9 LCP_LUU_O8 , [u8] "+v"(tu[J0 + 8])
+#define LCP_LUU_O10 LCP_LUU_O9 , [u9] "+v"(tu[J0 + 9])
+#define LCP_LUU_O11 LCP_LUU_O10 , [u10] "+v"(tu[J0 + 10])
+#define LCP_LUU_O12 LCP_LUU_O11 , [u11] "+v"(tu[J0 + 11])
+#define LCP_LUU_O13 LCP_LUU_O12 , [u12] "+v"(tu[J0 + 12])
+#define LCP_LUU_O14 LCP_LUU_O13 , [u13] "+v"(tu[J0 + 13])
+#define LCP_LUU_O15 LCP_LUU_O14 , [u14] "+v"(tu[J0 + 14])
+template <int K, int J0, int N> struct LuColsA;      // rows a and u of the lane, columns J0 .. J0+N-1, pivot row K
+template <int K, int J0, int N> struct LuColsU;      // row u only
+#define LCP_LUA_DEF(N)                                                                                                   \
+  template <int K, int J0> struct LuColsA<K, J0, N> {                                                                    \
+    static __device__ __forceinline__ void run(double (&ta)[32], double (&tu)[32], double la, double lu) {               \
+      asm("s_nop 1\n\t" LCP_LUA_S##N : LCP_LUA_O##N : [la] "v"(la), [lu] "v"(lu), [k] "n"(K));                           \
+    }                                                                                                                    \
+  };
+#define LCP_LUU_DEF(N)                                                                                                   \
+  template <int K, int J0> struct LuColsU<K, J0, N> {                                                                    \
+    static __device__ __forceinline__ void run(double (&tu)[32], double lu) {                                            \
+      asm("s_nop 1\n\t" LCP_LUU_S##N : LCP_LUU_O##N : [lu] "v"(lu), [k] "n"(K));                                         \
+    }                                                                                                                    \
+  };
+LCP_LUA_DEF(1)
+LCP_LUA_DEF(2)
+LCP_LUA_DEF(3)
+LCP_LUA_DEF(4)
+LCP_LUA_DEF(5)
+LCP_LUA_DEF(6)
+LCP_LUA_DEF(7)
+LCP_LUA_DEF(8)
+LCP_LUA_DEF(9)
+LCP_LUA_DEF(10)
+LCP_LUA_DEF(11)
+LCP_LUA_DEF(12)
+LCP_LUA_DEF(13)
+LCP_LUA_DEF(14)
+LCP_LUU_DEF(1)
+LCP_LUU_DEF(2)
+LCP_LUU_DEF(3)
+LCP_LUU_DEF(4)
+LCP_LUU_DEF(5)
+LCP_LUU_DEF(6)
+LCP_LUU_DEF(7)
+LCP_LUU_DEF(8)
+LCP_LUU_DEF(9)
+LCP_LUU_DEF(10)
+LCP_LUU_DEF(11)
+LCP_LUU_DEF(12)
+LCP_LUU_DEF(13)
+LCP_LUU_DEF(14)
+LCP_LUU_DEF(15)
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_a(double (&ta)[32], double (&tu)[32], double la, double lu) {
+  if constexpr (N > 14) { LuColsA<K, J0, 14>::run(ta, tu, la, lu); lu_cols_a<K, J0 + 14, N - 14>(ta, tu, la, lu); }
+  else if constexpr (N > 0) LuColsA<K, J0, N>::run(ta, tu, la, lu);
+}
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_u(double (&tu)[32], double lu) {
+  if constexpr (N > 0) LuColsU<K, J0, N>::run(tu, lu);
+}
+// fp32 arithmetic keeps the builtin form (32-bit DPP is folded by the compiler where it can be)
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_a(float (&ta)[32], float (&tu)[32], float la, float lu) {
+  static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; const float sj = bc<K>(ta[j]); tu[j] = fmaf(-lu, sj, tu[j]); ta[j] = fmaf(-la, sj, ta[j]); });
+}
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_u(float (&tu)[32], float lu) {
+  static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; tu[j] = fmaf(-lu, bc<K>(tu[j]), tu[j]); });
+}
+
 template <typename TI, typename TC, bool LDSW>
 __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC>& S, const TC* W2q,
                                          const M4<TC>& D, bool valid LCP_QPROF_ARG) {
-  const int l16 = launder(S.l16), nc = S.ncw;
+  const int l16 = launder(S.l16), nc = __builtin_amdgcn_readfirstlane(S.ncw);     // (keeps the step guards scalar branches)
   R.Dg = D.g;
   R.Sp = (TC)0.5 * (D.f1 + D.f2); R.Sm = (TC)0.5 * (D.f1 - D.f2);
   R.idet = fast_rcp(R.Sp * R.Dg + (TC)2);
@@ -324,14 +455,15 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
       ta[k] = (l16 > k) ? la : ta[k];
       tu[k] = lu;
       R.ua = (l16 == k) ? inv : R.ua;
-      fnmac_sel<k, LCP_Q_ASM_LU>(tu[k + 1], ta[k + 1], lu);          // (reads row k's ta[j] before it is updated below)
-      fnmac_sel<k, LCP_Q_ASM_LU>(ta[k + 1], ta[k + 1], la);
+      fnmac_sel<k, 0>(tu[k + 1], ta[k + 1], lu);                     // (reads row k's ta[j] before it is updated below)
+      fnmac_sel<k, 0>(ta[k + 1], ta[k + 1], la);
       if constexpr (k + 1 < 16) pivv = bc<(k + 1) & 15>(ta[k + 1]); else pivv = bc<0>(tu[16]);
       inv = fast_rcp(pivv);
-      static_for<30 - k>([&](auto JJ) LCP_INL {
+      if (LCP_Q_ASM_LU) lu_cols_a<k, k + 2, 30 - k>(ta, tu, la, lu);
+      else static_for<30 - k>([&](auto JJ) LCP_INL {
         constexpr int j = k + 2 + JJ;
-        fnmac_sel<k, LCP_Q_ASM_LU>(tu[j], ta[j], lu);
-        fnmac_sel<k, LCP_Q_ASM_LU>(ta[j], ta[j], la);
+        fnmac_sel<k, 0>(tu[j], ta[j], lu);
+        fnmac_sel<k, 0>(ta[j], ta[j], la);
       });
     }
   });
@@ -344,12 +476,13 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
       tu[k] = (l16 > kk) ? lu : tu[k];
       R.uu = (l16 == kk) ? inv : R.uu;
       if constexpr (kk < 15) {
-        fnmac_sel<kk, LCP_Q_ASM_LU>(tu[k + 1], tu[k + 1], lu);
+        fnmac_sel<kk, 0>(tu[k + 1], tu[k + 1], lu);
         pivv = bc<(kk + 1) & 15>(tu[k + 1]);
         inv = fast_rcp(pivv);
-        static_for<14 - kk>([&](auto JJ) LCP_INL {
+        if (LCP_Q_ASM_LU) lu_cols_u<kk, k + 2, 14 - kk>(tu, lu);
+        else static_for<14 - kk>([&](auto JJ) LCP_INL {
           constexpr int j = k + 2 + JJ;
-          fnmac_sel<kk, LCP_Q_ASM_LU>(tu[j], tu[j], lu);
+          fnmac_sel<kk, 0>(tu[j], tu[j], lu);
         });
       }
     }
@@ -362,7 +495,7 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
 template <typename TI, typename TC>
 __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R, const SceneQ<TI, TC>& S,
                                            const M4<TC>& hz) {
-  const int l16 = S.l16, nc = S.ncw;
+  const int l16 = S.l16, nc = __builtin_amdgcn_readfirstlane(S.ncw);
   const TC r12 = hz.f1 + hz.f2;
   const TC w0 = (R.Dg * r12 - (TC)2 * hz.g) * R.idet;
   TC ra = hz.n, ru = (TC)0.5 * (hz.f1 - hz.f2) - (TC)0.5 * R.Sm * w0;

@@ -222,3 +222,36 @@ def make_random_lcp(B, nz, m, e, seed=7, dtype=torch.float32, skew=0.5):
         A, b = None, None
     cast = lambda t: None if t is None else t.to(dtype)
     return tuple(cast(t) for t in (Q, p, G, h, A, b, F))
+
+
+def make_drop_world(B, nbox=4, box=40.0, seed=2024, gap=(0.3, 2.0), xjit=6.0):
+    """Inputs of a `physics.batched_world.ContactWorld`: a fixed floor (TotalConstraint, `constraints.py:176-192`) and
+    `nbox` boxes released slightly above each other (per-scene jitter of gaps, offsets, masses, friction and
+    restitution), so that contacts are created by the detection kernel as the stack settles.
+
+    Returns dict(shapes, p [B,nb,3] f64, v, Mdiag, f [B,nb,3] f32, rest, fric [B,nb] f32, Je [B,3,3nb] f32)."""
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    nb = nbox + 1
+    shapes = [("rect", FLOOR_DIMS)] + [("rect", (box, box))] * nbox
+    p = torch.zeros(B, nb, 3, dtype=torch.float64)
+    p[:, 0, 1], p[:, 0, 2] = 500.0, 500.0
+    y = torch.full((B,), 500.0 - FLOOR_DIMS[1] / 2, dtype=torch.float64)
+    for i in range(1, nb):
+        y = y - (gap[0] + (gap[1] - gap[0]) * rnd(B)) - box / 2
+        p[:, i, 1] = 500.0 + xjit * (2 * rnd(B) - 1)
+        p[:, i, 2] = y
+        y = y - box / 2
+    mass = torch.ones(B, nb, dtype=torch.float64)
+    mass[:, 1:] = 0.5 + 1.5 * rnd(B, nbox)
+    dims = torch.tensor([FLOOR_DIMS] + [(box, box)] * nbox, dtype=torch.float64)
+    Mdiag = _rect_mdiag(mass, dims[:, 0].unsqueeze(0), dims[:, 1].unsqueeze(0))
+    f = torch.zeros(B, nb, 3, dtype=torch.float64)
+    f[:, 1:, 2] = mass[:, 1:] * GRAVITY
+    rest = 0.1 + 0.4 * rnd(B, nb)
+    fric = 0.3 + 0.5 * rnd(B, nb)
+    Je = torch.zeros(B, 3, 3 * nb, dtype=torch.float64)
+    Je[:, :, :3] = torch.eye(3, dtype=torch.float64)
+    f32 = lambda t: t.to(torch.float32)
+    return dict(shapes=shapes, p=p, v=torch.zeros(B, nb, 3), Mdiag=f32(Mdiag), f=f32(f), rest=f32(rest), fric=f32(fric),
+                Je=f32(Je))
