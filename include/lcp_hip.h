@@ -33,6 +33,10 @@ extern "C" {
 
 #define LCP_COMPUTE_F32 0
 #define LCP_COMPUTE_F64 1
+/* May be OR-ed into the `compute` argument of lcp_pdipm_backward_f32: the caller asserts that EVERY scene of the batch
+ * was solved as a contact-structured LCP with diagonal Q by the four-scenes-per-wave kernel (true by construction after
+ * lcp_step_fused_f32 / lcp_solve_dynamics_f32).  The backward then skips the launches that serve the other classes. */
+#define LCP_HINT_ALL_CONTACT 0x100
 
 #define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
 #define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan  */

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LCP_HIP_LIB", os.path.join(_HERE, "csrc", "liblcp_hip
 
 COMPUTE_F32 = 0
 COMPUTE_F64 = 1
+HINT_ALL_CONTACT = 0x100
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2

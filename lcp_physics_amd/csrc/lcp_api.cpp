@@ -89,6 +89,8 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return LCP_E_BADARG;
   if (!G || !dl_dx || !ws) return LCP_E_BADARG;
   if (e > 0 && !A) return LCP_E_BADARG;
+  const int hint = compute & LCP_HINT_ALL_CONTACT;
+  compute &= ~LCP_HINT_ALL_CONTACT;
   const int cs = csize_of(io_f64, compute);
   const bool w64 = use_wave64(io_f64, nz, m, e);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
@@ -98,14 +100,15 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  if (w64) return lcp::wave64_backward(P, compute, stream);
+  if (w64) return lcp::wave64_backward(P, compute, hint != 0, stream);
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
 }
 
 int lcp_pdipm_backward_f32(int B, int nz, int m, int e, const float* G, const float* A, const float* dl_dx,
                            int compute, float* dQ, float* dp, float* dG, float* dh, float* dA, float* db,
                            float* dF, void* ws, void* stream) {
-  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  const int base = compute & ~LCP_HINT_ALL_CONTACT;
+  if (base != LCP_COMPUTE_F32 && base != LCP_COMPUTE_F64) return LCP_E_BADARG;
   return backward_common(0, B, nz, m, e, G, A, dl_dx, compute, dQ, dp, dG, dh, dA, db, dF, ws, stream);
 }
 

@@ -85,7 +85,7 @@ int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, 
 bool wave64_supported(int nz, int m, int e);
 size_t wave64_ws_bytes(int compute);
 int wave64_forward(const FwdArgs& P, int compute, void* stream);
-int wave64_backward(const BwdArgs& P, int compute, void* stream);
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
 // four-scenes-per-wave contact-structured path (nc <= 16, nz <= 16, neq <= 4, diagonal Q) - lcp_quad.hip

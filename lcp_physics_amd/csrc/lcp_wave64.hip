@@ -1256,11 +1256,11 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int wave64_backward(const BwdArgs& P, int compute, void* stream) {
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
-  if (quad) { int rc = quad_backward(P, compute, 2, stream); if (rc) return rc; }
+  if (quad) { int rc = quad_backward(P, compute, 2, stream); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
   if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls, quad);

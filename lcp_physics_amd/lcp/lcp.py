@@ -46,7 +46,7 @@ def _prep(t, B, ndim, device, dtype):
 
 class LCPSolution:
     """Result of one batched solve; keeps the workspace the backward kernel needs."""
-    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype")
+    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype", "all_contact")
 
 
 def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64",
@@ -114,7 +114,8 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
             rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
                                             *[P(o) for o in out], P(sol.ws), st)
         else:
-            rc = lib.lcp_pdipm_backward_f32(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute,
+            hint = _lib.HINT_ALL_CONTACT if getattr(sol, "all_contact", False) else 0
+            rc = lib.lcp_pdipm_backward_f32(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint,
                                             *[P(o) for o in out], P(sol.ws), st)
     _lib.check(rc, "lcp_pdipm_backward")
     return out

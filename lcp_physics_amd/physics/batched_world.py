@@ -100,7 +100,8 @@ def solution_of_step(sc, out, G, A, compute="f64"):
     sol = LCPSolution()
     B, nb, nc = sc.B, sc.nb, sc.nc
     e = A.shape[1] if A is not None else 0
-    sol.x = -out["v_new"].reshape(B, 3 * nb)
+    sol.x = None                                   # x = -v_new (engines.py:76-77); the backward reads it from the workspace
+    sol.all_contact = True                         # every scene went through the contact-structured kernel
     sol.y, sol.z, sol.s = out["y"], out["z"], out["s"]
     sol.iters, sol.status, sol.ws = out["iters"], out["status"], out["ws"]
     sol.G, sol.A, sol.sizes, sol.compute, sol.dtype = G, A, (B, 3 * nb, 4 * nc, e), _COMPUTE[compute], torch.float32
