@@ -16,3 +16,13 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
   echo "pmc $name rc=$?"
 done
 ls $OUT | grep prof_${TAG}
+# the world with contact detection (kernel trace only)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_world -o trace -- python $ROOT/tools/bench_world.py --cpu-scenes 0 --steps 50 > $OUT/prof_${TAG}_world.log 2>&1
+echo "world trace rc=$?"
+cd $ROOT
+for d in $OUT/prof_${TAG}_trace $OUT/prof_${TAG}_world; do
+  f=$(find $d -name "*.db" | head -1)
+  python tools/rocprof_summary.py $f > $d.summary.txt
+done
+python tools/pmc_summary.py $OUT/prof_${TAG}_pmc_* > $OUT/prof_${TAG}_pmc.summary.txt
+rm -rf $OUT/prof_${TAG}_*/      # the raw databases are large; the summaries are what gets committed
