@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--pts", type=int, default=4)
     ap.add_argument("--compute", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default="fused", choices=["dense", "fused"])
+    ap.add_argument("--bwd", default="dense", choices=["dense", "physical"],
+                    help="backward timed in the step: 'dense' = LCPFunction.backward (7 dense gradients, lcp.py:37-64); "
+                         "'physical' (fused mode only) = lcp_step_backward_f32, gradients w.r.t. the physical inputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     return ap.parse_args()
@@ -83,7 +86,7 @@ def main():
     from lcp_physics_amd import flops, scenes, shard
     from lcp_physics_amd.lcp import lcp_backward, lcp_solve
     from lcp_physics_amd.physics import assemble_contacts, fused_step
-    from lcp_physics_amd.physics.batched_world import solution_of_step
+    from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step
 
     rank, local_rank, world = shard.init_process_group()
     if not torch.cuda.is_available():
@@ -111,6 +114,11 @@ def main():
     # (the output buffers and the workspace are re-used every step, so the handle the backward takes is built once)
     step_sol = solution_of_step(sc, step_out, G, A, compute=args.compute) if args.mode == "fused" else None
 
+    if args.bwd == "physical" and args.mode != "fused":
+        raise SystemExit("--bwd physical needs --mode fused")
+    cot_v = (-cot).reshape(B, nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
+    pgrads = None
+
     def one_step(ev=None):
         nonlocal sol, step_out
         if ev is not None:
@@ -123,7 +131,11 @@ def main():
             s_ = step_sol
         if ev is not None:
             ev[1].record()
-        lcp_backward(s_, cot, out=grads)
+        if args.bwd == "physical":
+            nonlocal pgrads
+            pgrads = fused_step_backward(sc, step_out, cot_v, compute=args.compute, grads=pgrads)
+        else:
+            lcp_backward(s_, cot, out=grads)
         if ev is not None:
             ev[2].record()
 
@@ -175,8 +187,8 @@ def main():
         "dtype": args.compute,
         "data": "synthetic",
         "config": {"workload": "configs[2]: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
-                               "neq %d) per GPU, fp32 I/O, LCP forward + backward (implicit diff), mode=%s"
-                               % (B, nc, args.nbox, args.pts, nz, m, e, args.mode),
+                               "neq %d) per GPU, fp32 I/O, LCP forward + backward (implicit diff), mode=%s, bwd=%s"
+                               % (B, nc, args.nbox, args.pts, nz, m, e, args.mode, args.bwd),
                    "global_batch": B * world, "parallelism": "scenes sharded x%d, no collectives" % world,
                    "mean_pdipm_iters": mean_it, "nonzero_status": int((status != 0).sum())},
         "roofline": {"bound": "mfma",

@@ -131,6 +131,24 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
                        float* v_new, float* p_new, float* z, float* s, float* y,
                        int32_t* iters, int32_t* status, void* ws, void* stream);
 
+/* Backward of lcp_step_fused_f32 / lcp_solve_dynamics_f32 with respect to the PHYSICAL inputs of the step: what the
+ * reference obtains by autograd through PdipmEngine.solve_dynamics (physics/engines.py:31-32,50-77) and the World
+ * Jacobian builders (physics/world.py:144-234) on top of LCPFunction.backward (lcp/lcp.py:37-64).  The rank-1 LCP
+ * gradients (dQ, dp, dG, dh, dF of lcp.py:52-61) are contracted on chip and never written.  Must follow the forward on
+ * the same stream with the same workspace and the same (unchanged) inputs.
+ *   in : the inputs of the forward, dl_dv[B,nb,3] = d(loss)/d(v_new)
+ *   out: dMdiag[B,nb,3] dv[B,nb,3] df[B,nb,3] drest[B,nb] dfric[B,nb] dc_n[B,nc,2] dc_p1[B,nc,2] dc_p2[B,nc,2]
+ *        (any may be NULL; padded contact slots get 0).  The joint Jacobian Je is treated as a constant.
+ * Same size limits as lcp_solve_dynamics_f32 (3 nb <= 16, nc <= 16, e <= 4), else LCP_E_TOOLARGE. */
+int lcp_step_backward_f32(int B, int nb, int nc, int e,
+                          const float* Mdiag, const float* v, const float* f,
+                          const float* rest, const float* fric,
+                          const float* c_n, const float* c_p1, const float* c_p2,
+                          const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                          const float* dl_dv, int compute,
+                          float* dMdiag, float* dv, float* df, float* drest, float* dfric,
+                          float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream);
+
 /* Replaces PdipmEngine.solve_dynamics (physics/engines.py:26-78) for B scenes whose contact lists have
  * DIFFERENT lengths (what contact detection produces): scene k uses the first c_count[k] <= maxc records of
  * its padded contact list and solves the mixed LCP of exactly that size (nineq = 4 c_count[k], engines.py:51-76);

@@ -169,6 +169,24 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
+int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
+                          const float* rest, const float* fric, const float* c_n, const float* c_p1,
+                          const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                          const float* dl_dv, int compute, float* dMdiag, float* dv, float* df, float* drest,
+                          float* dfric, float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  lcp::StepArgs P;
+  int rc = fill_step(P, B, nb, nc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
+  if (rc) return rc;
+  if (!dl_dv || !ws) return LCP_E_BADARG;
+  if (!lcp::quad_supported(3 * nb, 4 * nc, e)) return LCP_E_TOOLARGE;
+  P.ws = ws;
+  lcp::StepBwdArgs G;
+  G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
+  G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
+  return lcp::quad_step_backward(P, G, compute, stream);
+}
+
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
                            const float* v, const float* f, const float* rest, const float* fric,
                            const float* c_n, const float* c_p1, const float* c_p2, const int32_t* c_i1,

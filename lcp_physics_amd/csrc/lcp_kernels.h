@@ -56,6 +56,11 @@ struct StepArgs {
   int ldT, t_in_lds;
 };
 
+struct StepBwdArgs {
+  const void* dl_dv;                                   // [B, nb, 3]  d(loss)/d(v_new)
+  void *dMdiag, *dv, *df, *drest, *dfric, *dcn, *dcp1, *dcp2;
+};
+
 struct ContactArgs {
   int B, nb, maxc;
   const int32_t *kind, *nverts;         // [B, nb]  0 = circle, 1 = hull ; vertex count of a hull
@@ -94,6 +99,7 @@ bool quad_supported(int nz, int m, int e);
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream);
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
 int quad_step(const StepArgs& P, int compute, void* stream);
+int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream);
 
 // narrow-phase contact generation + position update - lcp_contacts.hip
 int contacts_launch(const ContactArgs& P, void* stream);

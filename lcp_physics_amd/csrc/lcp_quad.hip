@@ -1045,6 +1045,122 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   }
 }
 
+
+// ---------------------------------------------------------------- backward of the fused step w.r.t. the physical inputs
+// d(loss)/d(v_new) -> d(loss)/d(Mdiag, v, f, restitution, friction, contact normal / arms): the reference gets these by
+// autograd through the engine assembly (engines.py:31-32,50-74; world.py:144-234) after LCPFunction.backward
+// (lcp.py:37-64) has materialised dQ, dp, dG, dh, dF.  Here the rank-1 LCP gradients are contracted in registers:
+//   dp = dx, dQ_jj = dx_j x_j, dG_row = dlam_row x + lam_row dx, dh = -dlam, dF[gamma_c, n_c] = -dlam_gamma lam_n
+// and only ~0.6 KB per scene leaves the chip instead of the 21.6 KB of dense gradients.
+template <typename TI, typename TC>
+__global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs Gd, int lds_per_scene) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
+  const int scene_raw = blockIdx.x * 4 + row;
+  const int scene = scene_raw < SP.B ? scene_raw : SP.B - 1;
+  const int nb = SP.nb, nz = 3 * SP.nb, nc = SP.nc, e = SP.e;
+  Ws<TI, TC> W(SP.ws, scene);
+  const bool live = scene_raw < SP.B;
+  SceneQ<TI, TC> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, false);
+  int ncs = (int)W.meta[19];                                             // contacts the forward solved with
+  ncs = ncs < 0 ? 0 : (ncs > nc ? nc : ncs);
+  int ncw = ncs;
+  ncw = max(ncw, __shfl_xor(ncw, 16, 64)); ncw = max(ncw, __shfl_xor(ncw, 32, 64));
+  ncw = __builtin_amdgcn_readfirstlane(ncw);
+  S.nz = nz; S.nc = ncs; S.ncw = ncw; S.ncap = nc; S.e = e; S.l16 = l16;
+  const bool vc = l16 < ncs;
+  TC p_, hn_, b_;
+  assemble_q<TI, TC>(S, SP, scene, p_, hn_, b_);                          // the same rows the forward solved with
+  static_for<EQ>([&](auto A_) LCP_INL {
+    S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
+    S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
+  });
+  __syncthreads();
+  const TC x = (l16 < nz) ? W.x[l16] : (TC)0;
+  const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
+  const TC g = (l16 < nz) ? -(TC)((const TI*)Gd.dl_dv)[(size_t)scene * nz + l16] : (TC)0;
+  const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
+  TC ta[32], tu[32];
+  RedQ<TC> R;
+#ifdef LCP_Q_PROFILE
+  Prof pr; pr.last = 0;
+#endif
+  factor_q<TI, TC, false>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
+  TC dx, dnu;
+  M4<TC> ds, dl;
+  const M4<TC> zero = m4<TC>(0, 0, 0, 0);
+  solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  // x-space vectors to LDS so that a contact lane can read the entries of its two bodies (GAL is free in this kernel)
+  TC* X = S.L.GAL; TC* DX = X + 16; TC* CR = X + 32; TC* CF = X + 48;
+  int* B12 = (int*)(X + 64);
+  X[l16] = x; DX[l16] = dx;
+  __syncthreads();
+  const TI* vv = (const TI*)SP.v + (size_t)scene * nz;
+  TC gh_rbar = 0;                                                         // (dh * rbar)_c: feeds d v through h = (Jc v) rbar
+  {
+    TC cr = 0, cf = 0, dnx = 0, dny = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+    int b1 = 0, b2 = 0;
+    if (vc) {
+      const size_t cb = (size_t)scene * nc + l16;
+      const TC nx = ((const TI*)SP.c_n)[cb * 2], ny = ((const TI*)SP.c_n)[cb * 2 + 1];
+      const TC p1x = ((const TI*)SP.c_p1)[cb * 2], p1y = ((const TI*)SP.c_p1)[cb * 2 + 1];
+      const TC p2x = ((const TI*)SP.c_p2)[cb * 2], p2y = ((const TI*)SP.c_p2)[cb * 2 + 1];
+      b1 = SP.c_i1[cb]; b2 = SP.c_i2[cb];
+      const TC rbar = (TC)0.5 * ((TC)((const TI*)SP.rest)[(size_t)scene * nb + b1] + (TC)((const TI*)SP.rest)[(size_t)scene * nb + b2]);
+      const TC jn[6] = {p1x * ny - p1y * nx, nx, ny, -(p2x * ny - p2y * nx), -nx, -ny};      // world.py:177-183
+      const TC gh = -dl.n;                                                  // dh = -dlam (lcp.py:56)
+      const TC af = dl.f1 - dl.f2, lf = z.f1 - z.f2;                        // Jf rows are +jt, -jt (world.py:191-192)
+      TC gjn[6], gjf[6], jnv = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
+        const TC xq = X[col], dxq = DX[col], vq = (TC)vv[col];
+        jnv = fma(jn[q], vq, jnv);
+        gjn[q] = dl.n * xq + z.n * dxq + gh * rbar * vq;                    // dG row n (lcp.py:53) + h = (Jc v) rbar
+        gjf[q] = af * xq + lf * dxq;
+      }
+      gh_rbar = gh * rbar;
+      cr = (TC)0.5 * gh * jnv;                                              // rbar = (rest_b1 + rest_b2) / 2 (world.py:144-151)
+      cf = (TC)0.5 * (-dl.g * z.n);                                         // dF[gamma_c, n_c] = -dlam_g lam_n (lcp.py:54), F = mu there
+      // jn = [p1 x n, n | -(p2 x n), -n] ; jf = [p1 x t, t | -(p2 x t), -t], t = (ny, -nx)   (utils.py:93-102)
+      dnx = -gjn[0] * p1y + gjn[1] + gjn[3] * p2y - gjn[4] - gjf[0] * p1x - gjf[2] + gjf[3] * p2x + gjf[5];
+      dny = gjn[0] * p1x + gjn[2] - gjn[3] * p2x - gjn[5] - gjf[0] * p1y + gjf[1] + gjf[3] * p2y - gjf[4];
+      d1x = gjn[0] * ny - gjf[0] * nx; d1y = -gjn[0] * nx - gjf[0] * ny;
+      d2x = -gjn[3] * ny + gjf[3] * nx; d2y = gjn[3] * nx + gjf[3] * ny;
+    }
+    CR[l16] = cr; CF[l16] = cf; B12[l16] = b1; B12[16 + l16] = b2;
+    if (live && l16 < nc) {
+      const size_t cb = (size_t)scene * nc + l16;
+      if (Gd.dcn) { ((TI*)Gd.dcn)[cb * 2] = (TI)dnx; ((TI*)Gd.dcn)[cb * 2 + 1] = (TI)dny; }
+      if (Gd.dcp1) { ((TI*)Gd.dcp1)[cb * 2] = (TI)d1x; ((TI*)Gd.dcp1)[cb * 2 + 1] = (TI)d1y; }
+      if (Gd.dcp2) { ((TI*)Gd.dcp2)[cb * 2] = (TI)d2x; ((TI*)Gd.dcp2)[cb * 2 + 1] = (TI)d2y; }
+    }
+  }
+  const TC dv_h = S.Gtw(gh_rbar, (TC)0);                                   // Jc^T (dh rbar)
+  __syncthreads();
+  if (!live) return;
+  if (l16 < nz) {
+    const size_t o = (size_t)scene * nz + l16;
+    const TC md = (TC)((const TI*)SP.Mdiag)[o], v = (TC)vv[l16];
+    if (Gd.dMdiag) ((TI*)Gd.dMdiag)[o] = (TI)(dx * x + dx * v);            // Q = diag(M) (dQ, lcp.py:59-60) and p = M v + dt f
+    if (Gd.dv) ((TI*)Gd.dv)[o] = (TI)(dx * md + dv_h);
+    if (Gd.df) ((TI*)Gd.df)[o] = (TI)(dx * (TC)SP.dt);
+  }
+  if (l16 < nb) {                                                          // per-body sums over the contacts, fixed order
+    TC ar = 0, af = 0;
+    for (int c = 0; c < ncs; ++c) {
+      const bool hit = (B12[c] == l16) || (B12[16 + c] == l16);
+      const TC w = ((B12[c] == l16) ? (TC)1 : (TC)0) + ((B12[16 + c] == l16) ? (TC)1 : (TC)0);
+      if (hit) { ar += w * CR[c]; af += w * CF[c]; }
+    }
+    if (Gd.drest) ((TI*)Gd.drest)[(size_t)scene * nb + l16] = (TI)ar;
+    if (Gd.dfric) ((TI*)Gd.dfric)[(size_t)scene * nb + l16] = (TI)af;
+  }
+}
+
 }  // namespace q16
 
 // ---------------------------------------------------------------- host-side launchers
@@ -1090,6 +1206,19 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream) {
   } else {
     const int ls = (int)q16_lds<float>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<float, float>), grid, blk, 4 * ls, st, P, ls, accept);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((SP.B + 3) / 4), blk(64);
+  if (compute == LCP_COMPUTE_F64) {
+    const int ls = (int)q16_lds<double>(false);
+    hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double>), grid, blk, 4 * ls, st, SP, Gd, ls);
+  } else {
+    const int ls = (int)q16_lds<float>(false);
+    hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, float>), grid, blk, 4 * ls, st, SP, Gd, ls);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

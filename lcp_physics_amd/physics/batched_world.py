@@ -94,6 +94,32 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
     return out
 
 
+def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
+    """Backward of `fused_step` with respect to the physical inputs of the scenes: d(loss)/d(v_new) [B,nb,3] ->
+    dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,nc,2]) - what the reference computes by
+    autograd through `engines.py:31-32,50-77` and `world.py:144-234` after `LCPFunction.backward`.  One launch of
+    `lcp_step_backward_f32`; the dense LCP gradients are never materialised.  `out` is the dict `fused_step`
+    returned (its workspace is read); the scene must not have changed in between."""
+    lib = _lib.load()
+    e = _check_scene(sc)
+    B, nb, nc = sc.B, sc.nb, sc.nc
+    dev = sc.v.device
+    dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
+    if grads is None:
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        grads = {"Mdiag": new(B, nb, 3), "v": new(B, nb, 3), "f": new(B, nb, 3), "rest": new(B, nb), "fric": new(B, nb),
+                 "c_n": new(B, nc, 2), "c_p1": new(B, nc, 2), "c_p2": new(B, nc, 2)}
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_step_backward_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n),
+                                       P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None,
+                                       float(sc.dt), P(dl_dv), _COMPUTE[compute], P(grads["Mdiag"]), P(grads["v"]),
+                                       P(grads["f"]), P(grads["rest"]), P(grads["fric"]), P(grads["c_n"]),
+                                       P(grads["c_p1"]), P(grads["c_p2"]), P(out["ws"]), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_step_backward_f32")
+    return grads
+
+
 def solution_of_step(sc, out, G, A, compute="f64"):
     """Wrap a fused step's workspace as an `LCPSolution` so `lcp.lcp_backward` can follow
     (G, A from `assemble_contacts`)."""

@@ -1,0 +1,100 @@
+"""GPU parity of the fused analytic backward (`lcp_step_backward_f32`): d(loss)/d(v_new) -> gradients with respect to
+the physical inputs of a step, against
+  (a) the SAME device solution's dense LCP gradients (`lcp_pdipm_backward_f32`) contracted through the engine
+      assembly by autograd of the oracle's restatement (engines.py:31-32,50-74; world.py:144-234) - every key, to
+      fp32 rounding, because both sides use the same multipliers; and
+  (b) the fp64 oracle end to end (oracle forward + `lcp.py:37-64` + autograd), within 1e-4 on the parameters whose
+      gradients are well defined for the scene family (tests/parity.py::err_physical)."""
+import pytest
+import torch
+
+from oracle import pdipm_oracle as O
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run(sc, cot_v):
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, fused_step_backward, solution_of_step
+    scg = sc.to(device=DEV)
+    out = fused_step(scg)
+    pg = fused_step_backward(scg, out, cot_v.to(DEV))
+    lcp = assemble_contacts(scg)
+    sol = solution_of_step(scg, out, lcp[2], lcp[4])
+    dense = lcp_backward(sol, (-cot_v).reshape(sc.B, -1).to(DEV))            # d(loss)/dx = -d(loss)/d(v_new)
+    torch.cuda.synchronize()
+    dense = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", dense)}
+    return {k: v.double().cpu() for k, v in pg.items()}, dense, out
+
+
+@pytest.mark.parametrize("nbox,pts", [(2, 2), (4, 2), (4, 4), (3, 4)])
+def test_matches_autograd_contraction_of_the_dense_gradients(nbox, pts):
+    from lcp_physics_amd import scenes
+    B = 64
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=300 + 10 * nbox + pts, dtype=torch.float32)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(8), dtype=torch.float32)
+    pg, dense, out = _run(sc, cot)
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    ref = parity.physical_grads(ph, sc.dt, dense, O)
+    for k in parity.PHYS_KEYS:
+        scale = ref[k].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+        err = (pg[k] - ref[k]).abs().reshape(B, -1).max(dim=1)[0] / scale
+        # the dense gradients were rounded to fp32 on their way out (dG, dF entries up to 1e4 larger than their sum)
+        bound = 2e-3 if k in ("c_n", "c_p1", "c_p2", "rest", "fric") else 1e-4
+        big = scale > 1e-6 * scale.max()
+        assert float(err[big].max()) < bound, (k, float(err[big].max()), int(err.argmax()))
+
+
+@pytest.mark.parametrize("nbox,pts", [(2, 2), (4, 4)])
+def test_matches_oracle_end_to_end(nbox, pts):
+    from lcp_physics_amd import scenes
+    B = 64
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=77 + nbox, dtype=torch.float32)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(9), dtype=torch.float32)
+    pg, _, out = _run(sc, cot)
+    lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    refsol = O.lcp_forward(*lcp64)
+    cx = (-cot).reshape(B, -1).double()
+    gref = O.lcp_backward(refsol, *lcp64, cx)
+    gref = {k: gref["d" + k] for k in "QpGhAbF"}
+    Q, p, G, h, A, b, F = lcp64
+    res_o = parity.kkt_backward_residual(Q, G, A, F, refsol.z, refsol.s, cx, gref["p"], -gref["h"], -gref["b"])
+    ok = torch.stack([v for v in res_o.values()]).max(dim=0)[0] < 1e-9
+    zs, ss = refsol.z.max(dim=1, keepdim=True)[0], refsol.s.max(dim=1, keepdim=True)[0]
+    ok = ok & (torch.maximum(refsol.z / zs, refsol.s / ss).min(dim=1)[0] > 1e-6)
+    assert float(ok.float().mean()) >= 0.4
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    pg_ref = parity.physical_grads(ph, sc.dt, gref, O)
+    scl = parity.free_scales(Q, p, cx)
+    floor = parity._n(cx) * torch.maximum(scl["x_free"], parity._n(refsol.x))
+    ep = parity.err_physical(pg, pg_ref, ph, floor, keys=["Mdiag", "v", "f"])     # (redundant rows: see err_physical)
+    assert float(ep[ok].max()) < 1e-4, (float(ep[ok].max()), int(ep.argmax()))
+
+
+def test_variable_contact_counts_and_padding():
+    """After lcp_solve_dynamics_f32 with per-scene counts: padded slots get zero geometry gradients and a scene
+    without contacts gets the free-body gradient d v = M^-1 ... (x = -M^-1 u: dMdiag, dv, df only)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import fused_step_backward, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 8
+    sc = scenes.make_stack_scenes(B=B, nbox=2, pts_per_interface=4, seed=5, dtype=torch.float32).to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
+    count = torch.tensor([8, 4, 0, 8, 2, 0, 6, 8], dtype=torch.int32, device=DEV)
+    out = solve_dynamics(B, sc.nb, sc.nc, 3, count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb, sc.Je, sc.dt)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(1), dtype=torch.float32).to(DEV)
+    pg = fused_step_backward(sc, out, cot)
+    torch.cuda.synchronize()
+    slot = torch.arange(sc.nc, device=DEV).unsqueeze(0) >= count.unsqueeze(1)
+    for k in ("c_n", "c_p1", "c_p2"):
+        assert float(pg[k][slot].abs().max()) == 0.0
+        assert bool(torch.isfinite(pg[k]).all())
+    # no contact, floor pinned by the joint: boxes are free bodies, v_new = v + dt f / M
+    free = (count == 0)
+    dv_expected = cot[free][:, 1:]                                  # d v_new / d v = 1 for the free boxes
+    assert torch.allclose(pg["v"][free][:, 1:], dv_expected, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pg["f"][free][:, 1:], cot[free][:, 1:] * sc.dt / sc.Mdiag[free][:, 1:], rtol=1e-5, atol=1e-7)
+    assert float(pg["rest"][free].abs().max()) == 0.0 and float(pg["fric"][free].abs().max()) == 0.0
