@@ -48,6 +48,8 @@ struct Body {             // world frame
   double rad;
   int nv;
   const V2* verts;        // hull vertices relative to pos, rotated (LDS)
+  const V2* nrm;          // outward unit normal of edge k = (verts[k], verts[k+1])  (LDS, formed once per trial pose)
+  const double* elen;     // length of edge k
 };
 
 struct Pt { V2 n, p1, p2; double pen; };
@@ -59,14 +61,14 @@ __device__ __forceinline__ int support(const V2* pts, int n, V2 dir) {
   return best;
 }
 
-__device__ __forceinline__ int circle_circle(const Body& b1, const Body& b2, double eps, Pt* out) {   // contacts.py:68-79
+__device__ __forceinline__ int circle_circle(const Body& b1, const Body& b2, double eps, Pt& out0) {   // contacts.py:68-79
   const double r = b1.rad + b2.rad;
   V2 n = b1.pos - b2.pos;
   const double dist = norm(n);
   const double pen = r - dist;
   if (pen < -eps) return 0;
   n = n * (1.0 / dist);
-  out[0].n = n; out[0].p1 = -n * (b1.rad - pen / 2); out[0].p2 = n * (b2.rad - pen / 2); out[0].pen = pen;
+  out0.n = n; out0.p1 = -n * (b1.rad - pen / 2); out0.p2 = n * (b2.rad - pen / 2); out0.pen = pen;
   return 1;
 }
 
@@ -85,59 +87,62 @@ __device__ __forceinline__ void bary3(V2 p, V2 a, V2 b, V2 c, double& u, double&
   w = ((a.y - b.y) * p.x + (b.x - a.x) * p.y + (a.x * b.y - b.x * a.y)) * id;
 }
 
-// contacts.py:295-330; simplex of 1..3 points, returns closest point and the ids used
-__device__ __forceinline__ V2 closest(V2 p, const V2* sx, int ns, int* ids, int& nid) {
-  if (ns == 1) { ids[0] = 0; nid = 1; return sx[0]; }
-  if (ns == 2) {
-    double u, v; bary2(p, sx[0], sx[1], u, v);
-    if (u <= 0) { ids[0] = 1; nid = 1; return sx[1]; }
-    if (v <= 0) { ids[0] = 0; nid = 1; return sx[0]; }
-    ids[0] = 0; ids[1] = 1; nid = 2; return u * sx[0] + v * sx[1];
+// (no private arrays anywhere below: dynamically indexed locals live in scratch memory on this target, and a scratch
+//  round trip costs as much as the whole arithmetic of a pair - the simplex, clip and manifold buffers are named scalars)
+struct Simplex { V2 a, b, c; int ia, ib, ic; int n; };     // up to 3 points with their vertex indices
+
+// contacts.py:295-330: closest point of the simplex to p; `keep` = the sub-simplex that supports it (the reference's
+// `ids_used`, in its order), keep.n == 3 means p is inside the triangle
+__device__ __forceinline__ V2 closest(V2 p, const Simplex& sx, Simplex& keep) {
+  keep = sx;
+  if (sx.n == 1) return sx.a;
+  if (sx.n == 2) {
+    double u, v; bary2(p, sx.a, sx.b, u, v);
+    if (u <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.n = 1; return sx.b; }
+    if (v <= 0) { keep.n = 1; return sx.a; }
+    return u * sx.a + v * sx.b;
   }
   double uAB, vAB, uBC, vBC, uCA, vCA, uABC, vABC, wABC;
-  bary2(p, sx[0], sx[1], uAB, vAB); bary2(p, sx[1], sx[2], uBC, vBC); bary2(p, sx[2], sx[0], uCA, vCA);
-  bary3(p, sx[0], sx[1], sx[2], uABC, vABC, wABC);
-  if (vAB <= 0 && uCA <= 0) { ids[0] = 0; nid = 1; return sx[0]; }
-  if (vBC <= 0 && uAB <= 0) { ids[0] = 1; nid = 1; return sx[1]; }
-  if (vCA <= 0 && uBC <= 0) { ids[0] = 2; nid = 1; return sx[2]; }
-  if (uAB > 0 && vAB > 0 && wABC <= 0) { ids[0] = 0; ids[1] = 1; nid = 2; return uAB * sx[0] + vAB * sx[1]; }
-  if (uBC > 0 && vBC > 0 && uABC <= 0) { ids[0] = 1; ids[1] = 2; nid = 2; return uBC * sx[1] + vBC * sx[2]; }
-  if (uCA > 0 && vCA > 0 && vABC <= 0) { ids[0] = 2; ids[1] = 0; nid = 2; return uCA * sx[2] + vCA * sx[0]; }
-  ids[0] = 0; ids[1] = 1; ids[2] = 2; nid = 3; return p;      // inside (the reference raises if nothing matched)
+  bary2(p, sx.a, sx.b, uAB, vAB); bary2(p, sx.b, sx.c, uBC, vBC); bary2(p, sx.c, sx.a, uCA, vCA);
+  bary3(p, sx.a, sx.b, sx.c, uABC, vABC, wABC);
+  if (vAB <= 0 && uCA <= 0) { keep.n = 1; return sx.a; }
+  if (vBC <= 0 && uAB <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.n = 1; return sx.b; }
+  if (vCA <= 0 && uBC <= 0) { keep.a = sx.c; keep.ia = sx.ic; keep.n = 1; return sx.c; }
+  if (uAB > 0 && vAB > 0 && wABC <= 0) { keep.n = 2; return uAB * sx.a + vAB * sx.b; }
+  if (uBC > 0 && vBC > 0 && uABC <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.b = sx.c; keep.ib = sx.ic; keep.n = 2; return uBC * sx.b + vBC * sx.c; }
+  if (uCA > 0 && vCA > 0 && vABC <= 0) { keep.a = sx.c; keep.ia = sx.ic; keep.b = sx.a; keep.ib = sx.ia; keep.n = 2; return uCA * sx.c + vCA * sx.a; }
+  return p;                                                      // inside (the reference raises if nothing matched)
 }
 
 // contacts.py:80-141: `circ` plays b1, `hull` b2
-__device__ __forceinline__ int circle_hull(const Body& circ, const Body& hull, double eps, bool circle_is_g2, Pt* out) {
+__device__ __forceinline__ int circle_hull(const Body& circ, const Body& hull, double eps, bool circle_is_g2, Pt& out0) {
   const V2* verts = hull.verts;
   const int nv = hull.nv;
   const V2 tp = circ.pos - hull.pos;
-  V2 sx[3]; int sid[3];                        // simplex points and their vertex indices
-  sx[0] = verts[0]; sid[0] = 0;
-  int ns = 1, ids[3], nid = 1;
-  V2 cl = sx[0];
+  Simplex sx, keep;
+  sx.a = verts[0]; sx.ia = 0; sx.b = sx.a; sx.c = sx.a; sx.ib = -1; sx.ic = -1; sx.n = 1;
+  keep = sx;
+  V2 cl = sx.a;
   for (int iter = 0; iter < 4 * NV; ++iter) {
-    cl = closest(tp, sx, ns, ids, nid);
-    if (nid == 3) break;
+    cl = closest(tp, sx, keep);
+    if (keep.n == 3) break;
     V2 sd;
-    if (nid == 2) {
-      sd = left_orth(sx[ids[0]] - sx[ids[1]]);
-      if (dot(sd, tp - sx[ids[0]]) < 0) sd = -sd;
+    if (keep.n == 2) {
+      sd = left_orth(keep.a - keep.b);
+      if (dot(sd, tp - keep.a) < 0) sd = -sd;
     } else {
       sd = tp - cl;
     }
     if (sd.x == 0 && sd.y == 0) break;
     const int si = support(verts, nv, sd);
-    bool in_simplex = false;
-    for (int q = 0; q < ns; ++q) in_simplex = in_simplex || (sid[q] == si);
+    const bool in_simplex = (si == sx.ia) || (sx.n > 1 && si == sx.ib) || (sx.n > 2 && si == sx.ic);
     if (in_simplex) break;
-    V2 nsx[3]; int nsid[3];
-    for (int q = 0; q < nid; ++q) { nsx[q] = sx[ids[q]]; nsid[q] = sid[ids[q]]; }
-    nsx[nid] = verts[si]; nsid[nid] = si;
-    ns = nid + 1;
-    for (int q = 0; q < ns; ++q) { sx[q] = nsx[q]; sid[q] = nsid[q]; }
+    sx = keep;                                                   // the used points, then the new support point
+    if (keep.n == 1) { sx.b = verts[si]; sx.ib = si; } else { sx.c = verts[si]; sx.ic = si; }
+    sx.n = keep.n + 1;
   }
   V2 bn, bp1, bp2; double bd;
-  if (nid < 3) {
+  if (keep.n < 3) {
     bp2 = cl;
     const V2 cw = cl + hull.pos;
     bp1 = cw - circ.pos;
@@ -147,8 +152,7 @@ __device__ __forceinline__ int circle_hull(const Body& circ, const Body& hull, d
   } else {                                     // centre inside the hull: SAT, contacts.py:114-137
     bd = -1e10; bn = v2(0, 0); bp1 = bn; bp2 = bn;
     for (int idx = 0; idx < nv; ++idx) {
-      const V2 edge = verts[(idx + 1) % nv] - verts[idx];
-      const V2 nrm = left_orth(edge) * (1.0 / norm(edge));
+      const V2 nrm = hull.nrm[idx];
       const V2 center = circ.pos - hull.pos;
       const double dist = dot(nrm, center - verts[idx]) - circ.rad;
       if (dist > bd) {
@@ -160,7 +164,7 @@ __device__ __forceinline__ int circle_hull(const Body& circ, const Body& hull, d
     }
   }
   if (circle_is_g2) { bn = -bn; const V2 t = bp1; bp1 = bp2; bp2 = t; }
-  out[0].n = bn; out[0].p1 = bp1; out[0].p2 = bp2; out[0].pen = -bd;
+  out0.n = bn; out0.p1 = bp1; out0.p2 = bp2; out0.pen = -bd;
   return 1;
 }
 
@@ -169,9 +173,8 @@ struct Sep { double dist; V2 normal; int vertex; double edge_norm; int edge; };
 __device__ __forceinline__ Sep test_separations(const Body& h1, const Body& h2, double eps) {      // contacts.py:220-250
   Sep best; best.dist = -1e10; best.normal = v2(0, 0); best.vertex = -1; best.edge_norm = 0; best.edge = 0;
   for (int idx = 0; idx < h1.nv; ++idx) {
-    const V2 edge = h1.verts[(idx + 1) % h1.nv] - h1.verts[idx];
-    const double en = norm(edge);
-    const V2 nrm = left_orth(edge) * (1.0 / en);
+    const double en = h1.elen[idx];
+    const V2 nrm = h1.nrm[idx];
     const int si = support(h2.verts, h2.nv, -nrm);
     const V2 sp = h2.verts[si] + h2.pos - h1.pos;
     const double dist = dot(nrm, sp - h1.verts[idx]);
@@ -188,27 +191,29 @@ __device__ __forceinline__ int incident_edge(V2 ref_normal, const Body& inc, int
   const int e0 = (inc_vertex - 1 + inc.nv) % inc.nv;
   for (int q = 0; q < 2; ++q) {
     const int i = q == 0 ? e0 : inc_vertex;
-    const V2 edge = inc.verts[(i + 1) % inc.nv] - inc.verts[i];
-    const V2 inrm = left_orth(edge) * (1.0 / norm(edge));
+    const V2 inrm = inc.nrm[i];
     const double d = dot(ref_normal, inrm);
     if (d < min_dot) { min_dot = d; best = i; }
   }
   return best;
 }
 
-__device__ __forceinline__ int clip(const V2* in, V2 nrm, double offset, V2* out) {                 // contacts.py:270-292
+__device__ __forceinline__ int clip(V2 in0, V2 in1, V2 nrm, double offset, V2& o0, V2& o1) {       // contacts.py:270-292
   int n = 0;
-  const double d0 = dot(nrm, in[0]) + offset, d1 = dot(nrm, in[1]) + offset;
-  if (d0 >= 0.0) out[n++] = in[0];
-  if (d1 >= 0.0) out[n++] = in[1];
+  const double d0 = dot(nrm, in0) + offset, d1 = dot(nrm, in1) + offset;
+  o0 = in0; o1 = in1;
+  if (d0 >= 0.0) { o0 = in0; n = 1; }
+  if (d1 >= 0.0) { if (n == 0) o0 = in1; else o1 = in1; ++n; }
   if (d0 * d1 < 0.0 || n < 2) {
     const double interp = d0 / (d0 - d1);
-    out[n++] = in[0] + interp * (in[1] - in[0]);
+    const V2 x = in0 + interp * (in1 - in0);
+    if (n == 0) o0 = x; else if (n == 1) o1 = x;             // (never a third point: two kept vertices imply d0 d1 >= 0)
+    ++n;
   }
   return n;
 }
 
-__device__ __forceinline__ int hull_hull(const Body& b1, const Body& b2, double eps, Pt* out) {       // contacts.py:142-201
+__device__ __forceinline__ int hull_hull(const Body& b1, const Body& b2, double eps, Pt& out0, Pt& out1) {  // contacts.py:142-201
   const Sep c1 = test_separations(b1, b2, eps);
   if (c1.dist > eps) return 0;
   const Sep c2 = test_separations(b2, b1, eps);
@@ -220,71 +225,123 @@ __device__ __forceinline__ int hull_hull(const Body& b1, const Body& b2, double 
   const V2 nrm = -c.normal;
   const double half_edge = c.edge_norm / 2;
   const int ie = incident_edge(nrm, inc, c.vertex);
-  V2 iv[2];
-  iv[0] = inc.verts[ie] + inc.pos - ref.pos;
-  iv[1] = inc.verts[(ie + 1) % inc.nv] + inc.pos - ref.pos;
+  const V2 iv0 = inc.verts[ie] + inc.pos - ref.pos;
+  const V2 iv1 = inc.verts[(ie + 1) % inc.nv] + inc.pos - ref.pos;
   const V2 plane = left_orth(nrm);
-  V2 cl1[3], cl2[3];
-  const int n1 = clip(iv, plane, half_edge, cl1);
+  V2 a0, a1, q0, q1;
+  const int n1 = clip(iv0, iv1, plane, half_edge, a0, a1);
   if (n1 < 2) return 0;
-  const int n2 = clip(cl1, -plane, half_edge, cl2);
+  const int n2 = clip(a0, a1, -plane, half_edge, q0, q1);
   int n = 0;
-  for (int q = 0; q < n2 && n < 2; ++q) {
-    const double dist = dot(nrm, cl2[q] - ref.verts[c.edge]);
-    if (dist <= eps) {
-      const V2 pt1 = cl2[q] + nrm * -dist;
+  const V2 refv = ref.verts[c.edge];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const V2 cq = q == 0 ? q0 : q1;
+    const double dist = dot(nrm, cq - refv);
+    if (q < n2 && dist <= eps) {
+      const V2 pt1 = cq + nrm * -dist;
       const V2 pt2 = pt1 + ref.pos - inc.pos;
-      if (ref_is_b2) { out[n].n = nrm; out[n].p1 = pt2; out[n].p2 = pt1; }          // contacts.py:170-175
-      else { out[n].n = -nrm; out[n].p1 = pt1; out[n].p2 = pt2; }                   // contacts.py:198-201
-      out[n].pen = -dist;
+      Pt r;
+      if (ref_is_b2) { r.n = nrm; r.p1 = pt2; r.p2 = pt1; }                        // contacts.py:170-175
+      else { r.n = -nrm; r.p1 = pt1; r.p2 = pt2; }                                 // contacts.py:198-201
+      r.pen = -dist;
+      if (n == 0) out0 = r; else out1 = r;
       ++n;
     }
   }
   return n;
 }
 
-__device__ __forceinline__ int collide_pair(const Body& b1, const Body& b2, double eps, Pt* out) {   // contacts.py:57-205
+__device__ __forceinline__ int collide_pair(const Body& b1, const Body& b2, double eps, Pt& out0, Pt& out1) {   // contacts.py:57-205
   const bool c1 = b1.kind == 0, c2 = b2.kind == 0;
-  if (c1 && c2) return circle_circle(b1, b2, eps, out);
-  if (c1) return circle_hull(b1, b2, eps, false, out);
-  if (c2) return circle_hull(b2, b1, eps, true, out);
-  return hull_hull(b1, b2, eps, out);
+  if (c1 && c2) return circle_circle(b1, b2, eps, out0);
+  if (c1) return circle_hull(b1, b2, eps, false, out0);
+  if (c2) return circle_hull(b2, b1, eps, true, out0);
+  return hull_hull(b1, b2, eps, out0, out1);
 }
 
 // One launch = the whole position update of World.step_dt (world.py:88-101) for every scene: try the step with
 // the current dt (Body.move), detect contacts, accept when no contact penetrates by more than `tol`, otherwise
-// halve dt, go back to the start pose and retry.  The loop is per scene (one wave), so no host round trip.
+// halve dt, go back to the start pose and retry.  The loop is per scene and runs on the device, so no host round trip.
+// LPS = lanes per scene: 64 (one wave per scene, the pairs are walked 64 at a time) or 16 (four scenes per wave when a
+// scene has at most 16 body pairs, i.e. nb <= 6 - the common case; the lanes of a scene are one DPP/shuffle row).
+// Scenes that share a wave advance in lock step: a scene whose step is accepted keeps recomputing the same accepted
+// trial (identical stores) until its neighbours are done.
+template <int LPS>
 __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs P) {
-  __shared__ V2 s_verts[MAXB * NV];
-  __shared__ double s_pose[MAXB * 3];
-  const int scene = blockIdx.x, lane = threadIdx.x;
+  constexpr int SPW = 64 / LPS;                                 // scenes per wave
+  constexpr int NBMAX = (LPS == 64) ? MAXB : 6;
+  __shared__ V2 s_verts_all[SPW * NBMAX * NV];
+  __shared__ V2 s_nrm_all[SPW * NBMAX * NV];
+  __shared__ double s_elen_all[SPW * NBMAX * NV];
+  __shared__ double s_pose_all[SPW * NBMAX * 3];
+  __shared__ V2 s_vloc_all[SPW * NBMAX * NV];                   // body-frame vertices (constant over the trials)
+  __shared__ V2 s_sc_all[SPW * NBMAX];                          // (sin, cos) of each body's rotation
+  __shared__ double s_rad_all[SPW * NBMAX];
+  __shared__ int s_kind_all[SPW * NBMAX], s_nv_all[SPW * NBMAX];
+  const int lane = threadIdx.x, ll = lane % LPS, row = lane / LPS;
+  const int scene_raw = blockIdx.x * SPW + row;
+  const bool live = scene_raw < P.B;
+  const int scene = live ? scene_raw : P.B - 1;                 // tail rows shadow the last scene and store nothing
+  V2* s_verts = s_verts_all + row * NBMAX * NV;
+  V2* s_nrm = s_nrm_all + row * NBMAX * NV;
+  double* s_elen = s_elen_all + row * NBMAX * NV;
+  V2* s_vloc = s_vloc_all + row * NBMAX * NV;
+  V2* s_sc = s_sc_all + row * NBMAX;
+  double* s_rad = s_rad_all + row * NBMAX;
+  int* s_kind = s_kind_all + row * NBMAX;
+  int* s_nv = s_nv_all + row * NBMAX;
+  double* s_pose = s_pose_all + row * NBMAX * 3;
   const int nb = P.nb;
   const int npairs = nb * (nb - 1) / 2;
   double dt = P.dt;
   int base = 0, trial = 0;
   double maxpen = -1e300;
+  bool done = false;
+  // geometry does not change over the trials: stage it in LDS once
+  for (int idx = ll; idx < nb * NV; idx += LPS) {
+    const double* vl = P.verts_local + ((size_t)scene * nb) * NV * 2 + (size_t)idx * 2;
+    s_vloc[idx] = v2(vl[0], vl[1]);
+  }
+  for (int b = ll; b < nb; b += LPS) {
+    s_kind[b] = P.kind[(size_t)scene * nb + b]; s_nv[b] = P.nverts[(size_t)scene * nb + b]; s_rad[b] = P.radius[(size_t)scene * nb + b];
+  }
   for (;;) {
     // bodies.py:80-82 (p <- p_start + v dt) and the vertex rotation of bodies.py:211-214
-    for (int idx = lane; idx < nb * 3; idx += 64) {
+    for (int idx = ll; idx < nb * 3; idx += LPS) {
       double pv = P.p_start[(size_t)scene * nb * 3 + idx];
       if (P.v) pv += (double)P.v[(size_t)scene * nb * 3 + idx] * dt;
       s_pose[idx] = pv;
     }
     __syncthreads();
-    for (int idx = lane; idx < nb * NV; idx += 64) {
-      const int bdy = idx / NV, k = idx - bdy * NV;
-      const double rot = s_pose[bdy * 3];
-      const double sn = sin(rot), cs = cos(rot);
-      const double* vl = P.verts_local + ((size_t)scene * nb + bdy) * NV * 2 + k * 2;
-      const double lx = vl[0], ly = vl[1];
+    for (int b = ll; b < nb; b += LPS) { const double rot = s_pose[b * 3]; s_sc[b] = v2(sin(rot), cos(rot)); }
+    __syncthreads();
+    for (int idx = ll; idx < nb * NV; idx += LPS) {
+      const int bdy = idx / NV;
+      const double sn = s_sc[bdy].x, cs = s_sc[bdy].y;
+      const double lx = s_vloc[idx].x, ly = s_vloc[idx].y;
       s_verts[idx] = v2(cs * lx - sn * ly, sn * lx + cs * ly);                      // utils.py:105-112
     }
     __syncthreads();
+    // edge normals and lengths of every hull, once per trial pose (every pair that touches the body re-uses them;
+    // the reference recomputes them per pair: contacts.py:118-119,224-226,260-261)
+    for (int idx = ll; idx < nb * NV; idx += LPS) {
+      const int bdy = idx / NV, k = idx - bdy * NV;
+      const int nvb = s_nv[bdy];
+      if (k < nvb) {
+        const V2 edge = s_verts[bdy * NV + (k + 1) % nvb] - s_verts[idx];
+        const double en = norm(edge);
+        s_elen[idx] = en;
+        s_nrm[idx] = left_orth(edge) * (1.0 / en);
+      }
+    }
+    __syncthreads();
     base = 0; maxpen = -1e300;
-    for (int p0 = 0; p0 < npairs; p0 += 64) {
-      const int pr = p0 + lane;
+    for (int p0 = 0; p0 < npairs; p0 += LPS) {
+      const int pr = p0 + ll;
       int cnt = 0, bi = 0, bj = 1;
-      Pt pts[2];
+      Pt pt0, pt1;
+      pt0.n = v2(0, 0); pt0.p1 = pt0.n; pt0.p2 = pt0.n; pt0.pen = 0; pt1 = pt0;
       if (pr < npairs) {
         int rem = pr;                                           // pair index -> (i, j), i < j, lexicographic
         while (rem >= nb - 1 - bi) { rem -= nb - 1 - bi; ++bi; }
@@ -292,55 +349,60 @@ __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs 
         const bool skip = P.no_contact && P.no_contact[((size_t)scene * nb + bi) * nb + bj];
         if (!skip) {
           Body b1, b2;
-          b1.kind = P.kind[(size_t)scene * nb + bi]; b2.kind = P.kind[(size_t)scene * nb + bj];
+          b1.kind = s_kind[bi]; b2.kind = s_kind[bj];
           b1.pos = v2(s_pose[bi * 3 + 1], s_pose[bi * 3 + 2]); b2.pos = v2(s_pose[bj * 3 + 1], s_pose[bj * 3 + 2]);
-          b1.rad = P.radius[(size_t)scene * nb + bi]; b2.rad = P.radius[(size_t)scene * nb + bj];
-          b1.nv = P.nverts[(size_t)scene * nb + bi]; b2.nv = P.nverts[(size_t)scene * nb + bj];
+          b1.rad = s_rad[bi]; b2.rad = s_rad[bj];
+          b1.nv = s_nv[bi]; b2.nv = s_nv[bj];
           b1.verts = s_verts + bi * NV; b2.verts = s_verts + bj * NV;
-          cnt = collide_pair(b1, b2, P.eps, pts);
+          b1.nrm = s_nrm + bi * NV; b2.nrm = s_nrm + bj * NV; b1.elen = s_elen + bi * NV; b2.elen = s_elen + bj * NV;
+          cnt = collide_pair(b1, b2, P.eps, pt0, pt1);
         }
       }
-      // exclusive prefix sum of cnt over the lanes (pair order = the reference's contact order)
+      // exclusive prefix sum of cnt over the lanes of the scene (pair order = the reference's contact order)
       int incl = cnt;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+      for (int off = 1; off < LPS; off <<= 1) { const int o = __shfl_up(incl, off, LPS); if (ll >= off) incl += o; }
       const int excl = incl - cnt;
-      const int total = __shfl(incl, 63, 64);
-      for (int q = 0; q < cnt; ++q) {
+      const int total = __shfl(incl, LPS - 1, LPS);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const Pt& pt = q == 0 ? pt0 : pt1;
         const int slot = base + excl + q;
-        if (slot < P.maxc) {
+        if (q < cnt && slot < P.maxc && live) {
           const size_t o = (size_t)scene * P.maxc + slot;
-          P.c_n[o * 2] = (float)pts[q].n.x; P.c_n[o * 2 + 1] = (float)pts[q].n.y;
-          P.c_p1[o * 2] = (float)pts[q].p1.x; P.c_p1[o * 2 + 1] = (float)pts[q].p1.y;
-          P.c_p2[o * 2] = (float)pts[q].p2.x; P.c_p2[o * 2 + 1] = (float)pts[q].p2.y;
-          if (P.c_pen) P.c_pen[o] = pts[q].pen;
+          P.c_n[o * 2] = (float)pt.n.x; P.c_n[o * 2 + 1] = (float)pt.n.y;
+          P.c_p1[o * 2] = (float)pt.p1.x; P.c_p1[o * 2 + 1] = (float)pt.p1.y;
+          P.c_p2[o * 2] = (float)pt.p2.x; P.c_p2[o * 2 + 1] = (float)pt.p2.y;
+          if (P.c_pen) P.c_pen[o] = pt.pen;
           P.c_i1[o] = bi; P.c_i2[o] = bj;
         }
-        maxpen = pts[q].pen > maxpen ? pts[q].pen : maxpen;
+        if (q < cnt) maxpen = pt.pen > maxpen ? pt.pen : maxpen;
       }
       base += total;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(maxpen, off, 64); maxpen = o > maxpen ? o : maxpen; }
-    ++trial;
-    // world.py:95-101
-    const bool ok = !(base > 0 && maxpen > P.tol);
-    if (ok) break;
-    if (!P.strict && dt < P.dt_floor) break;
-    if (trial >= P.max_trials || !P.v) break;               // (the reference would not terminate here)
-    dt *= 0.5;
+    for (int off = LPS / 2; off > 0; off >>= 1) { const double o = __shfl_xor(maxpen, off, LPS); maxpen = o > maxpen ? o : maxpen; }
+    if (!done) {
+      ++trial;
+      // world.py:95-101
+      const bool ok = !(base > 0 && maxpen > P.tol);
+      if (ok || (!P.strict && dt < P.dt_floor) || trial >= P.max_trials || !P.v) done = true;   // (max_trials: the reference would spin)
+      else dt *= 0.5;
+    }
+    if (__all(done)) break;
     __syncthreads();
   }
+  if (!live) return;
   // pad the unused contact slots with a harmless record (no normal, bodies 0/0)
   const int nfill = base < P.maxc ? base : P.maxc;
-  for (int slot = nfill + lane; slot < P.maxc; slot += 64) {
+  for (int slot = nfill + ll; slot < P.maxc; slot += LPS) {
     const size_t o = (size_t)scene * P.maxc + slot;
     P.c_n[o * 2] = 0; P.c_n[o * 2 + 1] = 0; P.c_p1[o * 2] = 0; P.c_p1[o * 2 + 1] = 0; P.c_p2[o * 2] = 0; P.c_p2[o * 2 + 1] = 0;
     if (P.c_pen) P.c_pen[o] = 0;
     P.c_i1[o] = 0; P.c_i2[o] = 0;
   }
-  if (P.p_out) for (int idx = lane; idx < nb * 3; idx += 64) P.p_out[(size_t)scene * nb * 3 + idx] = s_pose[idx];
-  if (lane == 0) {
+  if (P.p_out) for (int idx = ll; idx < nb * 3; idx += LPS) P.p_out[(size_t)scene * nb * 3 + idx] = s_pose[idx];
+  if (ll == 0) {
     P.count[scene] = base;                                  // may exceed maxc: the caller checks
     if (P.max_pen) P.max_pen[scene] = base > 0 ? maxpen : 0.0;
     if (P.dt_used) P.dt_used[scene] = dt;
@@ -353,7 +415,8 @@ __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs 
 
 int contacts_launch(const ContactArgs& P, void* stream) {
   if (P.nb > ct::MAXB) return LCP_E_TOOLARGE;
-  hipLaunchKernelGGL(ct::lcp_move_find_contacts_kernel, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P);
+  if (P.nb <= 6) hipLaunchKernelGGL(ct::lcp_move_find_contacts_kernel<16>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL(ct::lcp_move_find_contacts_kernel<64>, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 

@@ -118,11 +118,11 @@ def test_random_scenes_match_oracle():
     from lcp_physics_amd.physics.contacts import find_contacts
     rng = np.random.default_rng(7)
     total = 0
-    for nb in (3, 4, 6):
-        scenes = [_random_scene(rng, nb) for _ in range(96)]
+    for nb in (3, 4, 6, 7, 12):                  # 6 bodies: four scenes per wave; 7: one wave per scene; 12: 66 pairs > 64 lanes
+        scenes = [_random_scene(rng, nb) for _ in range(97 if nb < 12 else 24)]
         geom = _geom([s[0] for s in scenes])
         p = torch.tensor(np.stack([s[1] for s in scenes]), dtype=torch.float64, device=DEV)
-        cb = find_contacts(geom, p, maxc=24)
+        cb = find_contacts(geom, p, maxc=48)
         torch.cuda.synchronize()
         for k, (shapes, pose) in enumerate(scenes):
             try:
