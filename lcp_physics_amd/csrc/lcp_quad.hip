@@ -32,16 +32,14 @@ template <int K> __device__ __forceinline__ float bc(float v) {
 template <int K> __device__ __forceinline__ double bc(double v) {
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);     // one v_mov_b64_dpp (64-bit DPP: row_newbcast only)
 }
-// acc (+/-)= (lane K of the row's `src`) * mult with the broadcast folded into the FMA.  The fp64 ALU of gfx950
-// takes a 64-bit DPP operand (row_newbcast only) at full rate: 4.7 cycles per FMA against 8.8 for mov + FMA, and a
-// dependent chain (the triangular sweeps) runs at 8.5 instead of 16.4 (tools/microbench/pair_cost.hip).  The
-// hardware interlocks the DPP read-after-write of the DP ALU (tools/microbench/dpp_hazard.hip), no s_nop needed.
-template <int K> __device__ __forceinline__ void fmac_bc(double& acc, double src, double mult) {
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
-}
-template <int K> __device__ __forceinline__ void fnmac_bc(double& acc, double src, double mult) {
-  asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(K));
-}
+// acc (+/-)= (lane K of the row's `src`) * mult: one 64-bit DPP move + FMA, hazards handled by the compiler.  (The
+// single-instruction form v_fmac_f64_dpp exists but can only be emitted as inline asm, which the hazard recogniser
+// does not see; it is used where a whole block of them can be made safe by construction - the LU trailing update below.)
+template <int K, typename T> __device__ __forceinline__ void fmac_bc(T& acc, T src, T mult) { acc = fma(bc<K>(src), mult, acc); }
+template <int K, typename T> __device__ __forceinline__ void fnmac_bc(T& acc, T src, T mult) { acc = fma(bc<K>(src), -mult, acc); }
+#ifndef LCP_Q_ASM_LU
+#define LCP_Q_ASM_LU 1      // 0: LU trailing update through the builtin as well (A/B aid)
+#endif
 // LCP_Q_LDSW = 1 keeps a packed symmetric copy of W in LDS and rebuilds T from it instead of re-reading the workspace
 // (cuts the L2-miss traffic of the 11 factorisations).  Measured on MI355X, B = 4096 x 16 contacts: forward 0.260 ms
 // against 0.227 ms with the plain 16-byte global loads (64 ds_read_b64 + address selects per lane cost more than 32
@@ -49,36 +47,10 @@ template <int K> __device__ __forceinline__ void fnmac_bc(double& acc, double sr
 #ifndef LCP_Q_LDSW
 #define LCP_Q_LDSW 0
 #endif
-#ifndef LCP_Q_ASM_PROD
-#define LCP_Q_ASM_PROD 0
-#endif
-#ifndef LCP_Q_ASM_LU
-#define LCP_Q_ASM_LU 1
-#endif
-#ifndef LCP_Q_ASM_TS
-#define LCP_Q_ASM_TS 0
-#endif
-template <int K, int ASM> __device__ __forceinline__ void fmac_sel(double& acc, double src, double mult) {
-  if (ASM) fmac_bc<K>(acc, src, mult); else acc = fma(bc<K>(src), mult, acc);
-}
-template <int K, int ASM> __device__ __forceinline__ void fnmac_sel(double& acc, double src, double mult) {
-  if (ASM) fnmac_bc<K>(acc, src, mult); else acc = fma(bc<K>(src), -mult, acc);
-}
-template <int K, int ASM> __device__ __forceinline__ void fmac_sel(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), mult, acc); }
-template <int K, int ASM> __device__ __forceinline__ void fnmac_sel(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), -mult, acc); }
-template <int K> __device__ __forceinline__ void fmac_bc(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), mult, acc); }
-template <int K> __device__ __forceinline__ void fnmac_bc(float& acc, float src, float mult) { acc = fmaf(bc<K>(src), -mult, acc); }
 // v where keep, else (numerically) zero: clears the high dword only - what is left is below 2^-1042, which vanishes
 // in every accumulation it enters.  One v_cndmask instead of two for the masked triangular-solve multipliers.
 __device__ __forceinline__ double keep_if(double v, bool keep) { return __hiloint2double(keep ? __double2hiint(v) : 0, __double2loint(v)); }
 __device__ __forceinline__ float keep_if(float v, bool keep) { return keep ? v : 0.0f; }
-// the same with the condition taken from bit K of a per-lane bit mask: v_bfe_i32 + v_and, no compare, no VCC hazard
-// (the bit-field extract is opaque asm: written with the builtin, instcombine turns it back into compare + select)
-template <int K> __device__ __forceinline__ int bit_to_word(int mask) { int m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(mask), "n"(K)); return m; }
-template <int K> __device__ __forceinline__ double keep_bit(double v, int mask) {
-  return __hiloint2double(__double2hiint(v) & bit_to_word<K>(mask), __double2loint(v));
-}
-template <int K> __device__ __forceinline__ float keep_bit(float v, int mask) { return __int_as_float(__float_as_int(v) & bit_to_word<K>(mask)); }
 template <int CTRL> __device__ __forceinline__ float dppx(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
@@ -212,8 +184,8 @@ struct SceneQ {
     TC n0 = 0, n1 = 0, t0 = 0, t1 = 0;
     static_for<8>([&](auto H) LCP_INL {
       constexpr int J = 2 * H;
-      fmac_sel<J, LCP_Q_ASM_PROD>(n0, v, (TC)launder(jc[J])); fmac_sel<J, LCP_Q_ASM_PROD>(t0, v, (TC)launder(jt[J]));
-      fmac_sel<J + 1, LCP_Q_ASM_PROD>(n1, v, (TC)launder(jc[J + 1])); fmac_sel<J + 1, LCP_Q_ASM_PROD>(t1, v, (TC)launder(jt[J + 1]));
+      fmac_bc<J>(n0, v, (TC)launder(jc[J])); fmac_bc<J>(t0, v, (TC)launder(jt[J]));
+      fmac_bc<J + 1>(n1, v, (TC)launder(jc[J + 1])); fmac_bc<J + 1>(t1, v, (TC)launder(jt[J + 1]));
     });
     gn = n0 + n1; gt = t0 + t1;
   }
@@ -224,10 +196,10 @@ struct SceneQ {
     const TI* gtl = launder(L.GTL) + l16;
     static_for<8>([&](auto H) LCP_INL {
       constexpr int C = 2 * H;
-      fmac_sel<C, LCP_Q_ASM_PROD>(a0, wn, (TC)gl[C * 16]);
-      fmac_sel<C, LCP_Q_ASM_PROD>(a1, wt, (TC)gtl[C * 16]);
-      fmac_sel<C + 1, LCP_Q_ASM_PROD>(a2, wn, (TC)gl[(C + 1) * 16]);
-      fmac_sel<C + 1, LCP_Q_ASM_PROD>(a3, wt, (TC)gtl[(C + 1) * 16]);
+      fmac_bc<C>(a0, wn, (TC)gl[C * 16]);
+      fmac_bc<C>(a1, wt, (TC)gtl[C * 16]);
+      fmac_bc<C + 1>(a2, wn, (TC)gl[(C + 1) * 16]);
+      fmac_bc<C + 1>(a3, wt, (TC)gtl[(C + 1) * 16]);
     });
     return (a0 + a1) + (a2 + a3);
   }
@@ -236,21 +208,21 @@ struct SceneQ {
     const TI* ar = launder(L.AtL) + (l16 & (EQ - 1)) * 16;       // row l16 of A (rows >= e are zero; lanes >= EQ unused)
     static_for<4>([&](auto H) LCP_INL {
       constexpr int K = 4 * H;
-      fmac_sel<K, LCP_Q_ASM_PROD>(a0, v, (TC)ar[K]); fmac_sel<K + 1, LCP_Q_ASM_PROD>(a1, v, (TC)ar[K + 1]);
-      fmac_sel<K + 2, LCP_Q_ASM_PROD>(a2, v, (TC)ar[K + 2]); fmac_sel<K + 3, LCP_Q_ASM_PROD>(a3, v, (TC)ar[K + 3]);
+      fmac_bc<K>(a0, v, (TC)ar[K]); fmac_bc<K + 1>(a1, v, (TC)ar[K + 1]);
+      fmac_bc<K + 2>(a2, v, (TC)ar[K + 2]); fmac_bc<K + 3>(a3, v, (TC)ar[K + 3]);
     });
     return (l16 < EQ) ? (a0 + a1) + (a2 + a3) : (TC)0;
   }
   __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
     TC a0 = 0, a1 = 0;
     const TI* at = launder(L.AtL) + l16;
-    fmac_sel<0, LCP_Q_ASM_PROD>(a0, y, (TC)at[0]); fmac_sel<1, LCP_Q_ASM_PROD>(a1, y, (TC)at[16]);
-    fmac_sel<2, LCP_Q_ASM_PROD>(a0, y, (TC)at[32]); fmac_sel<3, LCP_Q_ASM_PROD>(a1, y, (TC)at[48]);
+    fmac_bc<0>(a0, y, (TC)at[0]); fmac_bc<1>(a1, y, (TC)at[16]);
+    fmac_bc<2>(a0, y, (TC)at[32]); fmac_bc<3>(a1, y, (TC)at[48]);
     return a0 + a1;
   }
   __device__ __forceinline__ void GAt(TC t, TC& gn, TC& gt) const {     // m-space <- e-space
     gn = 0; gt = 0;
-    static_for<EQ>([&](auto A) LCP_INL { fmac_sel<A, LCP_Q_ASM_PROD>(gn, t, gan[A]); fmac_sel<A, LCP_Q_ASM_PROD>(gt, t, gat[A]); });
+    static_for<EQ>([&](auto A) LCP_INL { fmac_bc<A>(gn, t, gan[A]); fmac_bc<A>(gt, t, gat[A]); });
   }
   __device__ __forceinline__ TC GAtw(TC wn, TC wt) const {              // e-space <- m-space
     TC out = 0;
@@ -259,8 +231,8 @@ struct SceneQ {
   }
   __device__ __forceinline__ TC S11v(TC v) const {
     TC a0 = 0, a1 = 0;
-    fmac_sel<0, LCP_Q_ASM_PROD>(a0, v, s11row[0]); fmac_sel<1, LCP_Q_ASM_PROD>(a1, v, s11row[1]);
-    fmac_sel<2, LCP_Q_ASM_PROD>(a0, v, s11row[2]); fmac_sel<3, LCP_Q_ASM_PROD>(a1, v, s11row[3]);
+    fmac_bc<0>(a0, v, s11row[0]); fmac_bc<1>(a1, v, s11row[1]);
+    fmac_bc<2>(a0, v, s11row[2]); fmac_bc<3>(a1, v, s11row[3]);
     return a0 + a1;
   }
 };
@@ -455,15 +427,15 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
       ta[k] = (l16 > k) ? la : ta[k];
       tu[k] = lu;
       R.ua = (l16 == k) ? inv : R.ua;
-      fnmac_sel<k, 0>(tu[k + 1], ta[k + 1], lu);                     // (reads row k's ta[j] before it is updated below)
-      fnmac_sel<k, 0>(ta[k + 1], ta[k + 1], la);
+      fnmac_bc<k>(tu[k + 1], ta[k + 1], lu);                     // (reads row k's ta[j] before it is updated below)
+      fnmac_bc<k>(ta[k + 1], ta[k + 1], la);
       if constexpr (k + 1 < 16) pivv = bc<(k + 1) & 15>(ta[k + 1]); else pivv = bc<0>(tu[16]);
       inv = fast_rcp(pivv);
       if (LCP_Q_ASM_LU) lu_cols_a<k, k + 2, 30 - k>(ta, tu, la, lu);
       else static_for<30 - k>([&](auto JJ) LCP_INL {
         constexpr int j = k + 2 + JJ;
-        fnmac_sel<k, 0>(tu[j], ta[j], lu);
-        fnmac_sel<k, 0>(ta[j], ta[j], la);
+        fnmac_bc<k>(tu[j], ta[j], lu);
+        fnmac_bc<k>(ta[j], ta[j], la);
       });
     }
   });
@@ -476,13 +448,13 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
       tu[k] = (l16 > kk) ? lu : tu[k];
       R.uu = (l16 == kk) ? inv : R.uu;
       if constexpr (kk < 15) {
-        fnmac_sel<kk, 0>(tu[k + 1], tu[k + 1], lu);
+        fnmac_bc<kk>(tu[k + 1], tu[k + 1], lu);
         pivv = bc<(kk + 1) & 15>(tu[k + 1]);
         inv = fast_rcp(pivv);
         if (LCP_Q_ASM_LU) lu_cols_u<kk, k + 2, 14 - kk>(tu, lu);
         else static_for<14 - kk>([&](auto JJ) LCP_INL {
           constexpr int j = k + 2 + JJ;
-          fnmac_sel<kk, 0>(tu[j], tu[j], lu);
+          fnmac_bc<kk>(tu[j], tu[j], lu);
         });
       }
     }
@@ -502,27 +474,27 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
   static_for<16>([&](auto K) LCP_INL {                     // L y = rhs
     constexpr int k = K;
     if (k < nc) {
-      fnmac_sel<k, LCP_Q_ASM_TS>(ru, ra, tu[k]);
-      fnmac_sel<k, LCP_Q_ASM_TS>(ra, ra, keep_if(ta[k], l16 > k));
+      fnmac_bc<k>(ru, ra, tu[k]);
+      fnmac_bc<k>(ra, ra, keep_if(ta[k], l16 > k));
     }
   });
   static_for<16>([&](auto K) LCP_INL {
     constexpr int kk = K, k = 16 + K;
-    if (kk < nc) fnmac_sel<kk, LCP_Q_ASM_TS>(ru, ru, keep_if(tu[k], l16 > kk));
+    if (kk < nc) fnmac_bc<kk>(ru, ru, keep_if(tu[k], l16 > kk));
   });
   static_for<16>([&](auto KR) LCP_INL {                    // U x = y
     constexpr int kk = 15 - KR, k = 16 + kk;
     if (kk < nc) {
       const TC xs = ru * R.uu;                             // x_kk lives in lane kk of xs
-      fnmac_sel<kk, LCP_Q_ASM_TS>(ra, xs, ta[k]);
-      fnmac_sel<kk, LCP_Q_ASM_TS>(ru, xs, keep_if(tu[k], l16 < kk));
+      fnmac_bc<kk>(ra, xs, ta[k]);
+      fnmac_bc<kk>(ru, xs, keep_if(tu[k], l16 < kk));
     }
   });
   static_for<16>([&](auto KR) LCP_INL {
     constexpr int k = 15 - KR;
     if (k < nc) {
       const TC xs = ra * R.ua;
-      fnmac_sel<k, LCP_Q_ASM_TS>(ra, xs, keep_if(ta[k], l16 < k));
+      fnmac_bc<k>(ra, xs, keep_if(ta[k], l16 < k));
     }
   });
   const TC a = ra * R.ua, u = ru * R.uu;
