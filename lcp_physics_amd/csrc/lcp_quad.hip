@@ -251,7 +251,7 @@ struct RedQ {
 // the builtin it costs v_mov_b64_dpp + v_fma_f64 per entry; v_fmac_f64_dpp folds the broadcast into the FMA (4.7 instead
 // of 6.7 cycles per entry, tools/microbench/pair_cost.hip).  clang never forms that instruction itself (its DPP combiner
 // skips FMAC), so it is emitted as inline asm - and inline asm is invisible to the hazard recogniser: gfx950 needs 2 wait
-// states between a VALU write of a VGPR and a DPP read of it (tools/microbench/dpp_hazard2.hip shows stale reads
+// states between a VALU write of a VGPR and a DPP read of it (tools/microbench/dpp_hazard.hip shows stale reads
 // without them).  Every asm statement below therefore starts with `s_nop 1` (covers whatever the compiler put in front:
 // copies, v_accvgpr_read ...) and inside a statement no DPP source is written before it is read; up to 14 column pairs
 // (30 operands) share one s_nop.
