@@ -155,8 +155,9 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
  * a scene without contacts takes the direct KKT solve of engines.py:36-50.  One launch, no position update
  * (that is lcp_move_find_contacts_f64).  Arguments as lcp_step_fused_f32; z, s use the row layout of a
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
- * The workspace it leaves feeds lcp_pdipm_backward_f32 with m = 4 maxc (padded slots get zero gradients).
- * Served by the four-scenes-per-wave kernel: 3 nb <= 16, maxc <= 16, e <= 4 (else LCP_E_TOOLARGE).
+ * Served by the four-scenes-per-wave kernel when 3 nb <= 16, maxc <= 16, e <= 4: the workspace it leaves then feeds
+ * lcp_pdipm_backward_f32 (m = 4 maxc) and lcp_step_backward_f32 (padded slots get zero gradients).  Any other size runs
+ * on the workgroup-per-scene kernels, forward only (LCP_E_TOOLARGE beyond their LDS / workspace plan).
  *   out: v_new[B,nb,3]  z[B,4 maxc]  s[B,4 maxc]  y[B,e]  iters[B]  status[B] */
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
                            const float* Mdiag, const float* v, const float* f,

@@ -199,12 +199,17 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   if (rc) return rc;
   if (!c_count || !v_new || !ws || max_iter < 0) return LCP_E_BADARG;
   const int nz = 3 * nb, m = 4 * maxc;
-  if (!lcp::quad_supported(nz, m, e)) return LCP_E_TOOLARGE;
   P.c_count = c_count;
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  return lcp::quad_step(P, compute, stream);
+  if (lcp::quad_supported(nz, m, e) && g_path != 1) return lcp::quad_step(P, compute, stream);
+  // any other size: the workgroup-per-scene kernels (forward only; see lcp_hip.h)
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
 int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,

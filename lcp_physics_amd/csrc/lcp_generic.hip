@@ -412,18 +412,19 @@ __device__ void load_dense(Scene<TC>& S, const FwdArgs& P, int scene) {
 // engines.py:31-32,50-74 + world.py:144-234: build Q (diag), p = M v + dt f, G = [Jc; Jf; 0],
 // h = [(Jc v) * restitution; 0; 0], mu per contact, A = Je, b = 0 directly in LDS.
 template <typename TI, typename TC>
-__device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene) {
-  const int nb = P.nb, nc = P.nc, nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
+__device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene, int ncs) {
+  // `ncs` = contacts of this scene (<= P.nc, the capacity the contact arrays are strided by); m = S.m = 4 ncs
+  const int nb = P.nb, ncap = P.nc, nc = ncs, nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
   const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
   const TI* vv = (const TI*)P.v + (size_t)scene * nz;
   const TI* ff = (const TI*)P.f + (size_t)scene * nz;
   const TI* rest = (const TI*)P.rest + (size_t)scene * nb;
   const TI* fric = (const TI*)P.fric + (size_t)scene * nb;
-  const TI* cn = (const TI*)P.c_n + (size_t)scene * nc * 2;
-  const TI* c1 = (const TI*)P.c_p1 + (size_t)scene * nc * 2;
-  const TI* c2 = (const TI*)P.c_p2 + (size_t)scene * nc * 2;
-  const int32_t* i1 = P.c_i1 + (size_t)scene * nc;
-  const int32_t* i2 = P.c_i2 + (size_t)scene * nc;
+  const TI* cn = (const TI*)P.c_n + (size_t)scene * ncap * 2;
+  const TI* c1 = (const TI*)P.c_p1 + (size_t)scene * ncap * 2;
+  const TI* c2 = (const TI*)P.c_p2 + (size_t)scene * ncap * 2;
+  const int32_t* i1 = P.c_i1 + (size_t)scene * ncap;
+  const int32_t* i2 = P.c_i2 + (size_t)scene * ncap;
   S.nc = nc;
   for (int i = tid; i < nz * nz; i += NT) { const int r = i / nz, c = i - r * nz; S.Q[i] = (r == c) ? (TC)Md[r] : (TC)0; }
   for (int i = tid; i < m * nz; i += NT) S.G[i] = 0;
@@ -478,6 +479,13 @@ __device__ void pdipm_loop(Scene<TC>& S, const FT& F, TC eps, int max_iter, int 
   TC best_resid = inf_of<TC>();
   bool have_best = false;
   int n_not = 0, iters = 0;
+  if (m == 0) {                              // no inequality at all: the initialisation solve IS the answer
+    for (int j = tid; j < nz; j += NT) S.bx[j] = S.x[j];          // (engines.py:36-50, the no-contact branch)
+    for (int a = tid; a < e; a += NT) S.by[a] = S.y[a];
+    __syncthreads();
+    iters_out = 0;
+    return;
+  }
   for (int it = 0; it < max_iter; ++it) {
     // residuals                                                             (:82-96)
     for (int j = tid; j < nz; j += NT) {
@@ -611,27 +619,48 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x;
-  const int nz = 3 * P.nb, m = 4 * P.nc, e = P.e;
-  WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
+  const int ncap = P.nc, mcap = 4 * ncap;                                 // capacity: array strides, workspace layout
+  int ncs = ncap;                                                         // contacts of this scene (engines.py:36,51)
+  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  const int nz = 3 * P.nb, m = 4 * ncs, e = P.e;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, mcap, e);
   Scene<TC> S;
   carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
   S.R = W.R;
-  assemble_scene<TI, TC>(S, P, scene);
-  FContact<TC> F{S.mu_c, P.nc};
+  assemble_scene<TI, TC>(S, P, scene, ncs);
+  FContact<TC> F{S.mu_c, ncs};
   int status = prefactor(S, F);
   int iters = 0;
   pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);
-  TI* z = P.z ? (TI*)P.z + (size_t)scene * m : nullptr;
-  TI* s = P.s ? (TI*)P.s + (size_t)scene * m : nullptr;
+  TI* z = P.z ? (TI*)P.z + (size_t)scene * mcap : nullptr;
+  TI* s = P.s ? (TI*)P.s + (size_t)scene * mcap : nullptr;
   TI* y = (e > 0 && P.y) ? (TI*)P.y + (size_t)scene * e : nullptr;
-  store_solution<TI, TC>(S, W, (TI*)nullptr, y, z, s, status);
-  const TI* pos = (const TI*)P.pos + (size_t)scene * nz;
+  if (ncs == ncap) {
+    store_solution<TI, TC>(S, W, (TI*)nullptr, y, z, s, status);
+  } else {
+    // fewer contacts than the capacity: the multipliers go to the row layout of a capacity-sized LCP
+    // ([normal | friction pairs | gamma] blocks of ncap, 2 ncap, ncap rows), padded slots are 0; the workspace is not
+    // laid out for a backward in this case
+    __syncthreads();
+    int bad = 0;
+    for (int i = threadIdx.x; i < mcap; i += NT) { if (z) z[i] = (TI)0; if (s) s[i] = (TI)0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += NT) {
+      const int slot = (i < ncs) ? i : (i < 3 * ncs) ? ncap + (i - ncs) : 3 * ncap + (i - 3 * ncs);
+      const TC a = S.bz[i], c = S.bs[i];
+      if (z) z[slot] = (TI)a;
+      if (s) s[slot] = (TI)c;
+      bad |= (a != a) | (c != c);
+    }
+    for (int j = threadIdx.x; j < nz; j += NT) bad |= (S.bx[j] != S.bx[j]);
+    for (int a = threadIdx.x; a < e; a += NT) if (y) y[a] = (TI)S.by[a];
+    if (__syncthreads_or(bad)) status |= LCP_ST_NAN;
+  }
   TI* vn = (TI*)P.v_new + (size_t)scene * nz;
-  TI* pn = (TI*)P.p_new + (size_t)scene * nz;
   for (int j = threadIdx.x; j < nz; j += NT) {
     const TC nv = -S.bx[j];                                               // engines.py:76-77
     vn[j] = (TI)nv;
-    pn[j] = (TI)((TC)pos[j] + nv * (TC)P.dt);                             // bodies.py:81
+    if (P.p_new) ((TI*)P.p_new)[(size_t)scene * nz + j] = (TI)((TC)((const TI*)P.pos)[(size_t)scene * nz + j] + nv * (TC)P.dt);   // bodies.py:81
   }
   if (threadIdx.x == 0) {
     if (P.iters) P.iters[scene] = iters;
@@ -647,7 +676,7 @@ __global__ void __launch_bounds__(NT) lcp_assemble_kernel(StepArgs P, TI* Q, TI*
   const int nz = 3 * P.nb, nc = P.nc, m = 4 * nc, e = P.e, tid = threadIdx.x;
   Scene<TI> S;
   carve(S, smem, nz, m, e, m, false, (TI*)nullptr);
-  assemble_scene<TI, TI>(S, P, scene);
+  assemble_scene<TI, TI>(S, P, scene, nc);
   FContact<TI> F{S.mu_c, nc};
   for (int i = tid; i < nz * nz; i += NT) Q[(size_t)scene * nz * nz + i] = S.Q[i];
   for (int i = tid; i < nz; i += NT) p[(size_t)scene * nz + i] = S.p[i];

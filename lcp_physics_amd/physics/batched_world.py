@@ -215,8 +215,9 @@ class ContactWorld:
     State: `p` [B,nb,3] float64 (rot, x, y), `v` [B,nb,3] float32, `t` [B] float64 (scenes advance by their own
     accepted dt, world.py:122), `contacts` (`contacts.ContactBuffers`: padded records + `count`).
     Restrictions: forces are constant (gravity-like), joints have a constant Jacobian `Je` (Total/X/Y/Rot
-    constraints), post-stabilisation (off by default in the reference, utils.py:30) is not implemented;
-    3 nb <= 16, maxc <= 16, e <= 4 (the four-scenes-per-wave solver).
+    constraints), post-stabilisation (off by default in the reference, utils.py:30) is not implemented; at most 16
+    bodies per scene.  Scenes with 3 nb <= 16, maxc <= 16, e <= 4 run on the four-scenes-per-wave solver, anything
+    else on the workgroup-per-scene kernels (slower, forward only).
     """
 
     def __init__(self, geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1.0 / 30, eps=0.1, tol=1e-6,

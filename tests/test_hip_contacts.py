@@ -206,14 +206,23 @@ def _variable_count_batch(rng, B, nb, maxc):
     return scenes, lists
 
 
+@pytest.fixture(params=["auto", "generic"])
+def solver_path(request):
+    """The four-scenes-per-wave kernel (auto, for these sizes) and the workgroup-per-scene kernels (any size)."""
+    from lcp_physics_amd import _lib
+    _lib.set_path(request.param)
+    yield request.param
+    _lib.set_path("auto")
+
+
 @pytest.mark.parametrize("with_joint", [True, False])
-def test_solve_dynamics_variable_counts_match_oracle(with_joint):
+def test_solve_dynamics_variable_counts_match_oracle(with_joint, solver_path):
     """engines.py:26-78 with per-scene contact counts (incl. the no-contact branch :36-50): new_v within 1e-4
     (scaled by the velocity scale of the scene) of the fp64 oracle."""
     from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import find_contacts
     rng = np.random.default_rng(5)
-    B, nb, maxc = 192, 4, 12
+    B, nb, maxc = (192, 4, 12) if solver_path == "auto" else (64, 4, 12)
     scenes, lists = _variable_count_batch(rng, B, nb, maxc)
     counts = [len(c) for c in lists]
     assert min(counts) == 0 and max(counts) >= 5 and len(set(counts)) >= 4
@@ -286,6 +295,35 @@ def test_contact_world_follows_reference_trajectory(name):
         worst_p, worst_v = max(worst_p, ep), max(worst_v, ev)
         assert ep <= 2e-4 and ev <= 2e-4, (name, k, ep, ev)
     print(name, "worst |dp|", worst_p, "worst |dv|", worst_v)
+
+
+def test_contact_world_beyond_the_quad_sizes_follows_oracle():
+    """7 bodies (nz = 21 > 16): contact kernel with one wave per scene + the workgroup-per-scene solver with per-scene
+    contact counts; a few steps against oracle/world_oracle.py (pinned on the reference World, tests/test_world_oracle.py)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    B, nbox, nsteps = 3, 6, 8
+    w = scenes.make_drop_world(B, nbox=nbox, box=30.0, seed=11, gap=(0.2, 0.6))
+    geom = _geom([w["shapes"]] * B)
+    g = lambda k: w[k].to(DEV)
+    world = ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=24)
+    refs = []
+    for s in range(B):
+        d = lambda k: w[k][s].double().numpy()
+        p, v = d("p"), d("v")
+        cs = C.find_contacts(W.bodies_at(w["shapes"], p), eps=0.1)
+        t = 0.0
+        for _ in range(nsteps):
+            p, v, cs, dt_used, _ = W.step_dt(w["shapes"], p, v, cs, d("Mdiag"), d("f"), d("rest"), d("fric"), d("Je"), 1.0 / 30)
+            t += dt_used
+        refs.append((p, v, len(cs), t))
+    for _ in range(nsteps):
+        world.step()
+    world.check_capacity()
+    for s in range(B):
+        p, v, n, t = refs[s]
+        assert abs(float(world.t[s]) - t) < 1e-12 and int(world.contacts.count[s]) == n, (s, float(world.t[s]), t, int(world.contacts.count[s]), n)
+        assert np.abs(world.p[s].cpu().numpy() - p).max() < 2e-4 and np.abs(world.v[s].double().cpu().numpy() - v).max() < 2e-3, s
 
 
 def test_contact_world_refuses_initial_penetration():
