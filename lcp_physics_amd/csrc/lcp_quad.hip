@@ -44,6 +44,9 @@ template <int K, typename T> __device__ __forceinline__ void fnmac_bc(T& acc, T 
 // (cuts the L2-miss traffic of the 11 factorisations).  Measured on MI355X, B = 4096 x 16 contacts: forward 0.260 ms
 // against 0.227 ms with the plain 16-byte global loads (64 ds_read_b64 + address selects per lane cost more than 32
 // L2/MALL-served dwordx4 loads), so it is off.
+#ifndef LCP_Q_TS_GROUP
+#define LCP_Q_TS_GROUP 4    // triangular-sweep steps per scalar guard (1, 2, 4, 8 or 16)
+#endif
 #ifndef LCP_Q_LDSW
 #define LCP_Q_LDSW 0
 #endif
@@ -471,31 +474,39 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
   const TC r12 = hz.f1 + hz.f2;
   const TC w0 = (R.Dg * r12 - (TC)2 * hz.g) * R.idet;
   TC ra = hz.n, ru = (TC)0.5 * (hz.f1 - hz.f2) - (TC)0.5 * R.Sm * w0;
-  static_for<16>([&](auto K) LCP_INL {                     // L y = rhs
-    constexpr int k = K;
-    if (k < nc) {
+  // The sweeps are guarded per group of LCP_Q_TS_GROUP steps: rows / columns at or beyond the contact count are identity
+  // (never touched by the factorisation), so the surplus steps of the last group are exact no-ops, the scalar branches
+  // between the steps go, and the compiler schedules across the steps of a group (measured: 0.2105 -> 0.1947 ms).
+  constexpr int TG = LCP_Q_TS_GROUP, NG = 16 / TG;
+  static_for<NG>([&](auto Gq) LCP_INL {                    // L y = rhs
+    if (TG * Gq < nc) static_for<TG>([&](auto Kq) LCP_INL {
+      constexpr int k = TG * Gq + Kq;
       fnmac_bc<k>(ru, ra, tu[k]);
       fnmac_bc<k>(ra, ra, keep_if(ta[k], l16 > k));
-    }
+    });
   });
-  static_for<16>([&](auto K) LCP_INL {
-    constexpr int kk = K, k = 16 + K;
-    if (kk < nc) fnmac_bc<kk>(ru, ru, keep_if(tu[k], l16 > kk));
+  static_for<NG>([&](auto Gq) LCP_INL {
+    if (TG * Gq < nc) static_for<TG>([&](auto Kq) LCP_INL {
+      constexpr int kk = TG * Gq + Kq, k = 16 + kk;
+      fnmac_bc<kk>(ru, ru, keep_if(tu[k], l16 > kk));
+    });
   });
-  static_for<16>([&](auto KR) LCP_INL {                    // U x = y
-    constexpr int kk = 15 - KR, k = 16 + kk;
-    if (kk < nc) {
+  static_for<NG>([&](auto GR) LCP_INL {                    // U x = y
+    constexpr int Gq = NG - 1 - GR;
+    if (TG * Gq < nc) static_for<TG>([&](auto KR) LCP_INL {
+      constexpr int kk = TG * Gq + TG - 1 - KR, k = 16 + kk;
       const TC xs = ru * R.uu;                             // x_kk lives in lane kk of xs
       fnmac_bc<kk>(ra, xs, ta[k]);
       fnmac_bc<kk>(ru, xs, keep_if(tu[k], l16 < kk));
-    }
+    });
   });
-  static_for<16>([&](auto KR) LCP_INL {
-    constexpr int k = 15 - KR;
-    if (k < nc) {
+  static_for<NG>([&](auto GR) LCP_INL {
+    constexpr int Gq = NG - 1 - GR;
+    if (TG * Gq < nc) static_for<TG>([&](auto KR) LCP_INL {
+      constexpr int k = TG * Gq + TG - 1 - KR;
       const TC xs = ra * R.ua;
       fnmac_bc<k>(ra, xs, keep_if(ta[k], l16 < k));
-    }
+    });
   });
   const TC a = ra * R.ua, u = ru * R.uu;
   const TC w = w0 + R.wa * a + R.wu * u;
