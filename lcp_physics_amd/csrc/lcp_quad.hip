@@ -10,10 +10,15 @@
 //   * x-space vectors (nz <= 16) live one entry per lane of the row, e-space (neq <= 4) likewise.
 //   * every cross-lane move is a DPP row operation: `row_newbcast:k` broadcasts lane k of each row to its row
 //     (pivot rows in the LU, vector entries in the products), quad_perm / row_mirror give row-local
-//     reductions.  Micro-benchmark (tools/microbench/pair_cost.hip): 8.8 cycles per fp64 FMA fed this way
-//     versus 21-29 through v_readlane, and one instruction serves four scenes.
+//     reductions.  Micro-benchmark (tools/microbench/pair_cost.hip): 6.7 cycles per fp64 FMA fed by a 64-bit DPP
+//     move, 4.7 with the broadcast folded into v_fmac_f64_dpp (the LU), versus 21-29 through v_readlane, and one
+//     instruction serves four scenes.
 //   * the pivot-free LU runs over the 2 x 32 register-resident row entries of each lane.
-// Scenes of a wave advance in lock-step; a scene that terminates (pdipm.py:133) freezes its state and waits.
+// Scenes of a wave advance in lock-step; a scene that terminates (pdipm.py:133) freezes its state and waits.  Scenes may
+// have different contact counts (the fused step with `c_count`): lane masks are per row, loops run to the wave maximum
+// over identity rows, a scene without contacts leaves after the initialisation solve (engines.py:36-50).
+// Kernels: lcp_fwd_quad (dense or fused forward), lcp_bwd_quad (lcp.py:37-64, dense gradients), lcp_bwd_step_quad
+// (gradients w.r.t. the physical inputs of the fused step).
 // Same algorithm and the same reference lines as lcp_wave64.hip / lcp_generic.hip.
 #include "lcp_wave_common.h"
 
