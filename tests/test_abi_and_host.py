@@ -111,3 +111,28 @@ def test_pure_fp32_reference_style_misses_tolerance_documented():
     ex = parity.err_x(s32.x.double(), ref.x, lcp64[0], lcp64[1])
     assert float(ex.median()) < 1e-5          # typical scenes are fine ...
     assert float(ex.max()) > 1e-4             # ... but the tail is not
+
+
+def test_geometry_batch_matches_reference_rect_convention():
+    """Host side of the contact path (no GPU): `GeometryBatch.from_shapes` stores a Rect's body-frame vertices in the
+    order of the reference (`bodies.py:261-264`: v0 = half, v1 = half * (-1, 1), -v0, -v1), which is what
+    oracle.contacts_oracle.rect_verts produces at rotation 0; circles carry a radius and no vertices."""
+    import numpy as np
+    from lcp_physics_amd.physics.contacts import CIRCLE, HULL, NV, GeometryBatch
+    from oracle import contacts_oracle as C
+    tri = [[0.0, -2.0], [2.0, 1.0], [-2.0, 1.0]]
+    g = GeometryBatch.from_shapes([("rect", (4.0, 2.0)), ("circle", 1.5), ("hull", tri)], B=3)
+    assert tuple(g.verts_local.shape) == (3, 3, NV, 2) and g.kind[0].tolist() == [HULL, CIRCLE, HULL]
+    assert np.allclose(g.verts_local[1, 0, :4].numpy(), C.rect_verts((4.0, 2.0), 0.0))
+    assert g.nverts[2].tolist() == [4, 0, 3] and float(g.radius[0, 1]) == 1.5
+    assert np.allclose(g.verts_local[0, 2, :3].numpy(), np.array(tri)) and float(g.verts_local[0, 2, 3:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        GeometryBatch.from_shapes([("hull", [[float(i), float(i * i)] for i in range(NV + 1)])])
+
+
+def test_contact_path_refuses_cpu_tensors():
+    """No CPU fallback on the contact path either."""
+    from lcp_physics_amd.physics.contacts import GeometryBatch, find_contacts
+    g = GeometryBatch.from_shapes([("rect", (4.0, 2.0)), ("circle", 1.5)], B=1)
+    with pytest.raises(RuntimeError):
+        find_contacts(g, torch.zeros(1, 2, 3, dtype=torch.float64))
