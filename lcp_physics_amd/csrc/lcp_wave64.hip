@@ -905,14 +905,19 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
   if (ok) {
     // G: lanes over columns, loop over rows (coalesced)
     const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
+    // (the tests are accumulated with `&`, not `&&`: a short-circuit would make every load wait for the previous compare)
+    int good = 1;
     if (lane < nz) {
-      for (int i = nc; i < 3 * nc; i += 2) ok = ok && (G[(i + 1) * nz + lane] == -G[i * nz + lane]);
-      for (int i = 3 * nc; i < m; ++i) ok = ok && (G[i * nz + lane] == (TI)0);
+#pragma unroll 4
+      for (int i = nc; i < 3 * nc; i += 2) good &= (G[(i + 1) * nz + lane] == -G[i * nz + lane]) ? 1 : 0;
+#pragma unroll 4
+      for (int i = 3 * nc; i < m; ++i) good &= (G[i * nz + lane] == (TI)0) ? 1 : 0;
     }
     // F: lane j holds column j of every row in turn (one coalesced 4 m-byte read per row)
     const TI* F = (const TI*)P.F + (size_t)scene * m * m;
     if (lane < m) {
       const int j = lane;
+#pragma unroll 8
       for (int i = 0; i < m; ++i) {
         const TI v = F[(size_t)i * m + j];
         TI want = (TI)0;
@@ -922,14 +927,17 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
           if (j == cg) want = v;
           else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = (TI)-1;
         }
-        ok = ok && (v == want);
+        good &= (v == want) ? 1 : 0;
       }
     }
+    ok = good != 0;
   }
   bool qdiag = true;
   {
     const TI* Q = (const TI*)P.Q + (size_t)scene * nz * nz;
-    for (int idx = lane; idx < nz * nz; idx += 64) { const int r = idx / nz, c = idx - r * nz; if (r != c) qdiag = qdiag && (Q[idx] == (TI)0); }
+    int qd = 1;
+    for (int idx = lane; idx < nz * nz; idx += 64) { const int r = idx / nz, c = idx - r * nz; qd &= (r == c || Q[idx] == (TI)0) ? 1 : 0; }
+    qdiag = qd != 0;
   }
   qdiag = __all(qdiag);
   const bool all_ok = __all(ok);
