@@ -123,7 +123,9 @@ template <typename T> __device__ __forceinline__ T row_pmin(T v) { const uint32_
 
 // Opaque pass-through: stops LICM from hoisting loop-invariant LDS loads / float->double conversions of the
 // Jacobian rows out of the PDIPM loop (it did, and the ~200 extra live registers spilled to scratch).
-template <typename T> __device__ __forceinline__ T* launder(T* p) { asm volatile("" : "+v"(p)); return p; }
+// (never launder an LDS POINTER: it loses its address space and every access through it becomes a flat load followed
+//  by a full s_waitcnt - launder an integer offset added to the pointer instead, see lds_opaque_zero)
+__device__ __forceinline__ int lds_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 __device__ __forceinline__ float launder(float f) { asm volatile("" : "+v"(f)); return f; }
 // the lane-index compares (l16 > k, l16 == k ...) are loop-invariant: hoisted, their 64-bit masks overflow the SGPR file and
 // come back through v_readlane spills; laundering the index per call keeps them local (one v_cmp each instead)
@@ -149,7 +151,8 @@ template <typename TC> __device__ __forceinline__ TC sum4(const M4<TC>& a) { ret
 // ---------------------------------------------------------------- per-scene LDS block
 template <typename TI, typename TC>
 struct LdsQ {
-  TI* GL;    // [16][16]  Jc rows: GL[c*16 + j]
+  TI* GL;    // [16][16]  Jc rows: GL[c*16 + j]  (lane j of G^T w reads GL[c*16 + j]: consecutive lanes, consecutive banks.
+             //           The transposed layout - 16 contiguous entries per lane - was tried: 8-way bank conflicts, slower.)
   TI* GTL;   // [16][16]  Jt rows
   TI* AtL;   // [EQ][16]  A rows
   TC* GAL;   // [16][2][EQ]  (J Q^-1 A^T) of the n / t row of every contact
@@ -200,20 +203,30 @@ struct SceneQ {
   // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
   __device__ __forceinline__ TC Gtw(TC wn, TC wt) const {
     TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const TI* gl = launder(L.GL) + l16;
-    const TI* gtl = launder(L.GTL) + l16;
-    static_for<8>([&](auto H) LCP_INL {
-      constexpr int C = 2 * H;
-      fmac_bc<C>(a0, wn, (TC)gl[C * 16]);
-      fmac_bc<C>(a1, wt, (TC)gtl[C * 16]);
-      fmac_bc<C + 1>(a2, wn, (TC)gl[(C + 1) * 16]);
-      fmac_bc<C + 1>(a3, wt, (TC)gtl[(C + 1) * 16]);
+    const int oz = lds_opaque_zero();
+    const TI* gl = L.GL + l16 + oz;
+    const TI* gtl = L.GTL + l16 + oz;
+    // two batches of 16 LDS loads, each fenced from its FMAs: left alone, the register-starved scheduler issues one
+    // ds_read per FMA pair and waits out the LDS latency sixteen times per product
+    static_for<2>([&](auto Hh) LCP_INL {
+      constexpr int C0 = 8 * Hh;
+      TI gv[8], tv[8];
+      static_for<8>([&](auto I) LCP_INL { gv[I] = gl[(C0 + I) * 16]; tv[I] = gtl[(C0 + I) * 16]; });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto H) LCP_INL {
+        constexpr int I = 2 * H, C = C0 + I;
+        fmac_bc<C>(a0, wn, (TC)gv[I]);
+        fmac_bc<C>(a1, wt, (TC)tv[I]);
+        fmac_bc<C + 1>(a2, wn, (TC)gv[I + 1]);
+        fmac_bc<C + 1>(a3, wt, (TC)tv[I + 1]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
     });
     return (a0 + a1) + (a2 + a3);
   }
   __device__ __forceinline__ TC Av(TC v) const {        // e-space <- x-space
     TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const TI* ar = launder(L.AtL) + (l16 & (EQ - 1)) * 16;       // row l16 of A (rows >= e are zero; lanes >= EQ unused)
+    const TI* ar = L.AtL + (l16 & (EQ - 1)) * 16 + lds_opaque_zero();   // row l16 of A (rows >= e are zero; lanes >= EQ unused)
     static_for<4>([&](auto H) LCP_INL {
       constexpr int K = 4 * H;
       fmac_bc<K>(a0, v, (TC)ar[K]); fmac_bc<K + 1>(a1, v, (TC)ar[K + 1]);
@@ -223,7 +236,7 @@ struct SceneQ {
   }
   __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
     TC a0 = 0, a1 = 0;
-    const TI* at = launder(L.AtL) + l16;
+    const TI* at = L.AtL + l16 + lds_opaque_zero();
     fmac_bc<0>(a0, y, (TC)at[0]); fmac_bc<1>(a1, y, (TC)at[16]);
     fmac_bc<2>(a0, y, (TC)at[32]); fmac_bc<3>(a1, y, (TC)at[48]);
     return a0 + a1;
@@ -397,7 +410,7 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
   const TC addU = valid ? (TC)0.5 * (R.Sp + R.Sm * R.wu) : (TC)1;                // on column 16 + c of row u_c
   if (LDSW) {
     // symmetric W from LDS: row r of lane (r = l16 for a, 16 + l16 for u), column q: (r, q) if q >= r else (q, r)
-    const TC* wl = launder(S.L.WL);
+    const TC* wl = S.L.WL + lds_opaque_zero();
     const int ra = wl_row(l16), ru = wl_row(16 + l16);
     static_for<32>([&](auto Qc) LCP_INL {
       constexpr int q = Qc;
