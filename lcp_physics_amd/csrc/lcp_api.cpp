@@ -34,6 +34,7 @@ size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
     const size_t w = lcp::wave64_ws_bytes(compute);
     if (w > per_scene) per_scene = w;
   }
+  if (lcp::big_supported(nz, m, e) && lcp::big_ws_bytes() > per_scene) per_scene = lcp::big_ws_bytes();
   return (size_t)B * per_scene;
 }
 
@@ -204,7 +205,9 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
   if (lcp::quad_supported(nz, m, e) && g_path != 1) return lcp::quad_step(P, compute, stream);
-  // any other size: the workgroup-per-scene kernels (forward only; see lcp_hip.h)
+  // up to 64 contacts: the register-tiled workgroup-per-scene kernel (forward only; see lcp_hip.h)
+  if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e) && g_path != 1) return lcp::big_step(P, stream);
+  // any other size: the generic workgroup-per-scene kernels (forward only)
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!pl.ok) return LCP_E_TOOLARGE;

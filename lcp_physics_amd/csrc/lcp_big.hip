@@ -1,0 +1,567 @@
+// lcp_big.hip - contact-structured PDIPM forward for LARGE scenes: up to 64 contacts (nineq 256), nz <= 45, neq <= 4,
+// diagonal Q, one 256-thread workgroup per scene.  BASELINE config 5 (4096 x 64 contacts) and every ContactWorld scene
+// beyond the four-scenes-per-wave kernel's 16 contacts / 5 bodies.
+//
+// Same algorithm and reference lines as lcp_quad.hip (pdipm.py:49-186, 325-454; engines.py:26-78; the exact 4nc -> 2nc
+// reduction of lcp_wave64.hip `Red`), different mapping because a 128 x 128 reduced system no longer fits one wave:
+//   * vector role - wave 0, lane c = contact c (all four inequality components of every m-space vector in the lane, as in
+//     the quad kernel), lane j = x-space entry j, lane a = e-space entry a.  Cross-lane traffic goes through small LDS
+//     buffers (a 64-lane scene has no DPP row to broadcast in).
+//   * matrix role - all 256 threads own the reduced matrix T (rows / columns 0..63 = a_c, 64..127 = u_c) as 8 x 8 register
+//     tiles in a 16 x 16 cyclic layout: thread (ti, tj) holds the entries (ti + 16 p, tj + 16 q).  The right-looking LU
+//     (no pivoting, as in the quad kernel) broadcasts the pivot row and the multiplier column through LDS, two barriers
+//     per pivot; the load stays balanced to the last step because the layout is cyclic.
+//   * the finished factors are parked in LDS column-major (128 KB - this is what sizes the kernel: one scene per CU) and
+//     wave 0 runs the triangular sweeps off conflict-free column reads.
+// W = J P J^T (the part of T that does not change over the iterations) is formed once, tile by tile, and kept in the
+// workspace in tile order (each thread re-reads its own 512 contiguous bytes per factorisation).
+// Forward only (the workspace it leaves is not the dense backward's): served through lcp_solve_dynamics_f32.
+#include "lcp_wave_common.h"
+
+namespace lcp {
+namespace big {
+
+using namespace w64;
+
+constexpr int NT = 256;          // threads per scene
+constexpr int NCB = 64;          // contact capacity
+constexpr int NRD = 128;         // rows of the reduced system
+constexpr int EQB = 4;           // padded neq
+constexpr int NZB = 64;          // x-space capacity (lanes of wave 0)
+
+template <typename TC> struct M4 { TC n, f1, f2, g; };
+template <typename TC> __device__ __forceinline__ M4<TC> m4(TC a, TC b, TC c, TC d) { M4<TC> r; r.n = a; r.f1 = b; r.f2 = c; r.g = d; return r; }
+
+// ---------------------------------------------------------------- wave-0 helpers
+// LDS traffic inside ONE wave needs no barrier (the LDS serves a wave's instructions in order); the fence only stops the
+// compiler from moving the accesses across it.
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {        // NaN-ignoring
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = v > o ? v : o; }
+  return v;
+}
+__device__ __forceinline__ uint32_t nan_key(double v) { return (uint32_t)__double2hiint(v) & 0x7fffffffu; }
+__device__ __forceinline__ bool key_is_nan(uint32_t k) { return k > 0x7ff00000u; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ double bcast_lane(double v, int src) {     // src uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+struct Lds {
+  double* LU;        // [128][128] column-major: LU[j * 128 + i]; before the first factorisation also prefactor scratch
+  double* prow;      // [2][128] pivot row, double-buffered over the pivot steps
+  double* pcol;      // [2][128] multiplier column
+  double* dU;        // [128] 1 / U[i][i]
+  double* add;       // [3][64] addA, addB, addU of the current factorisation
+  double* xv;        // [64] x-space exchange
+  double* wv;        // [2][64] m-space exchange (normal part, tangential part)
+  double* ev;        // [EQB] e-space exchange
+  double* qid;       // [64]
+  double* S11;       // [EQB][EQB]
+  float* Jc;         // [64][nzs]
+  float* Jt;         // [64][nzs]
+  float* At;         // [EQB][nzs]
+  int* flag;         // [4]: 0 singular pivot, 1 all done, 2 singular S11
+};
+__host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
+  unsigned char* q = smem;
+  auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
+  L.LU = (double*)take(sizeof(double) * NRD * NRD);
+  L.prow = (double*)take(sizeof(double) * 2 * NRD);
+  L.pcol = (double*)take(sizeof(double) * 2 * NRD);
+  L.dU = (double*)take(sizeof(double) * NRD);
+  L.add = (double*)take(sizeof(double) * 3 * NCB);
+  L.xv = (double*)take(sizeof(double) * NZB);
+  L.wv = (double*)take(sizeof(double) * 2 * NCB);
+  L.ev = (double*)take(sizeof(double) * EQB);
+  L.qid = (double*)take(sizeof(double) * NZB);
+  L.S11 = (double*)take(sizeof(double) * EQB * EQB);
+  L.Jc = (float*)take(sizeof(float) * NCB * nzs);
+  L.Jt = (float*)take(sizeof(float) * NCB * nzs);
+  L.At = (float*)take(sizeof(float) * EQB * nzs);
+  L.flag = (int*)take(sizeof(int) * 4);
+  return (size_t)(q - smem);
+}
+
+// row r of the stacked Jacobian [Jc; Jt] (r < 64: Jc row r, else Jt row r - 64)
+__device__ __forceinline__ const float* jrow(const Lds& L, int r, int nzs) { return (r < NCB ? L.Jc + (size_t)r * nzs : L.Jt + (size_t)(r - NCB) * nzs); }
+
+// ---------------------------------------------------------------- the kernel (fused step: contact list in, v_new out)
+__global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool w0 = wave == 0;
+  const int ti = tid >> 4, tj = tid & 15;                                 // tile coordinates of the matrix role
+  const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
+  Lds L;
+  carve(L, smem, nzs);
+  int ncs = ncap;
+  if (SP.c_count) { const int c = SP.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  const bool vc = w0 && lane < ncs;                                       // this lane owns a live contact
+  double* Wg = (double*)SP.ws + (size_t)scene * (NRD * NRD + 64);         // W tiles, thread-major
+
+  // ---- assembly (engines.py:31-32,50-74; world.py:144-234) ----------------------------------------------------------
+  for (int i = tid; i < NCB * nzs; i += NT) { L.Jc[i] = 0.0f; L.Jt[i] = 0.0f; }
+  for (int i = tid; i < EQB * nzs; i += NT) L.At[i] = 0.0f;
+  if (tid < 4) L.flag[tid] = 0;
+  __syncthreads();
+  const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
+  const float* vv = (const float*)SP.v + (size_t)scene * nz;
+  const float* ff = (const float*)SP.f + (size_t)scene * nz;
+  double mu_c = 0, hn = 0;
+  if (vc) {
+    const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
+                                                     (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
+                                                     SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
+                                                     (const float*)SP.fric + (size_t)scene * nb, vv, lane);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
+      L.Jc[(size_t)lane * nzs + col] = r.jn[q];
+      L.Jt[(size_t)lane * nzs + col] = r.jf[q];
+    }
+    mu_c = (double)r.mu; hn = (double)r.h;
+  }
+  double p = 0, qd = 0, qid = 0;
+  if (w0 && lane < nz) {
+    const float q = Md[lane];
+    qd = (double)q; qid = 1.0 / (double)q;
+    p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
+  }
+  if (w0) L.qid[lane] = qid;
+  for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz; L.At[(size_t)a * nzs + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  int status = 0;
+  __syncthreads();
+
+  // ---- pre_factor_kkt for diagonal Q (pdipm.py:357-408): GA = J Q^-1 A^T, S11 = (A Q^-1 A^T)^-1, W = J P J^T -----------
+  double* GA = L.LU;                       // [128][EQB]   (scratch inside the LU area, dead before the first factorisation)
+  double* CC = L.LU + NRD * EQB;           // [128][EQB]   GA S11
+  if (e > 0) {
+    if (tid < NRD) {
+      const float* jr = jrow(L, tid, nzs);
+      for (int a = 0; a < EQB; ++a) {
+        double acc = 0;
+        for (int k = 0; k < nz; ++k) acc = fma((double)jr[k] * L.qid[k], (double)L.At[(size_t)a * nzs + k], acc);
+        GA[tid * EQB + a] = acc;
+      }
+    }
+    if (tid < EQB * EQB) {
+      const int a = tid >> 2, c = tid & 3;
+      double acc = 0;
+      for (int k = 0; k < nz; ++k) acc = fma((double)L.At[(size_t)a * nzs + k] * L.qid[k], (double)L.At[(size_t)c * nzs + k], acc);
+      L.S11[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {                        // tiny e x e Gauss-Jordan
+      double* a = L.S11;
+      bool bad = false;
+      for (int k = 0; k < e; ++k) {
+        const double piv = a[k * EQB + k];
+        bad = bad || !(piv != 0.0) || (piv != piv);
+        const double pinv = 1.0 / piv;
+        for (int j = 0; j < e; ++j) if (j != k) a[k * EQB + j] *= pinv;
+        for (int i = 0; i < e; ++i) if (i != k) { const double f = a[i * EQB + k]; for (int j = 0; j < e; ++j) if (j != k) a[i * EQB + j] -= f * a[k * EQB + j]; a[i * EQB + k] = -f * pinv; }
+        a[k * EQB + k] = pinv;
+      }
+      for (int i = 0; i < EQB; ++i) for (int j = 0; j < EQB; ++j) if (i >= e || j >= e) a[i * EQB + j] = 0;
+      if (bad) L.flag[2] = 1;
+    }
+    __syncthreads();
+    if (tid < NRD) for (int a = 0; a < EQB; ++a) {
+      double acc = 0;
+      for (int c = 0; c < EQB; ++c) acc = fma(GA[tid * EQB + c], L.S11[c * EQB + a], acc);
+      CC[tid * EQB + a] = acc;
+    }
+    __syncthreads();
+    if (L.flag[2]) status |= LCP_ST_SINGULAR_S11;
+  }
+  // the rows of GA this contact needs in the solve, and the row of S11 this e-lane needs
+  double gan[EQB], gat[EQB], s11row[EQB];
+#pragma unroll
+  for (int a = 0; a < EQB; ++a) {
+    gan[a] = (vc && e > 0) ? GA[lane * EQB + a] : 0.0;
+    gat[a] = (vc && e > 0) ? GA[(NCB + lane) * EQB + a] : 0.0;
+    s11row[a] = (w0 && lane < EQB && e > 0) ? L.S11[lane * EQB + a] : 0.0;
+  }
+  {
+    // W tile of this thread: entries (ti + 16 p, tj + 16 q)
+    double wt_[8][8];
+    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
+    for (int k = 0; k < nz; ++k) {
+      const double qk = L.qid[k];
+      double ri[8], cj[8];
+      static_for<8>([&](auto P) LCP_INL { ri[P] = (double)jrow(L, ti + 16 * P, nzs)[k] * qk; cj[P] = (double)jrow(L, tj + 16 * P, nzs)[k]; });
+      static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
+    }
+    if (e > 0) {
+      for (int a = 0; a < EQB; ++a) {
+        double ci[8], gj[8];
+        static_for<8>([&](auto P) LCP_INL { ci[P] = CC[(ti + 16 * P) * EQB + a]; gj[P] = GA[(tj + 16 * P) * EQB + a]; });
+        static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
+      }
+    }
+    // rows / columns of contacts the scene does not have are identity in T: zero here, 1 arrives through addA / addU
+    static_for<8>([&](auto P) LCP_INL {
+      static_for<8>([&](auto Q) LCP_INL {
+        const int ci = (ti + 16 * P) & 63, cj_ = (tj + 16 * Q) & 63;
+        const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
+        Wg[(size_t)tid * 64 + P * 8 + Q] = v;
+      });
+    });
+  }
+  if (!(qd != 0.0) && w0 && lane < nz) L.flag[2] = 2;
+  __syncthreads();                                                        // GA / CC scratch dead from here on
+  if (L.flag[2] == 2) status |= LCP_ST_SINGULAR_Q;
+
+  // ---- products of the vector role (wave 0 only) ----------------------------------------------------------------------
+  auto Gv = [&](double v, double& gn, double& gt) {                       // m-space <- x-space
+    L.xv[lane] = v; wsync();
+    gn = 0; gt = 0;
+    if (lane < ncs) {
+      const float* jc = L.Jc + (size_t)lane * nzs; const float* jt = L.Jt + (size_t)lane * nzs;
+      for (int k = 0; k < nz; ++k) { const double xk = L.xv[k]; gn = fma((double)jc[k], xk, gn); gt = fma((double)jt[k], xk, gt); }
+    }
+    wsync();
+  };
+  auto Gtw = [&](double wn, double wt) -> double {                        // x-space <- m-space
+    L.wv[lane] = wn; L.wv[NCB + lane] = wt; wsync();
+    double acc = 0;
+    if (lane < nz) for (int c = 0; c < ncs; ++c) { acc = fma((double)L.Jc[(size_t)c * nzs + lane], L.wv[c], acc); acc = fma((double)L.Jt[(size_t)c * nzs + lane], L.wv[NCB + c], acc); }
+    wsync();
+    return acc;
+  };
+  auto Av = [&](double v) -> double {                                     // e-space <- x-space
+    L.xv[lane] = v; wsync();
+    double acc = 0;
+    if (lane < e) for (int k = 0; k < nz; ++k) acc = fma((double)L.At[(size_t)lane * nzs + k], L.xv[k], acc);
+    wsync();
+    return acc;
+  };
+  auto Aty = [&](double y) -> double {                                    // x-space <- e-space
+    if (lane < EQB) L.ev[lane] = y; wsync();
+    double acc = 0;
+    if (lane < nz) for (int a = 0; a < e; ++a) acc = fma((double)L.At[(size_t)a * nzs + lane], L.ev[a], acc);
+    wsync();
+    return acc;
+  };
+  auto GAt = [&](double t, double& gn, double& gt) {                      // m-space <- e-space
+    if (lane < EQB) L.ev[lane] = t; wsync();
+    gn = 0; gt = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { const double tb = L.ev[a]; gn = fma(gan[a], tb, gn); gt = fma(gat[a], tb, gt); }
+    wsync();
+  };
+  auto GAtw = [&](double wn, double wt) -> double {                       // e-space <- m-space
+    double out = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { const double sm = wave_sum(gan[a] * wn + gat[a] * wt); if (lane == a) out = sm; }
+    return out;
+  };
+  auto S11v = [&](double v) -> double {
+    if (lane < EQB) L.ev[lane] = v; wsync();
+    double acc = 0;
+#pragma unroll
+    for (int c = 0; c < EQB; ++c) acc = fma(s11row[c], L.ev[c], acc);
+    wsync();
+    return acc;
+  };
+
+  // ---- per-factorisation quantities of the 4nc -> 2nc reduction (lcp_wave64.hip `Red`) ------------------------------------
+  double rSp = 0, rSm = 0, rDg = 1, ridet = 0.5, rwa = 0, rwu = 0, ua = 1, uu = 1;
+  auto reduce_setup = [&](const M4<double>& D) {                          // D = 1 / d
+    rDg = D.g; rSp = 0.5 * (D.f1 + D.f2); rSm = 0.5 * (D.f1 - D.f2);
+    ridet = 1.0 / (rSp * rDg + 2.0);
+    rwa = 2.0 * mu_c * ridet; rwu = -rDg * rSm * ridet;
+    L.add[lane] = vc ? D.n : 1.0;
+    L.add[NCB + lane] = vc ? 0.5 * rSm * rwa : 0.0;
+    L.add[2 * NCB + lane] = vc ? 0.5 * (rSp + rSm * rwu) : 1.0;
+  };
+
+  // ---- factorisation: T = W + diag terms, LU in register tiles, factors to LDS (all 256 threads) ---------------------------
+  auto factor = [&]() {
+    double t[8][8];
+    const double* wg = Wg + (size_t)tid * 64;
+    static_for<8>([&](auto P) LCP_INL { static_for<4>([&](auto Q2) LCP_INL { load2(wg + P * 8 + 2 * Q2, t[P][2 * Q2], t[P][2 * Q2 + 1]); }); });
+    if (ti == tj) {
+      static_for<4>([&](auto P) LCP_INL {
+        const int c = ti + 16 * P;
+        t[P][P] += L.add[c];                                              // (a_c, a_c)
+        t[P + 4][P] += L.add[NCB + c];                                    // (u_c, a_c)
+        t[P + 4][P + 4] += L.add[2 * NCB + c];                            // (u_c, u_c)
+      });
+    }
+    int buf = 0;
+    static_for<8>([&](auto KB) LCP_INL {
+      constexpr int kb = KB;
+#pragma unroll 1
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 16 * kb + kk;
+        double* prow = L.prow + buf * NRD;
+        double* pcol = L.pcol + buf * NRD;
+        if (ti == kk) static_for<8 - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + 16 * q] = t[kb][q]; });
+        __syncthreads();
+        const double piv = prow[k];
+        if (piv == 0.0 && tid == 0) L.flag[0] = 1;
+        const double inv = fast_rcp(piv);
+        if (tj == kk) static_for<8 - kb>([&](auto PP) LCP_INL {
+          constexpr int pp = kb + PP;
+          const int i = ti + 16 * pp;
+          if (i > k) { const double l = t[pp][kb] * inv; t[pp][kb] = l; pcol[i] = l; }
+        });
+        __syncthreads();
+        double lm[8 - kb], rv[8 - kb];
+        static_for<8 - kb>([&](auto PP) LCP_INL {
+          constexpr int pp = kb + PP;
+          lm[PP] = (ti + 16 * pp > k) ? pcol[ti + 16 * pp] : 0.0;
+          rv[PP] = (tj + 16 * pp > k) ? prow[tj + 16 * pp] : 0.0;
+        });
+        static_for<8 - kb>([&](auto PP) LCP_INL { static_for<8 - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
+        buf ^= 1;
+      }
+    });
+    // park the factors: column-major, plus the reciprocals of U's diagonal
+    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * NRD + ti + 16 * P] = t[P][Q]; }); });
+    if (ti == tj) static_for<8>([&](auto P) LCP_INL { L.dU[ti + 16 * P] = 1.0 / t[P][P]; });
+  };
+
+  // ---- T^-1 hz through the reduced system (wave 0); rows: a_c = lane, u_c = 64 + lane --------------------------------------
+  auto tsolve = [&](const M4<double>& hz) -> M4<double> {
+    const double r12 = hz.f1 + hz.f2;
+    const double w0_ = (rDg * r12 - 2.0 * hz.g) * ridet;
+    double ra = hz.n, ru = 0.5 * (hz.f1 - hz.f2) - 0.5 * rSm * w0_;
+    const int n = ncs;                                                    // rows / columns >= ncs are identity
+    for (int k = 0; k < n; ++k) {                                         // L y = rhs, columns a_k
+      const double yk = bcast_lane(ra, k);
+      const double* col = L.LU + (size_t)k * NRD;
+      const double la = col[lane], lu = col[NCB + lane];
+      ra = fma(-((lane > k) ? la : 0.0), yk, ra);
+      ru = fma(-lu, yk, ru);
+    }
+    for (int k = 0; k < n; ++k) {                                         // columns u_k
+      const double yk = bcast_lane(ru, k);
+      const double lu = L.LU[(size_t)(NCB + k) * NRD + NCB + lane];
+      ru = fma(-((lane > k) ? lu : 0.0), yk, ru);
+    }
+    for (int k = n - 1; k >= 0; --k) {                                    // U x = y, columns u_k
+      const double xk = bcast_lane(ru, k) * L.dU[NCB + k];
+      const double* col = L.LU + (size_t)(NCB + k) * NRD;
+      const double ua_ = col[lane], uu_ = col[NCB + lane];
+      ra = fma(-ua_, xk, ra);
+      ru = fma(-((lane < k) ? uu_ : 0.0), xk, ru);
+    }
+    for (int k = n - 1; k >= 0; --k) {                                    // columns a_k
+      const double xk = bcast_lane(ra, k) * L.dU[k];
+      const double ua_ = L.LU[(size_t)k * NRD + lane];
+      ra = fma(-((lane < k) ? ua_ : 0.0), xk, ra);
+    }
+    const double a = ra * ua, u = ru * uu;
+    const double w = w0_ + rwa * a + rwu * u;
+    M4<double> dz;
+    dz.n = a; dz.f1 = 0.5 * (w + u); dz.f2 = 0.5 * (w - u);
+    dz.g = (r12 - rSm * u + rSp * (hz.g - mu_c * a)) * ridet;
+    return dz;
+  };
+
+  // solve_kkt (pdipm.py:325-354); di = 1 / d
+  auto solve_kkt = [&](const M4<double>& di, double rx, const M4<double>& rs, const M4<double>& rz, double ry,
+                       double& ox, M4<double>& os, M4<double>& oz, double& oy) {
+    const double v = qid * rx;                                            // :333 (diagonal Q)
+    double gn, gt;
+    Gv(v, gn, gt);
+    M4<double> hz = m4<double>(gn + rs.n * di.n - rz.n, gt + rs.f1 * di.f1 - rz.f1, -gt + rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);   // :334-340
+    double hy = 0;
+    if (e > 0) {
+      hy = Av(v) - ry;
+      double an, at;
+      GAt(S11v(hy), an, at);
+      hz.n -= an; hz.f1 -= at; hz.f2 += at;
+    }
+    if (!vc) hz = m4<double>(0, 0, 0, 0);
+    const M4<double> wz = tsolve(hz);
+    double dy = 0;
+    if (e > 0) dy = -S11v(hy - GAtw(vc ? wz.n : 0.0, vc ? wz.f1 - wz.f2 : 0.0));
+    oz = m4<double>(-wz.n, -wz.f1, -wz.f2, -wz.g);                        // :342
+    if (!vc) oz = m4<double>(0, 0, 0, 0);
+    os = m4<double>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
+    if (!vc) os = m4<double>(0, 0, 0, 0);
+    oy = dy;
+    double g1 = -rx - Gtw(oz.n, oz.f1 - oz.f2);                           // :344-346
+    if (e > 0) g1 -= Aty(dy);
+    ox = qid * g1;                                                        // :349
+  };
+
+  // get_step for (z, dz), (s, ds) (pdipm.py:182-186), NaN semantics as in lcp_quad.hip step_pair_q
+  auto step_pair = [&](const M4<double>& z, const M4<double>& dz, const M4<double>& s, const M4<double>& ds) -> double {
+    const double ninf = -inf_of<double>(), pinf = inf_of<double>();
+    const M4<double> az = m4<double>(-z.n / dz.n, -z.f1 / dz.f1, -z.f2 / dz.f2, -z.g / dz.g);
+    const M4<double> as = m4<double>(-s.n / ds.n, -s.f1 / ds.f1, -s.f2 / ds.f2, -s.g / ds.g);
+    auto key4 = [&](const M4<double>& a) { return umax(umax(nan_key(a.n), nan_key(a.f1)), umax(nan_key(a.f2), nan_key(a.g))); };
+    auto max4 = [&](const M4<double>& a) { return __builtin_fmax(__builtin_fmax(a.n, a.f1), __builtin_fmax(a.f2, a.g)); };
+    auto min4 = [&](const M4<double>& a) { return __builtin_fmin(__builtin_fmin(a.n, a.f1), __builtin_fmin(a.f2, a.g)); };
+    const uint32_t kmz = wave_umax(vc ? key4(az) : 0u), kms = wave_umax(vc ? key4(as) : 0u);
+    const double mz = wave_max(vc ? max4(az) : ninf), ms = wave_max(vc ? max4(as) : ninf);
+    const double fz = key_is_nan(kmz) ? 1.0 : __builtin_fmax(mz, 1.0), fs = key_is_nan(kms) ? 1.0 : __builtin_fmax(ms, 1.0);
+    auto pick = [&](double dv, double a, double fill) { return (dv > 0.0) ? fill : a; };
+    const M4<double> pz = m4<double>(pick(dz.n, az.n, fz), pick(dz.f1, az.f1, fz), pick(dz.f2, az.f2, fz), pick(dz.g, az.g, fz));
+    const M4<double> ps = m4<double>(pick(ds.n, as.n, fs), pick(ds.f1, as.f1, fs), pick(ds.f2, as.f2, fs), pick(ds.g, as.g, fs));
+    const uint32_t kl = wave_umax(vc ? umax(key4(pz), key4(ps)) : 0u);
+    const double l = wave_min(vc ? __builtin_fmin(min4(pz), min4(ps)) : pinf);
+    return key_is_nan(kl) ? nan_of<double>() : l;
+  };
+
+  // ---- the PDIPM loop (pdipm.py:49-179) -----------------------------------------------------------------------------------
+  const int max_iter = SP.max_iter, lim = SP.lim;
+  const double eps = SP.eps;
+  const double mf = (double)(4 * ncs);
+  double x = 0, y = 0, b = 0;
+  M4<double> s = m4<double>(1, 1, 1, 1), z = s, dinv = s;
+  double bx = 0, by = 0;
+  M4<double> bz = s, bs = s;
+  double best_resid = inf_of<double>();
+  bool have_best = false, done = false;
+  int n_not = 0, iters = 0;
+  for (int it = -1; it < max_iter; ++it) {
+    double rx = 0, ry = 0, mu = 0, resid = 0;
+    M4<double> rs = m4<double>(0, 0, 0, 0), rz = rs;
+    if (w0) {
+      if (it < 0) {                                                         // init: (p, 0, -h, -b), d = 1 (:57-63)
+        rx = p; ry = -b; rz = m4<double>(-hn, 0, 0, 0); dinv = m4<double>(1, 1, 1, 1);
+      } else {                                                              // residuals (:82-96)
+        rx = Gtw(z.n, z.f1 - z.f2) + qd * x + p;
+        if (e > 0) rx += Aty(y);
+        rs = z;
+        double gn, gt;
+        Gv(x, gn, gt);
+        rz = m4<double>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (mu_c * z.n - (z.f1 + z.f2)));
+        if (!vc) rz = m4<double>(0, 0, 0, 0);
+        ry = (e > 0) ? (Av(x) - b) : 0.0;
+        const double n_rx = wave_sum((lane < nz) ? rx * rx : 0.0);
+        const double n_rz = wave_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
+        const double n_ry = wave_sum((lane < e) ? ry * ry : 0.0);
+        const double sz = wave_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : 0.0);
+        mu = sz / mf; mu = mu < 0 ? -mu : mu;                               // (:91)
+        resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;             // (:92-96)
+        dinv = vc ? m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<double>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
+      }
+      reduce_setup(dinv);
+    }
+    __syncthreads();
+    factor();                                                               // (:99-100)
+    __syncthreads();
+    if (w0) {
+      ua = L.dU[lane]; uu = L.dU[NCB + lane];
+      const bool singular = L.flag[0] != 0;
+      if (it >= 0 && !done) {
+        ++iters;
+        if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
+        else {
+          const bool improved = !have_best || (resid < best_resid);             // (:107-132)
+          if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; by = y; bz = z; bs = s; }
+          else ++n_not;
+          if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;   // (:133)
+        }
+      }
+      if (!done) {
+        double ax = 0, ay = 0;
+        M4<double> as_ = m4<double>(0, 0, 0, 0), az = as_;
+        const int npass = (it < 0) ? 1 : 2;
+        for (int pass = 0; pass < npass; ++pass) {
+          double ox, oy;
+          M4<double> os, oz;
+          solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+          if (it < 0) {
+            x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
+            auto min4 = [&](const M4<double>& a) { return pmin(pmin(a.n, a.f1), pmin(a.f2, a.g)); };
+            const uint32_t ks = wave_umax(vc ? umax(umax(nan_key(s.n), nan_key(s.f1)), umax(nan_key(s.f2), nan_key(s.g))) : 0u);
+            const uint32_t kz = wave_umax(vc ? umax(umax(nan_key(z.n), nan_key(z.f1)), umax(nan_key(z.f2), nan_key(z.g))) : 0u);
+            double smin = wave_min(vc ? min4(s) : inf_of<double>()), zmin = wave_min(vc ? min4(z) : inf_of<double>());
+            if (key_is_nan(ks)) smin = nan_of<double>();
+            if (key_is_nan(kz)) zmin = nan_of<double>();
+            if (smin <= 0.0) { const double sh = 1.0 - smin; s = m4<double>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
+            if (zmin <= 0.0) { const double sh = 1.0 - zmin; z = m4<double>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
+            if (!vc) { s = m4<double>(1, 1, 1, 1); z = s; }
+            if (ncs == 0) { bx = x; by = y; done = true; }                      // engines.py:36-50: x = P^-1 u, no LCP
+          } else if (pass == 0) {
+            ax = ox; ay = oy; as_ = os; az = oz;                                // affine direction (:138-139)
+            const double alpha = pmin(step_pair(z, az, s, as_), 1.0);          // (:142-144)
+            auto sc = [&](double sv, double dsv, double zv, double dzv) { return (sv + alpha * dsv) * (zv + alpha * dzv); };
+            const double t3 = wave_sum(vc ? (sc(s.n, as_.n, z.n, az.n) + sc(s.f1, as_.f1, z.f1, az.f1)) + (sc(s.f2, as_.f2, z.f2, az.f2) + sc(s.g, as_.g, z.g, az.g)) : 0.0);
+            const double t4 = wave_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : 0.0);
+            const double r3 = t3 / t4, sig = r3 * r3 * r3;                      // (:146-150)
+            const double ms = -mu * sig;
+            rx = 0; ry = 0; rz = m4<double>(0, 0, 0, 0);
+            rs = vc ? m4<double>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
+                    : m4<double>(0, 0, 0, 0);                                   // (:153)
+          } else {
+            const double cx = ox + ax, cy = oy + ay;                            // (:160-163)
+            const M4<double> cs = m4<double>(os.n + as_.n, os.f1 + as_.f1, os.f2 + as_.f2, os.g + as_.g);
+            const M4<double> cz = m4<double>(oz.n + az.n, oz.f1 + az.f1, oz.f2 + az.f2, oz.g + az.g);
+            const double alpha = pmin(0.999 * step_pair(z, cz, s, cs), 1.0);   // (:164-166)
+            x += alpha * cx; y += alpha * cy;                                   // (:171-174)
+            if (vc) {
+              s = m4<double>(s.n + alpha * cs.n, s.f1 + alpha * cs.f1, s.f2 + alpha * cs.f2, s.g + alpha * cs.g);
+              z = m4<double>(z.n + alpha * cz.n, z.f1 + alpha * cz.f1, z.f2 + alpha * cz.f2, z.g + alpha * cz.g);
+            }
+          }
+        }
+      }
+      if (lane == 0) L.flag[1] = done ? 1 : 0;
+    }
+    __syncthreads();
+    if (L.flag[1]) break;
+  }
+
+  // ---- outputs (row layout of a capacity-sized LCP, padded slots 0) ---------------------------------------------------------
+  if (!w0) return;
+  bool bad = (lane < nz) && (bx != bx);
+  if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
+                (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
+  if (__any(bad)) status |= LCP_ST_NAN;
+  const int m = 4 * ncap;
+  if (lane < ncap) {
+    const float k = vc ? 1.0f : 0.0f;
+    if (SP.z) { float* o = (float*)SP.z + (size_t)scene * m; o[lane] = k * (float)bz.n; o[ncap + 2 * lane] = k * (float)bz.f1; o[ncap + 2 * lane + 1] = k * (float)bz.f2; o[3 * ncap + lane] = k * (float)bz.g; }
+    if (SP.s) { float* o = (float*)SP.s + (size_t)scene * m; o[lane] = k * (float)bs.n; o[ncap + 2 * lane] = k * (float)bs.f1; o[ncap + 2 * lane + 1] = k * (float)bs.f2; o[3 * ncap + lane] = k * (float)bs.g; }
+  }
+  if (lane < e && SP.y) ((float*)SP.y)[(size_t)scene * e + lane] = (float)by;
+  if (lane < nz) ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)(-bx);     // engines.py:76-77
+  if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+}
+
+}  // namespace big
+
+// nz <= 45: the two 64 x nz Jacobians have to fit next to the 128 KB of factors in the 160 KB of LDS
+bool big_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= big::NCB) && nz <= 45 && e <= big::EQB; }
+size_t big_ws_bytes() { return sizeof(double) * (big::NRD * big::NRD + 64); }
+
+int big_step(const StepArgs& SP, void* stream) {
+  const int nz = 3 * SP.nb, nzs = nz | 1;
+  big::Lds L;
+  const size_t lds = big::carve(L, nullptr, nzs);
+  auto k = big::lcp_fwd_big;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::NT), lds, (hipStream_t)stream, SP, nzs);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+}  // namespace lcp

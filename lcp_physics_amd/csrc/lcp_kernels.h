@@ -101,6 +101,11 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
 int quad_step(const StepArgs& P, int compute, void* stream);
 int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream);
 
+// workgroup-per-scene contact-structured forward for up to 64 contacts (fused step, forward only) - lcp_big.hip
+bool big_supported(int nz, int m, int e);
+size_t big_ws_bytes();
+int big_step(const StepArgs& P, void* stream);
+
 // narrow-phase contact generation + position update - lcp_contacts.hip
 int contacts_launch(const ContactArgs& P, void* stream);
 

@@ -326,6 +326,51 @@ def test_contact_world_beyond_the_quad_sizes_follows_oracle():
         assert np.abs(world.p[s].cpu().numpy() - p).max() < 2e-4 and np.abs(world.v[s].double().cpu().numpy() - v).max() < 2e-3, s
 
 
+def test_config5_pile_solve_dynamics_matches_oracle():
+    """BASELINE config 5 shape (11 bodies, 64 contacts, nineq 256) through lcp_solve_dynamics_f32 = the register-tiled
+    workgroup-per-scene kernel (lcp_big.hip), with ragged contact counts: new_v within 1e-4 (scaled) of the fp64 oracle
+    on the same fp32 inputs, and identical to the generic kernels' answer."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    from oracle import pdipm_oracle as O
+    B = 12
+    sc = scenes.make_pile_scenes(B=B, seed=21, dtype=torch.float32)
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    counts = [64, 64, 48, 33, 17, 64, 5, 0, 64, 20, 64, 1]
+    count = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    run = lambda: solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+    out = run()
+    torch.cuda.synchronize()
+    got = out["v_new"].double().cpu()
+    _lib.set_path("generic")
+    try:
+        ref_generic = run()["v_new"].double().cpu()
+    finally:
+        _lib.set_path("auto")
+    worst = 0.0
+    for k in range(B):
+        n = counts[k]
+        one = lambda t: t[k:k + 1]
+        if n > 0:
+            args = (one(sc.Mdiag), one(sc.v), one(sc.f), sc.dt, sc.c_n[k:k + 1, :n], sc.c_p1[k:k + 1, :n], sc.c_p2[k:k + 1, :n],
+                    sc.c_i1[k:k + 1, :n], sc.c_i2[k:k + 1, :n], one(sc.rest), one(sc.fric), one(sc.Je))
+            lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*args)]
+            ref = -O.lcp_forward(*lcp64).x.reshape(sc.nb, 3)
+        else:
+            ref = torch.tensor(W.solve_dynamics(sc.Mdiag[k].numpy(), sc.v[k].numpy(), sc.f[k].numpy(), sc.dt, [], sc.rest[k].numpy(),
+                                                sc.fric[k].numpy(), sc.Je[k].numpy()))
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((got[k] - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, n, err)
+        assert float((got[k] - ref_generic[k]).abs().max()) / scale <= 1e-5, (k, n, "vs generic")
+        assert int(out["status"][k]) & 8 == 0
+    print("config 5 worst scaled error", worst)
+
+
 def test_contact_world_refuses_initial_penetration():
     from lcp_physics_amd.physics.batched_world import ContactWorld
     shapes = [("rect", (500.0, 10.0)), ("rect", (40.0, 40.0))]

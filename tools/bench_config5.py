@@ -1,0 +1,34 @@
+"""BASELINE config 5 (4096 scenes x 64 contacts, nineq 256): lcp_solve_dynamics_f32 on the pile scenes, checked against the
+generic kernels on a few scenes and timed.   python tools/bench_config5.py [B]"""
+import sys, time
+import torch
+sys.path.insert(0, '.')
+from lcp_physics_amd import _lib, scenes
+from lcp_physics_amd.physics.batched_world import solve_dynamics
+from lcp_physics_amd.physics.contacts import ContactBuffers
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+sc = scenes.make_pile_scenes(B=B, seed=5, dtype=torch.float32).to('cuda')
+cb = ContactBuffers(B, sc.nb, sc.nc, 'cuda')
+cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
+count = torch.full((B,), sc.nc, dtype=torch.int32, device='cuda')
+run = lambda out=None: solve_dynamics(B, sc.nb, sc.nc, 3, count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb, sc.Je, sc.dt,
+                                      ws=None if out is None else out["ws"], out=out)
+out = run(); torch.cuda.synchronize()
+nchk = min(B, 64)
+_lib.set_path("generic")
+sub = lambda t: t[:nchk].contiguous()
+cb2 = ContactBuffers(nchk, sc.nb, sc.nc, 'cuda')
+cb2.c_n, cb2.c_p1, cb2.c_p2, cb2.c_i1, cb2.c_i2 = sub(sc.c_n), sub(sc.c_p1), sub(sc.c_p2), sub(sc.c_i1), sub(sc.c_i2)
+ref = solve_dynamics(nchk, sc.nb, sc.nc, 3, sub(count), sub(sc.Mdiag), sub(sc.v), sub(sc.f), sub(sc.rest), sub(sc.fric), cb2, sub(sc.Je), sc.dt)
+torch.cuda.synchronize()
+_lib.set_path("auto")
+d = (out["v_new"][:nchk] - ref["v_new"]).abs().max()
+print("max |v_new|", float(ref["v_new"].abs().max()), "max |z|", float(ref["z"].abs().max()), "max |z - z_generic|", float((out["z"][:nchk] - ref["z"]).abs().max()),
+      "max |s - s_generic|", float((out["s"][:nchk] - ref["s"]).abs().max()))
+print("nb", sc.nb, "nc", sc.nc, "max |v_new - generic| on %d scenes: %.3e" % (nchk, float(d)), "iters", float(out["iters"].float().mean()), float(ref["iters"].float().mean()),
+      "status!=0", int((out["status"] != 0).sum()))
+t = time.perf_counter()
+for _ in range(5): out = run(out)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 5
+print("B", B, "ms/step", dt * 1e3, "sim steps/s", B / dt)
