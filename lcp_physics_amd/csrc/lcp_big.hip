@@ -1,4 +1,4 @@
-// lcp_big.hip - contact-structured PDIPM forward for LARGE scenes: up to 64 contacts (nineq 256), nz <= 45, neq <= 4,
+// lcp_big.hip - contact-structured PDIPM forward for LARGE scenes: up to 64 contacts (nineq 256), nz <= 43, neq <= 4,
 // diagonal Q, one 256-thread workgroup per scene.  BASELINE config 5 (4096 x 64 contacts) and every ContactWorld scene
 // beyond the four-scenes-per-wave kernel's 16 contacts / 5 bodies.
 //
@@ -26,6 +26,7 @@ using namespace w64;
 constexpr int NT = 256;          // threads per scene
 constexpr int NCB = 64;          // contact capacity
 constexpr int NRD = 128;         // rows of the reduced system
+constexpr int LDU = NRD + 1;     // column stride of the parked factors (odd: the tile store hits 16 banks instead of one)
 constexpr int EQB = 4;           // padded neq
 constexpr int NZB = 64;          // x-space capacity (lanes of wave 0)
 
@@ -72,6 +73,7 @@ struct Lds {
   double* prow;      // [2][128] pivot row, double-buffered over the pivot steps
   double* pcol;      // [2][128] multiplier column
   double* dU;        // [128] 1 / U[i][i]
+  double* pinv;      // [2][2] (pivot, 1 / pivot) of the coming step, written by the owner of the diagonal entry
   double* add;       // [3][64] addA, addB, addU of the current factorisation
   double* xv;        // [64] x-space exchange
   double* wv;        // [2][64] m-space exchange (normal part, tangential part)
@@ -86,10 +88,11 @@ struct Lds {
 __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
-  L.LU = (double*)take(sizeof(double) * NRD * NRD);
+  L.LU = (double*)take(sizeof(double) * NRD * LDU);
   L.prow = (double*)take(sizeof(double) * 2 * NRD);
   L.pcol = (double*)take(sizeof(double) * 2 * NRD);
   L.dU = (double*)take(sizeof(double) * NRD);
+  L.pinv = (double*)take(sizeof(double) * 4);
   L.add = (double*)take(sizeof(double) * 3 * NCB);
   L.xv = (double*)take(sizeof(double) * NZB);
   L.wv = (double*)take(sizeof(double) * 2 * NCB);
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
   int ncs = ncap;
   if (SP.c_count) { const int c = SP.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
   const bool vc = w0 && lane < ncs;                                       // this lane owns a live contact
-  double* Wg = (double*)SP.ws + (size_t)scene * (NRD * NRD + 64);         // W tiles, thread-major
+  double* Wg = (double*)SP.ws + (size_t)scene * (NRD * NRD + 64);         // W tiles: Wg[(p * 8 + q) * 256 + tid]
 
   // ---- assembly (engines.py:31-32,50-74; world.py:144-234) ----------------------------------------------------------
   for (int i = tid; i < NCB * nzs; i += NT) { L.Jc[i] = 0.0f; L.Jt[i] = 0.0f; }
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
       static_for<8>([&](auto Q) LCP_INL {
         const int ci = (ti + 16 * P) & 63, cj_ = (tj + 16 * Q) & 63;
         const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
-        Wg[(size_t)tid * 64 + P * 8 + Q] = v;
+        Wg[(size_t)(P * 8 + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
       });
     });
   }
@@ -237,16 +240,29 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
   auto Gv = [&](double v, double& gn, double& gt) {                       // m-space <- x-space
     L.xv[lane] = v; wsync();
     gn = 0; gt = 0;
-    if (lane < ncs) {
+    if (lane < ncs) {                                                     // (x-space entries >= nz are 0 in xv, J columns >= nz are 0)
       const float* jc = L.Jc + (size_t)lane * nzs; const float* jt = L.Jt + (size_t)lane * nzs;
-      for (int k = 0; k < nz; ++k) { const double xk = L.xv[k]; gn = fma((double)jc[k], xk, gn); gt = fma((double)jt[k], xk, gt); }
+      for (int k0 = 0; k0 < nz; k0 += 8) {
+        float a_[8], b_[8]; double xk[8];
+        static_for<8>([&](auto I) LCP_INL { const int k = (k0 + I < nz) ? k0 + I : nz - 1; a_[I] = jc[k]; b_[I] = jt[k]; xk[I] = (k0 + I < nz) ? L.xv[k] : 0.0; });
+        static_for<8>([&](auto I) LCP_INL { gn = fma((double)a_[I], xk[I], gn); gt = fma((double)b_[I], xk[I], gt); });
+      }
     }
     wsync();
   };
   auto Gtw = [&](double wn, double wt) -> double {                        // x-space <- m-space
     L.wv[lane] = wn; L.wv[NCB + lane] = wt; wsync();
     double acc = 0;
-    if (lane < nz) for (int c = 0; c < ncs; ++c) { acc = fma((double)L.Jc[(size_t)c * nzs + lane], L.wv[c], acc); acc = fma((double)L.Jt[(size_t)c * nzs + lane], L.wv[NCB + c], acc); }
+    if (lane < nz) {                                                      // (contacts >= ncs have zero rows in Jc / Jt)
+      const int n8 = (ncs + 7) & ~7;
+      double a0 = 0, a1 = 0;
+      for (int c0 = 0; c0 < n8; c0 += 8) {
+        float a_[8], b_[8]; double wn_[8], wt_[8];
+        static_for<8>([&](auto I) LCP_INL { const int c = c0 + I; a_[I] = L.Jc[(size_t)c * nzs + lane]; b_[I] = L.Jt[(size_t)c * nzs + lane]; wn_[I] = L.wv[c]; wt_[I] = L.wv[NCB + c]; });
+        static_for<8>([&](auto I) LCP_INL { a0 = fma((double)a_[I], wn_[I], a0); a1 = fma((double)b_[I], wt_[I], a1); });
+      }
+      acc = a0 + a1;
+    }
     wsync();
     return acc;
   };
@@ -295,13 +311,19 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
     L.add[lane] = vc ? D.n : 1.0;
     L.add[NCB + lane] = vc ? 0.5 * rSm * rwa : 0.0;
     L.add[2 * NCB + lane] = vc ? 0.5 * (rSp + rSm * rwu) : 1.0;
+    if (lane == 0) L.flag[0] = 0;                                         // "singular pivot" is per factorisation
   };
 
+#ifdef LCP_BIG_PROFILE
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = clock64();
+#define BIG_TICK(i) { const long long now_ = clock64(); pc[i] += now_ - tk; tk = now_; }
+#else
+#define BIG_TICK(i)
+#endif
   // ---- factorisation: T = W + diag terms, LU in register tiles, factors to LDS (all 256 threads) ---------------------------
   auto factor = [&]() {
     double t[8][8];
-    const double* wg = Wg + (size_t)tid * 64;
-    static_for<8>([&](auto P) LCP_INL { static_for<4>([&](auto Q2) LCP_INL { load2(wg + P * 8 + 2 * Q2, t[P][2 * Q2], t[P][2 * Q2 + 1]); }); });
+    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * 8 + Q) * NT + tid]; }); });
     if (ti == tj) {
       static_for<4>([&](auto P) LCP_INL {
         const int c = ti + 16 * P;
@@ -311,6 +333,9 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
       });
     }
     int buf = 0;
+    bool singular_seen = false;
+    if (tid == 0) { L.pinv[0] = t[0][0]; L.pinv[1] = fast_rcp(t[0][0]); }
+    BIG_TICK(5)                                                             // (profile: W load + diagonal)
     static_for<8>([&](auto KB) LCP_INL {
       constexpr int kb = KB;
 #pragma unroll 1
@@ -318,29 +343,38 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
         const int k = 16 * kb + kk;
         double* prow = L.prow + buf * NRD;
         double* pcol = L.pcol + buf * NRD;
+        // the owners of pivot row k publish it, the owners of column k publish the RAW column; after ONE barrier
+        // every thread scales its multipliers by 1 / pivot itself (8 multiplies instead of a second barrier)
         if (ti == kk) static_for<8 - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + 16 * q] = t[kb][q]; });
+        if (tj == kk) static_for<8 - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + 16 * pp] = t[pp][kb]; });
         __syncthreads();
-        const double piv = prow[k];
-        if (piv == 0.0 && tid == 0) L.flag[0] = 1;
-        const double inv = fast_rcp(piv);
-        if (tj == kk) static_for<8 - kb>([&](auto PP) LCP_INL {
-          constexpr int pp = kb + PP;
-          const int i = ti + 16 * pp;
-          if (i > k) { const double l = t[pp][kb] * inv; t[pp][kb] = l; pcol[i] = l; }
-        });
-        __syncthreads();
+        // every LDS read of the step is issued here, ahead of any use, so that the step pays ONE LDS round trip
+        // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
         double lm[8 - kb], rv[8 - kb];
+        const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
+        static_for<8 - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + 16 * pp]; rv[PP] = prow[tj + 16 * pp]; });
+        __builtin_amdgcn_sched_barrier(0);
+        singular_seen = singular_seen || (piv == 0.0);
         static_for<8 - kb>([&](auto PP) LCP_INL {
           constexpr int pp = kb + PP;
-          lm[PP] = (ti + 16 * pp > k) ? pcol[ti + 16 * pp] : 0.0;
-          rv[PP] = (tj + 16 * pp > k) ? prow[tj + 16 * pp] : 0.0;
+          const double l = lm[PP] * inv;
+          lm[PP] = (ti + 16 * pp > k) ? l : 0.0;
+          rv[PP] = (tj + 16 * pp > k) ? rv[PP] : 0.0;
+          t[pp][kb] = (tj == kk && ti + 16 * pp > k) ? l : t[pp][kb];
         });
         static_for<8 - kb>([&](auto PP) LCP_INL { static_for<8 - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
         buf ^= 1;
+        if (ti == tj && ti == ((kk + 1) & 15)) {                              // next pivot: its owner publishes it with its reciprocal
+          double nxt = t[kb][kb];
+          if constexpr (kb < 7) { if (kk == 15) nxt = t[kb + 1][kb + 1]; }
+          L.pinv[2 * buf] = nxt; L.pinv[2 * buf + 1] = fast_rcp(nxt);
+        }
       }
     });
+    if (singular_seen && tid == 0) L.flag[0] = 1;
+    BIG_TICK(6)                                                             // (profile: LU loop)
     // park the factors: column-major, plus the reciprocals of U's diagonal
-    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * NRD + ti + 16 * P] = t[P][Q]; }); });
+    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * LDU + ti + 16 * P] = t[P][Q]; }); });
     if (ti == tj) static_for<8>([&](auto P) LCP_INL { L.dU[ti + 16 * P] = 1.0 / t[P][P]; });
   };
 
@@ -349,30 +383,49 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
     const double r12 = hz.f1 + hz.f2;
     const double w0_ = (rDg * r12 - 2.0 * hz.g) * ridet;
     double ra = hz.n, ru = 0.5 * (hz.f1 - hz.f2) - 0.5 * rSm * w0_;
-    const int n = ncs;                                                    // rows / columns >= ncs are identity
-    for (int k = 0; k < n; ++k) {                                         // L y = rhs, columns a_k
-      const double yk = bcast_lane(ra, k);
-      const double* col = L.LU + (size_t)k * NRD;
-      const double la = col[lane], lu = col[NCB + lane];
-      ra = fma(-((lane > k) ? la : 0.0), yk, ra);
-      ru = fma(-lu, yk, ru);
+    // Sweeps in chunks of 8 pivots: the column entries do not depend on the recurrence, so a chunk's 8 or 16 LDS reads
+    // are issued together in front of its 8 dependent steps.  Rows / columns at or beyond the contact count are identity
+    // (L = 0, 1 / U_ii = 1), so rounding the count up to a multiple of 8 only adds exact no-op steps.
+    const int n8 = (ncs + 7) & ~7;
+    for (int k0 = 0; k0 < n8; k0 += 8) {                                  // L y = rhs, columns a_k
+      double la[8], lu[8];
+      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(k0 + I) * LDU; la[I] = col[lane]; lu[I] = col[NCB + lane]; });
+      static_for<8>([&](auto I) LCP_INL {
+        const int k = k0 + I;
+        const double yk = bcast_lane(ra, k);
+        ra = fma(-((lane > k) ? la[I] : 0.0), yk, ra);
+        ru = fma(-lu[I], yk, ru);
+      });
     }
-    for (int k = 0; k < n; ++k) {                                         // columns u_k
-      const double yk = bcast_lane(ru, k);
-      const double lu = L.LU[(size_t)(NCB + k) * NRD + NCB + lane];
-      ru = fma(-((lane > k) ? lu : 0.0), yk, ru);
+    for (int k0 = 0; k0 < n8; k0 += 8) {                                  // columns u_k
+      double lu[8];
+      static_for<8>([&](auto I) LCP_INL { lu[I] = L.LU[(size_t)(NCB + k0 + I) * LDU + NCB + lane]; });
+      static_for<8>([&](auto I) LCP_INL {
+        const int k = k0 + I;
+        const double yk = bcast_lane(ru, k);
+        ru = fma(-((lane > k) ? lu[I] : 0.0), yk, ru);
+      });
     }
-    for (int k = n - 1; k >= 0; --k) {                                    // U x = y, columns u_k
-      const double xk = bcast_lane(ru, k) * L.dU[NCB + k];
-      const double* col = L.LU + (size_t)(NCB + k) * NRD;
-      const double ua_ = col[lane], uu_ = col[NCB + lane];
-      ra = fma(-ua_, xk, ra);
-      ru = fma(-((lane < k) ? uu_ : 0.0), xk, ru);
+    for (int k0 = n8 - 8; k0 >= 0; k0 -= 8) {                             // U x = y, columns u_k
+      double ua_[8], uu_[8], du[8];
+      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(NCB + k0 + I) * LDU; ua_[I] = col[lane]; uu_[I] = col[NCB + lane]; du[I] = L.dU[NCB + k0 + I]; });
+      static_for<8>([&](auto IR) LCP_INL {
+        constexpr int I = 7 - IR;
+        const int k = k0 + I;
+        const double xk = bcast_lane(ru, k) * du[I];
+        ra = fma(-ua_[I], xk, ra);
+        ru = fma(-((lane < k) ? uu_[I] : 0.0), xk, ru);
+      });
     }
-    for (int k = n - 1; k >= 0; --k) {                                    // columns a_k
-      const double xk = bcast_lane(ra, k) * L.dU[k];
-      const double ua_ = L.LU[(size_t)k * NRD + lane];
-      ra = fma(-((lane < k) ? ua_ : 0.0), xk, ra);
+    for (int k0 = n8 - 8; k0 >= 0; k0 -= 8) {                             // columns a_k
+      double ua_[8], du[8];
+      static_for<8>([&](auto I) LCP_INL { ua_[I] = L.LU[(size_t)(k0 + I) * LDU + lane]; du[I] = L.dU[k0 + I]; });
+      static_for<8>([&](auto IR) LCP_INL {
+        constexpr int I = 7 - IR;
+        const int k = k0 + I;
+        const double xk = bcast_lane(ra, k) * du[I];
+        ra = fma(-((lane < k) ? ua_[I] : 0.0), xk, ra);
+      });
     }
     const double a = ra * ua, u = ru * uu;
     const double w = w0_ + rwa * a + rwu * u;
@@ -382,6 +435,9 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
     return dz;
   };
 
+#ifdef LCP_BIG_PROFILE
+  long long pc_ts = 0;
+#endif
   // solve_kkt (pdipm.py:325-354); di = 1 / d
   auto solve_kkt = [&](const M4<double>& di, double rx, const M4<double>& rs, const M4<double>& rz, double ry,
                        double& ox, M4<double>& os, M4<double>& oz, double& oy) {
@@ -397,7 +453,13 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
       hz.n -= an; hz.f1 -= at; hz.f2 += at;
     }
     if (!vc) hz = m4<double>(0, 0, 0, 0);
+#ifdef LCP_BIG_PROFILE
+    const long long t0_ = clock64();
+#endif
     const M4<double> wz = tsolve(hz);
+#ifdef LCP_BIG_PROFILE
+    pc_ts += clock64() - t0_;
+#endif
     double dy = 0;
     if (e > 0) dy = -S11v(hy - GAtw(vc ? wz.n : 0.0, vc ? wz.f1 - wz.f2 : 0.0));
     oz = m4<double>(-wz.n, -wz.f1, -wz.f2, -wz.g);                        // :342
@@ -465,9 +527,12 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
       }
       reduce_setup(dinv);
     }
+    BIG_TICK(0)                                                             // residuals
     __syncthreads();
+    BIG_TICK(4)
     factor();                                                               // (:99-100)
     __syncthreads();
+    BIG_TICK(1)                                                             // factorisation
     if (w0) {
       ua = L.dU[lane]; uu = L.dU[NCB + lane];
       const bool singular = L.flag[0] != 0;
@@ -488,7 +553,9 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
         for (int pass = 0; pass < npass; ++pass) {
           double ox, oy;
           M4<double> os, oz;
+          BIG_TICK(2)
           solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+          BIG_TICK(3)                                                           // solve_kkt
           if (it < 0) {
             x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
             auto min4 = [&](const M4<double>& a) { return pmin(pmin(a.n, a.f1), pmin(a.f2, a.g)); };
@@ -527,9 +594,11 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
       }
       if (lane == 0) L.flag[1] = done ? 1 : 0;
     }
+    BIG_TICK(2)                                                             // step lengths, bookkeeping
     __syncthreads();
     if (L.flag[1]) break;
   }
+
 
   // ---- outputs (row layout of a capacity-sized LCP, padded slots 0) ---------------------------------------------------------
   if (!w0) return;
@@ -546,12 +615,16 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
   if (lane < e && SP.y) ((float*)SP.y)[(size_t)scene * e + lane] = (float)by;
   if (lane < nz) ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)(-bx);     // engines.py:76-77
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+#ifdef LCP_BIG_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap; for (int i = 0; i < 4; ++i) o[200 + i] = (float)pc[i]; o[204] = (float)pc_ts; o[205] = (float)pc[5]; o[206] = (float)pc[6]; }
+#endif
 }
 
 }  // namespace big
 
-// nz <= 45: the two 64 x nz Jacobians have to fit next to the 128 KB of factors in the 160 KB of LDS
-bool big_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= big::NCB) && nz <= 45 && e <= big::EQB; }
+// nz <= 43: the two 64 x nz Jacobians have to fit next to the 128 KB of factors in the 160 KB of LDS
+bool big_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= big::NCB) && nz <= 43 && e <= big::EQB; }
 size_t big_ws_bytes() { return sizeof(double) * (big::NRD * big::NRD + 64); }
 
 int big_step(const StepArgs& SP, void* stream) {
