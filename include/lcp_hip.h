@@ -156,8 +156,9 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
  * (that is lcp_move_find_contacts_f64).  Arguments as lcp_step_fused_f32; z, s use the row layout of a
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
  * Served by the four-scenes-per-wave kernel when 3 nb <= 16, maxc <= 16, e <= 4: the workspace it leaves then feeds
- * lcp_pdipm_backward_f32 (m = 4 maxc) and lcp_step_backward_f32 (padded slots get zero gradients).  Any other size runs
- * on the workgroup-per-scene kernels, forward only (LCP_E_TOOLARGE beyond their LDS / workspace plan).
+ * lcp_pdipm_backward_f32 (m = 4 maxc) and lcp_step_backward_f32 (padded slots get zero gradients).  Larger scenes are
+ * forward only: up to maxc <= 64, 3 nb <= 43, e <= 4 (fp64 arithmetic) on the register-tiled workgroup-per-scene kernel
+ * (BASELINE config 5), anything else on the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).
  *   out: v_new[B,nb,3]  z[B,4 maxc]  s[B,4 maxc]  y[B,e]  iters[B]  status[B] */
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
                            const float* Mdiag, const float* v, const float* f,

@@ -31,7 +31,11 @@ t = time.perf_counter()
 for _ in range(5): out = run(out)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
-print("B", B, "ms/step", dt * 1e3, "sim steps/s", B / dt)
+import json
+print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts, nineq 256, nz 33, neq 3), forward (lcp_solve_dynamics_f32)",
+                  "value": B / dt, "unit": "sim steps/s", "batch": B, "ms_per_step": dt * 1e3,
+                  "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),
+                  "kernel": "lcp::big::lcp_fwd_big (one 256-thread workgroup per scene)"}))
 import os
 if "bigprof" in os.environ.get("LCP_HIP_LIB", ""):
     pc = out["s"][:, 200:207].double().mean(dim=0).tolist()
