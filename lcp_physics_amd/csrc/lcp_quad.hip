@@ -1030,14 +1030,22 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   }
   if (P.dF) {
     TI* o = (TI*)P.dF + (size_t)scene * m * m;
-    // dF[i][j] = -dlam_i lam_j ; lane c' writes the four columns of its contact for every row i
+    // dF[i][j] = -dlam_i lam_j (lcp.py:54): 16 KB per scene, the bulk of what this kernel writes.  Each lane takes four
+    // CONSECUTIVE columns of every row (lam in the natural row order [n | friction pairs | gamma], fetched once through
+    // LDS), so a row leaves as one 16-byte store per lane - 256 contiguous bytes per scene and instruction.
+    TC* LAM = S.L.GAL;                                                   // (free in this kernel: 128 TC >= 4 nc)
+    __syncthreads();
+    if (vslot) { LAM[l16] = zq.n; LAM[nc + 2 * l16] = zq.f1; LAM[nc + 2 * l16 + 1] = zq.f2; LAM[3 * nc + l16] = zq.g; }
+    __syncthreads();
+    TC lq[4] = {0, 0, 0, 0};
+    if (vslot) { lq[0] = LAM[4 * l16]; lq[1] = LAM[4 * l16 + 1]; lq[2] = LAM[4 * l16 + 2]; lq[3] = LAM[4 * l16 + 3]; }
     static_for<16>([&](auto C) LCP_INL {
       if (C < nc) {
         const TC a0 = bc<C>(dl.n), a1 = bc<C>(dl.f1), a2 = bc<C>(dl.f2), a3 = bc<C>(dl.g);
         if (vslot) {
           auto wr = [&](int i, TC dli) {
-            TI* r = o + (size_t)i * m;
-            r[l16] = (TI)(-dli * zq.n); r[nc + 2 * l16] = (TI)(-dli * zq.f1); r[nc + 2 * l16 + 1] = (TI)(-dli * zq.f2); r[3 * nc + l16] = (TI)(-dli * zq.g);
+            TI* r = o + (size_t)i * m + 4 * l16;
+            store4(r, (TI)(-dli * lq[0]), (TI)(-dli * lq[1]), (TI)(-dli * lq[2]), (TI)(-dli * lq[3]));
           };
           wr(C, a0); wr(nc + 2 * C, a1); wr(nc + 2 * C + 1, a2); wr(3 * nc + C, a3);
         }

@@ -56,6 +56,10 @@ __device__ __forceinline__ void load2(const float* src, float& a, float& b) {
 __device__ __forceinline__ void load2(const double* src, double& a, double& b) {
   const double2 v = *reinterpret_cast<const double2*>(src); a = v.x; b = v.y;
 }
+__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) { *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void store4(double* dst, double a, double b, double c, double d) {
+  *reinterpret_cast<double2*>(dst) = make_double2(a, b); *reinterpret_cast<double2*>(dst + 2) = make_double2(c, d);
+}
 __device__ __forceinline__ void store2(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 __device__ __forceinline__ void store2(double* dst, double a, double b) { *reinterpret_cast<double2*>(dst) = make_double2(a, b); }
 
