@@ -151,11 +151,37 @@ class BatchedWorld:
         self.dt = scene.dt
         self._ws = None
         self._out = None
+        self._full_count = None
         self.last = None
 
+    def _forward_only_step(self):
+        """Scenes beyond the four-scenes-per-wave kernel (more than 16 contacts or 5 bodies): `lcp_solve_dynamics_f32`
+        reaches the register-tiled kernel of lcp_big.hip (forward only, which is all `step()` needs) where
+        `lcp_step_fused_f32` would fall back to the generic kernels; the integrator `p += v dt` (bodies.py:80-82) is
+        then one elementwise op."""
+        sc = self.scene
+        if self._full_count is None:
+            from .contacts import ContactBuffers
+            self._full_count = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=sc.v.device)
+            self._cb = ContactBuffers.__new__(ContactBuffers)
+        cb = self._cb
+        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
+        e = sc.Je.shape[1] if sc.Je is not None and sc.Je.numel() else 0
+        out = solve_dynamics(sc.B, sc.nb, sc.nc, e, self._full_count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb,
+                             sc.Je if e else None, sc.dt, eps=self.eps, not_improved_lim=self.lim,
+                             max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
+        if "p_new" not in out:
+            out["p_new"] = torch.empty_like(sc.p)
+        torch.add(sc.p, out["v_new"], alpha=float(sc.dt), out=out["p_new"])
+        return out
+
     def step(self):
-        out = fused_step(self.scene, eps=self.eps, not_improved_lim=self.lim, max_iter=self.max_iter,
-                         compute=self.compute, ws=self._ws, out=self._out)
+        sc = self.scene
+        if 3 * sc.nb > 16 or sc.nc > 16:
+            out = self._forward_only_step()
+        else:
+            out = fused_step(sc, eps=self.eps, not_improved_lim=self.lim, max_iter=self.max_iter,
+                             compute=self.compute, ws=self._ws, out=self._out)
         self._ws, self._out, self.last = out["ws"], out, out
         # double-buffer swap: new state becomes the scene state (world.py:87-90)
         self.scene.v, out["v_new"] = out["v_new"], self.scene.v

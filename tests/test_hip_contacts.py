@@ -371,6 +371,28 @@ def test_config5_pile_solve_dynamics_matches_oracle():
     print("config 5 worst scaled error", worst)
 
 
+@pytest.mark.parametrize("kind", ["stack", "pile"])
+def test_batched_world_step_fixed_contacts(kind):
+    """`BatchedWorld.step()` (fixed contact list): new_v = -x and p += v dt against the oracle, on the quad sizes
+    (one fused launch) and on config-5 sized piles (lcp_solve_dynamics_f32 -> lcp_big.hip, then the integrator)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import BatchedWorld
+    from oracle import pdipm_oracle as O
+    B = 6
+    sc = (scenes.make_stack_scenes(B=B, nbox=3, pts_per_interface=2, seed=4, dtype=torch.float32) if kind == "stack"
+          else scenes.make_pile_scenes(B=B, seed=4, dtype=torch.float32))
+    lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    v_ref = -O.lcp_forward(*lcp64).x.reshape(B, sc.nb, 3)
+    p_ref = sc.p.double() + v_ref * sc.dt
+    world = BatchedWorld(sc.to(device=DEV))
+    world.step()
+    torch.cuda.synchronize()
+    scale = v_ref.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0).reshape(B, 1, 1)
+    assert float(((world.get_v().double().cpu() - v_ref).abs() / scale).max()) < 1e-4
+    assert float((world.get_p().double().cpu() - p_ref).abs().max()) < 1e-3            # fp32 poses of ~500
+    assert abs(world.t - sc.dt) < 1e-12
+
+
 def test_contact_world_refuses_initial_penetration():
     from lcp_physics_amd.physics.batched_world import ContactWorld
     shapes = [("rect", (500.0, 10.0)), ("rect", (40.0, 40.0))]
