@@ -181,12 +181,14 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
   int rc = fill_step(P, B, nb, nc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
   if (rc) return rc;
   if (!dl_dv || !ws) return LCP_E_BADARG;
-  if (!lcp::quad_supported(3 * nb, 4 * nc, e)) return LCP_E_TOOLARGE;
   P.ws = ws;
   lcp::StepBwdArgs G;
   G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
   G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
-  return lcp::quad_step_backward(P, G, compute, stream);
+  if (lcp::quad_supported(3 * nb, 4 * nc, e)) return lcp::quad_step_backward(P, G, compute, stream);
+  // larger scenes: the forward must have been lcp_solve_dynamics_f32 (the lcp_big.hip kernel owns the workspace layout)
+  if (compute == LCP_COMPUTE_F64 && lcp::big_supported(3 * nb, 4 * nc, e)) return lcp::big_step_backward(P, G, stream);
+  return LCP_E_TOOLARGE;
 }
 
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,

@@ -15,7 +15,8 @@
 //     wave 0 runs the triangular sweeps off conflict-free column reads.
 // W = J P J^T (the part of T that does not change over the iterations) is formed once, tile by tile, and kept in the
 // workspace in tile order (each thread re-reads its own 512 contiguous bytes per factorisation).
-// Forward only (the workspace it leaves is not the dense backward's): served through lcp_solve_dynamics_f32.
+// Served through lcp_solve_dynamics_f32 (forward) and lcp_step_backward_f32 (gradients w.r.t. the physical inputs of the
+// step); the workspace it leaves is its own (W tiles + the best iterate), not the dense LCPFunction backward's.
 #include "lcp_wave_common.h"
 
 namespace lcp {
@@ -109,8 +110,17 @@ __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
 // row r of the stacked Jacobian [Jc; Jt] (r < 64: Jc row r, else Jt row r - 64)
 __device__ __forceinline__ const float* jrow(const Lds& L, int r, int nzs) { return (r < NCB ? L.Jc + (size_t)r * nzs : L.Jt + (size_t)(r - NCB) * nzs); }
 
-// ---------------------------------------------------------------- the kernel (fused step: contact list in, v_new out)
-__global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
+constexpr int WS_W = NRD * NRD;                 // workspace per scene (doubles): W tiles ...
+constexpr int WS_IT = WS_W + 64;                // ... then the best iterate the backward needs: x[64] y[8] z[4][64] s[4][64]
+constexpr int WS_TOTAL = WS_IT + 64 + 8 + 8 * NCB;
+
+// ---------------------------------------------------------------- the kernel
+// BWD = false: fused step (contact list in, v_new out; engines.py:26-78).
+// BWD = true : backward of that step w.r.t. its physical inputs (what lcp_bwd_step_quad does for the small scenes: one
+//              factorisation at the stored iterate, one KKT solve - lcp.py:37-64 - and the contraction of the rank-1
+//              LCP gradients through the engine assembly), reading W and the iterate the forward left in the workspace.
+template <bool BWD>
+__global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool w0 = wave == 0;
@@ -118,10 +128,14 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;
   carve(L, smem, nzs);
+  double* Wg = (double*)SP.ws + (size_t)scene * WS_TOTAL;                 // W tiles: Wg[(p * 8 + q) * 256 + tid]
+  double* Wit = Wg + WS_IT;                                               // best iterate
   int ncs = ncap;
-  if (SP.c_count) { const int c = SP.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  if (BWD) ncs = (int)Wg[WS_W];                                           // the count the forward solved with
+  else if (SP.c_count) ncs = SP.c_count[scene];
+  ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
+  if (!BWD && tid == 0) Wg[WS_W] = (double)ncs;
   const bool vc = w0 && lane < ncs;                                       // this lane owns a live contact
-  double* Wg = (double*)SP.ws + (size_t)scene * (NRD * NRD + 64);         // W tiles: Wg[(p * 8 + q) * 256 + tid]
 
   // ---- assembly (engines.py:31-32,50-74; world.py:144-234) ----------------------------------------------------------
   for (int i = tid; i < NCB * nzs; i += NT) { L.Jc[i] = 0.0f; L.Jt[i] = 0.0f; }
@@ -206,7 +220,7 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
     gat[a] = (vc && e > 0) ? GA[(NCB + lane) * EQB + a] : 0.0;
     s11row[a] = (w0 && lane < EQB && e > 0) ? L.S11[lane * EQB + a] : 0.0;
   }
-  {
+  if (!BWD) {
     // W tile of this thread: entries (ti + 16 p, tj + 16 q)
     double wt_[8][8];
     static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
@@ -491,6 +505,91 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
     return key_is_nan(kl) ? nan_of<double>() : l;
   };
 
+  if (BWD) {
+    // ---- backward: d(loss)/d(v_new) -> d(loss)/d(Mdiag, v, f, rest, fric, contact normal / arms) ----------------------------
+    double x = 0, dx = 0, dnu = 0;
+    M4<double> z = m4<double>(1, 1, 1, 1), s = z, dinv = z, ds, dl;
+    if (w0) {
+      x = (lane < nz) ? Wit[lane] : 0.0;
+      if (vc) {
+        z = m4<double>(Wit[72 + lane], Wit[72 + NCB + lane], Wit[72 + 2 * NCB + lane], Wit[72 + 3 * NCB + lane]);
+        s = m4<double>(Wit[72 + 4 * NCB + lane], Wit[72 + 5 * NCB + lane], Wit[72 + 6 * NCB + lane], Wit[72 + 7 * NCB + lane]);
+        dinv = m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                 // 1 / d, d = z / s (lcp.py:44)
+      }
+      reduce_setup(dinv);
+    }
+    __syncthreads();
+    factor();                                                               // lcp.py:46
+    __syncthreads();
+    if (!w0) return;
+    ua = L.dU[lane]; uu = L.dU[NCB + lane];
+    // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
+    const double g = (lane < nz) ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
+    const M4<double> zero = m4<double>(0, 0, 0, 0);
+    solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu);                   // lcp.py:47-50
+    // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
+    double* X = L.xv; double* DX = L.wv; double* CR = L.add; double* CF = L.add + NCB; int* B12 = (int*)(L.add + 2 * NCB);
+    X[lane] = x; DX[lane] = dx; wsync();
+    double gh_rbar = 0;
+    {
+      double cr = 0, cf = 0, dnx = 0, dny = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+      int b1 = 0, b2 = 0;
+      if (vc) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        const double nx = ((const float*)SP.c_n)[cb * 2], ny = ((const float*)SP.c_n)[cb * 2 + 1];
+        const double p1x = ((const float*)SP.c_p1)[cb * 2], p1y = ((const float*)SP.c_p1)[cb * 2 + 1];
+        const double p2x = ((const float*)SP.c_p2)[cb * 2], p2y = ((const float*)SP.c_p2)[cb * 2 + 1];
+        b1 = SP.c_i1[cb]; b2 = SP.c_i2[cb];
+        const double rbar = 0.5 * ((double)((const float*)SP.rest)[(size_t)scene * nb + b1] + (double)((const float*)SP.rest)[(size_t)scene * nb + b2]);
+        const double jn[6] = {p1x * ny - p1y * nx, nx, ny, -(p2x * ny - p2y * nx), -nx, -ny};      // world.py:177-183
+        const double gh = -dl.n;                                              // dh = -dlam (lcp.py:56)
+        const double af = dl.f1 - dl.f2, lf = z.f1 - z.f2;                    // Jf rows are +jt, -jt (world.py:191-192)
+        double gjn[6], gjf[6], jnv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
+          const double xq = X[col], dxq = DX[col], vq = (double)vv[col];
+          jnv = fma(jn[q], vq, jnv);
+          gjn[q] = dl.n * xq + z.n * dxq + gh * rbar * vq;                    // dG row n (lcp.py:53) + h = (Jc v) rbar
+          gjf[q] = af * xq + lf * dxq;
+        }
+        gh_rbar = gh * rbar;
+        cr = 0.5 * gh * jnv;                                                  // rbar = (rest_b1 + rest_b2) / 2 (world.py:144-151)
+        cf = 0.5 * (-dl.g * z.n);                                             // dF[gamma_c, n_c] = -dlam_g lam_n (lcp.py:54), F = mu there
+        dnx = -gjn[0] * p1y + gjn[1] + gjn[3] * p2y - gjn[4] - gjf[0] * p1x - gjf[2] + gjf[3] * p2x + gjf[5];
+        dny = gjn[0] * p1x + gjn[2] - gjn[3] * p2x - gjn[5] - gjf[0] * p1y + gjf[1] + gjf[3] * p2y - gjf[4];
+        d1x = gjn[0] * ny - gjf[0] * nx; d1y = -gjn[0] * nx - gjf[0] * ny;
+        d2x = -gjn[3] * ny + gjf[3] * nx; d2y = gjn[3] * nx + gjf[3] * ny;
+      }
+      wsync();
+      CR[lane] = cr; CF[lane] = cf; B12[lane] = b1; B12[NCB + lane] = b2;
+      if (lane < ncap) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        if (Gd.dcn) { ((float*)Gd.dcn)[cb * 2] = (float)dnx; ((float*)Gd.dcn)[cb * 2 + 1] = (float)dny; }
+        if (Gd.dcp1) { ((float*)Gd.dcp1)[cb * 2] = (float)d1x; ((float*)Gd.dcp1)[cb * 2 + 1] = (float)d1y; }
+        if (Gd.dcp2) { ((float*)Gd.dcp2)[cb * 2] = (float)d2x; ((float*)Gd.dcp2)[cb * 2 + 1] = (float)d2y; }
+      }
+    }
+    const double dv_h = Gtw(gh_rbar, 0.0);                                   // Jc^T (dh rbar)   (uses L.wv: DX is dead by now)
+    if (lane < nz) {
+      const size_t o = (size_t)scene * nz + lane;
+      const double md = (double)Md[lane], v = (double)vv[lane];
+      if (Gd.dMdiag) ((float*)Gd.dMdiag)[o] = (float)(dx * x + dx * v);      // Q = diag(M) (dQ, lcp.py:59-60) and p = M v + dt f
+      if (Gd.dv) ((float*)Gd.dv)[o] = (float)(dx * md + dv_h);
+      if (Gd.df) ((float*)Gd.df)[o] = (float)(dx * (double)SP.dt);
+    }
+    if (lane < nb) {                                                          // per-body sums over the contacts, fixed order
+      double ar = 0, af = 0;
+      for (int c = 0; c < ncs; ++c) {
+        const double w = ((B12[c] == lane) ? 1.0 : 0.0) + ((B12[NCB + c] == lane) ? 1.0 : 0.0);
+        if (w != 0.0) { ar += w * CR[c]; af += w * CF[c]; }
+      }
+      if (Gd.drest) ((float*)Gd.drest)[(size_t)scene * nb + lane] = (float)ar;
+      if (Gd.dfric) ((float*)Gd.dfric)[(size_t)scene * nb + lane] = (float)af;
+    }
+    return;
+  }
+
   // ---- the PDIPM loop (pdipm.py:49-179) -----------------------------------------------------------------------------------
   const int max_iter = SP.max_iter, lim = SP.lim;
   const double eps = SP.eps;
@@ -614,6 +713,11 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
   }
   if (lane < e && SP.y) ((float*)SP.y)[(size_t)scene * e + lane] = (float)by;
   if (lane < nz) ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)(-bx);     // engines.py:76-77
+  // the iterate the backward starts from (lcp.py:29 keeps nus, lams, slacks on the op)
+  Wit[lane] = (lane < nz) ? bx : 0.0;
+  if (lane < 8) Wit[64 + lane] = (lane < e) ? by : 0.0;
+  Wit[72 + lane] = bz.n; Wit[72 + NCB + lane] = bz.f1; Wit[72 + 2 * NCB + lane] = bz.f2; Wit[72 + 3 * NCB + lane] = bz.g;
+  Wit[72 + 4 * NCB + lane] = bs.n; Wit[72 + 5 * NCB + lane] = bs.f1; Wit[72 + 6 * NCB + lane] = bs.f2; Wit[72 + 7 * NCB + lane] = bs.g;
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_BIG_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
@@ -625,16 +729,19 @@ __global__ void __launch_bounds__(NT) lcp_fwd_big(StepArgs SP, int nzs) {
 
 // nz <= 43: the two 64 x nz Jacobians have to fit next to the 128 KB of factors in the 160 KB of LDS
 bool big_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= big::NCB) && nz <= 43 && e <= big::EQB; }
-size_t big_ws_bytes() { return sizeof(double) * (big::NRD * big::NRD + 64); }
+size_t big_ws_bytes() { return sizeof(double) * big::WS_TOTAL; }
 
-int big_step(const StepArgs& SP, void* stream) {
+template <bool BWD>
+static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   const int nz = 3 * SP.nb, nzs = nz | 1;
   big::Lds L;
   const size_t lds = big::carve(L, nullptr, nzs);
-  auto k = big::lcp_fwd_big;
+  auto k = big::lcp_big_kernel<BWD>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LCP_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::NT), lds, (hipStream_t)stream, SP, nzs);
+  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::NT), lds, (hipStream_t)stream, SP, Gd, nzs);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
+int big_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return big_launch<false>(SP, Gd, stream); }
+int big_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return big_launch<true>(SP, Gd, stream); }
 
 }  // namespace lcp

@@ -105,6 +105,7 @@ int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, voi
 bool big_supported(int nz, int m, int e);
 size_t big_ws_bytes();
 int big_step(const StepArgs& P, void* stream);
+int big_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
 
 // narrow-phase contact generation + position update - lcp_contacts.hip
 int contacts_launch(const ContactArgs& P, void* stream);

@@ -91,6 +91,7 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
                                     P(out["z"]), P(out["s"]), P(out["y"]), P(out["iters"]),
                                     P(out["status"]), P(ws), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_step_fused_f32")
+    out["path"] = "fused"
     return out
 
 
@@ -104,6 +105,9 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
     dev = sc.v.device
+    if (3 * nb > 16 or nc > 16) and out.get("path") != "solve_dynamics":
+        raise RuntimeError("scenes beyond 5 bodies / 16 contacts: the forward must be `solve_dynamics` "
+                           "(lcp_solve_dynamics_f32) - its kernel owns the workspace layout the backward reads")
     dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
     if grads is None:
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -226,6 +230,7 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
                                         int(not_improved_lim), comp, P(out["v_new"]), P(out["z"]), P(out["s"]),
                                         P(out["y"]), P(out["iters"]), P(out["status"]), P(ws), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_solve_dynamics_f32")
+    out["path"] = "solve_dynamics"
     return out
 
 

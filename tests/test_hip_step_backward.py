@@ -98,3 +98,53 @@ def test_variable_contact_counts_and_padding():
     assert torch.allclose(pg["v"][free][:, 1:], dv_expected, rtol=1e-5, atol=1e-6)
     assert torch.allclose(pg["f"][free][:, 1:], cot[free][:, 1:] * sc.dt / sc.Mdiag[free][:, 1:], rtol=1e-5, atol=1e-7)
     assert float(pg["rest"][free].abs().max()) == 0.0 and float(pg["fric"][free].abs().max()) == 0.0
+
+
+def test_large_scene_backward_matches_generic_dense_and_oracle():
+    """Config-5 sized piles (11 bodies, 64 contacts): `lcp_step_backward_f32` after `lcp_solve_dynamics_f32` (both in
+    lcp_big.hip) against (a) the generic kernels' dense backward contracted by autograd and (b) the fp64 oracle."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, fused_step_backward, solution_of_step, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 8
+    sc = scenes.make_pile_scenes(B=B, seed=31, dtype=torch.float32)
+    scg = sc.to(device=DEV)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float32)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
+    out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+    pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
+    with pytest.raises(RuntimeError):
+        fused_step_backward(scg, fused_step(scg), cot.to(DEV))                 # wrong forward for this size class
+    # (a) generic kernels: dense gradients of the same step, contracted through the assembly by autograd
+    gen = fused_step(scg)
+    lcp = assemble_contacts(scg)
+    dense = lcp_backward(solution_of_step(scg, gen, lcp[2], lcp[4]), (-cot).reshape(B, -1).to(DEV))
+    torch.cuda.synchronize()
+    dense = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", dense)}
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    ref = parity.physical_grads(ph, sc.dt, dense, O)
+    for k in ("Mdiag", "v", "f"):                                                # defined whatever the multipliers (err_physical)
+        scale = ref[k].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+        err = (pg[k] - ref[k]).abs().reshape(B, -1).max(dim=1)[0] / scale
+        assert float(err.max()) < 1e-3, (k, float(err.max()))
+    # (b) the oracle end to end
+    lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    refsol = O.lcp_forward(*lcp64)
+    cx = (-cot).reshape(B, -1).double()
+    gref = O.lcp_backward(refsol, *lcp64, cx)
+    gref = {k: gref["d" + k] for k in "QpGhAbF"}
+    Q, p, G, h, A, b, F = lcp64
+    res_o = parity.kkt_backward_residual(Q, G, A, F, refsol.z, refsol.s, cx, gref["p"], -gref["h"], -gref["b"])
+    ok = torch.stack([v for v in res_o.values()]).max(dim=0)[0] < 1e-9
+    zs, ss = refsol.z.max(dim=1, keepdim=True)[0], refsol.s.max(dim=1, keepdim=True)[0]
+    ok = ok & (torch.maximum(refsol.z / zs, refsol.s / ss).min(dim=1)[0] > 1e-6)
+    pg_ref = parity.physical_grads(ph, sc.dt, gref, O)
+    scl = parity.free_scales(Q, p, cx)
+    floor = parity._n(cx) * torch.maximum(scl["x_free"], parity._n(refsol.x))
+    ep = parity.err_physical(pg, pg_ref, ph, floor, keys=["Mdiag", "v", "f"])
+    if bool(ok.any()):
+        assert float(ep[ok].max()) < 1e-4, (float(ep[ok].max()), int(ok.sum()))
+    print("well-posed scenes", int(ok.sum()), "of", B)
