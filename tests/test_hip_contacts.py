@@ -369,6 +369,17 @@ def test_config5_pile_solve_dynamics_matches_oracle():
         assert float((got[k] - ref_generic[k]).abs().max()) / scale <= 1e-5, (k, n, "vs generic")
         assert int(out["status"][k]) & 8 == 0
     print("config 5 worst scaled error", worst)
+    # the same piles without the joint (a heavy free floor, neq = 0): big kernel against the generic kernels
+    Md = scg.Mdiag.clone(); Md[:, 0] *= 1e4
+    f0 = scg.f.clone(); f0[:, 0] = 0
+    run0 = lambda: solve_dynamics(B, sc.nb, sc.nc, 0, count, Md, scg.v, f0, scg.rest, scg.fric, cb, None, sc.dt)
+    a = run0()["v_new"].double().cpu()
+    _lib.set_path("generic")
+    try:
+        g = run0()["v_new"].double().cpu()
+    finally:
+        _lib.set_path("auto")
+    assert float((a - g).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max())), float((a - g).abs().max())
 
 
 @pytest.mark.parametrize("kind", ["stack", "pile"])
