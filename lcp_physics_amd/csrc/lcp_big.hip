@@ -350,10 +350,15 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     bool singular_seen = false;
     if (tid == 0) { L.pinv[0] = t[0][0]; L.pinv[1] = fast_rcp(t[0][0]); }
     BIG_TICK(5)                                                             // (profile: W load + diagonal)
+    const int nblk = (ncs + 15) >> 4;                                       // 16-pivot blocks that hold live contacts
     static_for<8>([&](auto KB) LCP_INL {
       constexpr int kb = KB;
+      // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
+      // (but the pivot published for its first step must still be replaced by the next live block's)
+      const int steps = ((kb & 3) < nblk) ? 16 : 0;
+      if constexpr (kb < 7) { if (steps == 0 && tid == 0) { L.pinv[2 * buf] = t[kb + 1][kb + 1]; L.pinv[2 * buf + 1] = fast_rcp(t[kb + 1][kb + 1]); } }
 #pragma unroll 1
-      for (int kk = 0; kk < 16; ++kk) {
+      for (int kk = 0; kk < steps; ++kk) {
         const int k = 16 * kb + kk;
         double* prow = L.prow + buf * NRD;
         double* pcol = L.pcol + buf * NRD;

@@ -20,15 +20,17 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--settle", type=int, default=40, help="untimed steps before the timed region (contacts form)")
     ap.add_argument("--cpu-scenes", type=int, default=2)
+    ap.add_argument("--maxc", type=int, default=16, help="contact capacity per scene")
+    ap.add_argument("--box", type=float, default=40.0)
     args = ap.parse_args()
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics import batched_world as bw
     from lcp_physics_amd.physics import contacts as ct
     dev = torch.device("cuda")
-    w = scenes.make_drop_world(args.batch, nbox=args.nbox)
+    w = scenes.make_drop_world(args.batch, nbox=args.nbox, box=args.box)
     geom = ct.GeometryBatch.from_shapes(w["shapes"], args.batch).to(dev)
     g = lambda k: w[k].to(dev)
-    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=16)
+    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc)
     for _ in range(args.settle):
         world.step()
     world.check_capacity()
