@@ -34,8 +34,8 @@ size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
     const size_t w = lcp::wave64_ws_bytes(compute);
     if (w > per_scene) per_scene = w;
   }
-  if (!lcp::quad_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes() > per_scene)
-    per_scene = lcp::big_ws_bytes();       // (the sizes the quad kernel takes never reach lcp_big.hip)
+  if (!lcp::quad_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes(m) > per_scene)
+    per_scene = lcp::big_ws_bytes(m);      // (the sizes the quad kernel takes never reach lcp_big.hip)
   return (size_t)B * per_scene;
 }
 

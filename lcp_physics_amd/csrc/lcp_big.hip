@@ -25,9 +25,10 @@ namespace big {
 using namespace w64;
 
 constexpr int NT = 256;          // threads per scene
-constexpr int NCB = 64;          // contact capacity
-constexpr int NRD = 128;         // rows of the reduced system
-constexpr int LDU = NRD + 1;     // column stride of the parked factors (odd: the tile store hits 16 banks instead of one)
+constexpr int LX = 64;           // lanes of wave 0 = stride of the exchange buffers and of the stored iterate
+// The kernel is instantiated for a contact capacity NCB of 64, 32 or 16: the reduced system has NRD = 2 NCB rows, the
+// register tile of a thread is TP x TP with TP = NRD / 16 (8, 4, 2), and the LDS footprint (NRD x (NRD + 1) doubles of
+// factors) lets 1, 3 or ~8 scenes share a CU.
 constexpr int EQB = 4;           // padded neq
 constexpr int NZB = 64;          // x-space capacity (lanes of wave 0)
 
@@ -86,17 +87,19 @@ struct Lds {
   float* At;         // [EQB][nzs]
   int* flag;         // [4]: 0 singular pivot, 1 all done, 2 singular S11
 };
+template <int NCB>
 __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
-  L.LU = (double*)take(sizeof(double) * NRD * LDU);
+  constexpr int NRD = 2 * NCB, LDU = NRD + 1;
+  L.LU = (double*)take(sizeof(double) * (NRD * LDU > 2 * NRD * EQB ? NRD * LDU : 2 * NRD * EQB));   // (also the prefactor scratch)
   L.prow = (double*)take(sizeof(double) * 2 * NRD);
   L.pcol = (double*)take(sizeof(double) * 2 * NRD);
-  L.dU = (double*)take(sizeof(double) * NRD);
+  L.dU = (double*)take(sizeof(double) * (NRD > 2 * LX ? NRD : 2 * LX));
   L.pinv = (double*)take(sizeof(double) * 4);
-  L.add = (double*)take(sizeof(double) * 3 * NCB);
+  L.add = (double*)take(sizeof(double) * 3 * LX);
   L.xv = (double*)take(sizeof(double) * NZB);
-  L.wv = (double*)take(sizeof(double) * 2 * NCB);
+  L.wv = (double*)take(sizeof(double) * 2 * LX);
   L.ev = (double*)take(sizeof(double) * EQB);
   L.qid = (double*)take(sizeof(double) * NZB);
   L.S11 = (double*)take(sizeof(double) * EQB * EQB);
@@ -108,26 +111,31 @@ __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
 }
 
 // row r of the stacked Jacobian [Jc; Jt] (r < 64: Jc row r, else Jt row r - 64)
+template <int NCB>
 __device__ __forceinline__ const float* jrow(const Lds& L, int r, int nzs) { return (r < NCB ? L.Jc + (size_t)r * nzs : L.Jt + (size_t)(r - NCB) * nzs); }
 
-constexpr int WS_W = NRD * NRD;                 // workspace per scene (doubles): W tiles ...
-constexpr int WS_IT = WS_W + 64;                // ... then the best iterate the backward needs: x[64] y[8] z[4][64] s[4][64]
-constexpr int WS_TOTAL = WS_IT + 64 + 8 + 8 * NCB;
+// workspace per scene (doubles): W tiles, a 64-entry header (contact count), then the best iterate the backward needs:
+// x[64] y[8] z[4][64] s[4][64]
+template <int NCB> struct WsLayout { static constexpr int W = 4 * NCB * NCB, IT = W + 64, TOTAL = IT + 64 + 8 + 8 * LX; };
 
 // ---------------------------------------------------------------- the kernel
 // BWD = false: fused step (contact list in, v_new out; engines.py:26-78).
 // BWD = true : backward of that step w.r.t. its physical inputs (what lcp_bwd_step_quad does for the small scenes: one
 //              factorisation at the stored iterate, one KKT solve - lcp.py:37-64 - and the contraction of the rank-1
 //              LCP gradients through the engine assembly), reading W and the iterate the forward left in the workspace.
-template <bool BWD>
-__global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
+// (second launch bound = waves per SIMD the register allocation must allow: the small classes share a CU)
+template <int NCB, bool BWD>
+__global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
+  constexpr int NRD = 2 * NCB, LDU = NRD + 1, TP = NRD / 16, TH = TP / 2;
+  constexpr int WS_W = WsLayout<NCB>::W, WS_IT = WsLayout<NCB>::IT, WS_TOTAL = WsLayout<NCB>::TOTAL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool w0 = wave == 0;
   const int ti = tid >> 4, tj = tid & 15;                                 // tile coordinates of the matrix role
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;
-  carve(L, smem, nzs);
+  carve<NCB>(L, smem, nzs);
+  const int lc = lane < NCB ? lane : NCB - 1;                             // (lanes beyond the contact capacity read in bounds, results unused)
   double* Wg = (double*)SP.ws + (size_t)scene * WS_TOTAL;                 // W tiles: Wg[(p * 8 + q) * 256 + tid]
   double* Wit = Wg + WS_IT;                                               // best iterate
   int ncs = ncap;
@@ -175,7 +183,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
   double* CC = L.LU + NRD * EQB;           // [128][EQB]   GA S11
   if (e > 0) {
     if (tid < NRD) {
-      const float* jr = jrow(L, tid, nzs);
+      const float* jr = jrow<NCB>(L, tid, nzs);
       for (int a = 0; a < EQB; ++a) {
         double acc = 0;
         for (int k = 0; k < nz; ++k) acc = fma((double)jr[k] * L.qid[k], (double)L.At[(size_t)a * nzs + k], acc);
@@ -216,33 +224,33 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
   double gan[EQB], gat[EQB], s11row[EQB];
 #pragma unroll
   for (int a = 0; a < EQB; ++a) {
-    gan[a] = (vc && e > 0) ? GA[lane * EQB + a] : 0.0;
-    gat[a] = (vc && e > 0) ? GA[(NCB + lane) * EQB + a] : 0.0;
+    gan[a] = (vc && e > 0) ? GA[lc * EQB + a] : 0.0;
+    gat[a] = (vc && e > 0) ? GA[(NCB + lc) * EQB + a] : 0.0;
     s11row[a] = (w0 && lane < EQB && e > 0) ? L.S11[lane * EQB + a] : 0.0;
   }
   if (!BWD) {
     // W tile of this thread: entries (ti + 16 p, tj + 16 q)
-    double wt_[8][8];
-    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
+    double wt_[TP][TP];
+    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
     for (int k = 0; k < nz; ++k) {
       const double qk = L.qid[k];
-      double ri[8], cj[8];
-      static_for<8>([&](auto P) LCP_INL { ri[P] = (double)jrow(L, ti + 16 * P, nzs)[k] * qk; cj[P] = (double)jrow(L, tj + 16 * P, nzs)[k]; });
-      static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
+      double ri[TP], cj[TP];
+      static_for<TP>([&](auto P) LCP_INL { ri[P] = (double)jrow<NCB>(L, ti + 16 * P, nzs)[k] * qk; cj[P] = (double)jrow<NCB>(L, tj + 16 * P, nzs)[k]; });
+      static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
     }
     if (e > 0) {
       for (int a = 0; a < EQB; ++a) {
-        double ci[8], gj[8];
-        static_for<8>([&](auto P) LCP_INL { ci[P] = CC[(ti + 16 * P) * EQB + a]; gj[P] = GA[(tj + 16 * P) * EQB + a]; });
-        static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
+        double ci[TP], gj[TP];
+        static_for<TP>([&](auto P) LCP_INL { ci[P] = CC[(ti + 16 * P) * EQB + a]; gj[P] = GA[(tj + 16 * P) * EQB + a]; });
+        static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
       }
     }
     // rows / columns of contacts the scene does not have are identity in T: zero here, 1 arrives through addA / addU
-    static_for<8>([&](auto P) LCP_INL {
-      static_for<8>([&](auto Q) LCP_INL {
-        const int ci = (ti + 16 * P) & 63, cj_ = (tj + 16 * Q) & 63;
+    static_for<TP>([&](auto P) LCP_INL {
+      static_for<TP>([&](auto Q) LCP_INL {
+        const int ci = (ti + 16 * P) & (NCB - 1), cj_ = (tj + 16 * Q) & (NCB - 1);
         const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
-        Wg[(size_t)(P * 8 + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
+        Wg[(size_t)(P * TP + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
       });
     });
   }
@@ -265,14 +273,14 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     wsync();
   };
   auto Gtw = [&](double wn, double wt) -> double {                        // x-space <- m-space
-    L.wv[lane] = wn; L.wv[NCB + lane] = wt; wsync();
+    L.wv[lane] = wn; L.wv[LX + lane] = wt; wsync();
     double acc = 0;
     if (lane < nz) {                                                      // (contacts >= ncs have zero rows in Jc / Jt)
       const int n8 = (ncs + 7) & ~7;
       double a0 = 0, a1 = 0;
       for (int c0 = 0; c0 < n8; c0 += 8) {
         float a_[8], b_[8]; double wn_[8], wt_[8];
-        static_for<8>([&](auto I) LCP_INL { const int c = c0 + I; a_[I] = L.Jc[(size_t)c * nzs + lane]; b_[I] = L.Jt[(size_t)c * nzs + lane]; wn_[I] = L.wv[c]; wt_[I] = L.wv[NCB + c]; });
+        static_for<8>([&](auto I) LCP_INL { const int c = c0 + I; a_[I] = L.Jc[(size_t)c * nzs + lane]; b_[I] = L.Jt[(size_t)c * nzs + lane]; wn_[I] = L.wv[c]; wt_[I] = L.wv[LX + c]; });
         static_for<8>([&](auto I) LCP_INL { a0 = fma((double)a_[I], wn_[I], a0); a1 = fma((double)b_[I], wt_[I], a1); });
       }
       acc = a0 + a1;
@@ -323,8 +331,8 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     ridet = 1.0 / (rSp * rDg + 2.0);
     rwa = 2.0 * mu_c * ridet; rwu = -rDg * rSm * ridet;
     L.add[lane] = vc ? D.n : 1.0;
-    L.add[NCB + lane] = vc ? 0.5 * rSm * rwa : 0.0;
-    L.add[2 * NCB + lane] = vc ? 0.5 * (rSp + rSm * rwu) : 1.0;
+    L.add[LX + lane] = vc ? 0.5 * rSm * rwa : 0.0;
+    L.add[2 * LX + lane] = vc ? 0.5 * (rSp + rSm * rwu) : 1.0;
     if (lane == 0) L.flag[0] = 0;                                         // "singular pivot" is per factorisation
   };
 
@@ -336,14 +344,14 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
 #endif
   // ---- factorisation: T = W + diag terms, LU in register tiles, factors to LDS (all 256 threads) ---------------------------
   auto factor = [&]() {
-    double t[8][8];
-    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * 8 + Q) * NT + tid]; }); });
+    double t[TP][TP];
+    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * TP + Q) * NT + tid]; }); });
     if (ti == tj) {
-      static_for<4>([&](auto P) LCP_INL {
+      static_for<TH>([&](auto P) LCP_INL {
         const int c = ti + 16 * P;
         t[P][P] += L.add[c];                                              // (a_c, a_c)
-        t[P + 4][P] += L.add[NCB + c];                                    // (u_c, a_c)
-        t[P + 4][P + 4] += L.add[2 * NCB + c];                            // (u_c, u_c)
+        t[P + TH][P] += L.add[LX + c];                                    // (u_c, a_c)
+        t[P + TH][P + TH] += L.add[2 * LX + c];                           // (u_c, u_c)
       });
     }
     int buf = 0;
@@ -351,12 +359,12 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     if (tid == 0) { L.pinv[0] = t[0][0]; L.pinv[1] = fast_rcp(t[0][0]); }
     BIG_TICK(5)                                                             // (profile: W load + diagonal)
     const int nblk = (ncs + 15) >> 4;                                       // 16-pivot blocks that hold live contacts
-    static_for<8>([&](auto KB) LCP_INL {
+    static_for<TP>([&](auto KB) LCP_INL {
       constexpr int kb = KB;
       // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
       // (but the pivot published for its first step must still be replaced by the next live block's)
-      const int steps = ((kb & 3) < nblk) ? 16 : 0;
-      if constexpr (kb < 7) { if (steps == 0 && tid == 0) { L.pinv[2 * buf] = t[kb + 1][kb + 1]; L.pinv[2 * buf + 1] = fast_rcp(t[kb + 1][kb + 1]); } }
+      const int steps = ((kb % TH) < nblk) ? 16 : 0;
+      if constexpr (kb < TP - 1) { if (steps == 0 && tid == 0) { L.pinv[2 * buf] = t[kb + 1][kb + 1]; L.pinv[2 * buf + 1] = fast_rcp(t[kb + 1][kb + 1]); } }
 #pragma unroll 1
       for (int kk = 0; kk < steps; ++kk) {
         const int k = 16 * kb + kk;
@@ -364,28 +372,28 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
         double* pcol = L.pcol + buf * NRD;
         // the owners of pivot row k publish it, the owners of column k publish the RAW column; after ONE barrier
         // every thread scales its multipliers by 1 / pivot itself (8 multiplies instead of a second barrier)
-        if (ti == kk) static_for<8 - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + 16 * q] = t[kb][q]; });
-        if (tj == kk) static_for<8 - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + 16 * pp] = t[pp][kb]; });
+        if (ti == kk) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + 16 * q] = t[kb][q]; });
+        if (tj == kk) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + 16 * pp] = t[pp][kb]; });
         __syncthreads();
         // every LDS read of the step is issued here, ahead of any use, so that the step pays ONE LDS round trip
         // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
-        double lm[8 - kb], rv[8 - kb];
+        double lm[TP - kb], rv[TP - kb];
         const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
-        static_for<8 - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + 16 * pp]; rv[PP] = prow[tj + 16 * pp]; });
+        static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + 16 * pp]; rv[PP] = prow[tj + 16 * pp]; });
         __builtin_amdgcn_sched_barrier(0);
         singular_seen = singular_seen || (piv == 0.0);
-        static_for<8 - kb>([&](auto PP) LCP_INL {
+        static_for<TP - kb>([&](auto PP) LCP_INL {
           constexpr int pp = kb + PP;
           const double l = lm[PP] * inv;
           lm[PP] = (ti + 16 * pp > k) ? l : 0.0;
           rv[PP] = (tj + 16 * pp > k) ? rv[PP] : 0.0;
           t[pp][kb] = (tj == kk && ti + 16 * pp > k) ? l : t[pp][kb];
         });
-        static_for<8 - kb>([&](auto PP) LCP_INL { static_for<8 - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
+        static_for<TP - kb>([&](auto PP) LCP_INL { static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
         buf ^= 1;
         if (ti == tj && ti == ((kk + 1) & 15)) {                              // next pivot: its owner publishes it with its reciprocal
           double nxt = t[kb][kb];
-          if constexpr (kb < 7) { if (kk == 15) nxt = t[kb + 1][kb + 1]; }
+          if constexpr (kb < TP - 1) { if (kk == 15) nxt = t[kb + 1][kb + 1]; }
           L.pinv[2 * buf] = nxt; L.pinv[2 * buf + 1] = fast_rcp(nxt);
         }
       }
@@ -393,8 +401,8 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     if (singular_seen && tid == 0) L.flag[0] = 1;
     BIG_TICK(6)                                                             // (profile: LU loop)
     // park the factors: column-major, plus the reciprocals of U's diagonal
-    static_for<8>([&](auto P) LCP_INL { static_for<8>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * LDU + ti + 16 * P] = t[P][Q]; }); });
-    if (ti == tj) static_for<8>([&](auto P) LCP_INL { L.dU[ti + 16 * P] = 1.0 / t[P][P]; });
+    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * LDU + ti + 16 * P] = t[P][Q]; }); });
+    if (ti == tj) static_for<TP>([&](auto P) LCP_INL { L.dU[ti + 16 * P] = 1.0 / t[P][P]; });
   };
 
   // ---- T^-1 hz through the reduced system (wave 0); rows: a_c = lane, u_c = 64 + lane --------------------------------------
@@ -408,7 +416,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     const int n8 = (ncs + 7) & ~7;
     for (int k0 = 0; k0 < n8; k0 += 8) {                                  // L y = rhs, columns a_k
       double la[8], lu[8];
-      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(k0 + I) * LDU; la[I] = col[lane]; lu[I] = col[NCB + lane]; });
+      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(k0 + I) * LDU; la[I] = col[lc]; lu[I] = col[NCB + lc]; });
       static_for<8>([&](auto I) LCP_INL {
         const int k = k0 + I;
         const double yk = bcast_lane(ra, k);
@@ -418,7 +426,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     }
     for (int k0 = 0; k0 < n8; k0 += 8) {                                  // columns u_k
       double lu[8];
-      static_for<8>([&](auto I) LCP_INL { lu[I] = L.LU[(size_t)(NCB + k0 + I) * LDU + NCB + lane]; });
+      static_for<8>([&](auto I) LCP_INL { lu[I] = L.LU[(size_t)(NCB + k0 + I) * LDU + NCB + lc]; });
       static_for<8>([&](auto I) LCP_INL {
         const int k = k0 + I;
         const double yk = bcast_lane(ru, k);
@@ -427,7 +435,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     }
     for (int k0 = n8 - 8; k0 >= 0; k0 -= 8) {                             // U x = y, columns u_k
       double ua_[8], uu_[8], du[8];
-      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(NCB + k0 + I) * LDU; ua_[I] = col[lane]; uu_[I] = col[NCB + lane]; du[I] = L.dU[NCB + k0 + I]; });
+      static_for<8>([&](auto I) LCP_INL { const double* col = L.LU + (size_t)(NCB + k0 + I) * LDU; ua_[I] = col[lc]; uu_[I] = col[NCB + lc]; du[I] = L.dU[NCB + k0 + I]; });
       static_for<8>([&](auto IR) LCP_INL {
         constexpr int I = 7 - IR;
         const int k = k0 + I;
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     }
     for (int k0 = n8 - 8; k0 >= 0; k0 -= 8) {                             // columns a_k
       double ua_[8], du[8];
-      static_for<8>([&](auto I) LCP_INL { ua_[I] = L.LU[(size_t)(k0 + I) * LDU + lane]; du[I] = L.dU[k0 + I]; });
+      static_for<8>([&](auto I) LCP_INL { ua_[I] = L.LU[(size_t)(k0 + I) * LDU + lc]; du[I] = L.dU[k0 + I]; });
       static_for<8>([&](auto IR) LCP_INL {
         constexpr int I = 7 - IR;
         const int k = k0 + I;
@@ -517,8 +525,8 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     if (w0) {
       x = (lane < nz) ? Wit[lane] : 0.0;
       if (vc) {
-        z = m4<double>(Wit[72 + lane], Wit[72 + NCB + lane], Wit[72 + 2 * NCB + lane], Wit[72 + 3 * NCB + lane]);
-        s = m4<double>(Wit[72 + 4 * NCB + lane], Wit[72 + 5 * NCB + lane], Wit[72 + 6 * NCB + lane], Wit[72 + 7 * NCB + lane]);
+        z = m4<double>(Wit[72 + lane], Wit[72 + LX + lane], Wit[72 + 2 * LX + lane], Wit[72 + 3 * LX + lane]);
+        s = m4<double>(Wit[72 + 4 * LX + lane], Wit[72 + 5 * LX + lane], Wit[72 + 6 * LX + lane], Wit[72 + 7 * LX + lane]);
         dinv = m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                 // 1 / d, d = z / s (lcp.py:44)
       }
       reduce_setup(dinv);
@@ -527,13 +535,13 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     factor();                                                               // lcp.py:46
     __syncthreads();
     if (!w0) return;
-    ua = L.dU[lane]; uu = L.dU[NCB + lane];
+    ua = L.dU[lc]; uu = L.dU[NCB + lc];
     // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
     const double g = (lane < nz) ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
     const M4<double> zero = m4<double>(0, 0, 0, 0);
     solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu);                   // lcp.py:47-50
     // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
-    double* X = L.xv; double* DX = L.wv; double* CR = L.add; double* CF = L.add + NCB; int* B12 = (int*)(L.add + 2 * NCB);
+    double* X = L.xv; double* DX = L.wv; double* CR = L.add; double* CF = L.add + LX; int* B12 = (int*)(L.add + 2 * LX);
     X[lane] = x; DX[lane] = dx; wsync();
     double gh_rbar = 0;
     {
@@ -567,7 +575,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
         d2x = -gjn[3] * ny + gjf[3] * nx; d2y = gjn[3] * nx + gjf[3] * ny;
       }
       wsync();
-      CR[lane] = cr; CF[lane] = cf; B12[lane] = b1; B12[NCB + lane] = b2;
+      CR[lane] = cr; CF[lane] = cf; B12[lane] = b1; B12[LX + lane] = b2;
       if (lane < ncap) {
         const size_t cb = (size_t)scene * ncap + lane;
         if (Gd.dcn) { ((float*)Gd.dcn)[cb * 2] = (float)dnx; ((float*)Gd.dcn)[cb * 2 + 1] = (float)dny; }
@@ -586,7 +594,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     if (lane < nb) {                                                          // per-body sums over the contacts, fixed order
       double ar = 0, af = 0;
       for (int c = 0; c < ncs; ++c) {
-        const double w = ((B12[c] == lane) ? 1.0 : 0.0) + ((B12[NCB + c] == lane) ? 1.0 : 0.0);
+        const double w = ((B12[c] == lane) ? 1.0 : 0.0) + ((B12[LX + c] == lane) ? 1.0 : 0.0);
         if (w != 0.0) { ar += w * CR[c]; af += w * CF[c]; }
       }
       if (Gd.drest) ((float*)Gd.drest)[(size_t)scene * nb + lane] = (float)ar;
@@ -638,7 +646,7 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
     __syncthreads();
     BIG_TICK(1)                                                             // factorisation
     if (w0) {
-      ua = L.dU[lane]; uu = L.dU[NCB + lane];
+      ua = L.dU[lc]; uu = L.dU[NCB + lc];
       const bool singular = L.flag[0] != 0;
       if (it >= 0 && !done) {
         ++iters;
@@ -721,8 +729,8 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
   // the iterate the backward starts from (lcp.py:29 keeps nus, lams, slacks on the op)
   Wit[lane] = (lane < nz) ? bx : 0.0;
   if (lane < 8) Wit[64 + lane] = (lane < e) ? by : 0.0;
-  Wit[72 + lane] = bz.n; Wit[72 + NCB + lane] = bz.f1; Wit[72 + 2 * NCB + lane] = bz.f2; Wit[72 + 3 * NCB + lane] = bz.g;
-  Wit[72 + 4 * NCB + lane] = bs.n; Wit[72 + 5 * NCB + lane] = bs.f1; Wit[72 + 6 * NCB + lane] = bs.f2; Wit[72 + 7 * NCB + lane] = bs.g;
+  Wit[72 + lane] = bz.n; Wit[72 + LX + lane] = bz.f1; Wit[72 + 2 * LX + lane] = bz.f2; Wit[72 + 3 * LX + lane] = bz.g;
+  Wit[72 + 4 * LX + lane] = bs.n; Wit[72 + 5 * LX + lane] = bs.f1; Wit[72 + 6 * LX + lane] = bs.f2; Wit[72 + 7 * LX + lane] = bs.g;
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_BIG_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
@@ -732,21 +740,39 @@ __global__ void __launch_bounds__(NT) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd
 
 }  // namespace big
 
-// nz <= 43: the two 64 x nz Jacobians have to fit next to the 128 KB of factors in the 160 KB of LDS
-bool big_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= big::NCB) && nz <= 43 && e <= big::EQB; }
-size_t big_ws_bytes() { return sizeof(double) * big::WS_TOTAL; }
+// capacity class of a scene batch: 16, 32 or 64 contacts
+static inline int big_class(int nc) { return nc <= 16 ? 16 : (nc <= 32 ? 32 : 64); }
+// 64 contacts: nz <= 43 (the two 64 x nz Jacobians have to fit next to the 129 KB of factors in the 160 KB of LDS);
+// smaller classes: nz <= 48 (16 bodies, the contact kernel's limit)
+bool big_supported(int nz, int m, int e) {
+  if ((m % 4) != 0 || m / 4 > 64 || e > big::EQB) return false;
+  return (m / 4 > 32) ? nz <= 43 : nz <= 48;
+}
+size_t big_ws_bytes(int m) {
+  const int c = big_class(m / 4);
+  const int total = c == 16 ? big::WsLayout<16>::TOTAL : (c == 32 ? big::WsLayout<32>::TOTAL : big::WsLayout<64>::TOTAL);
+  return sizeof(double) * (size_t)total;
+}
 
-template <bool BWD>
+template <int NCB, bool BWD>
 static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   const int nz = 3 * SP.nb, nzs = nz | 1;
   big::Lds L;
-  const size_t lds = big::carve(L, nullptr, nzs);
-  auto k = big::lcp_big_kernel<BWD>;
+  const size_t lds = big::carve<NCB>(L, nullptr, nzs);
+  auto k = big::lcp_big_kernel<NCB, BWD>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LCP_E_LAUNCH;
   hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::NT), lds, (hipStream_t)stream, SP, Gd, nzs);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
-int big_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return big_launch<false>(SP, Gd, stream); }
-int big_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return big_launch<true>(SP, Gd, stream); }
+template <bool BWD>
+static int big_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
+  switch (big_class(SP.nc)) {
+    case 16: return big_launch<16, BWD>(SP, Gd, stream);
+    case 32: return big_launch<32, BWD>(SP, Gd, stream);
+    default: return big_launch<64, BWD>(SP, Gd, stream);
+  }
+}
+int big_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return big_dispatch<false>(SP, Gd, stream); }
+int big_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return big_dispatch<true>(SP, Gd, stream); }
 
 }  // namespace lcp

@@ -103,7 +103,7 @@ int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, voi
 
 // workgroup-per-scene contact-structured forward for up to 64 contacts (fused step, forward only) - lcp_big.hip
 bool big_supported(int nz, int m, int e);
-size_t big_ws_bytes();
+size_t big_ws_bytes(int m);
 int big_step(const StepArgs& P, void* stream);
 int big_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
 

@@ -326,6 +326,35 @@ def test_contact_world_beyond_the_quad_sizes_follows_oracle():
         assert np.abs(world.p[s].cpu().numpy() - p).max() < 2e-4 and np.abs(world.v[s].double().cpu().numpy() - v).max() < 2e-3, s
 
 
+def test_mid_size_scenes_use_the_small_capacity_classes():
+    """6 bodies / <= 16 contacts and 7 bodies / <= 32 contacts (nz > 16: not the quad kernel's) run on the 16- and
+    32-contact instantiations of lcp_big.hip: new_v against the generic kernels and the fp64 oracle."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    from oracle import pdipm_oracle as O
+    for nbox, pts in ((5, 2), (6, 4)):                     # 10 contacts (class 16) and 24 contacts (class 32)
+        B = 10
+        sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=40 + nbox, dtype=torch.float32)
+        scg = sc.to(device=DEV)
+        cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+        counts = [sc.nc, sc.nc, sc.nc - 2, sc.nc // 2, 1, 0, sc.nc, 3, sc.nc - 1, sc.nc]
+        count = torch.tensor(counts, dtype=torch.int32, device=DEV)
+        run = lambda: solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+        got = run()["v_new"].double().cpu()
+        _lib.set_path("generic")
+        try:
+            gen = run()["v_new"].double().cpu()
+        finally:
+            _lib.set_path("auto")
+        assert float((got - gen).abs().max()) <= 1e-5 * max(1.0, float(gen.abs().max())), (nbox, float((got - gen).abs().max()))
+        k = 0                                               # full contact list: against the oracle
+        lcp64 = [None if t is None else t[k:k + 1].double() for t in O.assemble_lcp(*sc.assembly_args())]
+        ref = -O.lcp_forward(*lcp64).x.reshape(sc.nb, 3)
+        assert float((got[k] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_config5_pile_solve_dynamics_matches_oracle():
     """BASELINE config 5 shape (11 bodies, 64 contacts, nineq 256) through lcp_solve_dynamics_f32 = the register-tiled
     workgroup-per-scene kernel (lcp_big.hip), with ragged contact counts: new_v within 1e-4 (scaled) of the fp64 oracle
