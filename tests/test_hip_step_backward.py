@@ -100,6 +100,37 @@ def test_variable_contact_counts_and_padding():
     assert float(pg["rest"][free].abs().max()) == 0.0 and float(pg["fric"][free].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("nbox,pts", [(5, 2), (6, 4)])
+def test_mid_size_backward_matches_generic_dense(nbox, pts):
+    """6 bodies / 10 contacts and 7 bodies / 24 contacts: the 16- and 32-contact instantiations of lcp_big.hip, backward
+    against the generic kernels' dense gradients contracted by autograd (parameters entering through Q and p)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, fused_step_backward, solution_of_step, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 16
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=60 + nbox, dtype=torch.float32)
+    scg = sc.to(device=DEV)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(13), dtype=torch.float32)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
+    out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+    pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
+    gen = fused_step(scg)
+    lcp = assemble_contacts(scg)
+    dense = lcp_backward(solution_of_step(scg, gen, lcp[2], lcp[4]), (-cot).reshape(B, -1).to(DEV))
+    torch.cuda.synchronize()
+    dense = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", dense)}
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    ref = parity.physical_grads(ph, sc.dt, dense, O)
+    for k in ("Mdiag", "v", "f"):
+        scale = ref[k].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+        err = (pg[k] - ref[k]).abs().reshape(B, -1).max(dim=1)[0] / scale
+        big = scale > 1e-6 * scale.max()
+        assert float(err[big].max()) < 2e-3, (k, float(err[big].max()), int(err.argmax()))
+
+
 def test_large_scene_backward_matches_generic_dense_and_oracle():
     """Config-5 sized piles (11 bodies, 64 contacts): `lcp_step_backward_f32` after `lcp_solve_dynamics_f32` (both in
     lcp_big.hip) against (a) the generic kernels' dense backward contracted by autograd and (b) the fp64 oracle."""
