@@ -30,11 +30,11 @@ size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   size_t per_scene = pl.ws_stride * cs;
-  if (lcp::wave64_supported(nz, m, e)) {
+  if (lcp::wave64_supported(nz, m, e) || lcp::quad_step_supported(nz, m, e)) {   // (lcp_quad.hip uses the wave64 layout)
     const size_t w = lcp::wave64_ws_bytes(compute);
     if (w > per_scene) per_scene = w;
   }
-  if (!lcp::quad_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes(m) > per_scene)
+  if (!lcp::quad_step_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes(m) > per_scene)
     per_scene = lcp::big_ws_bytes(m);      // (the sizes the quad kernel takes never reach lcp_big.hip)
   return (size_t)B * per_scene;
 }
@@ -185,7 +185,7 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
   lcp::StepBwdArgs G;
   G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
   G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
-  if (lcp::quad_supported(3 * nb, 4 * nc, e)) return lcp::quad_step_backward(P, G, compute, stream);
+  if (lcp::quad_step_supported(3 * nb, 4 * nc, e)) return lcp::quad_step_backward(P, G, compute, stream);
   // larger scenes: the forward must have been lcp_solve_dynamics_f32 (the lcp_big.hip kernel owns the workspace layout)
   if (compute == LCP_COMPUTE_F64 && lcp::big_supported(3 * nb, 4 * nc, e)) return lcp::big_step_backward(P, G, stream);
   return LCP_E_TOOLARGE;
@@ -207,7 +207,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  if (lcp::quad_supported(nz, m, e) && g_path != 1) return lcp::quad_step(P, compute, stream);
+  if (lcp::quad_step_supported(nz, m, e) && g_path != 1) return lcp::quad_step(P, compute, stream);
   // up to 64 contacts: the register-tiled workgroup-per-scene kernel (forward only; see lcp_hip.h)
   if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e) && g_path != 1) return lcp::big_step(P, stream);
   // any other size: the generic workgroup-per-scene kernels (forward only)

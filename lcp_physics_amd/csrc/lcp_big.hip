@@ -130,7 +130,10 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
   constexpr int WS_W = WsLayout<NCB>::W, WS_IT = WsLayout<NCB>::IT, WS_TOTAL = WsLayout<NCB>::TOTAL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool w0 = wave == 0;
+  // The wave that plays the vector role rotates with the block index: the dispatcher puts wave i of every workgroup on
+  // SIMD i, so with a fixed choice the (serial, busy) vector waves of all the scenes sharing a CU would queue up on one
+  // SIMD while the other three idle.  Blocks 256 apart are the ones that tend to share a CU.
+  const bool w0 = wave == (NCB == 64 ? 0 : (int)((blockIdx.x >> 8) & 3));
   const int ti = tid >> 4, tj = tid & 15;                                 // tile coordinates of the matrix role
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;

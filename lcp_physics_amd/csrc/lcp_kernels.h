@@ -96,6 +96,7 @@ int wave64_step(const StepArgs& P, int compute, void* stream);
 // four-scenes-per-wave contact-structured path (nc <= 16, nz <= 16, neq <= 4, diagonal Q) - lcp_quad.hip
 // `accept`: classification flag value (workspace meta[0]) the launch serves
 bool quad_supported(int nz, int m, int e);
+bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream);
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
 int quad_step(const StepArgs& P, int compute, void* stream);

@@ -163,83 +163,99 @@ struct LdsQ {
 constexpr int NRED = 32;                                   // rows of the reduced system: a_0..a_15, u_0..u_15
 __host__ __device__ constexpr int wl_row(int i) { return i * NRED - (i * (i - 1)) / 2 - i; }   // (i, j >= i) lives at wl_row(i) + j
 constexpr int WL_ELEMS = NRED * (NRED + 1) / 2;
+// `xh` = x-space halves: 1 (nz <= 16, one entry per lane) or 2 (nz <= 32, entries j and 16 + j per lane); it is the row
+// length of GL / GTL / AtL in units of 16
 template <typename TI, typename TC>
-__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, bool with_w) {
+__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, bool with_w, int xh = 1) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
   L.GAL = (TC*)take(sizeof(TC) * NCQ * 2 * EQ);
   L.S11 = (TC*)take(sizeof(TC) * EQ * EQ);
-  L.GL = (TI*)take(sizeof(TI) * NCQ * 16);
-  L.GTL = (TI*)take(sizeof(TI) * NCQ * 16);
-  L.AtL = (TI*)take(sizeof(TI) * EQ * 16);
+  L.GL = (TI*)take(sizeof(TI) * NCQ * 16 * xh);
+  L.GTL = (TI*)take(sizeof(TI) * NCQ * 16 * xh);
+  L.AtL = (TI*)take(sizeof(TI) * EQ * 16 * xh);
   L.WL = with_w ? (TC*)take(sizeof(TC) * WL_ELEMS + 16) : nullptr;   // (+16 B: scene blocks do not all start on the same LDS bank)
   return (size_t)(q - smem);
 }
 
 // ---------------------------------------------------------------- per-lane scene data and products
-template <typename TI, typename TC>
+// An x-space vector: entry 16 h + l16 of the scene's nz-vector for h < XH (XH = 1: nz <= 16, the tuned headline case;
+// XH = 2: nz <= 32, six to ten bodies).
+template <typename TC, int XH> struct XV { TC v[XH]; };
+
+template <typename TI, typename TC, int XH = 1>
 struct SceneQ {
+  static constexpr int RS = 16 * XH;     // row length of GL / GTL / AtL
   LdsQ<TI, TC> L;
   int nz, nc, e, l16;      // nc: live contacts of THIS scene (row-uniform)
   int ncw, ncap;          // ncw: max nc over the scenes of the wave (loop bound); ncap: contact capacity (array strides)
-  TI jc[16], jt[16];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
+  TI jc[RS], jt[RS];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
   TC gan[EQ], gat[EQ];    // (J Q^-1 A^T) rows of this contact
   TC s11row[EQ];          // row l16 of (A Q^-1 A^T)^-1
-  TC qd, qid;             // Q[j][j], 1 / Q[j][j] for j = l16
+  TC qd[XH], qid[XH];     // Q[j][j], 1 / Q[j][j] for j = 16 h + l16
   TC mu;                  // friction coefficient of this contact
 
   // m-space <- x-space:  (Jc v)_c and (Jt v)_c
   // (the wave is alone on its SIMD: a single accumulator would serialise on the FMA latency, so every product below
   //  runs two to four independent partial sums)
-  __device__ __forceinline__ void Gv(TC v, TC& gn, TC& gt) const {
+  __device__ __forceinline__ void Gv(const XV<TC, XH>& v, TC& gn, TC& gt) const {
     TC n0 = 0, n1 = 0, t0 = 0, t1 = 0;
-    static_for<8>([&](auto H) LCP_INL {
-      constexpr int J = 2 * H;
-      fmac_bc<J>(n0, v, (TC)launder(jc[J])); fmac_bc<J>(t0, v, (TC)launder(jt[J]));
-      fmac_bc<J + 1>(n1, v, (TC)launder(jc[J + 1])); fmac_bc<J + 1>(t1, v, (TC)launder(jt[J + 1]));
+    static_for<8 * XH>([&](auto H) LCP_INL {
+      constexpr int J = 2 * H, hx = J >> 4;
+      fmac_bc<J & 15>(n0, v.v[hx], (TC)launder(jc[J])); fmac_bc<J & 15>(t0, v.v[hx], (TC)launder(jt[J]));
+      fmac_bc<(J + 1) & 15>(n1, v.v[hx], (TC)launder(jc[J + 1])); fmac_bc<(J + 1) & 15>(t1, v.v[hx], (TC)launder(jt[J + 1]));
     });
     gn = n0 + n1; gt = t0 + t1;
   }
   // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
-  __device__ __forceinline__ TC Gtw(TC wn, TC wt) const {
-    TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  __device__ __forceinline__ XV<TC, XH> Gtw(TC wn, TC wt) const {
+    XV<TC, XH> out;
     const int oz = lds_opaque_zero();
-    const TI* gl = L.GL + l16 + oz;
-    const TI* gtl = L.GTL + l16 + oz;
-    // two batches of 16 LDS loads, each fenced from its FMAs: left alone, the register-starved scheduler issues one
-    // ds_read per FMA pair and waits out the LDS latency sixteen times per product
-    static_for<2>([&](auto Hh) LCP_INL {
-      constexpr int C0 = 8 * Hh;
-      TI gv[8], tv[8];
-      static_for<8>([&](auto I) LCP_INL { gv[I] = gl[(C0 + I) * 16]; tv[I] = gtl[(C0 + I) * 16]; });
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<4>([&](auto H) LCP_INL {
-        constexpr int I = 2 * H, C = C0 + I;
-        fmac_bc<C>(a0, wn, (TC)gv[I]);
-        fmac_bc<C>(a1, wt, (TC)tv[I]);
-        fmac_bc<C + 1>(a2, wn, (TC)gv[I + 1]);
-        fmac_bc<C + 1>(a3, wt, (TC)tv[I + 1]);
+    static_for<XH>([&](auto HX) LCP_INL {
+      TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      const TI* gl = L.GL + 16 * HX + l16 + oz;
+      const TI* gtl = L.GTL + 16 * HX + l16 + oz;
+      // two batches of 16 LDS loads, each fenced from its FMAs: left alone, the register-starved scheduler issues one
+      // ds_read per FMA pair and waits out the LDS latency sixteen times per product
+      static_for<2>([&](auto Hh) LCP_INL {
+        constexpr int C0 = 8 * Hh;
+        TI gv[8], tv[8];
+        static_for<8>([&](auto I) LCP_INL { gv[I] = gl[(C0 + I) * RS]; tv[I] = gtl[(C0 + I) * RS]; });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto H) LCP_INL {
+          constexpr int I = 2 * H, C = C0 + I;
+          fmac_bc<C>(a0, wn, (TC)gv[I]);
+          fmac_bc<C>(a1, wt, (TC)tv[I]);
+          fmac_bc<C + 1>(a2, wn, (TC)gv[I + 1]);
+          fmac_bc<C + 1>(a3, wt, (TC)tv[I + 1]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
-      __builtin_amdgcn_sched_barrier(0);
+      out.v[HX] = (a0 + a1) + (a2 + a3);
     });
-    return (a0 + a1) + (a2 + a3);
+    return out;
   }
-  __device__ __forceinline__ TC Av(TC v) const {        // e-space <- x-space
+  __device__ __forceinline__ TC Av(const XV<TC, XH>& v) const {        // e-space <- x-space
     TC a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const TI* ar = L.AtL + (l16 & (EQ - 1)) * 16 + lds_opaque_zero();   // row l16 of A (rows >= e are zero; lanes >= EQ unused)
-    static_for<4>([&](auto H) LCP_INL {
-      constexpr int K = 4 * H;
-      fmac_bc<K>(a0, v, (TC)ar[K]); fmac_bc<K + 1>(a1, v, (TC)ar[K + 1]);
-      fmac_bc<K + 2>(a2, v, (TC)ar[K + 2]); fmac_bc<K + 3>(a3, v, (TC)ar[K + 3]);
+    const TI* ar = L.AtL + (l16 & (EQ - 1)) * RS + lds_opaque_zero();   // row l16 of A (rows >= e are zero; lanes >= EQ unused)
+    static_for<4 * XH>([&](auto H) LCP_INL {
+      constexpr int K = 4 * H, hx = K >> 4;
+      fmac_bc<K & 15>(a0, v.v[hx], (TC)ar[K]); fmac_bc<(K + 1) & 15>(a1, v.v[hx], (TC)ar[K + 1]);
+      fmac_bc<(K + 2) & 15>(a2, v.v[hx], (TC)ar[K + 2]); fmac_bc<(K + 3) & 15>(a3, v.v[hx], (TC)ar[K + 3]);
     });
     return (l16 < EQ) ? (a0 + a1) + (a2 + a3) : (TC)0;
   }
-  __device__ __forceinline__ TC Aty(TC y) const {       // x-space <- e-space
-    TC a0 = 0, a1 = 0;
-    const TI* at = L.AtL + l16 + lds_opaque_zero();
-    fmac_bc<0>(a0, y, (TC)at[0]); fmac_bc<1>(a1, y, (TC)at[16]);
-    fmac_bc<2>(a0, y, (TC)at[32]); fmac_bc<3>(a1, y, (TC)at[48]);
-    return a0 + a1;
+  __device__ __forceinline__ XV<TC, XH> Aty(TC y) const {       // x-space <- e-space
+    XV<TC, XH> out;
+    const int oz = lds_opaque_zero();
+    static_for<XH>([&](auto HX) LCP_INL {
+      TC a0 = 0, a1 = 0;
+      const TI* at = L.AtL + 16 * HX + l16 + oz;
+      fmac_bc<0>(a0, y, (TC)at[0]); fmac_bc<1>(a1, y, (TC)at[RS]);
+      fmac_bc<2>(a0, y, (TC)at[2 * RS]); fmac_bc<3>(a1, y, (TC)at[3 * RS]);
+      out.v[HX] = a0 + a1;
+    });
+    return out;
   }
   __device__ __forceinline__ void GAt(TC t, TC& gn, TC& gt) const {     // m-space <- e-space
     gn = 0; gt = 0;
@@ -397,8 +413,8 @@ template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_u(float 
   static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; tu[j] = fmaf(-lu, bc<K>(tu[j]), tu[j]); });
 }
 
-template <typename TI, typename TC, bool LDSW>
-__device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC>& S, const TC* W2q,
+template <typename TI, typename TC, bool LDSW, int XH>
+__device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC, XH>& S, const TC* W2q,
                                          const M4<TC>& D, bool valid LCP_QPROF_ARG) {
   const int l16 = launder(S.l16), nc = __builtin_amdgcn_readfirstlane(S.ncw);     // (keeps the step guards scalar branches)
   R.Dg = D.g;
@@ -485,8 +501,8 @@ __device__ __forceinline__ bool factor_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R
 }
 
 // T^-1 hz through the reduced system; everything except the two triangular sweeps is lane-local.
-template <typename TI, typename TC>
-__device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R, const SceneQ<TI, TC>& S,
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R, const SceneQ<TI, TC, XH>& S,
                                            const M4<TC>& hz) {
   const int l16 = S.l16, nc = __builtin_amdgcn_readfirstlane(S.ncw);
   const TC r12 = hz.f1 + hz.f2;
@@ -535,11 +551,12 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
 }
 
 // solve_kkt (pdipm.py:325-354).  rs, rz given per contact (M4), rx in x-space, ry in e-space.
-template <typename TI, typename TC>
-__device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R,
-                                            const M4<TC>& di, bool valid, TC rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
-                                            TC& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
-  const TC v = S.qid * rx;                                                 // :333 (diagonal Q)
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC, XH>& S, const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R,
+                                            const M4<TC>& di, bool valid, const XV<TC, XH>& rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
+                                            XV<TC, XH>& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
+  XV<TC, XH> v;
+  static_for<XH>([&](auto HX) LCP_INL { v.v[HX] = S.qid[HX] * rx.v[HX]; });    // :333 (diagonal Q)
   TC gn, gt;
   S.Gv(v, gn, gt);
   // `di` = 1 / d (already formed for T = R + diag(1/d)): rs / d is taken as rs * di - one rounding more than the
@@ -554,7 +571,7 @@ __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&
   }
   if (!valid) hz = m4<TC>(0, 0, 0, 0);
   LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
-  const M4<TC> wz = tsolve_q<TI, TC>(ta, tu, R, S, hz);
+  const M4<TC> wz = tsolve_q<TI, TC, XH>(ta, tu, R, S, hz);
   LCP_QTICK(pr, 4)                                                         // triangular sweeps
   TC dy = 0;
   if (S.e > 0) dy = -S.S11v(hy - S.GAtw(valid ? wz.n : (TC)0, valid ? wz.f1 - wz.f2 : (TC)0));    // dy = -wy
@@ -563,9 +580,11 @@ __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC>& S, const TC (&
   os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
   if (!valid) os = m4<TC>(0, 0, 0, 0);
   oy = dy;
-  TC g1 = -rx - S.Gtw(oz.n, oz.f1 - oz.f2);                                // :344-346
-  if (S.e > 0) g1 -= S.Aty(dy);
-  ox = S.qid * g1;                                                         // :349
+  const XV<TC, XH> gw = S.Gtw(oz.n, oz.f1 - oz.f2);                        // :344-346
+  XV<TC, XH> g1;
+  static_for<XH>([&](auto HX) LCP_INL { g1.v[HX] = -rx.v[HX] - gw.v[HX]; });
+  if (S.e > 0) { const XV<TC, XH> ay = S.Aty(dy); static_for<XH>([&](auto HX) LCP_INL { g1.v[HX] -= ay.v[HX]; }); }
+  static_for<XH>([&](auto HX) LCP_INL { ox.v[HX] = S.qid[HX] * g1.v[HX]; });    // :349
   LCP_QTICK(pr, 5)                                                         // solve_kkt: products after
 }
 
@@ -594,19 +613,22 @@ __device__ __forceinline__ TC step_pair_q(const M4<TC>& z, const M4<TC>& dz, con
 
 // workspace view of the quad path: W (8 KB) in the R2 region, the rest in the w64 fields
 //   W2q[((p*2 + slot)*16 + lane)*2 + (q&1)], p = q>>1, slot 0 = row a_lane, 1 = row u_lane
-template <typename TI, typename TC>
-__device__ __forceinline__ void store_scene_ws(const Ws<TI, TC>& W, const SceneQ<TI, TC>& S) {
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ void store_scene_ws(const Ws<TI, TC>& W, const SceneQ<TI, TC, XH>& S) {
   const int l16 = S.l16;
   static_for<EQ>([&](auto A) LCP_INL { W.GAc[(l16 * 2 + 0) * EQ + A] = S.gan[A]; W.GAc[(l16 * 2 + 1) * EQ + A] = S.gat[A]; });
   static_for<EQ>([&](auto C) LCP_INL { if (l16 < EQ) W.S11i[l16 * EQ + C] = S.s11row[C]; });
-  W.Qit[l16] = S.qid;
+  static_for<XH>([&](auto HX) LCP_INL { W.Qit[16 * HX + l16] = S.qid[HX]; });
 }
+// where the x-space part of the best iterate lives in the workspace: the 16-entry x field, or (nz > 16) a free stretch
+// of the Q^-1 field, which this path only uses for the diagonal
+template <int XH, typename TI, typename TC> __device__ __forceinline__ TC* ws_x(const Ws<TI, TC>& W) { return XH == 1 ? W.x : W.Qit + 64; }
 
 // ---------------------------------------------------------------- inputs
 // dense contact-structured LCP -> per-lane rows (+ LDS copies for the transposed products)
 template <typename TI, typename TC>
-__device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P, const Ws<TI, TC>& W, int scene,
-                                             TC& p, TC& hn, TC& b) {
+__device__ __forceinline__ void load_dense_q(SceneQ<TI, TC, 1>& S, const FwdArgs& P, const Ws<TI, TC>& W, int scene,
+                                             XV<TC, 1>& p, TC& hn, TC& b) {
   const int nz = S.nz, nc = S.ncap, e = S.e, l16 = S.l16, m = 4 * nc;
   const bool vc = l16 < S.nc;
   const TI* Grow_n = (const TI*)P.G + ((size_t)scene * m + (vc ? l16 : 0)) * nz;
@@ -622,23 +644,24 @@ __device__ __forceinline__ void load_dense_q(SceneQ<TI, TC>& S, const FwdArgs& P
     if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
   });
   const TI q = (l16 < nz) ? ((const TI*)P.Q)[(size_t)scene * nz * nz + l16 * nz + l16] : (TI)1;
-  S.qd = (l16 < nz) ? (TC)q : (TC)0;
-  S.qid = (l16 < nz) ? (TC)1 / (TC)q : (TC)0;
+  S.qd[0] = (l16 < nz) ? (TC)q : (TC)0;
+  S.qid[0] = (l16 < nz) ? (TC)1 / (TC)q : (TC)0;
   S.mu = vc ? W.meta[1 + l16] : (TC)0;
-  p = (l16 < nz) ? (TC)((const TI*)P.p)[(size_t)scene * nz + l16] : (TC)0;
+  p.v[0] = (l16 < nz) ? (TC)((const TI*)P.p)[(size_t)scene * nz + l16] : (TC)0;
   hn = vc ? (TC)((const TI*)P.h)[(size_t)scene * m + l16] : (TC)0;
   b = (l16 < e) ? (TC)((const TI*)P.b)[(size_t)scene * e + l16] : (TC)0;
 }
 
 // contact list -> per-lane rows (physics/engines.py:31-32,50-74; physics/world.py:144-234)
-template <typename TI, typename TC>
-__device__ __forceinline__ void assemble_q(SceneQ<TI, TC>& S, const StepArgs& P, int scene, TC& p, TC& hn, TC& b) {
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ void assemble_q(SceneQ<TI, TC, XH>& S, const StepArgs& P, int scene, XV<TC, XH>& p, TC& hn, TC& b) {
+  constexpr int RS = 16 * XH;
   const int nb = P.nb, nc = S.ncap, nz = S.nz, e = S.e, l16 = S.l16;
   const bool vc = l16 < S.nc;
   const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
   const TI* vv = (const TI*)P.v + (size_t)scene * nz;
   const TI* ff = (const TI*)P.f + (size_t)scene * nz;
-  static_for<16>([&](auto J) LCP_INL { S.L.GL[l16 * 16 + J] = (TI)0; S.L.GTL[l16 * 16 + J] = (TI)0; });
+  static_for<RS>([&](auto J) LCP_INL { S.L.GL[l16 * RS + J] = (TI)0; S.L.GTL[l16 * RS + J] = (TI)0; });
   TI hrow = (TI)0, mu = (TI)0;
   if (vc) {
     const ContactRows<TI> r = make_contact<TI>((const TI*)P.c_n + (size_t)scene * nc * 2, (const TI*)P.c_p1 + (size_t)scene * nc * 2,
@@ -648,47 +671,53 @@ __device__ __forceinline__ void assemble_q(SceneQ<TI, TC>& S, const StepArgs& P,
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
-      S.L.GL[l16 * 16 + col] = r.jn[q];
-      S.L.GTL[l16 * 16 + col] = r.jf[q];
+      S.L.GL[l16 * RS + col] = r.jn[q];
+      S.L.GTL[l16 * RS + col] = r.jf[q];
     }
     hrow = r.h; mu = r.mu;
   }
-  static_for<16>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * 16 + J]; S.jt[J] = S.L.GTL[l16 * 16 + J]; });   // own row only
+  static_for<RS>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * RS + J]; S.jt[J] = S.L.GTL[l16 * RS + J]; });   // own row only
   const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
-  static_for<16>([&](auto K) LCP_INL {
-    if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
+  static_for<RS>([&](auto K) LCP_INL {
+    if (l16 < EQ) S.L.AtL[l16 * RS + K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
   });
-  const TI q = (l16 < nz) ? Md[l16] : (TI)1;
-  S.qd = (l16 < nz) ? (TC)q : (TC)0;
-  S.qid = (l16 < nz) ? (TC)1 / (TC)q : (TC)0;
+  static_for<XH>([&](auto HX) LCP_INL {
+    const int j = 16 * HX + l16;
+    const TI q = (j < nz) ? Md[j] : (TI)1;
+    S.qd[HX] = (j < nz) ? (TC)q : (TC)0;
+    S.qid[HX] = (j < nz) ? (TC)1 / (TC)q : (TC)0;
+    p.v[HX] = (j < nz) ? (TC)momentum_entry<TI>(Md[j], vv[j], (TI)P.dt, ff[j]) : (TC)0;     // engines.py:32
+  });
   S.mu = (TC)mu;
-  p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16], vv[l16], (TI)P.dt, ff[l16]) : (TC)0;     // engines.py:32
   hn = (TC)hrow;
   b = (TC)0;
 }
 
 // pre_factor_kkt for diagonal Q: G Q^-1 A^T rows, (A Q^-1 A^T)^-1, W = J P J^T into the workspace
-template <typename TI, typename TC>
-__device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& W, bool live) {
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ int prefactor_q(SceneQ<TI, TC, XH>& S, const Ws<TI, TC>& W, bool live) {
+  constexpr int RS = 16 * XH;
   const int nc = S.nc, e = S.e, l16 = S.l16, nz = S.nz;
   int status = 0;
-  if (row_any(l16 < nz && !(S.qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
-  TC gqn[16], gqt[16];
-  static_for<16>([&](auto K) LCP_INL { const TC qi = bc<K>(S.qid); gqn[K] = (TC)S.jc[K] * qi; gqt[K] = (TC)S.jt[K] * qi; });
+  bool qbad = false;
+  static_for<XH>([&](auto HX) LCP_INL { qbad = qbad || (16 * HX + l16 < nz && !(S.qd[HX] != (TC)0)); });
+  if (row_any(qbad)) status |= LCP_ST_SINGULAR_Q;
+  TC gqn[RS], gqt[RS];
+  static_for<RS>([&](auto K) LCP_INL { const TC qi = bc<K & 15>(S.qid[K >> 4]); gqn[K] = (TC)S.jc[K] * qi; gqt[K] = (TC)S.jt[K] * qi; });
   TC ccn[EQ], cct[EQ];
   static_for<EQ>([&](auto A) LCP_INL { S.gan[A] = 0; S.gat[A] = 0; S.s11row[A] = 0; ccn[A] = 0; cct[A] = 0; });
   __syncthreads();                                   // LDS rows written by the loaders
   if (e > 0) {
     static_for<EQ>([&](auto A) LCP_INL {
       TC an = 0, at = 0;
-      static_for<16>([&](auto K) LCP_INL { const TC aak = (TC)S.L.AtL[A * 16 + K]; an = fma(gqn[K], aak, an); at = fma(gqt[K], aak, at); });
+      static_for<RS>([&](auto K) LCP_INL { const TC aak = (TC)S.L.AtL[A * RS + K]; an = fma(gqn[K], aak, an); at = fma(gqt[K], aak, at); });
       S.gan[A] = an; S.gat[A] = at;
       S.L.GAL[(l16 * 2 + 0) * EQ + A] = an; S.L.GAL[(l16 * 2 + 1) * EQ + A] = at;
     });
     {                                                 // S11 = A Q^-1 A^T, entry (a, c') in lane a*EQ + c'
       const int a = l16 >> 2, c = l16 & 3;
       TC acc = 0;
-      static_for<16>([&](auto K) LCP_INL { acc = fma((TC)S.L.AtL[a * 16 + K] * bc<K>(S.qid), (TC)S.L.AtL[c * 16 + K], acc); });
+      static_for<RS>([&](auto K) LCP_INL { acc = fma((TC)S.L.AtL[a * RS + K] * bc<K & 15>(S.qid[K >> 4]), (TC)S.L.AtL[c * RS + K], acc); });
       S.L.S11[l16] = acc;
     }
     __syncthreads();
@@ -722,10 +751,10 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& 
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int q = q0 + h2, cq = q & 15, kind = q >> 4;
-      const TI* jrow = (kind ? S.L.GTL : S.L.GL) + cq * 16;
+      const TI* jrow = (kind ? S.L.GTL : S.L.GL) + cq * RS;
       const TC* garow = S.L.GAL + (cq * 2 + kind) * EQ;
       TC a = 0, u = 0;
-      static_for<16>([&](auto K) LCP_INL { const TC jk = (TC)jrow[K]; a = fma(gqn[K], jk, a); u = fma(gqt[K], jk, u); });
+      static_for<RS>([&](auto K) LCP_INL { const TC jk = (TC)jrow[K]; a = fma(gqn[K], jk, a); u = fma(gqt[K], jk, u); });
       if (e > 0) static_for<EQ>([&](auto A) LCP_INL { const TC g = garow[A]; a = fma(-ccn[A], g, a); u = fma(-cct[A], g, u); });
       const bool ok = vr && (cq < nc);
       va[h2] = ok ? a : (TC)0; vu[h2] = ok ? u : (TC)0;
@@ -743,7 +772,7 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& 
       }
     }
   }
-  if (live) store_scene_ws<TI, TC>(W, S);
+  if (live) store_scene_ws<TI, TC, XH>(W, S);
   __threadfence_block();
   __syncthreads();
   return status;
@@ -751,8 +780,11 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC>& S, const Ws<TI, TC>& 
 
 // ---------------------------------------------------------------- forward kernel
 // `accept`: value of the classification flag (meta[0]) this kernel serves for dense inputs.
-template <typename TI, typename TC, bool FUSED>
+// XH: x-space halves (1: nz <= 16; 2: nz <= 32, fused inputs only)
+template <typename TI, typename TC, bool FUSED, int XH>
 __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
+  static_assert(XH == 1 || FUSED, "the dense loader is written for nz <= 16");
+  using XVt = XV<TC, XH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
   const int Btot = FUSED ? SP.B : P.B;
@@ -766,8 +798,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   bool live = scene_raw < Btot;
   if (!FUSED) live = live && ((int)W.meta[0] == accept);
   if (!__any(live)) return;
-  SceneQ<TI, TC> S;
-  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0);
+  SceneQ<TI, TC, XH> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0, XH);
   // per-scene contact count (solve_dynamics with detection); a scene without contacts takes the
   // direct KKT solve of engines.py:36-50, which is what the initialisation solve computes
   int ncs = nc;
@@ -777,20 +809,24 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   ncw = __builtin_amdgcn_readfirstlane(ncw);
   S.nz = nz; S.nc = ncs; S.ncw = ncw; S.ncap = nc; S.e = e; S.l16 = l16;
   const bool vc = l16 < ncs;                                             // this lane owns a contact
-  TC p, hn, b;
-  if (FUSED) {
-    assemble_q<TI, TC>(S, SP, scene, p, hn, b);
+  XVt p;
+  TC hn, b;
+  if constexpr (FUSED) {
+    assemble_q<TI, TC, XH>(S, SP, scene, p, hn, b);
     if (live && vc) W.meta[1 + l16] = S.mu;
     if (live && l16 == 0) { W.meta[0] = (TC)2; W.meta[18] = (TC)1; }
   } else {
     load_dense_q<TI, TC>(S, P, W, scene, p, hn, b);
   }
   if (live && l16 == 0) W.meta[19] = (TC)ncs;
-  int status = prefactor_q<TI, TC>(S, W, live);
+  int status = prefactor_q<TI, TC, XH>(S, W, live);
+  TC* const wsx = ws_x<XH>(W);
 
   TC ta[32], tu[32];
   RedQ<TC> R;
-  TC x = 0, y = 0;
+  XVt x;
+  static_for<XH>([&](auto HX) LCP_INL { x.v[HX] = 0; });
+  TC y = 0;
   M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), dinv = m4<TC>(1, 1, 1, 1);
   TC best_resid = inf_of<TC>();
   bool have_best = false, done = !live;
@@ -804,13 +840,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
 #pragma unroll 1
   for (int it = -1; it < max_iter; ++it) {
     if (!__any(!done)) break;
-    TC rx, ry, mu = 0, resid = 0;
+    XVt rx;
+    TC ry, mu = 0, resid = 0;
     M4<TC> rs, rz;
     if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63)
       rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); dinv = m4<TC>(1, 1, 1, 1);
     } else {                                                               // residuals (:82-96)
-      rx = S.Gtw(z.n, z.f1 - z.f2) + S.qd * x + p;
-      if (e > 0) rx += S.Aty(y);
+      rx = S.Gtw(z.n, z.f1 - z.f2);
+      static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = rx.v[HX] + S.qd[HX] * x.v[HX] + p.v[HX]; });
+      if (e > 0) { const XVt ay_ = S.Aty(y); static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] += ay_.v[HX]; }); }
       rs = z;
       TC gn, gt;
       S.Gv(x, gn, gt);
@@ -818,7 +856,9 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       rz = m4<TC>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (S.mu * z.n - (z.f1 + z.f2)));
       if (!vc) rz = m4<TC>(0, 0, 0, 0);
       ry = (e > 0) ? (S.Av(x) - b) : (TC)0;
-      const TC n_rx = row_sum((l16 < nz) ? rx * rx : (TC)0);
+      TC rx2 = 0;
+      static_for<XH>([&](auto HX) LCP_INL { rx2 += (16 * HX + l16 < nz) ? rx.v[HX] * rx.v[HX] : (TC)0; });
+      const TC n_rx = row_sum(rx2);
       const TC n_rz = row_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
       const TC n_ry = row_sum((l16 < e) ? ry * ry : (TC)0);
       const TC sz = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
@@ -827,7 +867,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
     }
     LCP_QTICK(pr, 0)                                                       // residuals, d
-    const bool singular = row_any(factor_q<TI, TC, LCP_Q_LDSW != 0>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS));     // (:99-100)
+    const bool singular = row_any(factor_q<TI, TC, LCP_Q_LDSW != 0, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS));     // (:99-100)
     if (it >= 0 && !done) {
       ++iters;
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
@@ -835,7 +875,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         const bool improved = !have_best || (resid < best_resid);             // (:107-132)
         if (improved) {                                                       // best iterate -> workspace
           best_resid = resid; n_not = 0; have_best = true;
-          if (l16 < nz) W.x[l16] = x;
+          static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = x.v[HX]; });
           if (l16 < e) W.y[l16] = y;
           if (vc) {
             W.z[l16] = z.n; W.z[nc + 2 * l16] = z.f1; W.z[nc + 2 * l16 + 1] = z.f2; W.z[3 * nc + l16] = z.g;
@@ -847,14 +887,17 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     }
     if (!__any(!done)) break;
     LCP_QTICK(pr, 6)                                                       // bookkeeping, best iterate
-    TC ax = 0, ay = 0;
+    XVt ax;
+    static_for<XH>([&](auto HX) LCP_INL { ax.v[HX] = 0; });
+    TC ay = 0;
     M4<TC> as_ = m4<TC>(0, 0, 0, 0), az = as_;
     const int npass = (it < 0) ? 1 : 2;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
-      TC ox, oy;
+      XVt ox;
+      TC oy;
       M4<TC> os, oz;
-      solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
+      solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
         const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());       // (once per solve)
@@ -863,7 +906,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
         if (!vc) { s = m4<TC>(1, 1, 1, 1); z = s; }
         if (ncs == 0 && !done) {                                              // engines.py:36-50: x = P^-1 u, no LCP
-          if (l16 < nz) W.x[l16] = x;
+          static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = x.v[HX]; });
           if (l16 < e) W.y[l16] = y;
           done = true;
         }
@@ -875,16 +918,20 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         const TC t4 = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
         const TC r3 = t3 / t4, sig = r3 * r3 * r3;                            // (:146-150)
         const TC ms = -mu * sig;
-        rx = 0; ry = 0; rz = m4<TC>(0, 0, 0, 0);
+        static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = 0; });
+        ry = 0; rz = m4<TC>(0, 0, 0, 0);
         rs = vc ? m4<TC>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
                 : m4<TC>(0, 0, 0, 0);                                         // (:153)
       } else {
-        const TC cx = ox + ax, cy = oy + ay;                                  // (:160-163)
+        XVt cx;
+        static_for<XH>([&](auto HX) LCP_INL { cx.v[HX] = ox.v[HX] + ax.v[HX]; });
+        const TC cy = oy + ay;                                                // (:160-163)
         const M4<TC> cs = m4<TC>(os.n + as_.n, os.f1 + as_.f1, os.f2 + as_.f2, os.g + as_.g);
         const M4<TC> cz = m4<TC>(oz.n + az.n, oz.f1 + az.f1, oz.f2 + az.f2, oz.g + az.g);
         const TC alpha = pmin((TC)0.999 * step_pair_q(z, cz, s, cs, vc), (TC)1);   // (:164-166)
         if (!done) {
-          x += alpha * cx; y += alpha * cy;                                   // (:171-174)
+          static_for<XH>([&](auto HX) LCP_INL { x.v[HX] += alpha * cx.v[HX]; });
+          y += alpha * cy;                                                    // (:171-174)
           if (vc) {
             s = m4<TC>(s.n + alpha * cs.n, s.f1 + alpha * cs.f1, s.f2 + alpha * cs.f2, s.g + alpha * cs.g);
             z = m4<TC>(z.n + alpha * cz.n, z.f1 + alpha * cz.f1, z.f2 + alpha * cz.f2, z.g + alpha * cz.g);
@@ -901,10 +948,13 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   // outputs (natural m-space order: n rows, friction pairs, gamma rows): read the best iterate back
   if (!live) return;
   __threadfence_block();
-  const TC bx = (l16 < nz) ? W.x[l16] : (TC)0, by = (l16 < e) ? W.y[l16] : (TC)0;
+  XVt bx;
+  static_for<XH>([&](auto HX) LCP_INL { bx.v[HX] = (16 * HX + l16 < nz) ? wsx[16 * HX + l16] : (TC)0; });
+  const TC by = (l16 < e) ? W.y[l16] : (TC)0;
   const M4<TC> bz = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> bs = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  bool bad = (l16 < nz) && (bx != bx);
+  bool bad = false;
+  static_for<XH>([&](auto HX) LCP_INL { bad = bad || (bx.v[HX] != bx.v[HX]); });
   if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
                 (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
   if (row_any(bad)) status |= LCP_ST_NAN;
@@ -924,14 +974,17 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   }
   if (l16 < e && yo) yo[(size_t)scene * e + l16] = (TI)by;
   if (FUSED) {
-    if (l16 < nz) {
-      const TC nv = -bx;                                                      // engines.py:76-77
-      ((TI*)SP.v_new)[(size_t)scene * nz + l16] = (TI)nv;
-      if (SP.p_new) ((TI*)SP.p_new)[(size_t)scene * nz + l16] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + l16] + nv * (TC)SP.dt);   // bodies.py:81
-    }
+    static_for<XH>([&](auto HX) LCP_INL {
+      const int j = 16 * HX + l16;
+      if (j < nz) {
+        const TC nv = -bx.v[HX];                                              // engines.py:76-77
+        ((TI*)SP.v_new)[(size_t)scene * nz + j] = (TI)nv;
+        if (SP.p_new) ((TI*)SP.p_new)[(size_t)scene * nz + j] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + j] + nv * (TC)SP.dt);   // bodies.py:81
+      }
+    });
     if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
   } else {
-    if (l16 < nz) ((TI*)P.x)[(size_t)scene * nz + l16] = (TI)bx;
+    if (l16 < nz) ((TI*)P.x)[(size_t)scene * nz + l16] = (TI)bx.v[0];
     if (l16 == 0) { if (P.iters) P.iters[scene] = iters; if (P.status) P.status[scene] = status; }
   }
 }
@@ -972,25 +1025,28 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
       S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
       S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
     });
-    S.qid = W.Qit[l16]; S.qd = 0;
+    S.qid[0] = W.Qit[l16]; S.qd[0] = 0;
     S.mu = vc ? W.meta[1 + l16] : (TC)0;
   }
   __syncthreads();
   const TC x = (l16 < nz) ? W.x[l16] : (TC)0, y = (l16 < e) ? W.y[l16] : (TC)0;
   const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  const TC g = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
+  XV<TC, 1> g;
+  g.v[0] = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
   const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);            // 1 / d, d = z / s (lcp.py:44)
   TC ta[32], tu[32];
   RedQ<TC> R;
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_q<TI, TC, false>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
-  TC dx, dnu;
+  factor_q<TI, TC, false, 1>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);             // lcp.py:46
+  XV<TC, 1> dxv;
+  TC dnu;
   M4<TC> ds, dl;
   const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  solve_kkt_q<TI, TC, 1>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dxv, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  const TC dx = dxv.v[0];
   if (!live) return;
   // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
   if (P.dp && l16 < nz) ((TI*)P.dp)[(size_t)scene * nz + l16] = (TI)dx;
@@ -1061,8 +1117,9 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
 // (lcp.py:37-64) has materialised dQ, dp, dG, dh, dF.  Here the rank-1 LCP gradients are contracted in registers:
 //   dp = dx, dQ_jj = dx_j x_j, dG_row = dlam_row x + lam_row dx, dh = -dlam, dF[gamma_c, n_c] = -dlam_gamma lam_n
 // and only ~0.6 KB per scene leaves the chip instead of the 21.6 KB of dense gradients.
-template <typename TI, typename TC>
+template <typename TI, typename TC, int XH>
 __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs Gd, int lds_per_scene) {
+  using XVt = XV<TC, XH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
   const int scene_raw = blockIdx.x * 4 + row;
@@ -1070,8 +1127,8 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   const int nb = SP.nb, nz = 3 * SP.nb, nc = SP.nc, e = SP.e;
   Ws<TI, TC> W(SP.ws, scene);
   const bool live = scene_raw < SP.B;
-  SceneQ<TI, TC> S;
-  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, false);
+  SceneQ<TI, TC, XH> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, false, XH);
   int ncs = (int)W.meta[19];                                             // contacts the forward solved with
   ncs = ncs < 0 ? 0 : (ncs > nc ? nc : ncs);
   int ncw = ncs;
@@ -1079,33 +1136,40 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   ncw = __builtin_amdgcn_readfirstlane(ncw);
   S.nz = nz; S.nc = ncs; S.ncw = ncw; S.ncap = nc; S.e = e; S.l16 = l16;
   const bool vc = l16 < ncs;
-  TC p_, hn_, b_;
-  assemble_q<TI, TC>(S, SP, scene, p_, hn_, b_);                          // the same rows the forward solved with
+  XVt p_;
+  TC hn_, b_;
+  assemble_q<TI, TC, XH>(S, SP, scene, p_, hn_, b_);                      // the same rows the forward solved with
   static_for<EQ>([&](auto A_) LCP_INL {
     S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
     S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
   });
   __syncthreads();
-  const TC x = (l16 < nz) ? W.x[l16] : (TC)0;
+  XVt x, g;
+  static_for<XH>([&](auto HX) LCP_INL {
+    const int j = 16 * HX + l16;
+    x.v[HX] = (j < nz) ? ws_x<XH>(W)[j] : (TC)0;
+    // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
+    g.v[HX] = (j < nz) ? -(TC)((const TI*)Gd.dl_dv)[(size_t)scene * nz + j] : (TC)0;
+  });
   const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
-  const TC g = (l16 < nz) ? -(TC)((const TI*)Gd.dl_dv)[(size_t)scene * nz + l16] : (TC)0;
   const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
   TC ta[32], tu[32];
   RedQ<TC> R;
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_q<TI, TC, false>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
-  TC dx, dnu;
+  factor_q<TI, TC, false, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);            // lcp.py:46
+  XVt dx;
+  TC dnu;
   M4<TC> ds, dl;
   const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
-  // x-space vectors to LDS so that a contact lane can read the entries of its two bodies (GAL is free in this kernel)
-  TC* X = S.L.GAL; TC* DX = X + 16; TC* CR = X + 32; TC* CF = X + 48;
-  int* B12 = (int*)(X + 64);
-  X[l16] = x; DX[l16] = dx;
+  solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  // x-space vectors to LDS so that a contact lane can read the entries of its two bodies (GAL is free in this kernel:
+  // 128 TC = X[32] DX[32] CR[16] CF[16] B12[32 ints])
+  TC* X = S.L.GAL; TC* DX = X + 32; TC* CR = X + 64; TC* CF = X + 80;
+  int* B12 = (int*)(X + 96);
+  static_for<XH>([&](auto HX) LCP_INL { X[16 * HX + l16] = x.v[HX]; DX[16 * HX + l16] = dx.v[HX]; });
   __syncthreads();
   const TI* vv = (const TI*)SP.v + (size_t)scene * nz;
   TC gh_rbar = 0;                                                         // (dh * rbar)_c: feeds d v through h = (Jc v) rbar
@@ -1148,16 +1212,19 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
       if (Gd.dcp2) { ((TI*)Gd.dcp2)[cb * 2] = (TI)d2x; ((TI*)Gd.dcp2)[cb * 2 + 1] = (TI)d2y; }
     }
   }
-  const TC dv_h = S.Gtw(gh_rbar, (TC)0);                                   // Jc^T (dh rbar)
+  const XVt dv_h = S.Gtw(gh_rbar, (TC)0);                                  // Jc^T (dh rbar)
   __syncthreads();
   if (!live) return;
-  if (l16 < nz) {
-    const size_t o = (size_t)scene * nz + l16;
-    const TC md = (TC)((const TI*)SP.Mdiag)[o], v = (TC)vv[l16];
-    if (Gd.dMdiag) ((TI*)Gd.dMdiag)[o] = (TI)(dx * x + dx * v);            // Q = diag(M) (dQ, lcp.py:59-60) and p = M v + dt f
-    if (Gd.dv) ((TI*)Gd.dv)[o] = (TI)(dx * md + dv_h);
-    if (Gd.df) ((TI*)Gd.df)[o] = (TI)(dx * (TC)SP.dt);
-  }
+  static_for<XH>([&](auto HX) LCP_INL {
+    const int j = 16 * HX + l16;
+    if (j < nz) {
+      const size_t o = (size_t)scene * nz + j;
+      const TC md = (TC)((const TI*)SP.Mdiag)[o], v = (TC)vv[j], dxj = dx.v[HX];
+      if (Gd.dMdiag) ((TI*)Gd.dMdiag)[o] = (TI)(dxj * x.v[HX] + dxj * v);  // Q = diag(M) (dQ, lcp.py:59-60) and p = M v + dt f
+      if (Gd.dv) ((TI*)Gd.dv)[o] = (TI)(dxj * md + dv_h.v[HX]);
+      if (Gd.df) ((TI*)Gd.df)[o] = (TI)(dxj * (TC)SP.dt);
+    }
+  });
   if (l16 < nb) {                                                          // per-body sums over the contacts, fixed order
     TC ar = 0, af = 0;
     for (int c = 0; c < ncs; ++c) {
@@ -1174,9 +1241,11 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
 
 // ---------------------------------------------------------------- host-side launchers
 bool quad_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
+// contact-list entry points only (lcp_solve_dynamics_f32 / lcp_step_backward_f32): up to ten bodies
+bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 32 && e <= q16::EQ; }
 
 template <typename TC>
-static size_t q16_lds(bool with_w) { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr, with_w); }
+static size_t q16_lds(bool with_w, int xh = 1) { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr, with_w, xh); }
 
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
   StepArgs SP = {};
@@ -1184,10 +1253,10 @@ int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
   const dim3 grid((P.B + 3) / 4), blk(64);
   if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else {
     const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1196,12 +1265,15 @@ int quad_step(const StepArgs& SP, int compute, void* stream) {
   FwdArgs P = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
+  const bool wide = 3 * SP.nb > 16;
   if (compute == LCP_COMPUTE_F64) {
-    const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0, wide ? 2 : 1);
+    if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {
-    const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, true>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0, wide ? 2 : 1);
+    if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1222,12 +1294,15 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream) {
 int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
+  const bool wide = 3 * SP.nb > 16;
   if (compute == LCP_COMPUTE_F64) {
-    const int ls = (int)q16_lds<double>(false);
-    hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double>), grid, blk, 4 * ls, st, SP, Gd, ls);
+    const int ls = (int)q16_lds<double>(false, wide ? 2 : 1);
+    if (wide) hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 2>), grid, blk, 4 * ls, st, SP, Gd, ls);
+    else hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 1>), grid, blk, 4 * ls, st, SP, Gd, ls);
   } else {
-    const int ls = (int)q16_lds<float>(false);
-    hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, float>), grid, blk, 4 * ls, st, SP, Gd, ls);
+    const int ls = (int)q16_lds<float>(false, wide ? 2 : 1);
+    if (wide) hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, float, 2>), grid, blk, 4 * ls, st, SP, Gd, ls);
+    else hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, float, 1>), grid, blk, 4 * ls, st, SP, Gd, ls);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

@@ -297,16 +297,18 @@ def test_contact_world_follows_reference_trajectory(name):
     print(name, "worst |dp|", worst_p, "worst |dv|", worst_v)
 
 
-def test_contact_world_beyond_the_quad_sizes_follows_oracle():
-    """7 bodies (nz = 21 > 16): contact kernel with one wave per scene + the workgroup-per-scene solver with per-scene
-    contact counts; a few steps against oracle/world_oracle.py (pinned on the reference World, tests/test_world_oracle.py)."""
+@pytest.mark.parametrize("nbox,maxc", [(6, 24), (6, 16), (5, 16)])
+def test_contact_world_beyond_the_quad_sizes_follows_oracle(nbox, maxc):
+    """6-7 bodies (nz = 18 / 21 > 16): contact kernel with one wave per scene + the solver with per-scene contact counts -
+    the 32-contact class of lcp_big.hip (capacity 24) and the two-halves instantiation of lcp_quad.hip (capacity 16);
+    a few steps against oracle/world_oracle.py (pinned on the reference World, tests/test_world_oracle.py)."""
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics.batched_world import ContactWorld
-    B, nbox, nsteps = 3, 6, 8
+    B, nsteps = 3, 8
     w = scenes.make_drop_world(B, nbox=nbox, box=30.0, seed=11, gap=(0.2, 0.6))
     geom = _geom([w["shapes"]] * B)
     g = lambda k: w[k].to(DEV)
-    world = ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=24)
+    world = ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=maxc)
     refs = []
     for s in range(B):
         d = lambda k: w[k][s].double().numpy()
@@ -326,14 +328,14 @@ def test_contact_world_beyond_the_quad_sizes_follows_oracle():
         assert np.abs(world.p[s].cpu().numpy() - p).max() < 2e-4 and np.abs(world.v[s].double().cpu().numpy() - v).max() < 2e-3, s
 
 
-def test_mid_size_scenes_use_the_small_capacity_classes():
-    """6 bodies / <= 16 contacts and 7 bodies / <= 32 contacts (nz > 16: not the quad kernel's) run on the 16- and
-    32-contact instantiations of lcp_big.hip: new_v against the generic kernels and the fp64 oracle."""
+def test_mid_size_scenes_match_generic_and_oracle():
+    """6-10 bodies with <= 16 contacts (the nz <= 32 instantiation of lcp_quad.hip) and 7 bodies / 24 contacts (the
+    32-contact class of lcp_big.hip): new_v against the generic kernels and the fp64 oracle, with ragged counts."""
     from lcp_physics_amd import _lib, scenes
     from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import ContactBuffers
     from oracle import pdipm_oracle as O
-    for nbox, pts in ((5, 2), (6, 4)):                     # 10 contacts (class 16) and 24 contacts (class 32)
+    for nbox, pts in ((5, 2), (8, 2), (9, 1), (6, 4)):     # nz 18 / 27 / 30 with 10 / 16 / 9 contacts; 24 contacts
         B = 10
         sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=40 + nbox, dtype=torch.float32)
         scg = sc.to(device=DEV)

@@ -1,0 +1,22 @@
+import sys, time, os
+import torch
+sys.path.insert(0, '.')
+from lcp_physics_amd import scenes
+from lcp_physics_amd.physics.batched_world import solve_dynamics
+from lcp_physics_amd.physics.contacts import ContactBuffers
+nbox, pts = int(sys.argv[1]), int(sys.argv[2])
+B = 4096
+sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=5, dtype=torch.float32).to('cuda')
+cb = ContactBuffers(B, sc.nb, sc.nc, 'cuda')
+cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
+count = torch.full((B,), sc.nc, dtype=torch.int32, device='cuda')
+run = lambda out=None: solve_dynamics(B, sc.nb, sc.nc, 3, count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb, sc.Je, sc.dt, ws=None if out is None else out["ws"], out=out)
+out = run(); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5): out = run(out)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 5
+print("nb", sc.nb, "nc", sc.nc, "ms/step", dt * 1e3, "steps/s", B / dt)
+if "bigprof" in os.environ.get("LCP_HIP_LIB", "") and sc.nc * 4 > 207:
+    pc = out["s"][:, 200:207].double().mean(dim=0).tolist()
+    print("cycles: residuals %.0f factor %.0f steps %.0f solve_kkt %.0f (sweeps %.0f) | W load %.0f LU %.0f" % tuple(pc))
