@@ -171,6 +171,26 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
                            float* v_new, float* z, float* s, float* y,
                            int32_t* iters, int32_t* status, void* ws, void* stream);
 
+/* Replaces PdipmEngine.post_stabilization (physics/engines.py:80-116) and the correction move World.step_dt makes with
+ * its result (physics/world.py:109-117), for B scenes in one launch.  Per scene the frictionless LCP
+ *   Q = M, p = 0, G = Jc (world.py:172-184), h = gc = Jc v + Jc v * -restitutions (:87-89), A = Je, b = ge = Je v (:86),
+ *   F = 0 (:110), solver defaults (lcp.py:12-13: pass eps = 1e-12, max_iter = 10, not_improved_lim = 3)
+ * over the first c_count[k] entries of the padded contact list; dp = -x (:115).  A scene without contacts takes the
+ * direct solve [[M, -Je^T], [Je, 0]]^-1 [0; ge] (:92-103).  `v` are the velocities AFTER the dynamics solve and the
+ * contacts those found after the move (world.py:87-94).  When p / p_out are given, p_out = p + (dp / 2) dt_k with
+ * dt_k = dt_scene[k] (the dt the scene's step ended up using; NULL: the scalar `dt`) - world.py:110-117; the caller
+ * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL).
+ * Runs on the workgroup-per-scene kernels (any size their plan takes: LCP_E_TOOLARGE beyond); workspace of
+ * lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
+ *   out: dp[B,nb,3]  p_out[B,nb,3] (optional)  iters[B]  status[B] */
+int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
+                               const float* Mdiag, const float* v, const float* rest,
+                               const float* c_n, const float* c_p1, const float* c_p2,
+                               const int32_t* c_i1, const int32_t* c_i2, const float* Je,
+                               double eps, int max_iter, int not_improved_lim, int compute,
+                               const double* p, const double* dt_scene, double dt, double* p_out,
+                               float* dp, int32_t* iters, int32_t* status, void* ws, void* stream);
+
 /* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the
  * contact generation it calls, for B independent scenes in one launch:
  *   Body.move (physics/bodies.py:80-82)         p_try = p_start + v dt

@@ -218,6 +218,33 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
+int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
+                               const float* v, const float* rest, const float* c_n, const float* c_p1,
+                               const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je,
+                               double eps, int max_iter, int not_improved_lim, int compute, const double* p,
+                               const double* dt_scene, double dt, double* p_out, float* dp, int32_t* iters,
+                               int32_t* status, void* ws, void* stream) {
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+  lcp::StepArgs P;
+  // (forces and friction do not enter this LCP: engines.py:80-116 reads M, v, Je, Jc and the restitutions only)
+  int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, /*f*/ v, rest, /*fric*/ rest, c_n, c_p1, c_p2, c_i1, c_i2, Je,
+                     (float)dt);
+  if (rc) return rc;
+  if (!c_count || !dp || !ws || max_iter < 0) return LCP_E_BADARG;
+  if ((p_out != nullptr) != (p != nullptr)) return LCP_E_BADARG;
+  const int nz = 3 * nb, m = 4 * maxc;
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  P.c_count = c_count;
+  P.dt = dt;
+  P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
+  P.v_new = dp; P.iters = iters; P.status = status;
+  P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
+  P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_post_stab(P, compute, pl.lds_bytes, stream);
+}
+
 int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,
                                const double* verts_local, const int32_t* nverts, const uint8_t* no_contact,
                                const double* p_start, const float* v, double dt, double dt_floor, int strict,

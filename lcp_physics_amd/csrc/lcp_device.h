@@ -73,6 +73,7 @@ struct ContactRows {
   TI jn[6];   // normal row:   cols 3*b1..3*b1+2 then 3*b2..3*b2+2          (world.py:177-183)
   TI jf[6];   // friction row for direction 1 (the direction-2 row is its negative, world.py:191-210)
   TI h;       // (Jc v)_c * restitution_c                                     (engines.py:53, world.py:144-151)
+  TI jv, rbar;  // (Jc v)_c and restitution_c by themselves (post-stabilisation: gc = jv + jv * -rbar, engines.py:87-89)
   TI mu;      // 0.5 (fric_b1 + fric_b2)                                       (world.py:213-224)
   int b1, b2;
 };
@@ -96,7 +97,9 @@ __device__ __forceinline__ ContactRows<TI> make_contact(const TI* cn, const TI* 
   const int blo = r.b1 < r.b2 ? r.b1 : r.b2, bhi = r.b1 < r.b2 ? r.b2 : r.b1;
   for (int q = 0; q < 3; ++q) acc = acc + r.jn[lo + q] * vv[3 * blo + q];
   for (int q = 0; q < 3; ++q) acc = acc + r.jn[hi + q] * vv[3 * bhi + q];
-  r.h = acc * ((TI)0.5 * (rest[r.b1] + rest[r.b2]));
+  r.jv = acc;
+  r.rbar = (TI)0.5 * (rest[r.b1] + rest[r.b2]);
+  r.h = acc * r.rbar;
   r.mu = (TI)0.5 * (fric[r.b1] + fric[r.b2]);
   return r;
 }

@@ -145,6 +145,13 @@ struct FContact {
   }
 };
 
+// F = 0: the frictionless LCP of post-stabilisation (engines.py:110)
+template <typename TC>
+struct FZero {
+  __device__ TC at(int, int) const { return (TC)0; }
+  __device__ void sub_Fz(const TC*, TC*) const {}
+};
+
 // ------------------------------------------------------------------------------------------
 // small dense building blocks (workgroup-cooperative, operands in LDS)
 // ------------------------------------------------------------------------------------------
@@ -411,7 +418,9 @@ __device__ void load_dense(Scene<TC>& S, const FwdArgs& P, int scene) {
 
 // engines.py:31-32,50-74 + world.py:144-234: build Q (diag), p = M v + dt f, G = [Jc; Jf; 0],
 // h = [(Jc v) * restitution; 0; 0], mu per contact, A = Je, b = 0 directly in LDS.
-template <typename TI, typename TC>
+// POST: the frictionless LCP of PdipmEngine.post_stabilization instead (engines.py:80-116): p = 0, G = Jc,
+// h = gc = Jc v + Jc v * -restitutions, A = Je, b = ge = Je v, F = 0; m = S.m = ncs.
+template <typename TI, typename TC, bool POST = false>
 __device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene, int ncs) {
   // `ncs` = contacts of this scene (<= P.nc, the capacity the contact arrays are strided by); m = S.m = 4 ncs
   const int nb = P.nb, ncap = P.nc, nc = ncs, nz = S.nz, m = S.m, e = S.e, tid = threadIdx.x;
@@ -428,14 +437,29 @@ __device__ void assemble_scene(Scene<TC>& S, const StepArgs& P, int scene, int n
   S.nc = nc;
   for (int i = tid; i < nz * nz; i += NT) { const int r = i / nz, c = i - r * nz; S.Q[i] = (r == c) ? (TC)Md[r] : (TC)0; }
   for (int i = tid; i < m * nz; i += NT) S.G[i] = 0;
-  for (int j = tid; j < nz; j += NT) S.p[j] = (TC)momentum_entry<TI>(Md[j], vv[j], (TI)P.dt, ff[j]);   // engines.py:32
+  for (int j = tid; j < nz; j += NT) S.p[j] = POST ? (TC)0 : (TC)momentum_entry<TI>(Md[j], vv[j], (TI)P.dt, ff[j]);   // engines.py:32 | :84
   for (int i = tid; i < m; i += NT) S.h[i] = 0;
   if (e > 0) {
     const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
     for (int i = tid; i < e * nz; i += NT) S.A[i] = (TC)Je[i];
-    for (int i = tid; i < e; i += NT) S.b[i] = 0;
+    for (int i = tid; i < e; i += NT) {
+      TC ge = 0;
+      if (POST) for (int j = 0; j < nz; ++j) ge += (TC)Je[i * nz + j] * (TC)vv[j];                     // ge = Je v (engines.py:86)
+      S.b[i] = ge;
+    }
   }
   __syncthreads();
+  if (POST) {
+    for (int c = tid; c < nc; c += NT) {
+      const ContactRows<TI> r = make_contact<TI>(cn, c1, c2, i1, i2, rest, fric, vv, c);
+      TC* gn = S.G + (size_t)c * nz;
+      for (int q = 0; q < 3; ++q) { gn[3 * r.b1 + q] = (TC)r.jn[q]; }
+      for (int q = 0; q < 3; ++q) { gn[3 * r.b2 + q] = (TC)r.jn[3 + q]; }
+      S.h[c] = (TC)r.jv + (TC)r.jv * -(TC)r.rbar;                                                      // engines.py:87-89
+    }
+    __syncthreads();
+    return;
+  }
   for (int c = tid; c < nc; c += NT) {
     const ContactRows<TI> r = make_contact<TI>(cn, c1, c2, i1, i2, rest, fric, vv, c);
     TC* gn = S.G + (size_t)c * nz;                                       // Jc row            world.py:177-183
@@ -608,6 +632,44 @@ __global__ void __launch_bounds__(NT) lcp_fwd_kernel(FwdArgs P) {
   TI* s = (TI*)P.s + (size_t)scene * m;
   TI* y = (e > 0 && P.y) ? (TI*)P.y + (size_t)scene * e : nullptr;
   store_solution<TI, TC>(S, W, x, y, z, s, status);
+  if (threadIdx.x == 0) {
+    if (P.iters) P.iters[scene] = iters;
+    if (P.status) P.status[scene] = status;
+  }
+}
+
+// PdipmEngine.post_stabilization (engines.py:80-116) for one scene per workgroup + the correction move of
+// World.step_dt (world.py:109-117): dp = -x of the frictionless LCP; p_out = p + (dp / 2) dt_scene.
+template <typename TI, typename TC, bool PIVOT>
+__global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x;
+  const int ncap = P.nc;
+  int ncs = ncap;
+  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  const int nz = 3 * P.nb, m = ncs, e = P.e;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, 4 * ncap, e);
+  Scene<TC> S;
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  S.R = W.R;
+  assemble_scene<TI, TC, true>(S, P, scene, ncs);
+  FZero<TC> F;
+  int status = prefactor(S, F);
+  int iters = 0;
+  pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);   // (m == 0: the direct KKT solve, :92-103)
+  __syncthreads();
+  int bad = 0;
+  TI* dpo = (TI*)P.v_new + (size_t)scene * nz;
+  for (int j = threadIdx.x; j < nz; j += NT) {
+    const TC dp = -S.bx[j];                                               // engines.py:115
+    bad |= (dp != dp);
+    dpo[j] = (TI)dp;
+    if (P.p_out64) {                                                      // world.py:110-117: dp /= 2 ; body.move(dt)
+      const double dts = P.dt_scene ? P.dt_scene[scene] : P.dt;
+      P.p_out64[(size_t)scene * nz + j] = P.pos64[(size_t)scene * nz + j] + ((double)dp * 0.5) * dts;
+    }
+  }
+  if (__syncthreads_or(bad)) status |= LCP_ST_NAN;
   if (threadIdx.x == 0) {
     if (P.iters) P.iters[scene] = iters;
     if (P.status) P.status[scene] = status;
@@ -820,6 +882,18 @@ int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void
   if (io_f64) return launch_bwd_t<double, double, true>(P, lds, st);
   if (compute == LCP_COMPUTE_F64) return launch_bwd_t<float, double, true>(P, lds, st);
   return launch_bwd_t<float, float, true>(P, lds, st);
+}
+template <typename TI, typename TC, bool PIVOT>
+static int launch_post_stab_t(const StepArgs& P, size_t lds, hipStream_t st) {
+  auto k = lcp_post_stab_kernel<TI, TC, PIVOT>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, st, P);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+int generic_post_stab(const StepArgs& P, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (compute == LCP_COMPUTE_F64) return launch_post_stab_t<float, double, true>(P, lds, st);
+  return launch_post_stab_t<float, float, true>(P, lds, st);
 }
 int generic_step(const StepArgs& P, int compute, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -54,6 +54,10 @@ struct StepArgs {
   void* ws;
   size_t ws_stride;
   int ldT, t_in_lds;
+  // post-stabilisation (generic_post_stab only): pose before / after the correction move and the dt every scene used
+  const double* pos64;
+  const double* dt_scene;
+  double* p_out64;
 };
 
 struct StepBwdArgs {
@@ -82,6 +86,7 @@ struct ContactArgs {
 Plan make_plan(int nz, int m, int e, int csize);
 int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
 int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
+int generic_post_stab(const StepArgs& P, int compute, size_t lds, void* stream);
 int generic_step(const StepArgs& P, int compute, size_t lds, void* stream);
 int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b,
                      float* F, void* stream);

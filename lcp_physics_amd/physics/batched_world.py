@@ -234,6 +234,36 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
     return out
 
 
+def post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, cb, Je, p=None, dt_scene=None, dt=0.0, p_out=None,
+                       eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None):
+    """`PdipmEngine.post_stabilization` (`engines.py:80-116`) for B scenes with per-scene contact counts: one launch
+    of `lcp_post_stabilization_f32`.  With `p` / `p_out` (float64 poses) it also makes the correction move of
+    `World.step_dt` (`world.py:110-117`): p_out = p + (dp / 2) dt_scene.  Returns dict(dp, iters, status, ws)."""
+    lib = _lib.load()
+    dev = v.device
+    comp = _COMPUTE[compute]
+    need = _lib.workspace_bytes(B, 3 * nb, 4 * maxc, e, comp)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = {"dp": torch.empty(B, nb, 3, dtype=torch.float32, device=dev),
+               "iters": torch.empty(B, dtype=torch.int32, device=dev),
+               "status": torch.empty(B, dtype=torch.int32, device=dev)}
+    out["ws"] = ws
+    for name, t in (("p", p), ("p_out", p_out), ("dt_scene", dt_scene)):
+        if t is not None:
+            _lib.require_gpu_tensor(t, name, torch.float64)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_post_stabilization_f32(B, nb, maxc, e, P(count), P(Mdiag), P(v), P(rest), P(cb.c_n), P(cb.c_p1),
+                                            P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(eps),
+                                            int(max_iter), int(not_improved_lim), comp, P(p), P(dt_scene), float(dt),
+                                            P(p_out), P(out["dp"]), P(out["iters"]), P(out["status"]), P(ws),
+                                            _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_post_stabilization_f32")
+    return out
+
+
 class ContactWorld:
     """B independent scenes WITH contact detection, advanced together on one GPU: the batched counterpart of
     the reference's `World` (`physics/world.py:17-122`) with its default `DiffContactHandler` and `PdipmEngine`.
@@ -246,15 +276,18 @@ class ContactWorld:
     State: `p` [B,nb,3] float64 (rot, x, y), `v` [B,nb,3] float32, `t` [B] float64 (scenes advance by their own
     accepted dt, world.py:122), `contacts` (`contacts.ContactBuffers`: padded records + `count`).
     Restrictions: forces are constant (gravity-like), joints have a constant Jacobian `Je` (Total/X/Y/Rot
-    constraints), post-stabilisation (off by default in the reference, utils.py:30) is not implemented; at most 16
-    bodies per scene.  Scenes with 3 nb <= 16, maxc <= 16, e <= 4 run on the four-scenes-per-wave solver, anything
-    else on the workgroup-per-scene kernels (slower, forward only).
+    constraints); at most 16 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the
+    four-scenes-per-wave solver, anything else on the workgroup-per-scene kernels (slower).
+    `post_stab=True` (off by default, as in the reference: utils.py:30) adds the two launches of world.py:109-121 to a
+    step: `lcp_post_stabilization_f32` (frictionless LCP + correction move) and a contact re-detection.
     """
 
     def __init__(self, geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1.0 / 30, eps=0.1, tol=1e-6,
                  strict_no_penetration=True, maxc=16, max_iter=10, compute="f64", solver_eps=1e-12,
-                 not_improved_lim=3, max_trials=64, check=True):
+                 not_improved_lim=3, max_trials=64, check=True, post_stab=False):
         from . import contacts as _contacts
+        self.post_stab = bool(post_stab)
+        self._ps_out = self._ps_ws = self._p_ps = None
         self._contacts_mod = _contacts
         self.geom = geom
         dev = p.device
@@ -294,6 +327,17 @@ class ContactWorld:
                                                   strict=self.strict, dt_floor=self.dt / 4,
                                                   max_trials=self.max_trials, t=self.t, out=cb)
         self.p, cb.p_out = cb.p_out, self.p                              # accepted pose becomes the state (double buffer)
+        if self.post_stab:                                               # world.py:109-121
+            if self._p_ps is None:
+                self._p_ps = torch.empty_like(self.p)
+            # the engine's defaults here (engines.py:114 `self.lcp_solver()`), not the dynamics solve's settings
+            ps = post_stabilization(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, self.rest, cb,
+                                    self.Je, p=self.p, dt_scene=cb.dt_used, dt=self.dt, p_out=self._p_ps,
+                                    compute=self.compute, ws=self._ps_ws, out=self._ps_out)
+            self._ps_ws, self._ps_out = ps["ws"], ps
+            self.p, self._p_ps = self._p_ps, self.p
+            self._contacts_mod.find_contacts(self.geom, self.p, maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
+            out["post_stab"] = ps
         return out
 
     def get_v(self):

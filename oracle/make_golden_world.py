@@ -1,6 +1,7 @@
 """Generate tests/golden/world_traj.npz: trajectories of the UNMODIFIED reference `World` (physics/world.py,
 through oracle/ref_shim.py) for small scenes that exercise contact creation, the penetration check with dt
-halving (world.py:88-101) and the no-contact branch of the engine (engines.py:36-50).
+halving (world.py:88-101), the no-contact branch of the engine (engines.py:36-50) and - the `*_poststab` records -
+post-stabilisation (world.py:109-121, engines.py:80-116).
 TEST INFRASTRUCTURE ONLY; needs /root/reference.
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_world.py
@@ -64,7 +65,9 @@ def _scenes():
         a.add_force(Gravity(g=100))
         return [fl, a], [j], 45, True
 
-    return dict(ball_floor=ball_floor, stack3=stack3, mixed=mixed(True), mixed_nonstrict=mixed(False), tumble=tumble)
+    return dict(ball_floor=ball_floor, stack3=stack3, mixed=mixed(True), mixed_nonstrict=mixed(False), tumble=tumble,
+                # the same scenes with post-stabilisation switched on (world.py:109-121, engines.py:80-116)
+                stack3_poststab=stack3, mixed_poststab=mixed(True), tumble_poststab=tumble)
 
 
 def record(name, make):
@@ -72,18 +75,51 @@ def record(name, make):
     from lcp_physics.physics.world import World
     random.seed(0)
     bodies, joints, nsteps, strict = make()
-    world = World(bodies, joints, dt=1.0 / 30, strict_no_penetration=strict)
+    post_stab = name.endswith("_poststab")
+    world = World(bodies, joints, dt=1.0 / 30, strict_no_penetration=strict, post_stab=post_stab)
     nb = len(bodies)
     kind = np.array([0 if isinstance(b, Circle) else 1 for b in bodies])
     size = np.array([[float(b.rad), 0.0] if isinstance(b, Circle) else b.dims.numpy().tolist() for b in bodies])
-    rec = dict(kind=kind, size=size, dt=np.float64(world.dt), strict=np.int64(strict), eps=np.float64(float(world.eps)),
+    rec = dict(kind=kind, size=size, dt=np.float64(world.dt), strict=np.int64(strict), post_stab=np.int64(post_stab),
+               eps=np.float64(float(world.eps)),
                tol=np.float64(float(world.tol)),
                Mdiag=torch.diagonal(world.M()).reshape(nb, 3).numpy().copy(),
                f=world.apply_forces(0).reshape(nb, 3).numpy().copy(),
                rest=np.array([float(b.restitution) for b in bodies]),
                fric=np.array([float(b.fric_coeff) for b in bodies]),
                Je=world.Je().numpy().copy())
-    P, V, T, NC = [], [], [], []
+    P, V, T, NC, DP, PMID = [], [], [], [], [], []
+    if post_stab:
+        # per step: the engine's post_stabilization output and the pose it was computed at (the pose before the
+        # post-stabilisation move) - lets the test pin that solve step by step on identical inputs.  The engine INSTANCE
+        # is wrapped; no reference file is touched.
+        inner = world.engine.post_stabilization
+        solver_cls = world.engine.lcp_solver
+        LCPS = []                    # the frictionless LCPs the engine handed to the solver: (step, Jc, gc, ge, x)
+        state = dict(on=False, step=0)
+
+        class SolverSpy:
+            def __init__(self, *a, **k):
+                self.f = solver_cls(*a, **k)
+
+            def __call__(self, Q, p_, G_, h_, A_, b_, F_):
+                x = self.f(Q, p_, G_, h_, A_, b_, F_)
+                if state["on"]:
+                    assert float(p_.abs().max()) == 0.0 and float(F_.abs().max()) == 0.0      # engines.py:84,110
+                    LCPS.append((state["step"], G_[0].numpy().copy(), h_[0].numpy().copy(), b_[0].numpy().copy(),
+                                 x.detach()[0].numpy().copy()))
+                return x
+        world.engine.lcp_solver = SolverSpy
+
+        def spy(wd):
+            state["on"] = True
+            out = inner(wd)
+            state["on"] = False
+            state["step"] += 1
+            PMID.append(torch.stack([b.p for b in bodies]).numpy().copy())
+            DP.append(out.detach().reshape(nb, 3).numpy().copy())
+            return out
+        world.engine.post_stabilization = spy
     snap = lambda: (torch.stack([b.p for b in bodies]).numpy().copy(), world.get_v().reshape(nb, 3).numpy().copy())
     p, v = snap()
     P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
@@ -92,6 +128,15 @@ def record(name, make):
         p, v = snap()
         P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
     rec.update(p=np.stack(P), v=np.stack(V), t=np.array(T), ncontacts=np.array(NC))
+    if post_stab:
+        rec.update(dp=np.stack(DP), p_mid=np.stack(PMID))
+        cap = max(1, max(l[1].shape[0] for l in LCPS))
+        nl = len(LCPS)
+        Jc = np.zeros((nl, cap, 3 * nb)); gc = np.zeros((nl, cap)); ge = np.zeros((nl, LCPS[0][3].shape[0])); xs = np.zeros((nl, 3 * nb))
+        for i, (_, G_, h_, b_, x_) in enumerate(LCPS):
+            Jc[i, :G_.shape[0]] = G_; gc[i, :h_.shape[0]] = h_; ge[i] = b_; xs[i] = x_[:3 * nb]
+        rec.update(ps_step=np.array([l[0] for l in LCPS]), ps_nc=np.array([l[1].shape[0] for l in LCPS]), ps_Jc=Jc, ps_gc=gc,
+                   ps_ge=ge, ps_x=xs)
     return rec
 
 

@@ -458,6 +458,34 @@ def solve_dynamics(Mdiag, v, f, dt, n, p1, p2, i1, i2, rest, fric, Je, **kw):
     return (-sol.x).reshape(B, nb, 3), sol, (Q, u, G, h, A, b, Fm)
 
 
+def assemble_post_stabilization(Mdiag, v, n, p1, p2, i1, i2, rest, Je):
+    """engines.py:80-116, contact case: the frictionless LCP (Q = M, p = 0, G = Jc, h = gc, A = Je, b = ge, F = 0)
+    with gc = Jc v + Jc v * -restitutions (:87-89) and ge = Je v (:86)."""
+    B, nb, _ = v.shape
+    nc = n.shape[1]
+    nz = 3 * nb
+    dtp = v.dtype
+    vv = v.reshape(B, nz)
+    Jc, _ = contact_jacobians(n, p1, p2, i1, i2, nb)
+    r, _ = contact_coefficients(rest, rest, i1, i2)
+    jv = _mv(Jc, vv)
+    gc = jv + jv * -r
+    Q = torch.diag_embed(Mdiag.reshape(B, nz))
+    if Je is not None and Je.numel() > 0:
+        A, b = Je, _mv(Je, vv)
+    else:
+        A, b = None, None
+    return Q, torch.zeros(B, nz, dtype=dtp), Jc, gc, A, b, torch.zeros(B, nc, nc, dtype=dtp)
+
+
+def post_stabilization(Mdiag, v, n, p1, p2, i1, i2, rest, Je, **kw):
+    """engines.py:80-116 contact case: dp = -x (:115)."""
+    lcp = assemble_post_stabilization(Mdiag, v, n, p1, p2, i1, i2, rest, Je)
+    sol = lcp_forward(*lcp, **kw)
+    B, nb, _ = v.shape
+    return (-sol.x).reshape(B, nb, 3), sol, lcp
+
+
 def integrate(p, v_new, dt):
     """bodies.py:80-82: p <- p + v*dt."""
     return p + v_new * dt

@@ -3,8 +3,9 @@
 Clean-room restatement (float64, one scene at a time) of `/root/reference/lcp_physics/physics`:
 
   world.py:83-122   World.step_dt           -> `step_dt`   (solve, move, find contacts, penetration check,
-                                                           dt halving and reset; post-stabilisation is off
-                                                           by default, utils.py:30, and not restated)
+                                                           dt halving and reset; post-stabilisation, off by
+                                                           default - utils.py:30 - behind `post_stab`)
+  engines.py:80-116 PdipmEngine.post_stabilization -> `post_stabilization`
   engines.py:26-78  PdipmEngine.solve_dynamics -> `solve_dynamics` (both branches: the direct KKT solve when
                                                            there is no contact, :36-50, and the mixed LCP, :51-76)
   bodies.py:80-82   Body.move               -> inside `move_and_find`
@@ -69,6 +70,33 @@ def solve_dynamics(Mdiag, v, f, dt, contacts, rest, fric, Je, max_iter=10):
     return new_v[0].numpy()
 
 
+def post_stabilization(Mdiag, v, contacts, rest, Je, max_iter=10):
+    """engines.py:80-116 for one scene: dp [nb,3].  (The reference needs at least one joint row here: `Je v` at :86.)"""
+    Mdiag, v = (np.asarray(t, dtype=np.float64) for t in (Mdiag, v))
+    nb = v.shape[0]
+    nz = 3 * nb
+    e = 0 if Je is None else int(np.asarray(Je).shape[0])
+    if not contacts:                                                             # :92-103
+        ge = np.asarray(Je, dtype=np.float64) @ v.reshape(-1) if e > 0 else np.zeros(0)
+        M = np.diag(Mdiag.reshape(-1))
+        if e > 0:
+            Jm = np.asarray(Je, dtype=np.float64)
+            P = np.block([[M, -Jm.T], [Jm, np.zeros((e, e))]])
+        else:
+            P = M
+        x = np.linalg.solve(P, np.concatenate([np.zeros(nz), ge]))
+        return -x[:nz].reshape(nb, 3)
+    t = lambda a, dt_=torch.float64: torch.as_tensor(np.asarray(a), dtype=dt_).unsqueeze(0)
+    n = t(np.stack([c[0][0] for c in contacts]))
+    p1 = t(np.stack([c[0][1] for c in contacts]))
+    p2 = t(np.stack([c[0][2] for c in contacts]))
+    i1 = t(np.array([c[1] for c in contacts]), torch.int64)
+    i2 = t(np.array([c[2] for c in contacts]), torch.int64)
+    Jet = t(Je) if e > 0 else None
+    dp, _, _ = O.post_stabilization(t(Mdiag), t(v), n, p1, p2, i1, i2, t(rest), Jet, max_iter=max_iter)
+    return dp[0].numpy()
+
+
 def move_and_find(shapes, p_start, v, dt, eps=0.1, tol=1e-6, strict=True, dt_floor=None, max_trials=64,
                   no_contact=()):
     """world.py:88-101: returns (p, contacts, dt_used, trials)."""
@@ -91,9 +119,13 @@ def move_and_find(shapes, p_start, v, dt, eps=0.1, tol=1e-6, strict=True, dt_flo
 
 
 def step_dt(shapes, p, v, contacts, Mdiag, f, rest, fric, Je, dt, eps=0.1, tol=1e-6, strict=True, max_iter=10,
-            no_contact=()):
-    """world.py:83-122 (post_stab off).  Returns (p_new, v_new, contacts_new, dt_used, trials)."""
+            no_contact=(), post_stab=False):
+    """world.py:83-122.  Returns (p_new, v_new, contacts_new, dt_used, trials)."""
     new_v = solve_dynamics(Mdiag, v, f, dt, contacts, rest, fric, Je, max_iter=max_iter)
     p_new, cs, dt_used, trials = move_and_find(shapes, p, new_v, dt, eps=eps, tol=tol, strict=strict,
                                                dt_floor=dt / 4, no_contact=no_contact)
+    if post_stab:                                                                # :109-121
+        dp = post_stabilization(Mdiag, new_v, cs, rest, Je) / 2
+        p_new = p_new + dp * dt_used
+        cs = C.find_contacts(bodies_at(shapes, p_new), eps=eps, no_contact=no_contact)
     return p_new, new_v, cs, dt_used, trials

@@ -267,7 +267,93 @@ def test_solve_dynamics_variable_counts_match_oracle(with_joint, solver_path):
     print("worst scaled new_v error", worst)
 
 
-@pytest.mark.parametrize("name", sorted(load_world_traj()))
+def _world_of(rec, B, k=0, **kw):
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    geom = _geom([shapes_of(rec)] * B)
+    rep = lambda a, dt_: torch.tensor(np.broadcast_to(a, (B,) + a.shape).copy(), dtype=dt_, device=DEV)
+    return ContactWorld(geom, rep(rec["p"][k], torch.float64), rep(rec["v"][k], torch.float32),
+                        rep(rec["Mdiag"], torch.float32), rep(rec["f"], torch.float32), rep(rec["rest"], torch.float32),
+                        rep(rec["fric"], torch.float32), Je=rep(rec["Je"], torch.float32), dt=float(rec["dt"]),
+                        eps=float(rec["eps"]), tol=float(rec["tol"]), strict_no_penetration=bool(rec["strict"]), maxc=8, **kw)
+
+
+@pytest.mark.parametrize("name", sorted(n for n, r in load_world_traj().items() if bool(r["post_stab"])))
+def test_contact_world_post_stabilization_steps_match_reference(name):
+    """ContactWorld(post_stab=True): every step of the reference trajectories recorded with post-stabilisation on
+    (world.py:109-121, engines.py:80-116), each started from the reference's own state (pose, velocities, contacts
+    re-detected at that pose).  Step by step because ten PDIPM iterations do not converge on the frictionless LCP of a
+    resting contact (rhs ~ 0) and its output then amplifies rounding by ~1e8 (tests/test_world_oracle.py): a free run
+    drifts by the 1e-5 the fp32 velocities put in.  Checked per step: dt accepted, contact count after the step, pose
+    and velocities to 2e-4, the engine's dp to 2e-3 + 1e-3 |dp|."""
+    rec = load_world_traj()[name]
+    B = 5
+    rep = lambda a, dt_: torch.tensor(np.broadcast_to(a, (B,) + a.shape).copy(), dtype=dt_, device=DEV)
+    world = _world_of(rec, B, post_stab=True)
+    from lcp_physics_amd.physics.contacts import find_contacts
+    worst_p = worst_v = worst_dp = 0.0
+    for k in range(1, len(rec["t"])):
+        world.p.copy_(rep(rec["p"][k - 1], torch.float64))
+        world.v.copy_(rep(rec["v"][k - 1], torch.float32))
+        world.t.fill_(float(rec["t"][k - 1]))
+        find_contacts(world.geom, world.p, maxc=world.maxc, eps=world.eps, out=world.contacts)
+        assert world.contacts.count.cpu().tolist() == [int(rec["ncontacts"][k - 1])] * B, (name, k, "contacts before")
+        out = world.step()
+        t = world.t.cpu().numpy()
+        assert np.abs(t - rec["t"][k]).max() < 1e-12, (name, k, "t", t, rec["t"][k])
+        assert world.contacts.count.cpu().tolist() == [int(rec["ncontacts"][k])] * B, (name, k, "contact count")
+        ep = np.abs(world.p.cpu().numpy() - rec["p"][k]).max()
+        ev = np.abs(world.v.double().cpu().numpy() - rec["v"][k]).max()
+        dp = out["post_stab"]["dp"].double().cpu().numpy()
+        edp = (np.abs(dp - rec["dp"][k - 1]) - 1e-3 * np.abs(rec["dp"][k - 1])).max()
+        worst_p, worst_v, worst_dp = max(worst_p, ep), max(worst_v, ev), max(worst_dp, edp)
+        assert ep <= 2e-4 and ev <= 2e-4 and edp <= 2e-3, (name, k, ep, ev, edp)
+    print(name, "worst |dp pose|", worst_p, "worst |dv|", worst_v, "worst post-stab dp error", worst_dp)
+
+
+def test_post_stabilization_matches_oracle_with_ragged_counts():
+    """`lcp_post_stabilization_f32` on stack scenes with random velocities and per-scene contact counts (0 = the direct
+    KKT solve, engines.py:92-103) against oracle/pdipm_oracle.post_stabilization per scene, and the correction move
+    p + (dp / 2) dt_k (world.py:110-117)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import post_stabilization
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    from oracle import pdipm_oracle as O
+    for nbox, pts in ((2, 2), (4, 4), (6, 4)):
+        B = 12
+        sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=70 + nbox, dtype=torch.float32)
+        scg = sc.to(device=DEV)
+        cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+        counts = [sc.nc, sc.nc, sc.nc - 1, sc.nc // 2, 1, 0, sc.nc, 3, 2, sc.nc, 0, sc.nc]
+        count = torch.tensor(counts, dtype=torch.int32, device=DEV)
+        g = torch.Generator().manual_seed(5)
+        p = (torch.randn(B, sc.nb, 3, generator=g, dtype=torch.float64) * 100).to(DEV)
+        dts = (torch.rand(B, generator=g, dtype=torch.float64) / 30).to(DEV)
+        p_out = torch.empty_like(p)
+        out = post_stabilization(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.rest, cb, scg.Je, p=p, dt_scene=dts,
+                                 p_out=p_out)
+        torch.cuda.synchronize()
+        dp = out["dp"].double().cpu()
+        # (the move uses the fp64 dp, `dp` is its fp32 rounding)
+        moved = (p + (out["dp"].double() * 0.5) * dts[:, None, None]).cpu()
+        assert float((p_out.cpu() - moved).abs().max()) <= 1e-7 * float(dp.abs().max()) / 30 + 1e-12
+        worst = 0.0
+        for k, n in enumerate(counts):
+            d = lambda t: t[k:k + 1].double().cpu()
+            if n == 0:
+                ref = torch.tensor(W.post_stabilization(d(sc.Mdiag)[0].numpy(), d(sc.v)[0].numpy(), [], d(sc.rest)[0].numpy(),
+                                                        d(sc.Je)[0].numpy()))
+            else:
+                ref = O.post_stabilization(d(sc.Mdiag), d(sc.v), d(sc.c_n)[:, :n], d(sc.c_p1)[:, :n], d(sc.c_p2)[:, :n],
+                                           sc.c_i1[k:k + 1, :n], sc.c_i2[k:k + 1, :n], d(sc.rest), d(sc.Je))[0][0]
+            err = float((dp[k] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            worst = max(worst, err)
+            assert err <= 1e-4, (nbox, k, n, err)
+            assert int(out["status"][k]) & 8 == 0
+        print("post-stabilisation", nbox, pts, "worst scaled dp error", worst)
+
+
+@pytest.mark.parametrize("name", sorted(n for n, r in load_world_traj().items() if not bool(r["post_stab"])))
 def test_contact_world_follows_reference_trajectory(name):
     """ContactWorld.step() against trajectories of the unmodified reference World (world.py:72-122).
     Velocities are carried in fp32 between the two kernels, so poses (coordinates of ~500) and velocities
