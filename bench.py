@@ -49,12 +49,14 @@ def parse():
     ap.add_argument("--bwd", default="dense", choices=["dense", "physical"],
                     help="backward timed in the step: 'dense' = LCPFunction.backward (7 dense gradients, lcp.py:37-64); "
                          "'physical' (fused mode only) = lcp_step_backward_f32, gradients w.r.t. the physical inputs")
+    ap.add_argument("--fwd-only", action="store_true",
+                    help="time the forward only (BASELINE configs[1] is forward-only); the default is the headline fwd+bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     return ap.parse_args()
 
 
-def cpu_baseline(sc_cpu, cot, budget_s=15.0):
+def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
     """Oracle (port of the reference algorithm, vectorised torch fp64) on the host cores: forward +
     backward on a bounded sample of the same scenes (sized from a calibration pass to ~budget_s)."""
     from oracle import pdipm_oracle as O
@@ -66,7 +68,8 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0):
         lcp = O.assemble_lcp(*sub.assembly_args())
         t0 = time.perf_counter()
         sol = O.lcp_forward(*lcp)
-        O.lcp_backward(sol, *lcp, cot[:n].double())
+        if not fwd_only:
+            O.lcp_backward(sol, *lcp, cot[:n].double())
         return time.perf_counter() - t0
 
     run(32)                                             # warm-up
@@ -77,8 +80,8 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0):
         total += run(sample)
         passes += 1
     return {"value": sample * passes / total, "unit": "sim steps/s", "cores": threads, "kind": "port",
-            "sample": "%d of the same scenes x %d passes, fwd+bwd, vectorised torch fp64 oracle, %.2f s"
-                      % (sample, passes, total)}
+            "sample": "%d of the same scenes x %d passes, %s, vectorised torch fp64 oracle, %.2f s"
+                      % (sample, passes, "forward only" if fwd_only else "fwd+bwd", total)}
 
 
 def main():
@@ -131,7 +134,9 @@ def main():
             s_ = step_sol
         if ev is not None:
             ev[1].record()
-        if args.bwd == "physical":
+        if args.fwd_only:
+            pass
+        elif args.bwd == "physical":
             nonlocal pgrads
             pgrads = fused_step_backward(sc, step_out, cot_v, compute=args.compute, grads=pgrads)
         else:
@@ -173,8 +178,12 @@ def main():
         tj = json.load(open(tpath)).get("%s_B%d_nc%d_%s" % (args.mode, B, nc, args.compute))
         if tj:
             traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0
+    # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
+    cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
+        (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
+    what = "forward only" if args.fwd_only else "forward + backward (implicit diff)"
     out = {
-        "metric": "sim steps/sec at batch=4096x16 contacts, fwd+bwd",
+        "metric": "sim steps/sec at batch=%dx%d contacts, %s" % (B, nc, "fwd" if args.fwd_only else "fwd+bwd"),
         "value": value,
         "unit": "sim steps/s",
         "n_gpus": world,
@@ -186,9 +195,10 @@ def main():
         "vs_baseline": None,
         "dtype": args.compute,
         "data": "synthetic",
-        "config": {"workload": "configs[2]: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
-                               "neq %d) per GPU, fp32 I/O, LCP forward + backward (implicit diff), mode=%s, bwd=%s"
-                               % (B, nc, args.nbox, args.pts, nz, m, e, args.mode, args.bwd),
+        "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
+                               "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s"
+                               % (cfg, B, nc, args.nbox, args.pts, nz, m, e, what, args.mode,
+                                  "none" if args.fwd_only else args.bwd),
                    "global_batch": B * world, "parallelism": "scenes sharded x%d, no collectives" % world,
                    "mean_pdipm_iters": mean_it, "nonzero_status": int((status != 0).sum())},
         "roofline": {"bound": "mfma",
@@ -204,7 +214,7 @@ def main():
                      "hbm_frac_algorithmic": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sc_cpu, cot_cpu, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(sc_cpu, cot_cpu, args.cpu_budget, args.fwd_only)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
