@@ -84,6 +84,45 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
                       % (sample, passes, "forward only" if fwd_only else "fwd+bwd", total)}
 
 
+def parity_vs_oracle(sc_cpu, cot, x_gpu, z_gpu, s_gpu, dp_gpu, n=256):
+    """The metric's second half ("fwd+bwd rel-err vs ref"): the step just timed against the fp64 oracle on the first
+    `n` scenes (identical fp32 inputs).  err_x = |x - x_ref| / max(|x_ref|, |Q^-1 p|) per scene; the
+    backward error is taken on dp = dx (lcp.py:52), scaled by |Q^-1 dl_dx|, over the scenes where the oracle's own
+    backward system is well posed (same mask as tests/test_hip_parity.py::test_stack_scenes_backward_parity)."""
+    from oracle import pdipm_oracle as O
+    from tests import parity
+    n = min(n, sc_cpu.B)
+    # identical LCP inputs: assembled in fp32 exactly as the step kernel assembles them (engines.py:50-74 in the
+    # data's dtype; tests/test_hip_parity.py::test_assembly_kernel_matches_oracle), then solved in fp64
+    lcp = [None if t is None else t.double() for t in O.assemble_lcp(*sc_cpu.slice(0, n).assembly_args())]
+    Q, p, G, h, A, b, F = lcp
+    ref = O.lcp_forward(*lcp)
+    ex = parity.err_x(x_gpu[:n].double().cpu(), ref.x, Q, p)
+    out = {"scenes": n, "tolerance": 1e-4, "fwd_err_x_max": float(ex.max()), "fwd_err_x_median": float(ex.median())}
+    # contact index sets {i : z_i > s_i} (SURVEY 8d): compared wherever the oracle's own decision is not a tie between
+    # two numbers that both converged to zero (tests/test_hip_parity.py::_decisive)
+    z, sl = z_gpu[:n].double().cpu(), s_gpu[:n].double().cpu()
+    big = torch.maximum(ref.z.abs(), ref.s.abs())
+    nondeg = torch.maximum(ref.z.abs() / ref.z.abs().max(dim=1, keepdim=True)[0],
+                           ref.s.abs() / ref.s.abs().max(dim=1, keepdim=True)[0]) > 1e-5
+    dec = ((ref.z - ref.s).abs() > 1e-3 * big) & nondeg
+    out["index_set_mismatches"] = int((((z > sl) != (ref.z > ref.s)) & dec).sum())
+    out["index_set_rows_compared"] = int(dec.sum())
+    if dp_gpu is not None:
+        c64 = cot[:n].double()
+        gref = O.lcp_backward(ref, *lcp, c64)
+        res = parity.kkt_backward_residual(Q, G, A, F, ref.z, ref.s, c64, gref["dp"], -gref["dh"], -gref["db"])
+        ok = torch.stack([v for v in res.values()]).max(dim=0)[0] < 1e-9
+        zs, ss = ref.z.max(dim=1, keepdim=True)[0], ref.s.max(dim=1, keepdim=True)[0]
+        ok = ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
+        fl = parity.grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
+        eg = parity.err_grads({"p": dp_gpu[:n].double().cpu()}, {"p": gref["dp"]}, fl)["p"]
+        if bool(ok.any()):
+            out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})
+        out["bwd_well_posed_scenes"] = int(ok.sum())
+    return out
+
+
 def main():
     args = parse()
     from lcp_physics_amd import flops, scenes, shard
@@ -215,6 +254,12 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc_cpu, cot_cpu, args.cpu_budget, args.fwd_only)
+        x_gpu = sol.x if args.mode == "dense" else -step_out["v_new"].reshape(B, nz)
+        dp_gpu = None if (args.fwd_only or args.bwd == "physical") else grads[1]
+        zs_src = sol if args.mode == "dense" else None
+        z_gpu = zs_src.z if zs_src is not None else step_out["z"]
+        s_gpu = zs_src.s if zs_src is not None else step_out["s"]
+        out["parity"] = parity_vs_oracle(sc_cpu, cot_cpu, x_gpu, z_gpu, s_gpu, dp_gpu)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
