@@ -179,7 +179,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
  * direct solve [[M, -Je^T], [Je, 0]]^-1 [0; ge] (:92-103).  `v` are the velocities AFTER the dynamics solve and the
  * contacts those found after the move (world.py:87-94).  When p / p_out are given, p_out = p + (dp / 2) dt_k with
  * dt_k = dt_scene[k] (the dt the scene's step ended up using; NULL: the scalar `dt`) - world.py:110-117; the caller
- * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL).
+ * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL); p_out may be p itself.
  * Runs on the workgroup-per-scene kernels (any size their plan takes: LCP_E_TOOLARGE beyond); workspace of
  * lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
  *   out: dp[B,nb,3]  p_out[B,nb,3] (optional)  iters[B]  status[B] */

@@ -287,7 +287,8 @@ class ContactWorld:
                  not_improved_lim=3, max_trials=64, check=True, post_stab=False):
         from . import contacts as _contacts
         self.post_stab = bool(post_stab)
-        self._ps_out = self._ps_ws = self._p_ps = None
+        self._ps_out = self._ps_ws = None
+        self._phase, self._graphs = 0, {}
         self._contacts_mod = _contacts
         self.geom = geom
         dev = p.device
@@ -315,8 +316,34 @@ class ContactWorld:
         if worst > self.maxc:
             raise RuntimeError("a scene has %d contacts but maxc = %d" % (worst, self.maxc))
 
+    def run(self, nsteps, graph=True):
+        """`nsteps` calls of `step()`.  With `graph=True` the launches of TWO consecutive steps (after two steps the
+        double-buffered state tensors are back in their slots) are captured once into a HIP graph and replayed: the
+        host then issues one graph launch per two simulation steps instead of 2-4 kernel launches with their Python
+        marshalling per step - what bounds small batches.  Same kernels, same order, same results."""
+        k = 0
+        if graph and nsteps >= 2:
+            while not self._graphs and k < 2:
+                self.step()                                                # warm-up: every buffer exists before capture
+                k += 1
+            g = self._graphs.get(self._phase)
+            if g is None and nsteps - k >= 2:
+                torch.cuda.synchronize(self.p.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.step()
+                    self.step()
+                self._graphs[self._phase] = g                              # (capture only records: nothing has run)
+            while g is not None and nsteps - k >= 2:
+                g.replay()
+                k += 2
+        while k < nsteps:
+            self.step()
+            k += 1
+
     def step(self):
         """`World.step()` = `step_dt(self.dt)` (`world.py:72-122`) for every scene."""
+        self._phase ^= 1
         cb = self.contacts
         out = solve_dynamics(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, self.f, self.rest,
                              self.fric, cb, self.Je, self.dt, eps=self.solver_eps, not_improved_lim=self.lim,
@@ -328,14 +355,12 @@ class ContactWorld:
                                                   max_trials=self.max_trials, t=self.t, out=cb)
         self.p, cb.p_out = cb.p_out, self.p                              # accepted pose becomes the state (double buffer)
         if self.post_stab:                                               # world.py:109-121
-            if self._p_ps is None:
-                self._p_ps = torch.empty_like(self.p)
-            # the engine's defaults here (engines.py:114 `self.lcp_solver()`), not the dynamics solve's settings
+            # the engine's defaults here (engines.py:114 `self.lcp_solver()`), not the dynamics solve's settings;
+            # the pose is corrected in place (every thread reads and writes its own entry)
             ps = post_stabilization(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, self.rest, cb,
-                                    self.Je, p=self.p, dt_scene=cb.dt_used, dt=self.dt, p_out=self._p_ps,
+                                    self.Je, p=self.p, dt_scene=cb.dt_used, dt=self.dt, p_out=self.p,
                                     compute=self.compute, ws=self._ps_ws, out=self._ps_out)
             self._ps_ws, self._ps_out = ps["ws"], ps
-            self.p, self._p_ps = self._p_ps, self.p
             self._contacts_mod.find_contacts(self.geom, self.p, maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
             out["post_stab"] = ps
         return out

@@ -310,6 +310,28 @@ def test_contact_world_post_stabilization_steps_match_reference(name):
     print(name, "worst |dp pose|", worst_p, "worst |dv|", worst_v, "worst post-stab dp error", worst_dp)
 
 
+@pytest.mark.parametrize("name", ["stack3", "mixed", "stack3_poststab"])
+def test_contact_world_graph_replay_is_bitwise_the_eager_run(name):
+    """ContactWorld.run(n, graph=True) replays pairs of steps from a captured HIP graph: same kernels in the same order on
+    the same buffers, so poses, velocities, times and contact lists must equal the eager run bit for bit."""
+    rec = load_world_traj()[name]
+    B, n = 6, 21                                                          # odd: two warm-up steps, nine replays, one eager tail
+    a = _world_of(rec, B, post_stab=bool(rec["post_stab"]))
+    b = _world_of(rec, B, post_stab=bool(rec["post_stab"]))
+    for _ in range(n):
+        a.step()
+    b.run(n, graph=True)
+    assert len(b._graphs) == 1
+    b.run(4, graph=True)                                                  # odd phase now: a second graph is captured
+    for _ in range(4):
+        a.step()
+    torch.cuda.synchronize()
+    assert len(b._graphs) == 2
+    assert torch.equal(a.p, b.p) and torch.equal(a.v, b.v) and torch.equal(a.t, b.t)
+    assert torch.equal(a.contacts.count, b.contacts.count) and torch.equal(a.contacts.c_p1, b.contacts.c_p1)
+    assert float(a.t.min()) > 0.3
+
+
 def test_post_stabilization_matches_oracle_with_ragged_counts():
     """`lcp_post_stabilization_f32` on stack scenes with random velocities and per-scene contact counts (0 = the direct
     KKT solve, engines.py:92-103) against oracle/pdipm_oracle.post_stabilization per scene, and the correction move

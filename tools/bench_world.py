@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=2)
     ap.add_argument("--maxc", type=int, default=16, help="contact capacity per scene")
     ap.add_argument("--box", type=float, default=40.0)
+    ap.add_argument("--graph", action="store_true", help="time ContactWorld.run(steps, graph=True): HIP graph replay")
     args = ap.parse_args()
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics import batched_world as bw
@@ -48,18 +49,32 @@ def main():
         out = move(*a, **kw); ev[k_["i"]][2].record(); return out
 
     bw.solve_dynamics, ct.move_and_find_contacts = solve_t, move_t
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        k_["i"] = i
-        world.step()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    if args.graph:
+        bw.solve_dynamics, ct.move_and_find_contacts = solve, move
+        world.run(4, graph=True)                                         # capture outside the timed region
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        world.run(args.steps, graph=True)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        for e in ev:
+            for x in e:
+                x.record()
+        torch.cuda.synchronize()
+    else:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            k_["i"] = i
+            world.step()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
     bw.solve_dynamics, ct.move_and_find_contacts = solve, move
     world.check_capacity()
-    solve_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    move_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    # (per-launch events cannot be timed inside a replayed graph: the split is reported for eager runs only)
+    solve_ms = None if args.graph else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    move_ms = None if args.graph else sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     out = {"metric": "sim steps/s with contact detection (ContactWorld.step)", "value": args.batch * args.steps / wall,
-           "unit": "sim steps/s", "batch": args.batch, "steps": args.steps, "ms_per_step": wall / args.steps * 1e3,
+           "unit": "sim steps/s", "batch": args.batch, "steps": args.steps, "hip_graph": bool(args.graph), "ms_per_step": wall / args.steps * 1e3,
            "solve_dynamics_ms": solve_ms, "move_find_contacts_ms": move_ms,
            "mean_contacts_start": float(counts0.mean()), "mean_contacts_end": float(world.contacts.count.float().mean()),
            "max_contacts": int(world.contacts.count.max()), "mean_trials_last_step": float(world.contacts.trials.float().mean()),
