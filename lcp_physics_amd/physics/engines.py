@@ -7,17 +7,19 @@ class with no arguments (`physics/world.py:26`, `physics/utils.py:142-150`) and 
 * `HipPdipmEngine` - differentiable.  Builds (M, u, G, h, Je, b, F) with the same torch
   expressions as `engines.py:50-74` (so autograd reaches masses, forces and contact geometry)
   and solves the mixed LCP with the HIP `LCPFunction`.
-* `HipFusedEngine` - inference.  Hands the raw contact list to the fused HIP step kernel
-  (assembly + solve in one launch); not differentiable.
+* `HipFusedEngine` - inference.  Hands the raw contact list to the device entry points of the batched
+  path (assembly + solve in one launch, both branches of `solve_dynamics`, and `post_stabilization`);
+  not differentiable.
 
-The no-contact branch (`engines.py:35-49`, an equality-only linear solve) and
-`post_stabilization` (`engines.py:80-116`) are the reference's formulas on torch tensors: they
-are SURVEY.md §8(f) row 3 ("next"), not part of the LCP hot path.
+In the differentiable `HipPdipmEngine` the no-contact branch (`engines.py:35-49`, an equality-only linear
+solve autograd must see through) stays the reference's formula on torch tensors; its `post_stabilization`
+(`engines.py:80-116`) solves the frictionless LCP with the HIP `LCPFunction`.
 """
 import torch
 
 from ..lcp.lcp import LCPFunction
 from . import batched_world
+from . import contacts as _contacts
 
 
 class Engine:
@@ -107,28 +109,52 @@ class HipPdipmEngine(Engine):
 
 
 class HipFusedEngine(HipPdipmEngine):
-    """Non-differentiable engine: contact list -> fused HIP step (assembly + LCP) in one launch."""
+    """Non-differentiable engine: the world's raw state goes to the device entry points of the batched path as a batch
+    of one - `lcp_solve_dynamics_f32` (both branches of `engines.py:26-78`: a world without contacts takes the direct
+    KKT solve inside the same kernel) and `lcp_post_stabilization_f32` (`engines.py:80-116`).  Joints are read
+    through `world.Je()`, so pose-dependent ones work (the Jacobian is re-read every call)."""
 
     def __init__(self, max_iter=10, compute="f64"):
         super().__init__(max_iter=max_iter)
         self.compute = compute
 
-    def solve_dynamics(self, world, dt):
-        if not world.contacts:
-            return super().solve_dynamics(world, dt)
-        base = world.get_v()
+    @staticmethod
+    def _device_state(world):
         nb = len(world.bodies)
+        dev = torch.device("cuda")
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        Je = world.Je()
+        e = Je.size(0) if Je.ndimension() > 0 and Je.numel() > 0 else 0
+        cs = world.contacts or []
+        maxc = max(1, len(cs))
+        cb = _contacts.ContactBuffers(1, nb, maxc, dev)
+        if cs:
+            st = lambda k: torch.stack([c[0][k].detach().reshape(2) for c in cs]).unsqueeze(0)
+            cb.c_n, cb.c_p1, cb.c_p2 = f32(st(0)), f32(st(1)), f32(st(2))
+            cb.c_i1 = torch.tensor([[int(c[1]) for c in cs]], dtype=torch.int32, device=dev)
+            cb.c_i2 = torch.tensor([[int(c[2]) for c in cs]], dtype=torch.int32, device=dev)
+        cb.count.fill_(len(cs))
+        return dict(
+            nb=nb, e=e, maxc=maxc, cb=cb,
+            v=f32(world.get_v().reshape(1, nb, 3)), Mdiag=f32(torch.diagonal(world.M()).reshape(1, nb, 3)),
+            rest=f32(torch.stack([b.restitution.reshape(()) for b in world.bodies]).unsqueeze(0)),
+            fric=f32(torch.stack([b.fric_coeff.reshape(()) for b in world.bodies]).unsqueeze(0)),
+            Je=f32(Je.unsqueeze(0)) if e else None)
+
+    def solve_dynamics(self, world, dt):
+        base = world.get_v()
         with torch.no_grad():
-            f32 = lambda t: t.detach().to(torch.float32)
-            Je = world.Je()
-            e = Je.size(0) if Je.ndimension() > 0 else 0
-            sc = batched_world.scene_from_contacts(
-                p=torch.stack([b.p for b in world.bodies]), v=base.reshape(nb, 3),
-                Mdiag=torch.diagonal(world.M()).reshape(nb, 3),
-                f=world.apply_forces(world.t).reshape(nb, 3),
-                rest=torch.stack([b.restitution.reshape(()) for b in world.bodies]),
-                fric=torch.stack([b.fric_coeff.reshape(()) for b in world.bodies]),
-                contacts=world.contacts, Je=Je if e else None, dt=float(dt))
-            out = batched_world.fused_step(sc.to(device="cuda", dtype=torch.float32),
-                                           max_iter=self.max_iter, compute=self.compute)
+            d = self._device_state(world)
+            f = world.apply_forces(world.t).detach().reshape(1, d["nb"], 3).to(device="cuda", dtype=torch.float32)
+            out = batched_world.solve_dynamics(1, d["nb"], d["maxc"], d["e"], d["cb"].count, d["Mdiag"], d["v"],
+                                               f.contiguous(), d["rest"], d["fric"], d["cb"], d["Je"], float(dt),
+                                               max_iter=self.max_iter, compute=self.compute)
             return out["v_new"].reshape(-1).to(device=base.device, dtype=base.dtype)
+
+    def post_stabilization(self, world):
+        base = world.get_v()
+        with torch.no_grad():
+            d = self._device_state(world)
+            out = batched_world.post_stabilization(1, d["nb"], d["maxc"], d["e"], d["cb"].count, d["Mdiag"], d["v"],
+                                                   d["rest"], d["cb"], d["Je"], compute=self.compute)
+            return out["dp"].reshape(-1).to(device=base.device, dtype=base.dtype)

@@ -5,6 +5,7 @@ Tolerances (stated, fp32 I/O): err_x <= 1e-4 (scaled, tests/parity.py), gradient
 contact index sets {i: z_i > s_i} identical wherever the oracle's decision is not a tie.
 The fp64-I/O kernel is held to 1e-7 (it follows the reference's native-dtype trajectory).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -496,3 +497,43 @@ def test_engine_plugin_reproduces_reference_new_v(name, st):
     lcp = golden_io.lcp_inputs(st)
     ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
     assert float(ev.max()) < 1e-7, (name, float(ev.max()))
+
+
+class _FakeBody:
+    def __init__(self, rest, fric):
+        self.restitution, self.fric_coeff = rest, fric
+
+
+class _FakeRawWorld(_FakeWorld):
+    """`_FakeWorld` + the per-body attributes the contact-list engine reads (`bodies[i].restitution / .fric_coeff`)."""
+
+    def __init__(self, st, with_contacts=True):
+        super().__init__(st)
+        self.bodies = [_FakeBody(st["rest"][i], st["fric"][i]) for i in range(st["v"].shape[0])]
+        if not with_contacts:
+            self.contacts = []
+
+
+@pytest.mark.parametrize("name,st", STEPS[::5], ids=IDS[::5])
+def test_fused_engine_plugin_runs_both_branches_and_post_stabilization_on_the_device(name, st):
+    """`HipFusedEngine` (the non-differentiable plug-in for the reference's `World`): contact branch against the
+    reference's recorded new_v, the no-contact branch (`engines.py:36-50`) and `post_stabilization`
+    (`engines.py:80-116`) against the oracle - all three through the device entry points, batch of one."""
+    from oracle import world_oracle as W
+    from lcp_physics_amd.physics import HipFusedEngine
+    eng = HipFusedEngine()
+    new_v = eng.solve_dynamics(_FakeRawWorld(st), st["dt"])
+    lcp = golden_io.lcp_inputs(st)
+    ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
+    assert float(ev.max()) < 1e-4, (name, "contact branch", float(ev.max()))       # (fp32 contact data on this path)
+    n = lambda k: st[k].double().numpy()
+    Md = torch.diagonal(lcp[0][0]).reshape(-1, 3).double().numpy()
+    free = eng.solve_dynamics(_FakeRawWorld(st, with_contacts=False), st["dt"]).reshape(-1, 3).double().numpy()
+    ref = W.solve_dynamics(Md, n("v"), n("f"), float(st["dt"]), [], n("rest"), n("fric"), n("Je"))
+    assert np.abs(free - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (name, "no-contact branch")
+    world = _FakeRawWorld(st)
+    dp = eng.post_stabilization(world).reshape(-1, 3).double().numpy()
+    cs = [((c[0][0].double().numpy(), c[0][1].double().numpy(), c[0][2].double().numpy(), float(c[0][3])), c[1], c[2])
+          for c in world.contacts]
+    ref = W.post_stabilization(Md, n("v"), cs, n("rest"), n("Je"))
+    assert np.abs(dp - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (name, "post_stabilization", np.abs(dp - ref).max())
