@@ -139,8 +139,9 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  *   in : the inputs of the forward, dl_dv[B,nb,3] = d(loss)/d(v_new)
  *   out: dMdiag[B,nb,3] dv[B,nb,3] df[B,nb,3] drest[B,nb] dfric[B,nb] dc_n[B,nc,2] dc_p1[B,nc,2] dc_p2[B,nc,2]
  *        (any may be NULL; padded contact slots get 0).  The joint Jacobian Je is treated as a constant.
- * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; up to nc <= 64, 3 nb <= 43, e <= 4 (fp64 arithmetic) after
- * lcp_solve_dynamics_f32 only (that kernel owns the workspace layout); else LCP_E_TOOLARGE. */
+ * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
+ * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout - lcp_step_fused_f32
+ * serves those sizes from the generic kernels, whose workspace this entry cannot read); else LCP_E_TOOLARGE. */
 int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* Mdiag, const float* v, const float* f,
                           const float* rest, const float* fric,
@@ -156,8 +157,9 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
  * a scene without contacts takes the direct KKT solve of engines.py:36-50.  One launch, no position update
  * (that is lcp_move_find_contacts_f64).  Arguments as lcp_step_fused_f32; z, s use the row layout of a
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
- * Served by the four-scenes-per-wave kernel when 3 nb <= 16, maxc <= 16, e <= 4: the workspace it leaves then feeds
- * lcp_pdipm_backward_f32 (m = 4 maxc) and lcp_step_backward_f32 (padded slots get zero gradients).  Larger scenes, up to
+ * Served by the four-scenes-per-wave kernel when 3 nb <= 32, maxc <= 16, e <= 4: the workspace it leaves then feeds
+ * lcp_step_backward_f32 (padded slots get zero gradients) and, for 3 nb <= 16, lcp_pdipm_backward_f32 (m = 4 maxc).
+ * Larger scenes, up to
  * maxc <= 64, 3 nb <= 43, e <= 4 (fp64 arithmetic), run on the register-tiled workgroup-per-scene kernel (BASELINE
  * config 5) and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs forward only on
  * the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).

@@ -98,7 +98,8 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream);
 int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
-// four-scenes-per-wave contact-structured path (nc <= 16, nz <= 16, neq <= 4, diagonal Q) - lcp_quad.hip
+// four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
+// list) - lcp_quad.hip
 // `accept`: classification flag value (workspace meta[0]) the launch serves
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32

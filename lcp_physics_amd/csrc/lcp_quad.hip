@@ -1,13 +1,14 @@
 // lcp_quad.hip - contact-structured PDIPM kernels, FOUR SCENES PER WAVEFRONT (16 lanes per scene).
 //
 // The fastest path: contact-structured LCPs (engines.py:67-73) with diagonal Q, nc <= 16 contacts,
-// nz <= 16, neq <= 4, fp32 I/O.  Mapping (CDNA4-first):
+// nz <= 16 (dense inputs) or nz <= 32 (contact-list inputs, template parameter XH = 2), neq <= 4, fp32 I/O.
+// Mapping (CDNA4-first):
 //   * one 16-lane DPP row = one scene, lane c = contact c.  The lane holds everything that belongs to its
 //     contact: the four inequality components (normal, friction +, friction -, gamma) of every m-space
 //     vector, its rows of Jc and Jt, and BOTH of its rows of the reduced 2nc x 2nc system (a_c and u_c,
 //     see lcp_wave64.hip `Red` for the algebra).  The per-contact 2x2 elimination, F z, the reduction's
 //     right-hand side and back-substitution are therefore lane-local - no cross-lane traffic at all.
-//   * x-space vectors (nz <= 16) live one entry per lane of the row, e-space (neq <= 4) likewise.
+//   * x-space vectors live one entry per lane of the row (two with XH = 2), e-space (neq <= 4) likewise.
 //   * every cross-lane move is a DPP row operation: `row_newbcast:k` broadcasts lane k of each row to its row
 //     (pivot rows in the LU, vector entries in the products), quad_perm / row_mirror give row-local
 //     reductions.  Micro-benchmark (tools/microbench/pair_cost.hip): 6.7 cycles per fp64 FMA fed by a 64-bit DPP

@@ -106,7 +106,7 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
     B, nb, nc = sc.B, sc.nb, sc.nc
     dev = sc.v.device
     if (3 * nb > 16 or nc > 16) and out.get("path") != "solve_dynamics":
-        raise RuntimeError("scenes beyond 5 bodies / 16 contacts: the forward must be `solve_dynamics` "
+        raise RuntimeError("scenes beyond 5 bodies or 16 contacts: the forward must be `solve_dynamics` "
                            "(lcp_solve_dynamics_f32) - its kernel owns the workspace layout the backward reads")
     dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
     if grads is None:
