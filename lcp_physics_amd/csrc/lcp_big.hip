@@ -661,6 +661,8 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
           if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;   // (:133)
         }
       }
+      // (the iterate the last pass would produce is never evaluated - pdipm.py:176-179 - so its solves are skipped)
+      if (it >= 0 && it == max_iter - 1) done = true;
       if (!done) {
         double ax = 0, ay = 0;
         M4<double> as_ = m4<double>(0, 0, 0, 0), az = as_;

@@ -548,6 +548,9 @@ __device__ void pdipm_loop(Scene<TC>& S, const FT& F, TC eps, int max_iter, int 
       ++n_not;
     }
     if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) break;                  // (:133)
+    // the iterate this pass would produce is never evaluated (:176-179): dead work, skipped (kept when the per-iteration
+    // trace is requested, which also records this pass's sigma and step length)
+    if (it == max_iter - 1 && !trace) break;
     // affine direction                                                      (:138-139)
     for (int i = tid; i < m; i += NT) S.rs[i] = S.z[i];
     __syncthreads();

@@ -887,6 +887,9 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       }
     }
     if (!__any(!done)) break;
+    // the iterate the last pass would produce is never evaluated (pdipm.py:176-179 returns `best` straight after the
+    // loop): its two solves and the update are dead work in the reference too, and skipped here
+    if (it >= 0 && it == max_iter - 1) break;
     LCP_QTICK(pr, 6)                                                       // bookkeeping, best iterate
     XVt ax;
     static_for<XH>([&](auto HX) LCP_INL { ax.v[HX] = 0; });

@@ -1045,6 +1045,9 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
       if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; bs = s; bz = z; by = y; }
       else ++n_not;
       if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) break;  // (:133)
+      // the iterate this pass would produce is never evaluated (:176-179): dead work, skipped (kept when the
+      // per-iteration trace is requested, which also records this pass's sigma and step length)
+      if (it == max_iter - 1 && !trace) break;
     }
     // one call site for the KKT solve (code size): pass 0 = init / affine, pass 1 = corrector
     TC ax = 0, as_ = 0, az = 0, ay = 0;
