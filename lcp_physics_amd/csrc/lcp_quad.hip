@@ -1248,8 +1248,18 @@ bool quad_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16
 // contact-list entry points only (lcp_solve_dynamics_f32 / lcp_step_backward_f32): up to ten bodies
 bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 32 && e <= q16::EQ; }
 
+// LDS bytes per scene.  The four scenes of a wave issue every LDS access together (16 lanes each, same offsets inside
+// their blocks): the block stride is padded to 64 B modulo 256 B = 16 banks modulo 64, so that the four 16-lane groups
+// land on four disjoint bank groups (a stride that is a multiple of 128 B - the unpadded 3456 B - puts them all on the
+// same banks).  Measured: SQ_LDS_BANK_CONFLICT 273 k -> 169 k cycles per launch; no change of the kernel time - the
+// single wave waits out the LDS latency either way.
 template <typename TC>
-static size_t q16_lds(bool with_w, int xh = 1) { q16::LdsQ<float, TC> L; return q16::carve_q<float, TC>(L, nullptr, with_w, xh); }
+static size_t q16_lds(bool with_w, int xh = 1) {
+  q16::LdsQ<float, TC> L;
+  size_t n = q16::carve_q<float, TC>(L, nullptr, with_w, xh);
+  while (n % 256 != 64) n += 16;
+  return n;
+}
 
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
   StepArgs SP = {};
