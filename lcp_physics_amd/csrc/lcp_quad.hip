@@ -555,16 +555,19 @@ __device__ __forceinline__ M4<TC> tsolve_q(const TC (&ta)[32], const TC (&tu)[32
 template <typename TI, typename TC, int XH>
 __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC, XH>& S, const TC (&ta)[32], const TC (&tu)[32], const RedQ<TC>& R,
                                             const M4<TC>& di, bool valid, const XV<TC, XH>& rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
-                                            XV<TC, XH>& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
+                                            XV<TC, XH>& ox, M4<TC>& os, M4<TC>& oz, TC& oy, bool rxy_zero LCP_QPROF_ARG) {
+  // `rxy_zero` (wave-uniform): rx = 0 and ry = 0, the corrector solve (pdipm.py:152-158).  Then Q^-1 rx, G Q^-1 rx and
+  // A Q^-1 rx - ry are exact zeros and the products that would form them are skipped: 10 of the 21 solves of a step.
+  TC gn = 0, gt = 0, hy = 0;
   XV<TC, XH> v;
-  static_for<XH>([&](auto HX) LCP_INL { v.v[HX] = S.qid[HX] * rx.v[HX]; });    // :333 (diagonal Q)
-  TC gn, gt;
-  S.Gv(v, gn, gt);
+  if (!rxy_zero) {
+    static_for<XH>([&](auto HX) LCP_INL { v.v[HX] = S.qid[HX] * rx.v[HX]; });    // :333 (diagonal Q)
+    S.Gv(v, gn, gt);
+  }
   // `di` = 1 / d (already formed for T = R + diag(1/d)): rs / d is taken as rs * di - one rounding more than the
   // reference's division, 8 fp64 divisions less per solve
   M4<TC> hz = m4<TC>(gn + rs.n * di.n - rz.n, gt + rs.f1 * di.f1 - rz.f1, -gt + rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);   // :334-340
-  TC hy = 0;
-  if (S.e > 0) {
+  if (S.e > 0 && !rxy_zero) {
     hy = S.Av(v) - ry;
     TC an, at;
     S.GAt(S.S11v(hy), an, at);
@@ -901,7 +904,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       XVt ox;
       TC oy;
       M4<TC> os, oz;
-      solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
+      solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy, pass == 1 LCP_QPROF_PASS);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
         const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());       // (once per solve)
@@ -1049,7 +1052,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   TC dnu;
   M4<TC> ds, dl;
   const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC, 1>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dxv, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  solve_kkt_q<TI, TC, 1>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dxv, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
   const TC dx = dxv.v[0];
   if (!live) return;
   // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
@@ -1168,7 +1171,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   TC dnu;
   M4<TC> ds, dl;
   const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu LCP_QPROF_PASS);  // lcp.py:47-50
+  solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
   // x-space vectors to LDS so that a contact lane can read the entries of its two bodies (GAL is free in this kernel:
   // 128 TC = X[32] DX[32] CR[16] CF[16] B12[32 ints])
   TC* X = S.L.GAL; TC* DX = X + 32; TC* CR = X + 64; TC* CF = X + 80;
