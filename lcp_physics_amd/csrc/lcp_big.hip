@@ -470,13 +470,14 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
 #endif
   // solve_kkt (pdipm.py:325-354); di = 1 / d
   auto solve_kkt = [&](const M4<double>& di, double rx, const M4<double>& rs, const M4<double>& rz, double ry,
-                       double& ox, M4<double>& os, M4<double>& oz, double& oy) {
+                       double& ox, M4<double>& os, M4<double>& oz, double& oy, bool rxy_zero) {
+    // `rxy_zero`: rx = ry = 0 (the corrector solve, pdipm.py:152-158) - the products of the zero vector are skipped
     const double v = qid * rx;                                            // :333 (diagonal Q)
-    double gn, gt;
-    Gv(v, gn, gt);
+    double gn = 0, gt = 0;
+    if (!rxy_zero) Gv(v, gn, gt);
     M4<double> hz = m4<double>(gn + rs.n * di.n - rz.n, gt + rs.f1 * di.f1 - rz.f1, -gt + rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);   // :334-340
     double hy = 0;
-    if (e > 0) {
+    if (e > 0 && !rxy_zero) {
       hy = Av(v) - ry;
       double an, at;
       GAt(S11v(hy), an, at);
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
     // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
     const double g = (lane < nz) ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
     const M4<double> zero = m4<double>(0, 0, 0, 0);
-    solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu);                   // lcp.py:47-50
+    solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu, false);                   // lcp.py:47-50
     // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
     double* X = L.xv; double* DX = L.wv; double* CR = L.add; double* CF = L.add + LX; int* B12 = (int*)(L.add + 2 * LX);
     X[lane] = x; DX[lane] = dx; wsync();
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
           double ox, oy;
           M4<double> os, oz;
           BIG_TICK(2)
-          solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+          solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy, pass == 1);
           BIG_TICK(3)                                                           // solve_kkt
           if (it < 0) {
             x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
