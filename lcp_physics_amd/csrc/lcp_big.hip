@@ -8,7 +8,7 @@
 //     the quad kernel), lane j = x-space entry j, lane a = e-space entry a.  Cross-lane traffic goes through small LDS
 //     buffers (a 64-lane scene has no DPP row to broadcast in).
 //   * matrix role - all 256 threads own the reduced matrix T (rows / columns 0..63 = a_c, 64..127 = u_c) as 8 x 8 register
-//     tiles in a 16 x 16 cyclic layout: thread (ti, tj) holds the entries (ti + 16 p, tj + 16 q).  The right-looking LU
+//     tiles in a G x G cyclic layout (G = 16): thread (ti, tj) holds the entries (ti + G p, tj + G q).  The right-looking LU
 //     (no pivoting, as in the quad kernel) broadcasts the pivot row and the multiplier column through LDS, two barriers
 //     per pivot; the load stays balanced to the last step because the layout is cyclic.
 //   * the finished factors are parked in LDS column-major (128 KB - this is what sizes the kernel: one scene per CU) and
@@ -24,11 +24,14 @@ namespace big {
 
 using namespace w64;
 
-constexpr int NT = 256;          // threads per scene
+// threads per scene: a G x G grid over the reduced matrix.  64 contacts: 16 x 16 = 256 threads (four waves, 8 x 8 tiles).
+// 32 contacts: 8 x 8 = ONE wave (again 8 x 8 tiles): the workgroup barriers of the pivot loop become wave-local and four
+// scenes share a CU, one per SIMD (measured against the 256-thread form: 1.0 M -> see DESIGN.md).  16 contacts: 16 x 16.
+template <int NCB> struct Grid { static constexpr int G = (NCB == 32) ? 8 : 16, NT = G * G; };
 constexpr int LX = 64;           // lanes of wave 0 = stride of the exchange buffers and of the stored iterate
 // The kernel is instantiated for a contact capacity NCB of 64, 32 or 16: the reduced system has NRD = 2 NCB rows, the
-// register tile of a thread is TP x TP with TP = NRD / 16 (8, 4, 2), and the LDS footprint (NRD x (NRD + 1) doubles of
-// factors) lets 1, 3 or ~8 scenes share a CU.
+// register tile of a thread is TP x TP with TP = NRD / G (8, 8, 2), and the LDS footprint (NRD x (NRD + 1) doubles of
+// factors) lets 1, 4 or ~8 scenes share a CU.
 constexpr int EQB = 4;           // padded neq
 constexpr int NZB = 64;          // x-space capacity (lanes of wave 0)
 
@@ -125,16 +128,17 @@ template <int NCB> struct WsLayout { static constexpr int W = 4 * NCB * NCB, IT 
 //              LCP gradients through the engine assembly), reading W and the iterate the forward left in the workspace.
 // (second launch bound = waves per SIMD the register allocation must allow: the small classes share a CU)
 template <int NCB, bool BWD>
-__global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
-  constexpr int NRD = 2 * NCB, LDU = NRD + 1, TP = NRD / 16, TH = TP / 2;
+__global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
+  constexpr int G = Grid<NCB>::G, NT = Grid<NCB>::NT, GSH = (G == 8) ? 3 : 4;
+  constexpr int NRD = 2 * NCB, LDU = NRD + 1, TP = NRD / G, TH = TP / 2;
   constexpr int WS_W = WsLayout<NCB>::W, WS_IT = WsLayout<NCB>::IT, WS_TOTAL = WsLayout<NCB>::TOTAL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // The wave that plays the vector role rotates with the block index: the dispatcher puts wave i of every workgroup on
   // SIMD i, so with a fixed choice the (serial, busy) vector waves of all the scenes sharing a CU would queue up on one
   // SIMD while the other three idle.  Blocks 256 apart are the ones that tend to share a CU.
-  const bool w0 = wave == (NCB == 64 ? 0 : (int)((blockIdx.x >> 8) & 3));
-  const int ti = tid >> 4, tj = tid & 15;                                 // tile coordinates of the matrix role
+  const bool w0 = wave == ((NCB == 64 || NT == 64) ? 0 : (int)((blockIdx.x >> 8) & 3));
+  const int ti = tid >> GSH, tj = tid & (G - 1);                          // tile coordinates of the matrix role
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;
   carve<NCB>(L, smem, nzs);
@@ -185,12 +189,12 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
   double* GA = L.LU;                       // [128][EQB]   (scratch inside the LU area, dead before the first factorisation)
   double* CC = L.LU + NRD * EQB;           // [128][EQB]   GA S11
   if (e > 0) {
-    if (tid < NRD) {
-      const float* jr = jrow<NCB>(L, tid, nzs);
+    for (int r = tid; r < NRD; r += NT) {
+      const float* jr = jrow<NCB>(L, r, nzs);
       for (int a = 0; a < EQB; ++a) {
         double acc = 0;
         for (int k = 0; k < nz; ++k) acc = fma((double)jr[k] * L.qid[k], (double)L.At[(size_t)a * nzs + k], acc);
-        GA[tid * EQB + a] = acc;
+        GA[r * EQB + a] = acc;
       }
     }
     if (tid < EQB * EQB) {
@@ -215,10 +219,10 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
       if (bad) L.flag[2] = 1;
     }
     __syncthreads();
-    if (tid < NRD) for (int a = 0; a < EQB; ++a) {
+    for (int r = tid; r < NRD; r += NT) for (int a = 0; a < EQB; ++a) {
       double acc = 0;
-      for (int c = 0; c < EQB; ++c) acc = fma(GA[tid * EQB + c], L.S11[c * EQB + a], acc);
-      CC[tid * EQB + a] = acc;
+      for (int c = 0; c < EQB; ++c) acc = fma(GA[r * EQB + c], L.S11[c * EQB + a], acc);
+      CC[r * EQB + a] = acc;
     }
     __syncthreads();
     if (L.flag[2]) status |= LCP_ST_SINGULAR_S11;
@@ -232,26 +236,26 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
     s11row[a] = (w0 && lane < EQB && e > 0) ? L.S11[lane * EQB + a] : 0.0;
   }
   if (!BWD) {
-    // W tile of this thread: entries (ti + 16 p, tj + 16 q)
+    // W tile of this thread: entries (ti + G p, tj + G q)
     double wt_[TP][TP];
     static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
     for (int k = 0; k < nz; ++k) {
       const double qk = L.qid[k];
       double ri[TP], cj[TP];
-      static_for<TP>([&](auto P) LCP_INL { ri[P] = (double)jrow<NCB>(L, ti + 16 * P, nzs)[k] * qk; cj[P] = (double)jrow<NCB>(L, tj + 16 * P, nzs)[k]; });
+      static_for<TP>([&](auto P) LCP_INL { ri[P] = (double)jrow<NCB>(L, ti + G * P, nzs)[k] * qk; cj[P] = (double)jrow<NCB>(L, tj + G * P, nzs)[k]; });
       static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
     }
     if (e > 0) {
       for (int a = 0; a < EQB; ++a) {
         double ci[TP], gj[TP];
-        static_for<TP>([&](auto P) LCP_INL { ci[P] = CC[(ti + 16 * P) * EQB + a]; gj[P] = GA[(tj + 16 * P) * EQB + a]; });
+        static_for<TP>([&](auto P) LCP_INL { ci[P] = CC[(ti + G * P) * EQB + a]; gj[P] = GA[(tj + G * P) * EQB + a]; });
         static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
       }
     }
     // rows / columns of contacts the scene does not have are identity in T: zero here, 1 arrives through addA / addU
     static_for<TP>([&](auto P) LCP_INL {
       static_for<TP>([&](auto Q) LCP_INL {
-        const int ci = (ti + 16 * P) & (NCB - 1), cj_ = (tj + 16 * Q) & (NCB - 1);
+        const int ci = (ti + G * P) & (NCB - 1), cj_ = (tj + G * Q) & (NCB - 1);
         const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
         Wg[(size_t)(P * TP + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
       });
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
     static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * TP + Q) * NT + tid]; }); });
     if (ti == tj) {
       static_for<TH>([&](auto P) LCP_INL {
-        const int c = ti + 16 * P;
+        const int c = ti + G * P;
         t[P][P] += L.add[c];                                              // (a_c, a_c)
         t[P + TH][P] += L.add[LX + c];                                    // (u_c, a_c)
         t[P + TH][P + TH] += L.add[2 * LX + c];                           // (u_c, u_c)
@@ -361,42 +365,50 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
     bool singular_seen = false;
     if (tid == 0) { L.pinv[0] = t[0][0]; L.pinv[1] = fast_rcp(t[0][0]); }
     BIG_TICK(5)                                                             // (profile: W load + diagonal)
-    const int nblk = (ncs + 15) >> 4;                                       // 16-pivot blocks that hold live contacts
+    const int nblk = (ncs + G - 1) >> GSH;                                  // G-pivot blocks that hold live contacts
     static_for<TP>([&](auto KB) LCP_INL {
       constexpr int kb = KB;
       // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
       // (but the pivot published for its first step must still be replaced by the next live block's)
-      const int steps = ((kb % TH) < nblk) ? 16 : 0;
+      const int steps = ((kb % TH) < nblk) ? G : 0;
       if constexpr (kb < TP - 1) { if (steps == 0 && tid == 0) { L.pinv[2 * buf] = t[kb + 1][kb + 1]; L.pinv[2 * buf + 1] = fast_rcp(t[kb + 1][kb + 1]); } }
 #pragma unroll 1
       for (int kk = 0; kk < steps; ++kk) {
-        const int k = 16 * kb + kk;
-        double* prow = L.prow + buf * NRD;
+        double* prow = L.prow + buf * NRD;                                  // (pivot k = G * kb + kk)
         double* pcol = L.pcol + buf * NRD;
         // the owners of pivot row k publish it, the owners of column k publish the RAW column; after ONE barrier
         // every thread scales its multipliers by 1 / pivot itself (8 multiplies instead of a second barrier)
-        if (ti == kk) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + 16 * q] = t[kb][q]; });
-        if (tj == kk) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + 16 * pp] = t[pp][kb]; });
-        __syncthreads();
+        if (ti == kk) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + G * q] = t[kb][q]; });
+        if (tj == kk) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + G * pp] = t[pp][kb]; });
+        // (a one-wave scene needs no barrier and no wait here: the LDS serves one wave's instructions in order)
+        if constexpr (NT == 64) wsync(); else __syncthreads();
         // every LDS read of the step is issued here, ahead of any use, so that the step pays ONE LDS round trip
         // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
         double lm[TP - kb], rv[TP - kb];
         const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
-        static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + 16 * pp]; rv[PP] = prow[tj + 16 * pp]; });
+        static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + G * pp]; rv[PP] = prow[tj + G * pp]; });
         __builtin_amdgcn_sched_barrier(0);
         singular_seen = singular_seen || (piv == 0.0);
+        // rows / columns of the LATER tile blocks (pp > kb) lie below / right of the pivot whatever the thread: only the
+        // pivot's own block needs the "strictly below / right of k" masks (one compare each instead of TP - kb)
+        const bool colk = tj == kk;
         static_for<TP - kb>([&](auto PP) LCP_INL {
           constexpr int pp = kb + PP;
           const double l = lm[PP] * inv;
-          lm[PP] = (ti + 16 * pp > k) ? l : 0.0;
-          rv[PP] = (tj + 16 * pp > k) ? rv[PP] : 0.0;
-          t[pp][kb] = (tj == kk && ti + 16 * pp > k) ? l : t[pp][kb];
+          if constexpr (PP == 0) {
+            lm[0] = (ti > kk) ? l : 0.0;
+            rv[0] = (tj > kk) ? rv[0] : 0.0;
+            t[pp][kb] = (colk && ti > kk) ? l : t[pp][kb];
+          } else {
+            lm[PP] = l;
+            t[pp][kb] = colk ? l : t[pp][kb];
+          }
         });
         static_for<TP - kb>([&](auto PP) LCP_INL { static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
         buf ^= 1;
-        if (ti == tj && ti == ((kk + 1) & 15)) {                              // next pivot: its owner publishes it with its reciprocal
+        if (ti == tj && ti == ((kk + 1) & (G - 1))) {                         // next pivot: its owner publishes it with its reciprocal
           double nxt = t[kb][kb];
-          if constexpr (kb < TP - 1) { if (kk == 15) nxt = t[kb + 1][kb + 1]; }
+          if constexpr (kb < TP - 1) { if (kk == G - 1) nxt = t[kb + 1][kb + 1]; }
           L.pinv[2 * buf] = nxt; L.pinv[2 * buf + 1] = fast_rcp(nxt);
         }
       }
@@ -404,8 +416,8 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
     if (singular_seen && tid == 0) L.flag[0] = 1;
     BIG_TICK(6)                                                             // (profile: LU loop)
     // park the factors: column-major, plus the reciprocals of U's diagonal
-    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + 16 * Q) * LDU + ti + 16 * P] = t[P][Q]; }); });
-    if (ti == tj) static_for<TP>([&](auto P) LCP_INL { L.dU[ti + 16 * P] = 1.0 / t[P][P]; });
+    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + G * Q) * LDU + ti + G * P] = t[P][Q]; }); });
+    if (ti == tj) static_for<TP>([&](auto P) LCP_INL { L.dU[ti + G * P] = 1.0 / t[P][P]; });
   };
 
   // ---- T^-1 hz through the reduced system (wave 0); rows: a_c = lane, u_c = 64 + lane --------------------------------------
@@ -740,7 +752,7 @@ __global__ void __launch_bounds__(NT, NCB == 64 ? 1 : (NCB == 32 ? 2 : 4)) lcp_b
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_BIG_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
-  if (tid == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap; for (int i = 0; i < 4; ++i) o[200 + i] = (float)pc[i]; o[204] = (float)pc_ts; o[205] = (float)pc[5]; o[206] = (float)pc[6]; }
+  if (tid == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap + (4 * ncap - 8); for (int i = 0; i < 4; ++i) o[i] = (float)pc[i]; o[4] = (float)pc_ts; o[5] = (float)pc[5]; o[6] = (float)pc[6]; }
 #endif
 }
 
@@ -767,7 +779,7 @@ static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   const size_t lds = big::carve<NCB>(L, nullptr, nzs);
   auto k = big::lcp_big_kernel<NCB, BWD>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LCP_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::NT), lds, (hipStream_t)stream, SP, Gd, nzs);
+  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::Grid<NCB>::NT), lds, (hipStream_t)stream, SP, Gd, nzs);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 template <bool BWD>

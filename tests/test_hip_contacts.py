@@ -443,7 +443,9 @@ def test_mid_size_scenes_match_generic_and_oracle():
     from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import ContactBuffers
     from oracle import pdipm_oracle as O
-    for nbox, pts in ((5, 2), (8, 2), (9, 1), (6, 4)):     # nz 18 / 27 / 30 with 10 / 16 / 9 contacts; 24 contacts
+    # nz 18 / 27 / 30 with 10 / 16 / 9 contacts (quad, two x-halves); 24 contacts (lcp_big, 32-contact class);
+    # 12 bodies / 11 contacts: nz 36 > 32 (lcp_big, 16-contact class)
+    for nbox, pts in ((5, 2), (8, 2), (9, 1), (6, 4), (11, 1)):
         B = 10
         sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=40 + nbox, dtype=torch.float32)
         scg = sc.to(device=DEV)

@@ -100,7 +100,7 @@ def test_variable_contact_counts_and_padding():
     assert float(pg["rest"][free].abs().max()) == 0.0 and float(pg["fric"][free].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("nbox,pts", [(5, 2), (8, 2), (9, 1), (6, 4)])
+@pytest.mark.parametrize("nbox,pts", [(5, 2), (8, 2), (9, 1), (6, 4), (11, 1)])
 def test_mid_size_backward_matches_generic_dense(nbox, pts):
     """6 / 9 / 10 bodies with 10 / 16 / 9 contacts (the nz <= 32 instantiation of lcp_quad.hip) and 7 bodies / 24
     contacts (the 32-contact class of lcp_big.hip): backward against the generic kernels' dense gradients contracted by

@@ -38,7 +38,7 @@ print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts
                   "kernel": "lcp::big::lcp_fwd_big (one 256-thread workgroup per scene)"}))
 import os
 if "bigprof" in os.environ.get("LCP_HIP_LIB", ""):
-    pc = out["s"][:, 200:207].double().mean(dim=0).tolist()
+    pc = out["s"][:, 248:255].double().mean(dim=0).tolist()
     print("factor split: W load + diag %.0f   LU loop %.0f" % (pc[5], pc[6]))
     tot = sum(pc[:4])
     print("cycles per scene: residuals %.0f  factor %.0f  steps+bookkeeping %.0f  solve_kkt %.0f (of which triangular sweeps %.0f)  total %.0f" % (pc[0], pc[1], pc[2], pc[3], pc[4], tot))

@@ -17,6 +17,7 @@ for _ in range(5): out = run(out)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
 print("nb", sc.nb, "nc", sc.nc, "ms/step", dt * 1e3, "steps/s", B / dt)
-if "bigprof" in os.environ.get("LCP_HIP_LIB", "") and sc.nc * 4 > 207:
-    pc = out["s"][:, 200:207].double().mean(dim=0).tolist()
+if "bigprof" in os.environ.get("LCP_HIP_LIB", ""):
+    m = 4 * sc.nc
+    pc = out["s"][:, m - 8:m - 1].double().mean(dim=0).tolist()
     print("cycles: residuals %.0f factor %.0f steps %.0f solve_kkt %.0f (sweeps %.0f) | W load %.0f LU %.0f" % tuple(pc))
