@@ -376,26 +376,31 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     }
     int buf = 0;
     bool singular_seen = false;
-    if (tid == 0) { L.pinv[0] = t[0][0]; L.pinv[1] = fast_rcp(t[0][0]); }
     BIG_TICK(5)                                                             // (profile: W load + diagonal)
     const int nblk = (ncs + G - 1) >> GSH;                                  // G-pivot blocks that hold live contacts
+    auto sync = [&]() { if constexpr (NT == 64) wsync(); else __syncthreads(); };   // (one wave: the LDS is in order)
+    // Right-looking LU, no pivoting.  Pivot row, RAW multiplier column and (pivot, 1 / pivot) travel through LDS, double
+    // buffered.  The step is software-pipelined: it first updates the border of the trailing tile - which holds the NEXT
+    // pivot's row and column -, lets their owners publish them (and the owner of the diagonal entry run the reciprocal
+    // chain), and only then sweeps the interior: the LDS round trip and the reciprocal of step k + 1 run under the
+    // interior FMAs of step k, and one barrier per step remains.
     static_for<TP>([&](auto KB) LCP_INL {
       constexpr int kb = KB;
       // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
-      // (but the pivot published for its first step must still be replaced by the next live block's)
       const int steps = ((kb % TH) < nblk) ? G : 0;
-      if constexpr (kb < TP - 1) { if (steps == 0 && tid == 0) { L.pinv[2 * buf] = t[kb + 1][kb + 1]; L.pinv[2 * buf + 1] = fast_rcp(t[kb + 1][kb + 1]); } }
+      if (steps) {                                                          // prologue: the block's first pivot
+        double* prow = L.prow + buf * NRD;
+        double* pcol = L.pcol + buf * NRD;
+        if (ti == 0) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + G * q] = t[kb][q]; });
+        if (tj == 0) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + G * pp] = t[pp][kb]; });
+        if (tid == 0) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
+        sync();
+      }
 #pragma unroll 1
       for (int kk = 0; kk < steps; ++kk) {
-        double* prow = L.prow + buf * NRD;                                  // (pivot k = G * kb + kk)
-        double* pcol = L.pcol + buf * NRD;
-        // the owners of pivot row k publish it, the owners of column k publish the RAW column; after ONE barrier
-        // every thread scales its multipliers by 1 / pivot itself (8 multiplies instead of a second barrier)
-        if (ti == kk) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + G * q] = t[kb][q]; });
-        if (tj == kk) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + G * pp] = t[pp][kb]; });
-        // (a one-wave scene needs no barrier and no wait here: the LDS serves one wave's instructions in order)
-        if constexpr (NT == 64) wsync(); else __syncthreads();
-        // every LDS read of the step is issued here, ahead of any use, so that the step pays ONE LDS round trip
+        const double* prow = L.prow + buf * NRD;                            // (pivot k = G * kb + kk)
+        const double* pcol = L.pcol + buf * NRD;
+        // every LDS read of the step is issued here, ahead of any use
         // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
         double lm[TP - kb], rv[TP - kb];
         const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
@@ -417,13 +422,24 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
             t[pp][kb] = colk ? l : t[pp][kb];
           }
         });
-        static_for<TP - kb>([&](auto PP) LCP_INL { static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); }); });
+        // border of the trailing tile: its first row and first column
+        static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb][kb + QQ] = fma(-lm[0], rv[QQ], t[kb][kb + QQ]); });
+        static_for<TP - kb - 1>([&](auto P1) LCP_INL { constexpr int PP = 1 + P1; t[kb + PP][kb] = fma(-lm[PP], rv[0], t[kb + PP][kb]); });
         buf ^= 1;
-        if (ti == tj && ti == ((kk + 1) & (G - 1))) {                         // next pivot: its owner publishes it with its reciprocal
-          double nxt = t[kb][kb];
-          if constexpr (kb < TP - 1) { if (kk == G - 1) nxt = t[kb + 1][kb + 1]; }
-          L.pinv[2 * buf] = nxt; L.pinv[2 * buf + 1] = fast_rcp(nxt);
+        if (kk + 1 < G) {                                                   // publish pivot k + 1 (same tile block)
+          double* nrow = L.prow + buf * NRD;
+          double* ncol = L.pcol + buf * NRD;
+          if (ti == kk + 1) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; nrow[tj + G * q] = t[kb][q]; });
+          if (tj == kk + 1) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; ncol[ti + G * pp] = t[pp][kb]; });
+          if (ti == kk + 1 && tj == kk + 1) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // interior
+        static_for<TP - kb - 1>([&](auto P1) LCP_INL {
+          constexpr int PP = 1 + P1;
+          static_for<TP - kb - 1>([&](auto Q1) LCP_INL { constexpr int QQ = 1 + Q1; t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); });
+        });
+        sync();
       }
     });
     if (singular_seen && tid == 0) L.flag[0] = 1;
