@@ -1,0 +1,57 @@
+"""Time the UNMODIFIED reference solver (lcp/solvers/pdipm.py through oracle/ref_shim.py) on the headline workload's
+scenes, on the CPU cores of the machine this runs on.  TEST / MEASUREMENT INFRASTRUCTURE ONLY; needs /root/reference, so it
+cannot run on the GPU box: the number it prints is recorded in DESIGN.md §7 and profiles/r01_reference_cpu_timing.json
+next to bench.py's `cpu_baseline` (the vectorised port, which does run there).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/time_reference.py [--batch 256] [--dtype float64]
+
+The reference is called exactly as `physics/engines.py:76` calls it, but with the whole batch at once (its batched form:
+one `LCPFunction(max_iter=10)(Q, p, G, h, A, b, F)` + `.backward`).  Batch-global termination (pdipm.py:116-133) makes
+the batched call do at least the work of the slowest scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import pdipm_oracle as O, ref_shim  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="float64", choices=["float32", "float64"])
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    from lcp_physics_amd import scenes
+    ref_shim.load_reference()
+    dt = getattr(torch, args.dtype)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sc = scenes.make_stack_scenes(B=args.batch, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32)
+    lcp = [None if t is None else t.to(dt) for t in O.assemble_lcp(*sc.assembly_args())]
+    cot = torch.randn(args.batch, lcp[0].shape[1], generator=torch.Generator().manual_seed(4321), dtype=dt)
+    best = None
+    for _ in range(args.reps):
+        ins = [t.clone().requires_grad_(True) for t in lcp]
+        t0 = time.perf_counter()
+        x = ref_shim.RefLCPFunction(max_iter=10)(*ins)
+        t1 = time.perf_counter()
+        x.backward(cot)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    out = {"what": "unmodified reference pdipm (through oracle/ref_shim.py), fwd+bwd, batched call",
+           "workload": "first %d scenes of the headline workload (4-box stack, 16 contacts, nineq 64)" % args.batch,
+           "dtype": args.dtype, "cpu_threads": threads, "value": args.batch / best[0], "unit": "sim steps/s",
+           "fwd_s": best[1], "bwd_s": best[2], "machine": "build container (not the GPU box)"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
