@@ -159,10 +159,10 @@ class BatchedWorld:
         self.last = None
 
     def _forward_only_step(self):
-        """Scenes beyond the four-scenes-per-wave kernel (more than 16 contacts or 5 bodies): `lcp_solve_dynamics_f32`
-        reaches the register-tiled kernel of lcp_big.hip (forward only, which is all `step()` needs) where
-        `lcp_step_fused_f32` would fall back to the generic kernels; the integrator `p += v dt` (bodies.py:80-82) is
-        then one elementwise op."""
+        """Scenes with more than 5 bodies or 16 contacts: `lcp_solve_dynamics_f32` reaches the two-halves instantiation
+        of the quad kernel (up to 10 bodies) or the register-tiled kernel of lcp_big.hip (up to 64 contacts), where
+        `lcp_step_fused_f32` would fall back to the generic kernels; its workspace also feeds `fused_step_backward`.
+        The integrator `p += v dt` (bodies.py:80-82) is then one elementwise op."""
         sc = self.scene
         if self._full_count is None:
             from .contacts import ContactBuffers
