@@ -833,6 +833,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   TC y = 0;
   M4<TC> s = m4<TC>(1, 1, 1, 1), z = m4<TC>(1, 1, 1, 1), dinv = m4<TC>(1, 1, 1, 1);
   TC best_resid = inf_of<TC>();
+  XVt bx;                                                                 // best iterate (pdipm.py:107-132)
+  static_for<XH>([&](auto HX) LCP_INL { bx.v[HX] = 0; });
+  TC by = 0;
+  M4<TC> bz = m4<TC>(1, 1, 1, 1), bs = bz;
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
   const TC mf = (TC)(4 * ncs);                                           // nineq of this scene
@@ -877,14 +881,9 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
       else {
         const bool improved = !have_best || (resid < best_resid);             // (:107-132)
-        if (improved) {                                                       // best iterate -> workspace
+        if (improved) {                                                       // best iterate (registers; stored once, below)
           best_resid = resid; n_not = 0; have_best = true;
-          static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = x.v[HX]; });
-          if (l16 < e) W.y[l16] = y;
-          if (vc) {
-            W.z[l16] = z.n; W.z[nc + 2 * l16] = z.f1; W.z[nc + 2 * l16 + 1] = z.f2; W.z[3 * nc + l16] = z.g;
-            W.s[l16] = s.n; W.s[nc + 2 * l16] = s.f1; W.s[nc + 2 * l16 + 1] = s.f2; W.s[3 * nc + l16] = s.g;
-          }
+          bx = x; by = y; bz = z; bs = s;
         } else ++n_not;
         if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
       }
@@ -913,8 +912,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
         if (!vc) { s = m4<TC>(1, 1, 1, 1); z = s; }
         if (ncs == 0 && !done) {                                              // engines.py:36-50: x = P^-1 u, no LCP
-          static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = x.v[HX]; });
-          if (l16 < e) W.y[l16] = y;
+          bx = x; by = y;
           done = true;
         }
       } else if (pass == 0) {
@@ -952,14 +950,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   if (!FUSED && P.trace && lane == 0) { double* tr = P.trace + (size_t)scene * 4 * max_iter; for (int i = 0; i < 8; ++i) tr[i] = (double)pr.t[i]; tr[8] = (double)iters; }
 #endif
 
-  // outputs (natural m-space order: n rows, friction pairs, gamma rows): read the best iterate back
+  // outputs (natural m-space order: n rows, friction pairs, gamma rows).  The best iterate also goes to the workspace,
+  // in fp64, for the backward kernels (lcp.py:29,34: the op keeps its solution)
   if (!live) return;
-  __threadfence_block();
-  XVt bx;
-  static_for<XH>([&](auto HX) LCP_INL { bx.v[HX] = (16 * HX + l16 < nz) ? wsx[16 * HX + l16] : (TC)0; });
-  const TC by = (l16 < e) ? W.y[l16] : (TC)0;
-  const M4<TC> bz = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  const M4<TC> bs = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
+  static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = bx.v[HX]; else bx.v[HX] = 0; });
+  if (l16 < e) W.y[l16] = by; else by = 0;
+  if (vc) {
+    W.z[l16] = bz.n; W.z[nc + 2 * l16] = bz.f1; W.z[nc + 2 * l16 + 1] = bz.f2; W.z[3 * nc + l16] = bz.g;
+    W.s[l16] = bs.n; W.s[nc + 2 * l16] = bs.f1; W.s[nc + 2 * l16 + 1] = bs.f2; W.s[3 * nc + l16] = bs.g;
+  } else { bz = m4<TC>(1, 1, 1, 1); bs = bz; }
   bool bad = false;
   static_for<XH>([&](auto HX) LCP_INL { bad = bad || (bx.v[HX] != bx.v[HX]); });
   if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
