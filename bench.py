@@ -8,18 +8,25 @@ step   : one pass of the hot path over one batch of synthetic scenes already res
          new velocities and poses) + lcp_pdipm_backward_f32, for B = 4096 scenes per GPU (floor + 4-box
          stack, 4 contact points per interface: nz 15, nineq 64, neq 3).  `--mode dense` times the dense
          LCPFunction boundary instead (lcp_pdipm_forward_f32 on pre-assembled (Q,p,G,h,A,b,F) + backward).
-N GPUs : one process per GPU (torchrun), every rank owns its own 4096 scenes (weak scaling,
-         config 4 = 8 x 4096); no collective on the solve path - torch.distributed (RCCL) is only
-         used for the barriers and the MAX-over-ranks wall time.
+N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling, config 4 = 8 x 4096); no
+         collective on the solve path - torch.distributed (RCCL) is only used for the barriers and the
+         MAX-over-ranks wall time.  `python bench.py --gpus N` started WITHOUT a launcher starts the N ranks
+         itself (torch.distributed.run on 127.0.0.1, one per visible device) and refuses when fewer than N
+         devices are visible; under torchrun (the driver's form) --gpus must equal WORLD_SIZE.  `n_gpus` in
+         the output is the number of ranks that reported, on distinct devices.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - dominant kernel (the forward PDIPM kernel): algorithmic FLOPs (SURVEY.md §8d,
-                 lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by
-                 its average launch duration measured with HIP events on the launch stream inside
-                 the timed region; peak = the FP64 vector/matrix rate when the parity path
-                 (fp64 arithmetic) runs, the FP32 rate for --compute f32.
-  cpu_baseline - the oracle (a port, torch CPU fp64) timed on this host's cores on the same
-                 workload (rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      - dominant kernel (the forward PDIPM kernel): `frac` = ALGORITHMIC FLOPs (SURVEY.md §8d dense
+                  formulation, lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by
+                  its average launch duration measured with HIP events on the launch stream inside the timed
+                  region, over the FP64 vector rate (the kernel issues no MFMA: `bound` says "valu_fp64");
+                  `frac_executed` = the FLOPs the structure-exploiting kernel really executes (reduced 2nc
+                  system) over the same peak; counters / registers quoted from the committed rocprof and
+                  compiler reports under profiles/.
+  cpu_baseline  - the oracle (a port, torch CPU fp64) timed on this host's cores on the same workload (rank 0,
+                  N=1 only);  cpu_reference - the UNMODIFIED reference timed in the build container
+                  (profiles/r01_reference_cpu_timing.json; /root/reference does not exist on the GPU box).
+  sustained     - the same step repeated for >= 1 s after the timed region (independent evidence of GPU work).
 """
 import argparse
 import json
@@ -36,7 +43,7 @@ PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X FP64 / FP32 vector = matrix
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -53,9 +60,106 @@ def parse():
                     help="time the forward only (BASELINE configs[1] is forward-only); the default is the headline fwd+bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
-    return ap.parse_args()
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of the untimed sustained loop after the timed steps (0 = off)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="TESTING AID: let several ranks use one GPU (gloo instead of RCCL); the line then says devices_used < n_gpus")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ rank protocol
+def timed_steps(work, steps, warmup, sync, reduce_dev):
+    """The contract's timing rule: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier +
+    device synchronisation on both sides; returns the MAX wall time over the ranks and the per-step events."""
+    from lcp_physics_amd import shard
+    for _ in range(warmup):
+        work.step()
+    events = [work.new_events() for _ in range(steps)]
+    sync()
+    shard.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        work.step(events[k])
+    sync()
+    shard.barrier()
+    wall = time.perf_counter() - t0
+    return shard.max_over_ranks(wall, device=reduce_dev), events
+
+
+def run_rank(args, make_work, device=None):
+    """Everything one rank does.  `make_work(args, rank, device)` builds the workload (HipStackWorkload below; the CPU
+    test of the N > 1 protocol passes a stand-in whose step launches nothing).  Returns the JSON object on rank 0."""
+    from lcp_physics_amd import shard
+    rank, local_rank, world = shard.env_rank()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    shard.init_process_group(backend="gloo" if (args.share_devices or device is not None) else None)
+    dev = device if device is not None else shard.rank_device(local_rank, share_devices=args.share_devices)
+    is_gpu = torch.device(dev).type == "cuda"
+    if is_gpu:
+        torch.cuda.set_device(dev)
+    rdev = shard.reduce_device(dev)
+    sync = torch.cuda.synchronize if is_gpu else (lambda: None)
+    work = make_work(args, rank, dev)
+    wall, events = timed_steps(work, args.steps, args.warmup, sync, rdev)
+    # how many ranks really ran, and on how many distinct devices
+    reported = int(round(shard.sum_over_ranks(1.0, device=rdev)))
+    dev_index = torch.device(dev).index or 0
+    devices = shard.gather_scenes(torch.tensor([[float(dev_index)]], dtype=torch.float64, device=rdev), world, device=rdev) \
+        if world > 1 else torch.tensor([[float(dev_index)]])
+    devices_used = len(set(int(v) for v in devices.flatten().tolist()))
+    if reported != world:
+        raise SystemExit("bench.py: %d of %d ranks reported" % (reported, world))
+    if is_gpu and devices_used != world and not args.share_devices:
+        raise SystemExit("bench.py: %d ranks on %d distinct devices" % (world, devices_used))
+    sustained = None
+    if args.sustain > 0:
+        sync()
+        t0, n = time.perf_counter(), 0
+        while True:
+            for _ in range(max(1, args.steps)):
+                work.step()
+            n += max(1, args.steps)
+            sync()
+            if time.perf_counter() - t0 >= args.sustain:
+                break
+        dt = time.perf_counter() - t0
+        sustained = {"seconds": dt, "steps": n, "value": work.units_per_step * world * n / dt, "unit": "sim steps/s",
+                     "note": "untimed-region repeat of the same step (this rank's clock), not the metric"}
+    total_units = work.units_per_step * world * args.steps
+    out = {
+        "metric": work.metric_name(),
+        "value": total_units / wall,
+        "unit": "sim steps/s",
+        "n_gpus": reported,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.compute,
+        "data": "synthetic",
+    }
+    out.update(work.report(events, world))
+    out["config"]["global_batch"] = work.units_per_step * world
+    out["config"]["parallelism"] = "scenes sharded x%d, no collectives" % world
+    if is_gpu and devices_used != reported:
+        out["devices_used"] = devices_used
+    if sustained is not None:
+        out["sustained"] = sustained
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(work.host_side_checks())
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+# ------------------------------------------------------------------------------------------------ CPU side (rank 0, N = 1)
 def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
     """Oracle (port of the reference algorithm, vectorised torch fp64) on the host cores: forward +
     backward on a bounded sample of the same scenes (sized from a calibration pass to ~budget_s)."""
@@ -84,6 +188,18 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
                       % (sample, passes, "forward only" if fwd_only else "fwd+bwd", total)}
 
 
+def cpu_reference_quote():
+    """The unmodified reference's own timing of this workload (build container; it cannot run on the GPU box)."""
+    path = os.path.join(ROOT, "profiles", "r01_reference_cpu_timing.json")
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    r = j["runs"][0]
+    return {"value": r["value"], "unit": r["unit"], "cores": r["cpu_threads"], "kind": "reference", "dtype": r["dtype"],
+            "machine": r.get("machine", "build container"), "what": r["what"], "workload": r["workload"],
+            "measured_in_this_run": False, "source": "profiles/r01_reference_cpu_timing.json (" + j["source"] + ")"}
+
+
 def parity_vs_oracle(sc_cpu, cot, x_gpu, z_gpu, s_gpu, dp_gpu, n=256):
     """The metric's second half ("fwd+bwd rel-err vs ref"): the step just timed against the fp64 oracle on the first
     `n` scenes (identical fp32 inputs).  err_x = |x - x_ref| / max(|x_ref|, |Q^-1 p|) per scene; the
@@ -99,174 +215,189 @@ def parity_vs_oracle(sc_cpu, cot, x_gpu, z_gpu, s_gpu, dp_gpu, n=256):
     ref = O.lcp_forward(*lcp)
     ex = parity.err_x(x_gpu[:n].double().cpu(), ref.x, Q, p)
     out = {"scenes": n, "tolerance": 1e-4, "fwd_err_x_max": float(ex.max()), "fwd_err_x_median": float(ex.median())}
-    # contact index sets {i : z_i > s_i}: compared wherever the oracle's own decision is not a tie between
-    # two numbers that both converged to zero (tests/test_hip_parity.py::_decisive)
+    # contact index sets {i : z_i > s_i}: bit-exact wherever the oracle's own decision is not a tie between
+    # two numbers that both converged to zero (parity.decisive_rows); the masked-out share is reported and gated
     z, sl = z_gpu[:n].double().cpu(), s_gpu[:n].double().cpu()
-    big = torch.maximum(ref.z.abs(), ref.s.abs())
-    nondeg = torch.maximum(ref.z.abs() / ref.z.abs().max(dim=1, keepdim=True)[0],
-                           ref.s.abs() / ref.s.abs().max(dim=1, keepdim=True)[0]) > 1e-5
-    dec = ((ref.z - ref.s).abs() > 1e-3 * big) & nondeg
+    dec = parity.decisive_rows(ref.z, ref.s)
     out["index_set_mismatches"] = int((((z > sl) != (ref.z > ref.s)) & dec).sum())
     out["index_set_rows_compared"] = int(dec.sum())
+    out["index_set_rows_total"] = int(dec.numel())
+    out["index_set_masked_frac"] = 1.0 - float(dec.sum()) / dec.numel()
     if dp_gpu is not None:
         c64 = cot[:n].double()
         gref = O.lcp_backward(ref, *lcp, c64)
-        res = parity.kkt_backward_residual(Q, G, A, F, ref.z, ref.s, c64, gref["dp"], -gref["dh"], -gref["db"])
-        ok = torch.stack([v for v in res.values()]).max(dim=0)[0] < 1e-9
-        zs, ss = ref.z.max(dim=1, keepdim=True)[0], ref.s.max(dim=1, keepdim=True)[0]
-        ok = ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
+        ok = parity.backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = parity.grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
         eg = parity.err_grads({"p": dp_gpu[:n].double().cpu()}, {"p": gref["dp"]}, fl)["p"]
         if bool(ok.any()):
             out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})
         out["bwd_well_posed_scenes"] = int(ok.sum())
+        out["bwd_well_posed_frac"] = float(ok.sum()) / n
     return out
 
 
-def main():
-    args = parse()
-    from lcp_physics_amd import flops, scenes, shard
-    from lcp_physics_amd.lcp import lcp_backward, lcp_solve
-    from lcp_physics_amd.physics import assemble_contacts, fused_step
-    from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step
+def _quoted(name, key):
+    """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            j = json.load(open(path)).get(key)
+            if j:
+                j = dict(j)
+                j.setdefault("source", "profiles/%s_%s.json" % (rnd, name))
+                return j
+    return None
 
-    rank, local_rank, world = shard.init_process_group()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
-    B = args.batch
-    nb, nc = args.nbox + 1, args.nbox * args.pts
-    nz, m, e = 3 * nb, 4 * nc, 3
 
-    # synthetic scenes, generated on the host, then resident in HBM before any timing
-    sc_cpu = scenes.make_stack_scenes(B=B, nbox=args.nbox, pts_per_interface=args.pts, seed=1236 + 1000 * rank,
-                                      dtype=torch.float32)
-    sc = sc_cpu.to(device=dev)
-    g = torch.Generator().manual_seed(4321 + rank)
-    cot_cpu = torch.randn(B, nz, generator=g, dtype=torch.float32)
-    cot = cot_cpu.to(dev)
-    lcp = assemble_contacts(sc)            # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel
-    G, A = lcp[2], lcp[4]
-    sol = lcp_solve(*lcp, compute=args.compute)
-    grads = lcp_backward(sol, cot)
-    step_out = fused_step(sc, compute=args.compute) if args.mode == "fused" else None
-    torch.cuda.synchronize()
+# ------------------------------------------------------------------------------------------------ the HIP workload
+class HipStackWorkload:
+    """B stack scenes per rank resident in HBM; step = fused step kernel (or the dense operator) + backward."""
 
-    # (the output buffers and the workspace are re-used every step, so the handle the backward takes is built once)
-    step_sol = solution_of_step(sc, step_out, G, A, compute=args.compute) if args.mode == "fused" else None
+    def __init__(self, args, rank, dev):
+        from lcp_physics_amd import scenes
+        from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+        from lcp_physics_amd.physics import assemble_contacts, fused_step
+        from lcp_physics_amd.physics.batched_world import solution_of_step
+        if torch.device(dev).type != "cuda":
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        if args.bwd == "physical" and args.mode != "fused":
+            raise SystemExit("--bwd physical needs --mode fused")
+        self.args, self.rank, self.dev = args, rank, dev
+        B = self.B = self.units_per_step = args.batch
+        self.nb, self.nc = args.nbox + 1, args.nbox * args.pts
+        self.nz, self.m, self.e = 3 * self.nb, 4 * self.nc, 3
+        # synthetic scenes, generated on the host, then resident in HBM before any timing
+        self.sc_cpu = scenes.make_stack_scenes(B=B, nbox=args.nbox, pts_per_interface=args.pts, seed=1236 + 1000 * rank,
+                                               dtype=torch.float32)
+        self.sc = self.sc_cpu.to(device=dev)
+        g = torch.Generator().manual_seed(4321 + rank)
+        self.cot_cpu = torch.randn(B, self.nz, generator=g, dtype=torch.float32)
+        self.cot = self.cot_cpu.to(dev)
+        self.lcp = assemble_contacts(self.sc)   # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel
+        G, A = self.lcp[2], self.lcp[4]
+        self.sol = lcp_solve(*self.lcp, compute=args.compute)
+        self.grads = lcp_backward(self.sol, self.cot)
+        self.step_out = fused_step(self.sc, compute=args.compute) if args.mode == "fused" else None
+        torch.cuda.synchronize()
+        # (the output buffers and the workspace are re-used every step, so the handle the backward takes is built once)
+        self.step_sol = solution_of_step(self.sc, self.step_out, G, A, compute=args.compute) if args.mode == "fused" else None
+        self.cot_v = (-self.cot).reshape(B, self.nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
+        self.pgrads = None
 
-    if args.bwd == "physical" and args.mode != "fused":
-        raise SystemExit("--bwd physical needs --mode fused")
-    cot_v = (-cot).reshape(B, nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
-    pgrads = None
+    def new_events(self):
+        return [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
-    def one_step(ev=None):
-        nonlocal sol, step_out
+    def step(self, ev=None):
+        from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+        from lcp_physics_amd.physics import fused_step
+        from lcp_physics_amd.physics.batched_world import fused_step_backward
+        a = self.args
         if ev is not None:
             ev[0].record()
-        if args.mode == "dense":
-            lcp_solve(*lcp, compute=args.compute, ws=sol.ws, out=sol)
-            s_ = sol
+        if a.mode == "dense":
+            lcp_solve(*self.lcp, compute=a.compute, ws=self.sol.ws, out=self.sol)
+            s_ = self.sol
         else:
-            step_out = fused_step(sc, compute=args.compute, ws=step_out["ws"], out=step_out)
-            s_ = step_sol
+            self.step_out = fused_step(self.sc, compute=a.compute, ws=self.step_out["ws"], out=self.step_out)
+            s_ = self.step_sol
         if ev is not None:
             ev[1].record()
-        if args.fwd_only:
+        if a.fwd_only:
             pass
-        elif args.bwd == "physical":
-            nonlocal pgrads
-            pgrads = fused_step_backward(sc, step_out, cot_v, compute=args.compute, grads=pgrads)
+        elif a.bwd == "physical":
+            self.pgrads = fused_step_backward(self.sc, self.step_out, self.cot_v, compute=a.compute, grads=self.pgrads)
         else:
-            lcp_backward(s_, cot, out=grads)
+            lcp_backward(s_, self.cot, out=self.grads)
         if ev is not None:
             ev[2].record()
 
-    for _ in range(args.warmup):
-        one_step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    shard.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(events[k])
-    torch.cuda.synchronize()
-    shard.barrier()
-    wall = time.perf_counter() - t0
-    wall = shard.max_over_ranks(wall, device=dev)
+    def metric_name(self):
+        return "sim steps/sec at batch=%dx%d contacts, %s" % (self.B, self.nc, "fwd" if self.args.fwd_only else "fwd+bwd")
 
-    fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in events) / args.steps
-    bwd_ms = sum(ev[1].elapsed_time(ev[2]) for ev in events) / args.steps
-    iters = (sol.iters if args.mode == "dense" else step_out["iters"]).double()
-    status = (sol.status if args.mode == "dense" else step_out["status"])
-    mean_it = float(iters.mean())
-    fl_fwd = float(sum(flops.flops_forward(nz, m, e, it) for it in iters.cpu().tolist()))
-    fl_bwd = flops.flops_backward(nz, m, e) * B
-    total_steps = B * world * args.steps
-    value = total_steps / wall
-    achieved = fl_fwd / (fwd_ms * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.compute]
-    alg_bytes = (flops.bytes_fused_step(nb, nc) if args.mode == "fused" else flops.bytes_forward(nz, m, e)) * B
-    # HBM traffic of the forward kernel: measured separately with rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in their
-    # own passes; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/; bench.py cannot run
-    # the counters itself, so it quotes that file when it matches this configuration.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath)).get("%s_B%d_nc%d_%s" % (args.mode, B, nc, args.compute))
-        if tj:
-            traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0
-    # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
-    cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
-        (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
-    what = "forward only" if args.fwd_only else "forward + backward (implicit diff)"
-    out = {
-        "metric": "sim steps/sec at batch=%dx%d contacts, %s" % (B, nc, "fwd" if args.fwd_only else "fwd+bwd"),
-        "value": value,
-        "unit": "sim steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.compute,
-        "data": "synthetic",
-        "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
-                               "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s"
-                               % (cfg, B, nc, args.nbox, args.pts, nz, m, e, what, args.mode,
-                                  "none" if args.fwd_only else args.bwd),
-                   "global_batch": B * world, "parallelism": "scenes sharded x%d, no collectives" % world,
-                   "mean_pdipm_iters": mean_it, "nonzero_status": int((status != 0).sum())},
-        "roofline": {"bound": "mfma",
-                     "kernel": "lcp_fwd_quad<float,%s,%s> (PDIPM forward%s)" % (
-                         "double" if args.compute == "f64" else "float", "true" if args.mode == "fused" else "false",
-                         ", fused assembly + integrate" if args.mode == "fused" else "; the event-timed forward call also contains the classify launch"),
-                     "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                     "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
-                     "bwd_achieved": fl_bwd / (bwd_ms * 1e-3) / 1e12,
-                     "algorithmic_flops_per_launch": fl_fwd,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "hbm_frac_algorithmic": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sc_cpu, cot_cpu, args.cpu_budget, args.fwd_only)
-        x_gpu = sol.x if args.mode == "dense" else -step_out["v_new"].reshape(B, nz)
-        dp_gpu = None if (args.fwd_only or args.bwd == "physical") else grads[1]
-        zs_src = sol if args.mode == "dense" else None
-        z_gpu = zs_src.z if zs_src is not None else step_out["z"]
-        s_gpu = zs_src.s if zs_src is not None else step_out["s"]
-        out["parity"] = parity_vs_oracle(sc_cpu, cot_cpu, x_gpu, z_gpu, s_gpu, dp_gpu)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    def report(self, events, world):
+        from lcp_physics_amd import flops
+        a, B, nb, nc, nz, m, e = self.args, self.B, self.nb, self.nc, self.nz, self.m, self.e
+        fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in events) / len(events)
+        bwd_ms = sum(ev[1].elapsed_time(ev[2]) for ev in events) / len(events)
+        iters = (self.sol.iters if a.mode == "dense" else self.step_out["iters"]).double()
+        status = (self.sol.status if a.mode == "dense" else self.step_out["status"])
+        it_list = iters.cpu().tolist()
+        fl_fwd = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
+        fl_exec = float(sum(flops.flops_forward_executed(nz, nc, e, it) for it in it_list))
+        fl_bwd = flops.flops_backward(nz, m, e) * B
+        achieved = fl_fwd / (fwd_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[a.compute]
+        alg_bytes = (flops.bytes_fused_step(nb, nc) if a.mode == "fused" else flops.bytes_forward(nz, m, e)) * B
+        key = "%s_B%d_nc%d_%s" % (a.mode, B, nc, a.compute)
+        # HBM traffic and issue counters of the forward kernel: measured separately with rocprofv3 --pmc (FETCH_SIZE,
+        # WRITE_SIZE in their own passes; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/;
+        # bench.py cannot run the counters itself, so it quotes the committed file when it matches this configuration.
+        tj = _quoted("traffic", key)
+        traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
+        cj = _quoted("counters", key)
+        rj = _quoted("kernel_resources", "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))
+        # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
+        cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
+            (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
+        what = "forward only" if a.fwd_only else "forward + backward (implicit diff)"
+        st = status.cpu()
+        roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
+                "kernel": "lcp_fwd_quad<float,%s,%s> (PDIPM forward%s)" % (
+                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false",
+                    ", fused assembly + integrate" if a.mode == "fused" else "; the event-timed forward call also contains the classify launch"),
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "executed_flops_per_launch": fl_exec,
+                "achieved_executed": fl_exec / (fwd_ms * 1e-3) / 1e12,
+                "frac_executed": fl_exec / (fwd_ms * 1e-3) / 1e12 / peak,
+                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+                "bwd_achieved": fl_bwd / (bwd_ms * 1e-3) / 1e12,
+                "algorithmic_flops_per_launch": fl_fwd,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_frac_algorithmic": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "frac = SURVEY 8d dense-formulation FLOPs / time / FP64 vector peak (no MFMA is issued by this kernel); "
+                        "frac_executed counts the reduced 2nc system the kernel really factors"}
+        if cj:
+            roof.update({"valu_active": cj.get("valu_active"), "wait_frac": cj.get("wait_frac"), "counters_source": cj["source"]})
+        if rj:
+            roof["regs"] = rj
+        return {
+            "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
+                                   "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s"
+                                   % (cfg, B, nc, a.nbox, a.pts, nz, m, e, what, a.mode, "none" if a.fwd_only else a.bwd),
+                       "mean_pdipm_iters": float(iters.mean()), "nonzero_status": int((st != 0).sum()),
+                       "status_bits": {name: int(((st & bit) != 0).sum()) for name, bit in
+                                       (("singular_Q", 1), ("singular_S11", 2), ("singular_T", 4), ("nan", 8), ("truncated", 16))}},
+            "roofline": roof,
+        }
+
+    def host_side_checks(self):
+        a, B, nz = self.args, self.B, self.nz
+        out = {"cpu_baseline": cpu_baseline(self.sc_cpu, self.cot_cpu, a.cpu_budget, a.fwd_only),
+               "cpu_reference": cpu_reference_quote()}
+        x_gpu = self.sol.x if a.mode == "dense" else -self.step_out["v_new"].reshape(B, nz)
+        dp_gpu = None if (a.fwd_only or a.bwd == "physical") else self.grads[1]
+        src = self.sol if a.mode == "dense" else None
+        z_gpu = src.z if src is not None else self.step_out["z"]
+        s_gpu = src.s if src is not None else self.step_out["s"]
+        out["parity"] = parity_vs_oracle(self.sc_cpu, self.cot_cpu, x_gpu, z_gpu, s_gpu, dp_gpu)
+        return out
+
+
+def main(argv=None):
+    args = parse(argv)
+    from lcp_physics_amd import shard
+    if not shard.under_launcher():
+        if args.gpus > 1:
+            # no launcher around us: start the N ranks ourselves, one per visible device
+            try:
+                rc = shard.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv),
+                                        share_devices=args.share_devices)
+            except RuntimeError as ex:
+                raise SystemExit("bench.py: " + str(ex))
+            raise SystemExit(rc)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    run_rank(args, HipStackWorkload)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,9 @@
  *    may be 0: then A, b, y and their gradients may be NULL).
  *  - `compute`: arithmetic type used inside the kernels.  LCP_COMPUTE_F64 is the parity
  *    path (fp32 I/O, fp64 arithmetic); LCP_COMPUTE_F32 computes everything in fp32.
+ *  - threading: the library holds no process-global mutable state.  Every launch is planned from its own arguments and
+ *    ordered on the caller's stream of the CURRENT device, so host threads may drive different streams / devices
+ *    concurrently; the two lcp_debug_* settings are per calling thread.
  */
 #ifndef LCP_HIP_H
 #define LCP_HIP_H
@@ -37,6 +40,9 @@ extern "C" {
  * was solved as a contact-structured LCP with diagonal Q by the four-scenes-per-wave kernel (true by construction after
  * lcp_step_fused_f32 / lcp_solve_dynamics_f32).  The backward then skips the launches that serve the other classes. */
 #define LCP_HINT_ALL_CONTACT 0x100
+/* May be OR-ed into any `compute` argument: serve this call from the generic workgroup-per-scene kernels whatever the
+ * sizes (A/B and debugging aid; a backward must carry the same flag as its forward - they share the workspace layout). */
+#define LCP_PATH_GENERIC 0x200
 
 #define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
 #define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan  */
@@ -47,6 +53,8 @@ extern "C" {
 #define LCP_ST_SINGULAR_S11 2  /* zero/NaN pivot in A Q^-1 A^T                                  */
 #define LCP_ST_SINGULAR_T   4  /* exact zero pivot in LU(T): best iterate returned (pdipm.py:99-102) */
 #define LCP_ST_NAN          8  /* the returned iterate contains NaN                             */
+#define LCP_ST_TRUNCATED   16  /* c_count[k] > maxc: the scene was solved with its first maxc contacts only (the reference's
+                                  list is unbounded, world.py:139-142) - enlarge maxc and redo the step      */
 
 /* Library / build identification: returns a static string such as
  * "lcp_hip 0.1.0 gfx950".  Host-only, never touches the GPU. */
@@ -227,7 +235,8 @@ int lcp_move_find_contacts_f64(int B, int nb, int maxc,
  * lcp_debug_set_trace: when non-NULL, the dense forward writes trace[B, max_iter, 4] =
  *   (resid, mu, sigma, alpha) per PDIPM iteration (device pointer to doubles).
  * lcp_debug_set_path : 0 = automatic kernel selection, 1 = generic (workgroup-per-scene) kernels only,
- *   2 = wave-per-scene kernels whenever the sizes allow (the default behaviour of 0 today). */
+ *   2 = wave-per-scene kernels whenever the sizes allow (the default behaviour of 0 today).
+ * Both settings are thread_local: they affect the calls of the thread that made them, nobody else's. */
 void lcp_debug_set_trace(double* device_trace);
 void lcp_debug_set_path(int path);
 

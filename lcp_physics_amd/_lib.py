@@ -14,11 +14,13 @@ LIB_PATH = os.environ.get("LCP_HIP_LIB", os.path.join(_HERE, "csrc", "liblcp_hip
 COMPUTE_F32 = 0
 COMPUTE_F64 = 1
 HINT_ALL_CONTACT = 0x100
+PATH_GENERIC = 0x200
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2
 ST_SINGULAR_T = 4
 ST_NAN = 8
+ST_TRUNCATED = 16
 
 _ERRORS = {-1: "LCP_E_BADARG", -2: "LCP_E_TOOLARGE", -3: "LCP_E_LAUNCH"}
 

@@ -7,14 +7,36 @@
 
 namespace {
 
-double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
-int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels
+// The library keeps NO process-global mutable state: launches are planned from their arguments alone and ordered on the
+// caller's stream, so any number of host threads may drive any number of streams / devices concurrently.  The two
+// debugging aids below are per calling thread (thread_local), and the kernel family can also be forced per call with
+// LCP_PATH_GENERIC in the `compute` word.
+thread_local double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
+thread_local int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels
+
+// `compute` word of an entry point -> arithmetic type; *generic = the caller (or this thread's debug setting) forces the
+// workgroup-per-scene kernels
+inline int split_compute(int compute, bool* generic) {
+  *generic = (compute & LCP_PATH_GENERIC) != 0 || g_path == 1;
+  return compute & ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT);
+}
 
 // Which kernel family serves a problem.  Deterministic in (sizes, io type) so that forward and
 // backward of one op agree on the workspace layout.
-inline bool use_wave64(int io_f64, int nz, int m, int e) {
-  if (io_f64 || g_path == 1) return false;
+inline bool use_wave64(int io_f64, int nz, int m, int e, bool generic) {
+  if (io_f64 || generic) return false;
   return lcp::wave64_supported(nz, m, e);
+}
+
+// Kernel family of the contact-list entry points (lcp_step_fused_f32, lcp_solve_dynamics_f32, lcp_step_backward_f32):
+// ONE function of (sizes, arithmetic, forced path), so that a backward always reads the workspace layout its forward wrote.
+enum StepFamily { FAM_QUAD, FAM_BIG, FAM_WAVE64, FAM_GENERIC };
+inline StepFamily step_family(int nz, int m, int e, int compute, bool generic) {
+  if (generic) return FAM_GENERIC;
+  if (lcp::quad_step_supported(nz, m, e)) return FAM_QUAD;                     // <= 16 contacts, <= 10 bodies, e <= 4
+  if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e)) return FAM_BIG;   // <= 64 contacts (fp64 arithmetic)
+  if (lcp::wave64_supported(nz, m, e)) return FAM_WAVE64;                      // nz <= 16, e 5..8
+  return FAM_GENERIC;
 }
 
 inline int csize_of(int io_f64, int compute) { return (io_f64 || compute == LCP_COMPUTE_F64) ? 8 : 4; }
@@ -53,8 +75,11 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   if (B <= 0 || nz <= 0 || m <= 0 || e < 0 || max_iter < 0) return LCP_E_BADARG;
   if (!Q || !p || !G || !h || !F || !x || !z || !s || !ws) return LCP_E_BADARG;
   if (e > 0 && (!A || !b)) return LCP_E_BADARG;
+  bool generic;
+  compute = split_compute(compute, &generic);
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
-  const bool w64 = use_wave64(io_f64, nz, m, e);
+  const bool w64 = use_wave64(io_f64, nz, m, e, generic);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   lcp::FwdArgs P;
@@ -72,7 +97,6 @@ int lcp_pdipm_forward_f32(int B, int nz, int m, int e, const float* Q, const flo
                           const float* h, const float* A, const float* b, const float* F, double eps,
                           int max_iter, int not_improved_lim, int compute, float* x, float* y, float* z,
                           float* s, int32_t* iters, int32_t* status, void* ws, void* stream) {
-  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   return forward_common(0, B, nz, m, e, Q, p, G, h, A, b, F, eps, max_iter, not_improved_lim, compute, x, y,
                         z, s, iters, status, ws, stream);
 }
@@ -92,9 +116,11 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (!G || !dl_dx || !ws) return LCP_E_BADARG;
   if (e > 0 && !A) return LCP_E_BADARG;
   const int hint = compute & LCP_HINT_ALL_CONTACT;
-  compute &= ~LCP_HINT_ALL_CONTACT;
+  bool generic;
+  compute = split_compute(compute, &generic);
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
-  const bool w64 = use_wave64(io_f64, nz, m, e);
+  const bool w64 = use_wave64(io_f64, nz, m, e, generic);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   lcp::BwdArgs P;
@@ -109,8 +135,6 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
 int lcp_pdipm_backward_f32(int B, int nz, int m, int e, const float* G, const float* A, const float* dl_dx,
                            int compute, float* dQ, float* dp, float* dG, float* dh, float* dA, float* db,
                            float* dF, void* ws, void* stream) {
-  const int base = compute & ~LCP_HINT_ALL_CONTACT;
-  if (base != LCP_COMPUTE_F32 && base != LCP_COMPUTE_F64) return LCP_E_BADARG;
   return backward_common(0, B, nz, m, e, G, A, dl_dx, compute, dQ, dp, dG, dh, dA, db, dF, ws, stream);
 }
 
@@ -120,6 +144,8 @@ int lcp_pdipm_backward_f64(int B, int nz, int m, int e, const double* G, const d
   return backward_common(1, B, nz, m, e, G, A, dl_dx, LCP_COMPUTE_F64, dQ, dp, dG, dh, dA, db, dF, ws,
                          stream);
 }
+
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream);
 
 static int fill_step(lcp::StepArgs& P, int B, int nb, int nc, int e, const float* pos, const float* Mdiag,
                      const float* v, const float* f, const float* rest, const float* fric, const float* c_n,
@@ -154,21 +180,18 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
                        const float* Je, float dt, double eps, int max_iter, int not_improved_lim, int compute,
                        float* v_new, float* p_new, float* z, float* s, float* y, int32_t* iters,
                        int32_t* status, void* ws, void* stream) {
+  bool generic;
+  compute = split_compute(compute, &generic);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, nc, e, pos, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
   if (rc) return rc;
   if (!pos || !v_new || !p_new || !ws || max_iter < 0) return LCP_E_BADARG;
   const int nz = 3 * nb, m = 4 * nc;
-  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
-  const bool w64 = use_wave64(0, nz, m, e);
-  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = p_new; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
-  P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  if (w64) return lcp::wave64_step(P, compute, stream);
-  return lcp::generic_step(P, compute, pl.lds_bytes, stream);
+  P.ws = ws;
+  return launch_step(P, nz, m, e, compute, generic, stream);
 }
 
 int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
@@ -176,6 +199,8 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
                           const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
                           const float* dl_dv, int compute, float* dMdiag, float* dv, float* df, float* drest,
                           float* dfric, float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream) {
+  bool generic;
+  compute = split_compute(compute, &generic);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, nc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -185,10 +210,27 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
   lcp::StepBwdArgs G;
   G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
   G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
-  if (lcp::quad_step_supported(3 * nb, 4 * nc, e)) return lcp::quad_step_backward(P, G, compute, stream);
-  // larger scenes: the forward must have been lcp_solve_dynamics_f32 (the lcp_big.hip kernel owns the workspace layout)
-  if (compute == LCP_COMPUTE_F64 && lcp::big_supported(3 * nb, 4 * nc, e)) return lcp::big_step_backward(P, G, stream);
-  return LCP_E_TOOLARGE;
+  // the same family decision as the forward entry points (launch_step): the workspace layout is the family's
+  switch (step_family(3 * nb, 4 * nc, e, compute, generic)) {
+    case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream);
+    case FAM_BIG: return lcp::big_step_backward(P, G, stream);
+    default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read
+  }
+}
+
+// forward of the contact-list entry points, by family
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream) {
+  switch (step_family(nz, m, e, compute, generic)) {
+    case FAM_QUAD: return lcp::quad_step(P, compute, stream);
+    case FAM_BIG: return lcp::big_step(P, stream);
+    case FAM_WAVE64: if (!P.c_count) return lcp::wave64_step(P, compute, stream);   // (its kernel takes full lists only)
+    default: break;
+  }
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_step(P, compute, pl.lds_bytes, stream);
 }
 
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
@@ -197,25 +239,18 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
                            const int32_t* c_i2, const float* Je, float dt, double eps, int max_iter,
                            int not_improved_lim, int compute, float* v_new, float* z, float* s, float* y,
                            int32_t* iters, int32_t* status, void* ws, void* stream) {
+  bool generic;
+  compute = split_compute(compute, &generic);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
   if (rc) return rc;
   if (!c_count || !v_new || !ws || max_iter < 0) return LCP_E_BADARG;
-  const int nz = 3 * nb, m = 4 * maxc;
   P.c_count = c_count;
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  if (lcp::quad_step_supported(nz, m, e) && g_path != 1) return lcp::quad_step(P, compute, stream);
-  // up to 64 contacts: the register-tiled workgroup-per-scene kernel (forward only; see lcp_hip.h)
-  if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e) && g_path != 1) return lcp::big_step(P, stream);
-  // any other size: the generic workgroup-per-scene kernels (forward only)
-  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
-  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!pl.ok) return LCP_E_TOOLARGE;
-  P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  return lcp::generic_step(P, compute, pl.lds_bytes, stream);
+  return launch_step(P, 3 * nb, 4 * maxc, e, compute, generic, stream);
 }
 
 int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
@@ -224,6 +259,8 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
                                double eps, int max_iter, int not_improved_lim, int compute, const double* p,
                                const double* dt_scene, double dt, double* p_out, float* dp, int32_t* iters,
                                int32_t* status, void* ws, void* stream) {
+  bool generic_unused;
+  compute = split_compute(compute, &generic_unused);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   // (forces and friction do not enter this LCP: engines.py:80-116 reads M, v, Je, Jc and the restitutions only)

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   int ncs = ncap;
   if (BWD) ncs = (int)Wg[WS_W];                                           // the count the forward solved with
   else if (SP.c_count) ncs = SP.c_count[scene];
+  const int truncated = (ncs > ncap) ? LCP_ST_TRUNCATED : 0;               // more contacts found than the list holds
   ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
   if (!BWD && tid == 0) Wg[WS_W] = (double)ncs;
   const bool vc = w0 && lane < ncs;                                       // this lane owns a live contact
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   }
   if (w0) L.qid[lane] = qid;
   for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz; L.At[(size_t)a * nzs + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
-  int status = 0;
+  int status = truncated;
   __syncthreads();
 
   // ---- pre_factor_kkt for diagonal Q (pdipm.py:357-408): GA = J Q^-1 A^T, S11 = (A Q^-1 A^T)^-1, W = J P J^T -----------
@@ -772,7 +773,11 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     if (SP.s) { float* o = (float*)SP.s + (size_t)scene * m; o[lane] = k * (float)bs.n; o[ncap + 2 * lane] = k * (float)bs.f1; o[ncap + 2 * lane + 1] = k * (float)bs.f2; o[3 * ncap + lane] = k * (float)bs.g; }
   }
   if (lane < e && SP.y) ((float*)SP.y)[(size_t)scene * e + lane] = (float)by;
-  if (lane < nz) ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)(-bx);     // engines.py:76-77
+  if (lane < nz) {
+    const double nv = -bx;                                                            // engines.py:76-77
+    ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)nv;
+    if (SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
+  }
   // the iterate the backward starts from (lcp.py:29 keeps nus, lams, slacks on the op)
   Wit[lane] = (lane < nz) ? bx : 0.0;
   if (lane < 8) Wit[64 + lane] = (lane < e) ? by : 0.0;

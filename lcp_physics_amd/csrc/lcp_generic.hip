@@ -649,7 +649,8 @@ __global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
   const int scene = blockIdx.x;
   const int ncap = P.nc;
   int ncs = ncap;
-  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  int truncated = 0;                                                       // the detection kernel found more contacts than the list holds
+  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; truncated = c > ncap ? LCP_ST_TRUNCATED : 0; }
   const int nz = 3 * P.nb, m = ncs, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, 4 * ncap, e);
   Scene<TC> S;
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
   S.R = W.R;
   assemble_scene<TI, TC, true>(S, P, scene, ncs);
   FZero<TC> F;
-  int status = prefactor(S, F);
+  int status = prefactor(S, F) | truncated;
   int iters = 0;
   pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);   // (m == 0: the direct KKT solve, :92-103)
   __syncthreads();
@@ -686,7 +687,8 @@ __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   const int scene = blockIdx.x;
   const int ncap = P.nc, mcap = 4 * ncap;                                 // capacity: array strides, workspace layout
   int ncs = ncap;                                                         // contacts of this scene (engines.py:36,51)
-  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; }
+  int truncated = 0;                                                       // the detection kernel found more contacts than the list holds
+  if (P.c_count) { const int c = P.c_count[scene]; ncs = c < ncap ? (c < 0 ? 0 : c) : ncap; truncated = c > ncap ? LCP_ST_TRUNCATED : 0; }
   const int nz = 3 * P.nb, m = 4 * ncs, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, mcap, e);
   Scene<TC> S;
@@ -694,7 +696,7 @@ __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   S.R = W.R;
   assemble_scene<TI, TC>(S, P, scene, ncs);
   FContact<TC> F{S.mu_c, ncs};
-  int status = prefactor(S, F);
+  int status = prefactor(S, F) | truncated;
   int iters = 0;
   pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);
   TI* z = P.z ? (TI*)P.z + (size_t)scene * mcap : nullptr;
@@ -843,12 +845,11 @@ Plan make_plan(int nz, int m, int e, int csize) {
 // Raise the dynamic-LDS cap of a kernel once per (kernel, size) - gfx950 allows 160 KiB.
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
-  static size_t granted = 64 * 1024;       // one instance per kernel type K... per instantiation of set_lds
-  if (bytes > granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) return LCP_E_LAUNCH;
-    granted = bytes;
-  }
+  // stateless on purpose: the opt-in is per device and per kernel, a cached "granted" size would be wrong on the second
+  // GPU of a process and racy between host threads.  The attribute call is a host-side table update (no launch, no sync).
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return LCP_E_LAUNCH;
   return 0;
 }
 

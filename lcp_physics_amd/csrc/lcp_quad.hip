@@ -807,7 +807,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   // per-scene contact count (solve_dynamics with detection); a scene without contacts takes the
   // direct KKT solve of engines.py:36-50, which is what the initialisation solve computes
   int ncs = nc;
-  if (FUSED && SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; }
+  int truncated = 0;                                                     // more contacts found than the list holds
+  if (FUSED && SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; truncated = c > nc ? LCP_ST_TRUNCATED : 0; }
   int ncw = ncs;
   ncw = max(ncw, __shfl_xor(ncw, 16, 64)); ncw = max(ncw, __shfl_xor(ncw, 32, 64));
   ncw = __builtin_amdgcn_readfirstlane(ncw);
@@ -823,7 +824,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     load_dense_q<TI, TC>(S, P, W, scene, p, hn, b);
   }
   if (live && l16 == 0) W.meta[19] = (TC)ncs;
-  int status = prefactor_q<TI, TC, XH>(S, W, live);
+  int status = prefactor_q<TI, TC, XH>(S, W, live) | truncated;
   TC* const wsx = ws_x<XH>(W);
 
   TC ta[32], tu[32];

@@ -1214,12 +1214,11 @@ static inline dim3 w64_grid(int B) { return dim3((B + w64::WPB - 1) / w64::WPB);
 // dynamic LDS above 64 KiB needs an explicit opt-in per kernel (gfx950 has 160 KiB per CU)
 template <typename K>
 static int w64_allow_lds(K kernel, size_t bytes) {
-  static size_t granted = 64 * 1024;
-  if (bytes > granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) return LCP_E_LAUNCH;
-    granted = bytes;
-  }
+  // stateless on purpose: the opt-in is per device and per kernel, a cached "granted" size would be wrong on the second
+  // GPU of a process and racy between host threads.  The attribute call is a host-side table update (no launch, no sync).
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return LCP_E_LAUNCH;
   return 0;
 }
 #define LCP_W64_LAUNCH(KERNEL, GRID, LW, ...)                                            \

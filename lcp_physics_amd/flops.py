@@ -15,6 +15,24 @@ def flops_forward(nz, m, e, it):
     return P + Fk + Sk + it * I
 
 
+def flops_forward_executed(nz, nc, e, it):
+    """FLOPs the contact-structured kernels really EXECUTE per scene (lcp_quad.hip / lcp_big.hip): the 4nc inequality
+    rows are reduced exactly to n = 2nc unknowns (normal multipliers + friction differences), Q is diagonal, and the
+    corrector solve skips the products of its zero right-hand sides.  Dense arithmetic on the reduced system is counted
+    (the kernels do not exploit the sparsity of J inside W = J P J^T), element-wise work as a small multiple of nc."""
+    n = 2 * nc
+    P = 2 * n * n * nz + (2 * n * nz * e + 2 * e * e * nz + 2 * n * e * e + 2 * n * n * e if e > 0 else 0)   # W = J P J^T (+ equality correction)
+    Fk = (2.0 / 3) * n ** 3 + 12 * nc                   # LU of the reduced matrix + the per-contact 2x2 eliminations
+    prod = 2 * n * nz                                   # one J v or J^T w product
+    tri = 2 * n * n                                     # the two triangular sweeps
+    eq = (4 * e * nz + 4 * n * e + 2 * e * e) if e > 0 else 0
+    S_full = 2 * prod + tri + eq + 40 * nc + 2 * nz     # solve_kkt with a full right-hand side
+    S_corr = prod + tri + (2 * n * e + 2 * e * e + 2 * e * nz if e > 0 else 0) + 40 * nc + 2 * nz   # rx = ry = 0
+    Rk = 2 * prod + (4 * e * nz if e > 0 else 0) + 2 * nz + 30 * nc
+    I = Fk + S_full + S_corr + Rk + 60 * nc
+    return P + Fk + S_full + it * I
+
+
 def flops_backward(nz, m, e):
     k = e + m
     Fk = (2.0 / 3) * m ** 3 + m

@@ -61,7 +61,7 @@ def assemble_contacts(sc):
     return Q, p, G, h, A, b, F
 
 
-def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None):
+def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto"):
     """One fused simulation step for every scene of `sc` (float32 CUDA `SceneBatch`).
 
     Returns a dict with v_new, p_new [B,nb,3], z, s [B,4nc], y [B,e], iters, status [B] and the
@@ -73,6 +73,7 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
     dev = sc.v.device
     comp = _COMPUTE[compute]
     need = _lib.workspace_bytes(B, nz, m, e, comp)
+    comp |= _PATH[path]
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
@@ -91,8 +92,11 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
                                     P(out["z"]), P(out["s"]), P(out["y"]), P(out["iters"]),
                                     P(out["status"]), P(ws), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_step_fused_f32")
-    out["path"] = "fused"
+    out["path"] = path
     return out
+
+
+_PATH = {"auto": 0, "generic": _lib.PATH_GENERIC}     # `path="generic"`: force the workgroup-per-scene kernels (A/B aid)
 
 
 def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
@@ -105,9 +109,6 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
     dev = sc.v.device
-    if (3 * nb > 16 or nc > 16) and out.get("path") != "solve_dynamics":
-        raise RuntimeError("scenes beyond 5 bodies or 16 contacts: the forward must be `solve_dynamics` "
-                           "(lcp_solve_dynamics_f32) - its kernel owns the workspace layout the backward reads")
     dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
     if grads is None:
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -117,7 +118,8 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
     with torch.cuda.device(dev):
         rc = lib.lcp_step_backward_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n),
                                        P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None,
-                                       float(sc.dt), P(dl_dv), _COMPUTE[compute], P(grads["Mdiag"]), P(grads["v"]),
+                                       float(sc.dt), P(dl_dv), _COMPUTE[compute] | _PATH[out.get("path", "auto")],
+                                       P(grads["Mdiag"]), P(grads["v"]),
                                        P(grads["f"]), P(grads["rest"]), P(grads["fric"]), P(grads["c_n"]),
                                        P(grads["c_p1"]), P(grads["c_p2"]), P(out["ws"]), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_step_backward_f32")
@@ -134,7 +136,8 @@ def solution_of_step(sc, out, G, A, compute="f64"):
     sol.all_contact = True                         # every scene went through the contact-structured kernel
     sol.y, sol.z, sol.s = out["y"], out["z"], out["s"]
     sol.iters, sol.status, sol.ws = out["iters"], out["status"], out["ws"]
-    sol.G, sol.A, sol.sizes, sol.compute, sol.dtype = G, A, (B, 3 * nb, 4 * nc, e), _COMPUTE[compute], torch.float32
+    sol.G, sol.A, sol.sizes, sol.dtype = G, A, (B, 3 * nb, 4 * nc, e), torch.float32
+    sol.compute = _COMPUTE[compute] | _PATH[out.get("path", "auto")]     # the backward must pick the forward's kernel family
     return sol
 
 
@@ -155,47 +158,29 @@ class BatchedWorld:
         self.dt = scene.dt
         self._ws = None
         self._out = None
-        self._full_count = None
         self.last = None
-
-    def _forward_only_step(self):
-        """Scenes with more than 5 bodies or 16 contacts: `lcp_solve_dynamics_f32` reaches the two-halves instantiation
-        of the quad kernel (up to 10 bodies) or the register-tiled kernel of lcp_big.hip (up to 64 contacts), where
-        `lcp_step_fused_f32` would fall back to the generic kernels; its workspace also feeds `fused_step_backward`.
-        The integrator `p += v dt` (bodies.py:80-82) is then one elementwise op."""
-        sc = self.scene
-        if self._full_count is None:
-            from .contacts import ContactBuffers
-            self._full_count = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=sc.v.device)
-            self._cb = ContactBuffers.__new__(ContactBuffers)
-        cb = self._cb
-        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
-        e = sc.Je.shape[1] if sc.Je is not None and sc.Je.numel() else 0
-        out = solve_dynamics(sc.B, sc.nb, sc.nc, e, self._full_count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb,
-                             sc.Je if e else None, sc.dt, eps=self.eps, not_improved_lim=self.lim,
-                             max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
-        if "p_new" not in out:
-            out["p_new"] = torch.empty_like(sc.p)
-        torch.add(sc.p, out["v_new"], alpha=float(sc.dt), out=out["p_new"])
-        return out
 
     def step(self):
         sc = self.scene
-        if 3 * sc.nb > 16 or sc.nc > 16:
-            out = self._forward_only_step()
-        else:
-            out = fused_step(sc, eps=self.eps, not_improved_lim=self.lim, max_iter=self.max_iter,
-                             compute=self.compute, ws=self._ws, out=self._out)
-        self._ws, self._out, self.last = out["ws"], out, out
-        # double-buffer swap: new state becomes the scene state (world.py:87-90)
+        # (lcp_step_fused_f32 picks the kernel family from the sizes: four scenes per wave up to 16 contacts / 10 bodies,
+        # the register-tiled workgroup kernel up to 64 contacts, the generic kernels beyond)
+        out = fused_step(sc, eps=self.eps, not_improved_lim=self.lim, max_iter=self.max_iter,
+                         compute=self.compute, ws=self._ws, out=self._out)
+        self._ws, self._out = out["ws"], out
+        # double-buffer swap: new state becomes the scene state (world.py:87-90); the dict handed back (and kept as
+        # `last`) names the NEW tensors, the spare buffers stay private
         self.scene.v, out["v_new"] = out["v_new"], self.scene.v
         self.scene.p, out["p_new"] = out["p_new"], self.scene.p
+        ret = dict(out)
+        ret["v_new"], ret["p_new"] = self.scene.v, self.scene.p
+        ret["v_prev"], ret["p_prev"] = out["v_new"], out["p_new"]          # state the step started from (until the next step)
+        self.last = ret
         if self.contact_fn is not None:
             c_n, c_p1, c_p2, c_i1, c_i2 = self.contact_fn(self)
             self.scene.c_n, self.scene.c_p1, self.scene.c_p2 = c_n, c_p1, c_p2
             self.scene.c_i1, self.scene.c_i2 = c_i1, c_i2
         self.t += self.dt
-        return out
+        return ret
 
     def get_v(self):
         return self.scene.v
@@ -205,7 +190,7 @@ class BatchedWorld:
 
 
 def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, eps=1e-12, not_improved_lim=3,
-                   max_iter=10, compute="f64", ws=None, out=None):
+                   max_iter=10, compute="f64", ws=None, out=None, path="auto"):
     """`PdipmEngine.solve_dynamics` (`engines.py:26-78`) for B scenes with per-scene contact counts
     (`count` [B] int32, contact records in `cb`, a `contacts.ContactBuffers`): one launch of
     `lcp_solve_dynamics_f32`.  Returns dict(v_new, z, s, y, iters, status, ws)."""
@@ -214,6 +199,7 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
     comp = _COMPUTE[compute]
     nz, m = 3 * nb, 4 * maxc
     need = _lib.workspace_bytes(B, nz, m, e, comp)
+    comp |= _PATH[path]
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
@@ -230,7 +216,7 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
                                         int(not_improved_lim), comp, P(out["v_new"]), P(out["z"]), P(out["s"]),
                                         P(out["y"]), P(out["iters"]), P(out["status"]), P(ws), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_solve_dynamics_f32")
-    out["path"] = "solve_dynamics"
+    out["path"] = path
     return out
 
 
@@ -303,6 +289,10 @@ class ContactWorld:
         self.solver_eps, self.lim, self.max_trials = solver_eps, not_improved_lim, max_trials
         self.t = torch.zeros(self.B, dtype=torch.float64, device=dev)
         self._ws = self._out = None
+        self.check = bool(check)
+        # OR of every step's per-scene status bits (device side, no synchronisation): LCP_ST_TRUNCATED in here means a
+        # scene once had more contacts than `maxc` and was solved with a cut list - `assert_not_truncated()` / `run()`
+        self.sticky_status = torch.zeros(self.B, dtype=torch.int32, device=dev)
         # world.py:65-66: contacts of the initial pose; :67-70: refuse interpenetration at start
         self.contacts = _contacts.find_contacts(geom, self.p, maxc=self.maxc, eps=self.eps)
         if check:
@@ -315,6 +305,19 @@ class ContactWorld:
         worst = int(self.contacts.count.max())
         if worst > self.maxc:
             raise RuntimeError("a scene has %d contacts but maxc = %d" % (worst, self.maxc))
+
+    def truncated_scenes(self):
+        """Scenes that at some step had more than `maxc` contacts (synchronises)."""
+        return torch.nonzero(self.sticky_status & _lib.ST_TRUNCATED).flatten()
+
+    def assert_not_truncated(self):
+        """Host check (synchronises): the reference's contact list is unbounded (world.py:139-142), ours is capped at
+        `maxc`; a scene that overflowed was solved without its surplus contacts and the run is not the reference's."""
+        bad = self.truncated_scenes()
+        if bad.numel():
+            raise RuntimeError("%d scene(s) exceeded maxc = %d contacts during the run (first: scene %d): their "
+                               "contact lists were truncated - rebuild the world with a larger maxc"
+                               % (bad.numel(), self.maxc, int(bad[0])))
 
     def run(self, nsteps, graph=True):
         """`nsteps` calls of `step()`.  With `graph=True` the launches of TWO consecutive steps (after two steps the
@@ -340,6 +343,8 @@ class ContactWorld:
         while k < nsteps:
             self.step()
             k += 1
+        if self.check:
+            self.assert_not_truncated()                                    # one synchronisation per run, none per step
 
     def step(self):
         """`World.step()` = `step_dt(self.dt)` (`world.py:72-122`) for every scene."""
@@ -349,6 +354,7 @@ class ContactWorld:
                              self.fric, cb, self.Je, self.dt, eps=self.solver_eps, not_improved_lim=self.lim,
                              max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
         self._ws, self._out = out["ws"], out
+        torch.bitwise_or(self.sticky_status, out["status"], out=self.sticky_status)
         self.v, out["v_new"] = out["v_new"], self.v                      # world.py:87 set_v(new_v)
         self._contacts_mod.move_and_find_contacts(self.geom, self.p, self.v, self.dt, eps=self.eps, tol=self.tol,
                                                   strict=self.strict, dt_floor=self.dt / 4,
@@ -363,7 +369,9 @@ class ContactWorld:
             self._ps_ws, self._ps_out = ps["ws"], ps
             self._contacts_mod.find_contacts(self.geom, self.p, maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
             out["post_stab"] = ps
-        return out
+        ret = dict(out)
+        ret["v_new"], ret["v_prev"] = self.v, out["v_new"]               # the NEW velocities; the spare buffer holds the old
+        return ret
 
     def get_v(self):
         return self.v

@@ -66,6 +66,33 @@ def active_sets(z, s, nc=None):
     return z > s
 
 
+def decisive_rows(z, s, rel=1e-3, floor=1e-5):
+    """Rows where the ORACLE's z_i > s_i decision is meaningful: not a near-tie, and not a degenerate pair where
+    BOTH z_i and s_i have converged to zero (a contact exactly at the boundary: which of two 1e-9 numbers is larger
+    is decided by the rounding of the last PDIPM iteration).  Index sets are compared bit-exactly on these rows; the
+    share of rows this mask drops is reported and gated (MAX_MASKED_FRAC) so that the mask cannot grow silently."""
+    big = torch.maximum(z.abs(), s.abs())
+    zs = z.abs().max(dim=1, keepdim=True)[0]
+    ss = s.abs().max(dim=1, keepdim=True)[0]
+    nondegenerate = torch.maximum(z.abs() / zs, s.abs() / ss) > floor
+    return ((z - s).abs() > rel * big) & nondegenerate
+
+
+MAX_MASKED_FRAC = 0.02          # index-set rows the decisive_rows mask may drop on the BASELINE stack configs
+MIN_WELL_POSED_FRAC = 0.9       # scenes whose backward system the oracle itself solves (stack configs)
+
+
+def backward_well_posed(Q, G, A, F, ref, cot, gref):
+    """Scenes where the oracle's own backward (lcp.py:44-50) is a solved system: its KKT residual is small (scenes that
+    over-converged, mu ~ 1e-17, leave a matrix singular to fp64 working precision) and the solution is strictly
+    complementary (a pair with z_i ~ s_i ~ 0 makes the gradient one-sided).  `gref` holds dp, dh, db."""
+    res = kkt_backward_residual(Q, G, A, F, ref.z, ref.s, cot, gref["dp"], -gref["dh"],
+                                None if gref.get("db") is None else -gref["db"])
+    ok = torch.stack([v for v in res.values()]).max(dim=0)[0] < 1e-9
+    zs, ss = ref.z.max(dim=1, keepdim=True)[0], ref.s.max(dim=1, keepdim=True)[0]
+    return ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
+
+
 # ----------------------------------------------------------------------------
 # backward parity that is well-posed on degenerate contact LCPs
 # ----------------------------------------------------------------------------

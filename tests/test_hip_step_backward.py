@@ -118,7 +118,7 @@ def test_mid_size_backward_matches_generic_dense(nbox, pts):
     count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
     out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
     pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
-    gen = fused_step(scg)
+    gen = fused_step(scg, path="generic")
     lcp = assemble_contacts(scg)
     dense = lcp_backward(solution_of_step(scg, gen, lcp[2], lcp[4]), (-cot).reshape(B, -1).to(DEV))
     torch.cuda.synchronize()
@@ -148,10 +148,14 @@ def test_large_scene_backward_matches_generic_dense_and_oracle():
     count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
     out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
     pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
+    # either forward entry picks the same kernel family for these sizes: same workspace, same gradients
+    pg2 = fused_step_backward(scg, fused_step(scg), cot.to(DEV))
+    for k in pg:
+        assert torch.equal(pg2[k].double().cpu(), pg[k]), k
     with pytest.raises(RuntimeError):
-        fused_step_backward(scg, fused_step(scg), cot.to(DEV))                 # wrong forward for this size class
+        fused_step_backward(scg, fused_step(scg, path="generic"), cot.to(DEV))   # the generic kernels keep no workspace for it
     # (a) generic kernels: dense gradients of the same step, contracted through the assembly by autograd
-    gen = fused_step(scg)
+    gen = fused_step(scg, path="generic")
     lcp = assemble_contacts(scg)
     dense = lcp_backward(solution_of_step(scg, gen, lcp[2], lcp[4]), (-cot).reshape(B, -1).to(DEV))
     torch.cuda.synchronize()

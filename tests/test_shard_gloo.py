@@ -1,7 +1,13 @@
 """CPU, world_size 2 over gloo: the multi-GPU path shards scenes with no data-path collective; only
-the barrier / MAX-timing reduction / optional gather use torch.distributed."""
+the barrier / MAX-timing reduction / optional gather use torch.distributed.  The second half runs bench.py's own
+rank protocol (`bench.run_rank`: launcher checks, barriers, MAX-over-ranks wall time, n_gpus accounting, the JSON
+line) on two gloo ranks with a stand-in workload whose step launches nothing - the HIP launch is what is mocked, not
+the protocol - and checks that `bench.py --gpus N` refuses to run when N devices are not there."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -62,3 +68,83 @@ def test_two_rank_gloo_sharded_step_equals_single_process():
         assert p.exitcode == 0
     t, n, same, shape = q.get()
     assert t == 2.0 and n == total and same and shape == (total, 3, 3)
+
+
+# ---------------------------------------------------------------------------------------------- bench.py's rank protocol
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _NoLaunchWork:
+    """Stand-in for bench.HipStackWorkload: same interface, the step is a host-side no-op of known duration."""
+
+    def __init__(self, args, rank, dev):
+        self.units_per_step = args.batch
+        self.rank, self.calls = rank, 0
+
+    def new_events(self):
+        return None
+
+    def step(self, ev=None):
+        import time
+        self.calls += 1
+        time.sleep(0.002 * (1 + self.rank))          # rank 1 is the slow one: the MAX rule must pick it up
+
+    def metric_name(self):
+        return "protocol test"
+
+    def report(self, events, world):
+        return {"config": {"workload": "no-launch stand-in", "calls": self.calls}, "roofline": None}
+
+    def host_side_checks(self):
+        return {}
+
+
+def _bench_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse(["--gpus", str(world), "--steps", "5", "--warmup", "2", "--batch", "4096", "--sustain", "0"])
+    out = bench.run_rank(args, _NoLaunchWork, device="cpu")
+    if rank == 0:
+        q.put(out)
+
+
+def test_bench_rank_protocol_two_gloo_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    out = q.get()
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
+    assert out["config"]["calls"] == 7                      # warm-up + timed steps, nothing else inside the protocol
+    assert out["ms_per_step"] >= 4.0                        # MAX over ranks: the slow rank's 4 ms per step
+    assert abs(out["value"] - 8192 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    assert out["cpu_baseline"] is None                      # reported at N = 1 only
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run_bench(["--gpus", str(n + 2), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "refusing to run" in (r.stderr + r.stdout) and "n_gpus" not in r.stdout
+
+
+def test_bench_rejects_gpus_flag_that_disagrees_with_the_launcher():
+    r = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0"],
+                   env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
