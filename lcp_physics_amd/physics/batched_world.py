@@ -158,9 +158,37 @@ class BatchedWorld:
         self.dt = scene.dt
         self._ws = None
         self._out = None
+        self._count = None
         self.last = None
 
-    def step(self):
+    def step_autograd(self):
+        """The same step as a node of torch's autograd graph (`demos/grad_demo.py:45-50`, `experiments/inference.py:55-61`
+        back-propagate through many `World.step`s): `SolveDynamicsFunction` (HIP forward + HIP analytic backward) for the
+        velocities and `p + v_new dt` (`bodies.py:80-82`) for the poses.  Scene tensors may require grad (masses, forces,
+        restitution, friction, initial velocities, the contact frame); the state tensors are REPLACED, not overwritten, so
+        every step of a roll-out keeps what its backward needs."""
+        from dataclasses import replace
+        sc = self.scene
+        if self._count is None or self._count.shape[0] != sc.B:
+            self._count = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=sc.v.device)
+        opts = {"max_iter": self.max_iter, "eps": self.eps, "not_improved_lim": self.lim, "compute": self.compute}
+        e = sc.Je.shape[1] if sc.Je is not None and sc.Je.numel() else 0
+        v_new = SolveDynamicsFunction.apply(sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1,
+                                            sc.c_i2, self._count, sc.Je if e else None, sc.dt, opts)
+        p_new = sc.p + v_new * sc.dt
+        ret = dict(opts["last"])
+        ret["v_prev"], ret["p_prev"], ret["v_new"], ret["p_new"] = sc.v, sc.p, v_new, p_new
+        self.scene = replace(sc, v=v_new, p=p_new)
+        self.last = ret
+        if self.contact_fn is not None:
+            c_n, c_p1, c_p2, c_i1, c_i2 = self.contact_fn(self)
+            self.scene = replace(self.scene, c_n=c_n, c_p1=c_p1, c_p2=c_p2, c_i1=c_i1, c_i2=c_i2)
+        self.t += self.dt
+        return ret
+
+    def step(self, differentiable=False):
+        if differentiable:
+            return self.step_autograd()
         sc = self.scene
         # (lcp_step_fused_f32 picks the kernel family from the sizes: four scenes per wave up to 16 contacts / 10 bodies,
         # the register-tiled workgroup kernel up to 64 contacts, the generic kernels beyond)
@@ -218,6 +246,81 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
     _lib.check(rc, "lcp_solve_dynamics_f32")
     out["path"] = path
     return out
+
+
+def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt, dl_dv, out, compute="f64", grads=None):
+    """Backward of `solve_dynamics` with respect to its physical inputs (what the reference gets by autograd through
+    `engines.py:31-32,50-77`, `world.py:144-234` and `lcp.py:37-64`): one launch of `lcp_step_backward_f32` on the
+    workspace the forward left in `out`.  Padded contact slots get zero gradients; the joint Jacobian is a constant.
+    Returns dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,maxc,2])."""
+    lib = _lib.load()
+    dev = v.device
+    dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
+    if grads is None:
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        grads = {"Mdiag": new(B, nb, 3), "v": new(B, nb, 3), "f": new(B, nb, 3), "rest": new(B, nb), "fric": new(B, nb),
+                 "c_n": new(B, maxc, 2), "c_p1": new(B, maxc, 2), "c_p2": new(B, maxc, 2)}
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_step_backward_f32(B, nb, maxc, e, P(Mdiag), P(v), P(f), P(rest), P(fric), P(cb.c_n), P(cb.c_p1),
+                                       P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(dt), P(dl_dv),
+                                       _COMPUTE[compute] | _PATH[out.get("path", "auto")],
+                                       P(grads["Mdiag"]), P(grads["v"]), P(grads["f"]), P(grads["rest"]), P(grads["fric"]),
+                                       P(grads["c_n"]), P(grads["c_p1"]), P(grads["c_p2"]), P(out["ws"]),
+                                       _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_step_backward_f32")
+    return grads
+
+
+class _Frame:
+    """The contact list fields the entry points read (a `contacts.ContactBuffers` also qualifies)."""
+    __slots__ = ("c_n", "c_p1", "c_p2", "c_i1", "c_i2")
+
+    def __init__(self, c_n, c_p1, c_p2, c_i1, c_i2):
+        self.c_n, self.c_p1, self.c_p2, self.c_i1, self.c_i2 = c_n, c_p1, c_p2, c_i1, c_i2
+
+
+class SolveDynamicsFunction(torch.autograd.Function):
+    """`PdipmEngine.solve_dynamics` (`engines.py:26-78`) for B scenes as ONE differentiable op.
+
+        v_new = SolveDynamicsFunction.apply(Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts)
+
+    forward  = `lcp_solve_dynamics_f32` (assembly + PDIPM solve + `new_v = -x` in one launch; a scene with count 0
+               takes the direct KKT solve of `engines.py:36-50`);
+    backward = `lcp_step_backward_f32` (implicit differentiation, `lcp.py:37-64`, contracted through the assembly):
+               gradients for Mdiag, v, f, rest, fric and the contact frame (c_n, c_p1, c_p2).
+    All tensors float32, contiguous, on the GPU ([B,nb,3], [B,nb], [B,maxc,2], int32 [B,maxc] / [B]); `Je` [B,e,3nb] or
+    None (treated as a constant); `opts`: dict(max_iter, eps, not_improved_lim, compute) - it receives the forward's
+    `out` dict under "last" (z, s, y, iters, status).  Every call owns its workspace, so the steps of a roll-out can be
+    back-propagated in reverse order."""
+
+    @staticmethod
+    def forward(ctx, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts):
+        B, nb = v.shape[0], v.shape[1]
+        maxc = c_n.shape[1]
+        e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+        for name, t in (("Mdiag", Mdiag), ("v", v), ("f", f), ("rest", rest), ("fric", fric), ("c_n", c_n),
+                        ("c_p1", c_p1), ("c_p2", c_p2)):
+            _lib.require_gpu_tensor(t, name, torch.float32)
+        for name, t in (("c_i1", c_i1), ("c_i2", c_i2), ("count", count)):
+            _lib.require_gpu_tensor(t, name, torch.int32)
+        frame = _Frame(c_n, c_p1, c_p2, c_i1, c_i2)
+        out = solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, frame, Je if e else None, float(dt),
+                             eps=opts.get("eps", 1e-12), not_improved_lim=opts.get("not_improved_lim", 3),
+                             max_iter=opts.get("max_iter", 10), compute=opts.get("compute", "f64"))
+        ctx.save_for_backward(Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2)
+        ctx.Je, ctx.out, ctx.dims, ctx.dt, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), float(dt), opts.get("compute", "f64")
+        opts["last"] = out
+        return out["v_new"]
+
+    @staticmethod
+    def backward(ctx, dl_dv):
+        Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2 = ctx.saved_tensors
+        B, nb, maxc, e = ctx.dims
+        g = solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, _Frame(c_n, c_p1, c_p2, c_i1, c_i2), ctx.Je,
+                                    ctx.dt, dl_dv, ctx.out, compute=ctx.compute)
+        keys = ("Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2")
+        return tuple(g[k] if need else None for k, need in zip(keys, ctx.needs_input_grad[:8])) + (None,) * 6
 
 
 def post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, cb, Je, p=None, dt_scene=None, dt=0.0, p_out=None,

@@ -1,25 +1,28 @@
 """Engine plug-ins for the reference's `World` (`lcp_physics/physics/engines.py:11-116`).
 
-`World(bodies, joints, engine=HipPdipmEngine)` works unchanged: the reference instantiates the
-class with no arguments (`physics/world.py:26`, `physics/utils.py:142-150`) and calls
-`engine.solve_dynamics(world, dt) -> new_v` every step (`world.py:86`).
+`World(bodies, joints, engine=HipPdipmEngine)` works unchanged: the reference instantiates the class with no
+arguments (`physics/world.py:26`, `physics/utils.py:142-150`) and calls `engine.solve_dynamics(world, dt) -> new_v`
+every step (`world.py:86`) and, when `world.post_stab`, `engine.post_stabilization(world) -> dp` (`world.py:109-111`).
 
-* `HipPdipmEngine` - differentiable.  Builds (M, u, G, h, Je, b, F) with the same torch
-  expressions as `engines.py:50-74` (so autograd reaches masses, forces and contact geometry)
-  and solves the mixed LCP with the HIP `LCPFunction`.
-* `HipFusedEngine` - inference.  Hands the raw contact list to the device entry points of the batched
-  path (assembly + solve in one launch, both branches of `solve_dynamics`, and `post_stabilization`);
-  not differentiable.
+Neither engine assembles a dense LCP on the host.  The world's raw state - diagonal of `M`, velocities, forces,
+per-body restitution / friction, the contact list `((normal, p1, p2, penetration), i1, i2)` and the joint Jacobian -
+is lifted to the GPU as a batch of ONE scene and handed to the contact-list entry points of the C ABI:
 
-In the differentiable `HipPdipmEngine` the no-contact branch (`engines.py:35-49`, an equality-only linear
-solve autograd must see through) stays the reference's formula on torch tensors; its `post_stabilization`
-(`engines.py:80-116`) solves the frictionless LCP with the HIP `LCPFunction`.
+* `HipPdipmEngine` - differentiable.  `solve_dynamics` is one `SolveDynamicsFunction` node (forward
+  `lcp_solve_dynamics_f32`: assembly + PDIPM solve, both branches of `engines.py:26-78`; backward
+  `lcp_step_backward_f32`: the implicit differentiation of `lcp.py:37-64` contracted through the assembly on chip), so
+  `loss.backward()` reaches masses, forces, velocities, restitution / friction coefficients and the contact frame
+  exactly where the reference's autograd does.  The joint Jacobian is treated as a constant.
+* `HipFusedEngine` - the same launches without recording a graph (inference).
+
+`post_stabilization` (`engines.py:80-116`) runs `lcp_post_stabilization_f32` in both; its result only corrects poses
+and carries no gradient here.  Sizes: what the contact-list kernels take (64 contacts, 14 bodies, 4 joint rows for the
+differentiable backward); beyond that the call raises - there is no CPU or dense fallback.
 """
 import torch
 
-from ..lcp.lcp import LCPFunction
 from . import batched_world
-from . import contacts as _contacts
+from .batched_world import SolveDynamicsFunction
 
 
 class Engine:
@@ -29,132 +32,82 @@ class Engine:
         raise NotImplementedError
 
 
+def _gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("lcp_physics_amd needs a GPU (MI355X); no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class _Lifted:
+    """What `Engine.solve_dynamics` reads from the reference's `World` (`world.py:124-234`), as float32 GPU tensors with a
+    leading batch axis of one.  Built with differentiable torch ops only (stack / reshape / `.to`), so gradients that
+    arrive at these tensors flow on to the world's own leaves."""
+
+    def __init__(self, world, forces=True):
+        dev = _gpu()
+        bodies = world.bodies
+        nb = len(bodies)
+        up = lambda t, *shape: t.reshape(1, *shape).to(device=dev, dtype=torch.float32).contiguous()
+        self.nb, self.dev = nb, dev
+        self.v = up(world.get_v(), nb, 3)
+        self.Mdiag = up(torch.diagonal(world.M()), nb, 3)
+        self.rest = up(torch.stack([b.restitution.reshape(()) for b in bodies]), nb)
+        self.fric = up(torch.stack([b.fric_coeff.reshape(()) for b in bodies]), nb)
+        self.f = up(world.apply_forces(world.t), nb, 3) if forces else None
+        Je = world.Je()
+        self.e = Je.size(0) if (Je.ndimension() > 1 and Je.numel() > 0) else 0
+        self.Je = up(Je.detach(), self.e, 3 * nb) if self.e else None
+        contacts = world.contacts or []
+        self.nc = len(contacts)
+        cap = max(1, self.nc)
+        if contacts:
+            col = lambda k: up(torch.stack([c[0][k].reshape(2) for c in contacts]), cap, 2)
+            self.c_n, self.c_p1, self.c_p2 = col(0), col(1), col(2)
+            ids = lambda k: torch.tensor([[int(c[k]) for c in contacts]], dtype=torch.int32, device=dev)
+            self.c_i1, self.c_i2 = ids(1), ids(2)
+        else:                                       # engines.py:35-49: the no-contact branch, a list of capacity one, count 0
+            z2 = lambda: torch.zeros(1, cap, 2, dtype=torch.float32, device=dev)
+            self.c_n, self.c_p1, self.c_p2 = z2(), z2(), z2()
+            self.c_i1 = torch.zeros(1, cap, dtype=torch.int32, device=dev)
+            self.c_i2 = torch.zeros(1, cap, dtype=torch.int32, device=dev)
+        self.cap = cap
+        self.count = torch.full((1,), self.nc, dtype=torch.int32, device=dev)
+
+
 class HipPdipmEngine(Engine):
-    """Engine that uses the MI355X primal-dual interior point LCP solver."""
+    """Engine that uses the MI355X primal-dual interior point LCP solver (differentiable)."""
 
-    def __init__(self, max_iter=10):
-        self.lcp_solver = LCPFunction
-        self.cached_inverse = None
+    differentiable = True
+
+    def __init__(self, max_iter=10, compute="f64"):
         self.max_iter = max_iter
+        self.compute = compute
+        self.last = None                              # z, s, y, iters, status of the latest solve (device tensors)
 
-    def _no_contact(self, world, u, Je, neq):
-        # engines.py:35-49 (Cline eq. 2.41): [[M, -Je^T], [Je, 0]] x = u
-        if neq > 0:
-            P = torch.cat([torch.cat([world.M(), -Je.t()], dim=1),
-                           torch.cat([Je, Je.new_zeros(neq, neq)], dim=1)])
-        else:
-            P = world.M()
-        if self.cached_inverse is None:
-            inv = torch.inverse(P)
-            if world.static_inverse:
-                self.cached_inverse = inv
-        else:
-            inv = self.cached_inverse
-        return torch.matmul(inv, u)
+    def _options(self):
+        return {"max_iter": self.max_iter, "eps": 1e-12, "not_improved_lim": 3, "compute": self.compute}
 
     def solve_dynamics(self, world, dt):
-        t = world.t
-        Je = world.Je()
-        neq = Je.size(0) if Je.ndimension() > 0 else 0
-        f = world.apply_forces(t)
-        u = torch.matmul(world.M(), world.get_v()) + dt * f            # engines.py:32
-        if neq > 0:
-            u = torch.cat([u, u.new_zeros(neq)])
-        if not world.contacts:
-            x = self._no_contact(world, u, Je, neq)
-        else:
-            Jc = world.Jc()
-            v = torch.matmul(Jc, world.get_v()) * world.restitutions()  # engines.py:53
-            M = world.M().unsqueeze(0)
-            if neq > 0:
-                b = Je.new_zeros(Je.size(0)).unsqueeze(0)
-                Je = Je.unsqueeze(0)
-            else:
-                b = torch.tensor([])
-                Je = torch.tensor([])
-            Jc = Jc.unsqueeze(0)
-            u = u[:world.M().size(0)].unsqueeze(0)
-            v = v.unsqueeze(0)
-            E = world.E().unsqueeze(0)
-            mu = world.mu().unsqueeze(0)
-            Jf = world.Jf().unsqueeze(0)
-            nc, nf = Jc.size(1), Jf.size(1)
-            G = torch.cat([Jc, Jf, Jf.new_zeros(1, nc, Jf.size(2))], dim=1)         # engines.py:67-68
-            F = G.new_zeros(1, G.size(1), G.size(1))
-            F[:, nc:nc + nf, nc + nf:] = E                                           # engines.py:70
-            F[:, nc + nf:, :nc] = mu                                                 # engines.py:71
-            F[:, nc + nf:, nc:nc + nf] = -E.transpose(1, 2)                          # engines.py:72-73
-            h = torch.cat([v, v.new_zeros(1, nf + nc)], 1)                           # engines.py:74
-            x = -self.lcp_solver(max_iter=self.max_iter, verbose=-1)(M, u, G, h, Je, b, F)
-        new_v = x[:world.vec_len * len(world.bodies)].squeeze(0)
-        return new_v
+        base = world.get_v()
+        opts = self._options()
+        with torch.set_grad_enabled(self.differentiable and torch.is_grad_enabled()):
+            s = _Lifted(world)
+            new_v = SolveDynamicsFunction.apply(s.Mdiag, s.v, s.f, s.rest, s.fric, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2,
+                                                s.count, s.Je, float(dt), opts)
+            self.last = opts.get("last")
+            return new_v.reshape(-1).to(device=base.device, dtype=base.dtype)
 
     def post_stabilization(self, world):
-        # engines.py:80-116; the contact case is a frictionless LCP (G = Jc, F = 0)
-        v = world.get_v()
-        M = world.M()
-        Je = world.Je()
-        Jc = world.Jc() if world.contacts else None
-        ge = torch.matmul(Je, v)
-        u = torch.cat([Je.new_zeros(Je.size(1)), ge])
-        if Jc is None:
-            neq = Je.size(0) if Je.ndimension() > 0 else 0
-            x = self._no_contact(world, u, Je, neq)
-        else:
-            gc = torch.matmul(Jc, v) + torch.matmul(Jc, v) * -world.restitutions()
-            F = Jc.new_zeros(1, Jc.size(0), Jc.size(0))
-            x = self.lcp_solver()(M.unsqueeze(0), u[:M.size(0)].unsqueeze(0), Jc.unsqueeze(0),
-                                  gc.unsqueeze(0), Je.unsqueeze(0), u[M.size(0):].unsqueeze(0), F)
-        return -x[:M.size(0)]
+        base = world.get_v()
+        with torch.no_grad():
+            s = _Lifted(world, forces=False)
+            frame = batched_world._Frame(s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2)
+            out = batched_world.post_stabilization(1, s.nb, s.cap, s.e, s.count, s.Mdiag, s.v, s.rest, frame, s.Je,
+                                                   compute=self.compute)
+            return out["dp"].reshape(-1).to(device=base.device, dtype=base.dtype)
 
 
 class HipFusedEngine(HipPdipmEngine):
-    """Non-differentiable engine: the world's raw state goes to the device entry points of the batched path as a batch
-    of one - `lcp_solve_dynamics_f32` (both branches of `engines.py:26-78`: a world without contacts takes the direct
-    KKT solve inside the same kernel) and `lcp_post_stabilization_f32` (`engines.py:80-116`).  Joints are read
-    through `world.Je()`, so pose-dependent ones work (the Jacobian is re-read every call)."""
+    """The same device path without autograd bookkeeping (inference): nothing of the step is kept for a backward."""
 
-    def __init__(self, max_iter=10, compute="f64"):
-        super().__init__(max_iter=max_iter)
-        self.compute = compute
-
-    @staticmethod
-    def _device_state(world):
-        nb = len(world.bodies)
-        dev = torch.device("cuda")
-        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        Je = world.Je()
-        e = Je.size(0) if Je.ndimension() > 0 and Je.numel() > 0 else 0
-        cs = world.contacts or []
-        maxc = max(1, len(cs))
-        cb = _contacts.ContactBuffers(1, nb, maxc, dev)
-        if cs:
-            st = lambda k: torch.stack([c[0][k].detach().reshape(2) for c in cs]).unsqueeze(0)
-            cb.c_n, cb.c_p1, cb.c_p2 = f32(st(0)), f32(st(1)), f32(st(2))
-            cb.c_i1 = torch.tensor([[int(c[1]) for c in cs]], dtype=torch.int32, device=dev)
-            cb.c_i2 = torch.tensor([[int(c[2]) for c in cs]], dtype=torch.int32, device=dev)
-        cb.count.fill_(len(cs))
-        return dict(
-            nb=nb, e=e, maxc=maxc, cb=cb,
-            v=f32(world.get_v().reshape(1, nb, 3)), Mdiag=f32(torch.diagonal(world.M()).reshape(1, nb, 3)),
-            rest=f32(torch.stack([b.restitution.reshape(()) for b in world.bodies]).unsqueeze(0)),
-            fric=f32(torch.stack([b.fric_coeff.reshape(()) for b in world.bodies]).unsqueeze(0)),
-            Je=f32(Je.unsqueeze(0)) if e else None)
-
-    def solve_dynamics(self, world, dt):
-        base = world.get_v()
-        with torch.no_grad():
-            d = self._device_state(world)
-            f = world.apply_forces(world.t).detach().reshape(1, d["nb"], 3).to(device="cuda", dtype=torch.float32)
-            out = batched_world.solve_dynamics(1, d["nb"], d["maxc"], d["e"], d["cb"].count, d["Mdiag"], d["v"],
-                                               f.contiguous(), d["rest"], d["fric"], d["cb"], d["Je"], float(dt),
-                                               max_iter=self.max_iter, compute=self.compute)
-            return out["v_new"].reshape(-1).to(device=base.device, dtype=base.dtype)
-
-    def post_stabilization(self, world):
-        base = world.get_v()
-        with torch.no_grad():
-            d = self._device_state(world)
-            out = batched_world.post_stabilization(1, d["nb"], d["maxc"], d["e"], d["cb"].count, d["Mdiag"], d["v"],
-                                                   d["rest"], d["cb"], d["Je"], compute=self.compute)
-            return out["dp"].reshape(-1).to(device=base.device, dtype=base.dtype)
+    differentiable = False

@@ -51,7 +51,7 @@ def _decisive(z, s, rel=1e-3, floor=1e-5):
     return ((z - s).abs() > rel * big) & nondegenerate
 
 
-def _check_forward(sol, ref, Q, p, tol_x, name=""):
+def _check_forward(sol, ref, Q, p, tol_x, name="", max_masked=None):
     x = sol.x.double().cpu()
     ex = parity.err_x(x, ref.x, Q.double(), p.double())
     assert float(ex.max()) <= tol_x, (name, "err_x", float(ex.max()), int(ex.argmax()))
@@ -59,6 +59,9 @@ def _check_forward(sol, ref, Q, p, tol_x, name=""):
     dec = _decisive(ref.z, ref.s)
     same = (parity.active_sets(z, s) == parity.active_sets(ref.z, ref.s)) | ~dec
     assert bool(same.all()), (name, "active set", torch.nonzero(~same)[:8].tolist())
+    if max_masked is not None:                      # the mask on "bit-exact index sets" is itself gated
+        masked = 1.0 - float(dec.float().mean())
+        assert masked <= max_masked, (name, "index-set rows masked out as ties", masked)
     return ex
 
 
@@ -132,6 +135,13 @@ def test_backward_matches_reference_fixture(name, st, dtype):
 
 # ------------------------------------------------------------------ synthetic BASELINE configs
 CONFIGS = [("cfg2_stack2x4", 2, 4, 256), ("cfg3_stack4x4", 4, 4, 256), ("faithful_stack4x2", 4, 2, 128)]
+# Gates on the two masks of this file, measured with the oracle alone (CPU, fp64) on these seeds:
+#   index-set rows that are ties of two converged-to-zero numbers   cfg3 2.2 %   faithful 0 %     cfg2 18.5 %
+#   scenes whose backward system the oracle itself solves           cfg3 93.8 %  faithful 95.3 %  cfg2 51.6 %
+# (cfg2: four collinear points under ONE light box - the redundant pairs converge to z = s = 0 far more often.)
+# A regression of the solver cannot hide behind a growing mask: the shares are asserted.
+MAX_MASKED = {"cfg2_stack2x4": 0.20, "cfg3_stack4x4": parity.MAX_MASKED_FRAC + 0.005, "faithful_stack4x2": 0.0}
+MIN_WELL_POSED = {"cfg2_stack2x4": 0.5, "cfg3_stack4x4": parity.MIN_WELL_POSED_FRAC, "faithful_stack4x2": parity.MIN_WELL_POSED_FRAC}
 
 
 @pytest.mark.parametrize("name,nbox,pts,B", CONFIGS, ids=[c[0] for c in CONFIGS])
@@ -141,7 +151,7 @@ def test_stack_scenes_forward_parity(name, nbox, pts, B):
     lcp32 = O.assemble_lcp(*sc.assembly_args())
     ref = O.lcp_forward(*[None if t is None else t.double() for t in lcp32])   # identical inputs, fp64
     sol = _solve(lcp32, torch.float32)
-    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name, max_masked=MAX_MASKED[name])
     di = (sol.iters.cpu() - ref.iters).abs()
     assert int(di.max()) <= 1 and float((di == 0).float().mean()) >= 0.97, (name, "iteration counts", di.tolist())
 
@@ -174,7 +184,7 @@ def test_stack_scenes_backward_parity(name, nbox, pts, B):
     zs = ref.z.max(dim=1, keepdim=True)[0]
     ss = ref.s.max(dim=1, keepdim=True)[0]
     ok = ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
-    assert float(ok.float().mean()) >= 0.4, (name, "too few well-posed scenes", int(ok.sum()))
+    assert float(ok.float().mean()) >= MIN_WELL_POSED[name], (name, "too few well-posed scenes", int(ok.sum()))
     fl = parity.grad_floors(Q, p, cot.double(), ref.x, ref.z, ref.y)
     errs = parity.err_grads({k: grads[k] for k in "QpAb"}, {k: gref[k] for k in "QpAb"}, fl)
     worst = max(float(e[ok].max()) for e in errs.values())
@@ -453,65 +463,65 @@ def test_singular_Q_raises_like_reference():
         LCPFunction()(Q, p, G, h, torch.tensor([]), torch.tensor([]), F)
 
 
-class _FakeWorld:
-    """Just the attributes `Engine.solve_dynamics` reads from the reference's World
-    (`physics/world.py:124-234`), filled from a golden fixture."""
-
-    def __init__(self, st):
-        self.st, self.t, self.vec_len = st, 0.0, 3
-        nb = st["v"].shape[0]
-        self.bodies = [None] * nb
-        self.contacts = [((st["c_n"][i], st["c_p1"][i], st["c_p2"][i], st["c_pen"][i]),
-                          int(st["c_i1"][i]), int(st["c_i2"][i])) for i in range(st["c_n"].shape[0])]
-        self.static_inverse = True
-        lcp = golden_io.lcp_inputs(st)
-        self._lcp = lcp
-        nc = len(self.contacts)
-        self._G = lcp[2][0]
-        self._nc = nc
-
-    def M(self): return self._lcp[0][0]
-    def get_v(self): return self.st["v"].reshape(-1)
-    def apply_forces(self, t): return self.st["f"].reshape(-1)
-    def Je(self): return self.st["Je"]
-    def Jc(self): return self._G[:self._nc]
-    def Jf(self): return self._G[self._nc:3 * self._nc]
-    def restitutions(self):
-        r = self.st["rest"]
-        return torch.stack([0.5 * (r[c[1]] + r[c[2]]) for c in self.contacts])
-    def mu(self):
-        f = self.st["fric"]
-        return torch.diag(torch.stack([0.5 * (f[c[1]] + f[c[2]]) for c in self.contacts]))
-    def E(self):
-        E = torch.zeros(2 * self._nc, self._nc, dtype=torch.float64)
-        for i in range(self._nc):
-            E[2 * i:2 * i + 2, i] = 1
-        return E
-
-
 @pytest.mark.parametrize("name,st", STEPS[::4], ids=IDS[::4])
 def test_engine_plugin_reproduces_reference_new_v(name, st):
+    """`HipPdipmEngine` driven by the recorded answers of the reference's real `World` (tests/world_io.py::RecordedWorld)
+    returns the `new_v` the reference's own engine returned at that step (fp32 contact data on the device path)."""
     from lcp_physics_amd.physics import HipPdipmEngine
+    from tests.world_io import RecordedWorld
     eng = HipPdipmEngine()                      # zero-arg construction, as world.py:26 does
-    new_v = eng.solve_dynamics(_FakeWorld(st), st["dt"])
+    new_v = eng.solve_dynamics(RecordedWorld(st), st["dt"])
+    assert new_v.dtype == torch.float64 and not new_v.is_cuda       # comes back where the world keeps its state
     lcp = golden_io.lcp_inputs(st)
     ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
-    assert float(ev.max()) < 1e-7, (name, float(ev.max()))
+    assert float(ev.max()) < 1e-4, (name, float(ev.max()))
+    assert int(eng.last["status"].item()) & ~4 == 0
 
 
-class _FakeBody:
-    def __init__(self, rest, fric):
-        self.restitution, self.fric_coeff = rest, fric
+def test_engine_plugin_follows_every_recorded_step_of_the_ball_and_floor_world():
+    """BASELINE configs[0] end to end: every LCP step the reference's `World` recorded for the falling ball + floor scene
+    (the ball landing, bouncing and coming to rest), through both plug-ins."""
+    from lcp_physics_amd.physics import HipFusedEngine, HipPdipmEngine
+    from tests.world_io import RecordedWorld
+    steps = golden_io.load_steps("ball_floor")
+    assert len(steps) >= 4
+    for Eng in (HipPdipmEngine, HipFusedEngine):
+        eng = Eng()
+        for k, st in enumerate(steps):
+            new_v = eng.solve_dynamics(RecordedWorld(st), st["dt"])
+            lcp = golden_io.lcp_inputs(st)
+            ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
+            assert float(ev.max()) < 1e-4, (Eng.__name__, k, float(ev.max()))
 
 
-class _FakeRawWorld(_FakeWorld):
-    """`_FakeWorld` + the per-body attributes the contact-list engine reads (`bodies[i].restitution / .fric_coeff`)."""
-
-    def __init__(self, st, with_contacts=True):
-        super().__init__(st)
-        self.bodies = [_FakeBody(st["rest"][i], st["fric"][i]) for i in range(st["v"].shape[0])]
-        if not with_contacts:
-            self.contacts = []
+@pytest.mark.parametrize("name,st", STEPS[::5], ids=IDS[::5])
+def test_engine_plugin_is_differentiable_like_the_reference(name, st, kernel_path):
+    """`loss.backward()` through `HipPdipmEngine.solve_dynamics` reaches the world's leaves (masses, velocities, forces,
+    restitution, friction, contact frame) with the gradients the reference's autograd produces: its recorded
+    `LCPFunction.backward` outputs (lcp.py:37-64) contracted through the engine assembly (engines.py:31-32,50-74)."""
+    from lcp_physics_amd.physics import HipPdipmEngine
+    from tests.world_io import RecordedWorld
+    if kernel_path == "generic":
+        pytest.skip("the analytic step backward belongs to the quad / big kernel families (lcp_step_backward_f32)")
+    world = RecordedWorld(st, leaf=True)
+    new_v = HipPdipmEngine().solve_dynamics(world, st["dt"])
+    nz = new_v.numel()
+    cot_x = st["cot"].reshape(-1)[:nz].double()                 # the fixture's cotangent is on x = -new_v
+    (new_v * (-cot_x)).sum().backward()
+    lv = world.leaves()
+    assert all(t.grad is not None for t in lv.values())
+    dense = {k: g for k, g in golden_io.ref_grads(st).items() if g is not None}
+    ph = {k: v.detach().unsqueeze(0) for k, v in lv.items()}
+    ph["c_i1"], ph["c_i2"], ph["Je"] = st["c_i1"].unsqueeze(0), st["c_i2"].unsqueeze(0), st["Je"].unsqueeze(0).double()
+    ref = parity.physical_grads(ph, st["dt"], dense, O)
+    # the same joint metric as test_backward_matches_reference_fixture (err_physical: blocks weighted by the parameter
+    # norms, floored by |cot| x free motion), every physical key, fp32 tolerance
+    lcp = golden_io.lcp_inputs(st)
+    sc = parity.free_scales(lcp[0], lcp[1], st["cot"])
+    floor = parity._n(st["cot"]) * torch.maximum(sc["x_free"], parity._n(st["x"]))
+    pg = {k: lv[k].grad.unsqueeze(0) for k in parity.PHYS_KEYS}
+    ep = parity.err_physical(pg, ref, ph, floor)
+    assert float(ep.max()) < TOL_G32, (name, float(ep.max()))
 
 
 @pytest.mark.parametrize("name,st", STEPS[::5], ids=IDS[::5])
@@ -521,19 +531,20 @@ def test_fused_engine_plugin_runs_both_branches_and_post_stabilization_on_the_de
     (`engines.py:80-116`) against the oracle - all three through the device entry points, batch of one."""
     from oracle import world_oracle as W
     from lcp_physics_amd.physics import HipFusedEngine
+    from tests.world_io import RecordedWorld
     eng = HipFusedEngine()
-    new_v = eng.solve_dynamics(_FakeRawWorld(st), st["dt"])
+    new_v = eng.solve_dynamics(RecordedWorld(st), st["dt"])
     lcp = golden_io.lcp_inputs(st)
     ev = parity.err_x(-new_v.reshape(1, -1), -st["new_v"].reshape(1, -1), lcp[0], lcp[1])
     assert float(ev.max()) < 1e-4, (name, "contact branch", float(ev.max()))       # (fp32 contact data on this path)
     n = lambda k: st[k].double().numpy()
-    Md = torch.diagonal(lcp[0][0]).reshape(-1, 3).double().numpy()
-    free = eng.solve_dynamics(_FakeRawWorld(st, with_contacts=False), st["dt"]).reshape(-1, 3).double().numpy()
+    Md = n("Mdiag")
+    free = eng.solve_dynamics(RecordedWorld(st, with_contacts=False), st["dt"]).reshape(-1, 3).double().numpy()
     ref = W.solve_dynamics(Md, n("v"), n("f"), float(st["dt"]), [], n("rest"), n("fric"), n("Je"))
     assert np.abs(free - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (name, "no-contact branch")
-    world = _FakeRawWorld(st)
+    world = RecordedWorld(st)
     dp = eng.post_stabilization(world).reshape(-1, 3).double().numpy()
-    cs = [((c[0][0].double().numpy(), c[0][1].double().numpy(), c[0][2].double().numpy(), float(c[0][3])), c[1], c[2])
+    cs = [((c[0][0].detach().numpy(), c[0][1].detach().numpy(), c[0][2].detach().numpy(), float(c[0][3])), c[1], c[2])
           for c in world.contacts]
     ref = W.post_stabilization(Md, n("v"), cs, n("rest"), n("Je"))
     assert np.abs(dp - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (name, "post_stabilization", np.abs(dp - ref).max())

@@ -64,7 +64,7 @@ def test_matches_oracle_end_to_end(nbox, pts):
     ok = torch.stack([v for v in res_o.values()]).max(dim=0)[0] < 1e-9
     zs, ss = refsol.z.max(dim=1, keepdim=True)[0], refsol.s.max(dim=1, keepdim=True)[0]
     ok = ok & (torch.maximum(refsol.z / zs, refsol.s / ss).min(dim=1)[0] > 1e-6)
-    assert float(ok.float().mean()) >= 0.4
+    assert float(ok.float().mean()) >= parity.MIN_WELL_POSED_FRAC          # (oracle alone, these seeds: 100 % / 90.6 %)
     ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
     pg_ref = parity.physical_grads(ph, sc.dt, gref, O)
     scl = parity.free_scales(Q, p, cx)

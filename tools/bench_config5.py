@@ -2,7 +2,7 @@
 generic kernels on a few scenes and timed.   python tools/bench_config5.py [B]"""
 import sys, time
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lcp_physics_amd import _lib, scenes
 from lcp_physics_amd.physics.batched_world import solve_dynamics
 from lcp_physics_amd.physics.contacts import ContactBuffers

@@ -1,6 +1,6 @@
 import sys, time, os
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lcp_physics_amd import scenes
 from lcp_physics_amd.physics.batched_world import solve_dynamics
 from lcp_physics_amd.physics.contacts import ContactBuffers
