@@ -33,6 +33,19 @@ constexpr int LX = 64;           // lanes of wave 0 = stride of the exchange buf
 // register tile of a thread is TP x TP with TP = NRD / G (8, 8, 2), and the LDS footprint (NRD x (NRD + 1) doubles of
 // factors) lets 1, 4 or ~8 scenes share a CU.
 constexpr int EQB = 4;           // padded neq
+// LCP_BIG_MFMA = 1 (default): the 64- and 32-contact classes factor T with the BLOCKED right-looking LU below (16-wide
+// panels, trailing rank-16 updates on v_mfma_f64_16x16x4_f64, two barriers per PANEL); 0 keeps the round-1 rank-1 LU
+// (one barrier per pivot) for A/B runs.  The 16-contact class (2 x 2 register tiles) always uses the rank-1 form.
+#ifndef LCP_BIG_MFMA
+#define LCP_BIG_MFMA 1
+#endif
+typedef double d4 __attribute__((ext_vector_type(4)));
+// lane K of every 16-lane DPP row, broadcast to its row (one v_mov_b64_dpp row_newbcast:K)
+template <int K> __device__ __forceinline__ double bc16(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
+// Pins a value where it is computed.  The panel results are stored under `if (valid)`: without this LLVM SINKS the whole
+// dependent chain of a tile into that branch and keeps all 120 broadcast pivot-row values alive for it (measured: 256 + 256
+// registers and 1.4 KB of scratch per lane instead of ~90 registers).
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
 constexpr int NZB = 64;          // x-space capacity (lanes of wave 0)
 
 template <typename TC> struct M4 { TC n, f1, f2, g; };
@@ -102,6 +115,7 @@ struct Lds {
   float* Jt;         // [64][nzs]
   float* At;         // [EQB][nzs]
   int* flag;         // [4]: 0 singular pivot, 1 all done, 2 singular S11
+  double* dt;        // [16][17] raw diagonal tile of the current panel step (blocked LU)
 };
 template <int NCB>
 __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
@@ -123,6 +137,7 @@ __host__ __device__ inline size_t carve(Lds& L, unsigned char* smem, int nzs) {
   L.Jt = (float*)take(sizeof(float) * NCB * nzs);
   L.At = (float*)take(sizeof(float) * EQB * nzs);
   L.flag = (int*)take(sizeof(int) * 4);
+  L.dt = (double*)take(sizeof(double) * 16 * 17);
   return (size_t)(q - smem);
 }
 
@@ -156,6 +171,18 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   Lds L;
   carve<NCB>(L, smem, nzs);
   const int lc = lane < NCB ? lane : NCB - 1;                             // (lanes beyond the contact capacity read in bounds, results unused)
+  // ---- blocked LU (MF): T as NTL x NTL tiles of 16 x 16, each tile one MFMA accumulator (4 doubles per lane:
+  // register r of lane l = element (hg + 4 r, lo), hg = l >> 4, lo = l & 15).  64 contacts: four waves in a 2 x 2 grid,
+  // cyclic over the tiles (wave (wr, wc) owns the tiles (2a + wr, 2b + wc)); 32 contacts: one wave owns all 4 x 4 tiles.
+  // Tiles BELOW the diagonal are held TRANSPOSED (register r of lane l = element (lo, hg + 4 r)): then every trailing
+  // update is an MFMA whose A / B operands are plain lane-linear reads of the finished panels (see `trailing`).
+  constexpr bool MF = (LCP_BIG_MFMA != 0) && (NCB != 16);
+  constexpr int NTL = NRD / 16, NWV = NT / 64;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);                 // (scalar: tile ownership tests become scalar branches)
+  const int wr = (NWV == 4) ? (wave_u >> 1) : 0, wc = (NWV == 4) ? (wave_u & 1) : 0;
+  const int lo = lane & 15, hg = lane >> 4;
+  auto gI = [&](int a) { return (NWV == 4) ? 2 * a + wr : a; };          // global tile row / column of a local index
+  auto gJ = [&](int b) { return (NWV == 4) ? 2 * b + wc : b; };
   double* Wg = (double*)SP.ws + (size_t)scene * WS_TOTAL;                 // W tiles: Wg[(p * 8 + q) * 256 + tid]
   double* Wit = Wg + WS_IT;                                               // best iterate
   int ncs = ncap;
@@ -250,30 +277,68 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     s11row[a] = (w0 && lane < EQB && e > 0) ? L.S11[lane * EQB + a] : 0.0;
   }
   if (!BWD) {
-    // W tile of this thread: entries (ti + G p, tj + G q)
-    double wt_[TP][TP];
-    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
-    for (int k = 0; k < nz; ++k) {
-      const double qk = L.qid[k];
-      double ri[TP], cj[TP];
-      static_for<TP>([&](auto P) LCP_INL { ri[P] = (double)jrow<NCB>(L, ti + G * P, nzs)[k] * qk; cj[P] = (double)jrow<NCB>(L, tj + G * P, nzs)[k]; });
-      static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
-    }
-    if (e > 0) {
-      for (int a = 0; a < EQB; ++a) {
-        double ci[TP], gj[TP];
-        static_for<TP>([&](auto P) LCP_INL { ci[P] = CC[(ti + G * P) * EQB + a]; gj[P] = GA[(tj + G * P) * EQB + a]; });
-        static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
-      }
-    }
-    // rows / columns of contacts the scene does not have are identity in T: zero here, 1 arrives through addA / addU
-    static_for<TP>([&](auto P) LCP_INL {
-      static_for<TP>([&](auto Q) LCP_INL {
-        const int ci = (ti + G * P) & (NCB - 1), cj_ = (tj + G * Q) & (NCB - 1);
-        const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
-        Wg[(size_t)(P * TP + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
+    if constexpr (MF) {
+      // W = J P J^T in tile order: the thread's four entries of tile (a, b) pair its `lo` index with one tile index and
+      // its four `hg + 4 r` indices with the other (W[row][col] = sum_k (J[row][k] / q_k) J[col][k], as the rank-1 form)
+      static_for<4>([&](auto A_) LCP_INL {
+        static_for<4>([&](auto B_) LCP_INL {
+          constexpr int a = A_, b = B_;
+          const int I = gI(a), J = gJ(b);
+          const bool up = I <= J;                                             // stored as is (else transposed)
+          const int il = 16 * (up ? J : I) + lo;                              // the matrix index that runs along `lo`
+          const int ih0 = 16 * (up ? I : J) + hg;                             // ... along `hg + 4 r`: ih0 + 4 r
+          const float* jl = jrow<NCB>(L, il, nzs);
+          const float* jh0 = jrow<NCB>(L, ih0, nzs); const float* jh1 = jrow<NCB>(L, ih0 + 4, nzs);
+          const float* jh2 = jrow<NCB>(L, ih0 + 8, nzs); const float* jh3 = jrow<NCB>(L, ih0 + 12, nzs);
+          double w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0;
+          for (int k = 0; k < nz; ++k) {
+            const double qk = L.qid[k], cl = (double)jl[k];
+            const double h0 = (double)jh0[k], h1 = (double)jh1[k], h2 = (double)jh2[k], h3 = (double)jh3[k];
+            if (up) { w0_ = fma(h0 * qk, cl, w0_); w1_ = fma(h1 * qk, cl, w1_); w2_ = fma(h2 * qk, cl, w2_); w3_ = fma(h3 * qk, cl, w3_); }
+            else { const double rl = cl * qk; w0_ = fma(rl, h0, w0_); w1_ = fma(rl, h1, w1_); w2_ = fma(rl, h2, w2_); w3_ = fma(rl, h3, w3_); }
+          }
+          double wv[4] = {w0_, w1_, w2_, w3_};
+          if (e > 0) {
+            for (int q = 0; q < EQB; ++q) {
+              static_for<4>([&](auto R_) LCP_INL {
+                const int ih = ih0 + 4 * R_;
+                const int row = up ? ih : il, col = up ? il : ih;
+                wv[R_] = fma(-CC[row * EQB + q], GA[col * EQB + q], wv[R_]);
+              });
+            }
+          }
+          static_for<4>([&](auto R_) LCP_INL {
+            const int cl_ = il & (NCB - 1), ch_ = (ih0 + 4 * R_) & (NCB - 1);
+            Wg[((size_t)(a * 4 + b) * NT + tid) * 4 + R_] = (cl_ < ncs && ch_ < ncs) ? wv[R_] : 0.0;   // (32 B per lane and tile)
+          });
+        });
       });
-    });
+    } else {
+      // W tile of this thread: entries (ti + G p, tj + G q)
+      double wt_[TP][TP];
+      static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = 0; }); });
+      for (int k = 0; k < nz; ++k) {
+        const double qk = L.qid[k];
+        double ri[TP], cj[TP];
+        static_for<TP>([&](auto P) LCP_INL { ri[P] = (double)jrow<NCB>(L, ti + G * P, nzs)[k] * qk; cj[P] = (double)jrow<NCB>(L, tj + G * P, nzs)[k]; });
+        static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(ri[P], cj[Q], wt_[P][Q]); }); });
+      }
+      if (e > 0) {
+        for (int a = 0; a < EQB; ++a) {
+          double ci[TP], gj[TP];
+          static_for<TP>([&](auto P) LCP_INL { ci[P] = CC[(ti + G * P) * EQB + a]; gj[P] = GA[(tj + G * P) * EQB + a]; });
+          static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { wt_[P][Q] = fma(-ci[P], gj[Q], wt_[P][Q]); }); });
+        }
+      }
+      // rows / columns of contacts the scene does not have are identity in T: zero here, 1 arrives through addA / addU
+      static_for<TP>([&](auto P) LCP_INL {
+        static_for<TP>([&](auto Q) LCP_INL {
+          const int ci = (ti + G * P) & (NCB - 1), cj_ = (tj + G * Q) & (NCB - 1);
+          const double v = (ci < ncs && cj_ < ncs) ? wt_[P][Q] : 0.0;
+          Wg[(size_t)(P * TP + Q) * NT + tid] = v;                            // entry-major: every store / load instruction is coalesced
+        });
+      });
+    }
   }
   if (!(qd != 0.0) && w0 && lane < nz) L.flag[2] = 2;
   __syncthreads();                                                        // GA / CC scratch dead from here on
@@ -359,95 +424,311 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
 
 #ifdef LCP_BIG_PROFILE
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = clock64();
+  long long pcm[5] = {0, 0, 0, 0, 0}, tm = 0;      // blocked LU: publish + barrier, panel, barrier, trailing update
+#define MF_TICK(i) { const long long now_ = clock64(); pcm[i] += now_ - tm; tm = now_; }
 #define BIG_TICK(i) { const long long now_ = clock64(); pc[i] += now_ - tk; tk = now_; }
 #else
 #define BIG_TICK(i)
+#define MF_TICK(i)
 #endif
   // ---- factorisation: T = W + diag terms, LU in register tiles, factors to LDS (all 256 threads) ---------------------------
-  auto factor = [&]() {
-    double t[TP][TP];
-    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * TP + Q) * NT + tid]; }); });
-    if (ti == tj) {
-      static_for<TH>([&](auto P) LCP_INL {
-        const int c = ti + G * P;
-        t[P][P] += L.add[c];                                              // (a_c, a_c)
-        t[P + TH][P] += L.add[LX + c];                                    // (u_c, a_c)
-        t[P + TH][P + TH] += L.add[2 * LX + c];                           // (u_c, u_c)
-      });
-    }
-    int buf = 0;
-    bool singular_seen = false;
-    BIG_TICK(5)                                                             // (profile: W load + diagonal)
-    const int nblk = (ncs + G - 1) >> GSH;                                  // G-pivot blocks that hold live contacts
-    auto sync = [&]() { if constexpr (NT == 64) wsync(); else __syncthreads(); };   // (one wave: the LDS is in order)
-    // Right-looking LU, no pivoting.  Pivot row, RAW multiplier column and (pivot, 1 / pivot) travel through LDS, double
-    // buffered.  The step is software-pipelined: it first updates the border of the trailing tile - which holds the NEXT
-    // pivot's row and column -, lets their owners publish them (and the owner of the diagonal entry run the reciprocal
-    // chain), and only then sweeps the interior: the LDS round trip and the reciprocal of step k + 1 run under the
-    // interior FMAs of step k, and one barrier per step remains.
-    static_for<TP>([&](auto KB) LCP_INL {
-      constexpr int kb = KB;
-      // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
-      const int steps = ((kb % TH) < nblk) ? G : 0;
-      if (steps) {                                                          // prologue: the block's first pivot
-        double* prow = L.prow + buf * NRD;
-        double* pcol = L.pcol + buf * NRD;
-        if (ti == 0) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + G * q] = t[kb][q]; });
-        if (tj == 0) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + G * pp] = t[pp][kb]; });
-        if (tid == 0) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
-        sync();
+  auto factor = [&]() LCP_INL {
+    if constexpr (MF) {
+      // ================= blocked right-looking LU, no pivoting (same elimination order as the rank-1 form) ===============
+      // per panel step k:  (1) the owners publish the diagonal tile (k, k) and the panel tiles (k, J > k), (I > k, k)
+      //                    (2) every 16-lane DPP row takes ONE panel tile: lane = row of an L tile (or column of a U tile),
+      //                        the tile's 16 entries in registers, and eliminates the 16 pivots of the diagonal tile -
+      //                        which every DPP row factors redundantly, bit-identically - with row_newbcast broadcasts:
+      //                        L_Ik = A_Ik U_kk^-1 and U_kJ = L_kk^-1 A_kJ by SUBSTITUTION (backward stable; the
+      //                        explicit-inverse TRSM is not, and T is singular to working precision near convergence)
+      //                    (3) trailing update A_IJ -= L_Ik U_kJ on v_mfma_f64_16x16x4_f64, four chained MFMAs per tile
+      // two barriers per PANEL (the rank-1 form: one per pivot); the finished factors are left in LDS column-major,
+      // exactly where the triangular sweeps of `tsolve` read them.
+      d4 acc[4][4];
+      static_for<4>([&](auto A_) LCP_INL { static_for<4>([&](auto B_) LCP_INL {       // 32 B per lane and tile: two dwordx4 loads
+        acc[A_][B_] = *reinterpret_cast<const d4*>(Wg + ((size_t)(A_ * 4 + B_) * NT + tid) * 4);
+      }); });
+      // T = W + the diagonal terms of the reduction.  A lane holds at most ONE diagonal element of a tile: lo == hg + 4 rd.
+      // Diagonal tiles (a, a) carry (a_c, a_c) / (u_c, u_c); the tiles (a, a - 2) - rows u_c, columns a_c, held transposed -
+      // carry (u_c, a_c) on their diagonal.  With four waves they belong to the waves with wr == wc.
+      if (wr == wc) {
+        const bool dgl = (((lo - hg) & 3) == 0) && lo >= hg;
+        const int rd = (lo - hg) >> 2;
+        static_for<4>([&](auto A_) LCP_INL {
+          const int row = 16 * gI(A_) + lo;
+          double av = L.add[(row < NCB) ? row : 2 * LX + row - NCB];
+          av = dgl ? av : 0.0;
+          static_for<4>([&](auto R_) LCP_INL { acc[A_][A_][(int)R_] += (rd == R_) ? av : 0.0; });
+        });
+        static_for<2>([&](auto Q_) LCP_INL {
+          constexpr int a = 2 + Q_, b = Q_;
+          double av = L.add[LX + 16 * gJ(b) + lo];
+          av = dgl ? av : 0.0;
+          static_for<4>([&](auto R_) LCP_INL { acc[a][b][(int)R_] += (rd == R_) ? av : 0.0; });
+        });
       }
-#pragma unroll 1
-      for (int kk = 0; kk < steps; ++kk) {
-        const double* prow = L.prow + buf * NRD;                            // (pivot k = G * kb + kk)
-        const double* pcol = L.pcol + buf * NRD;
-        // every LDS read of the step is issued here, ahead of any use
-        // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
-        double lm[TP - kb], rv[TP - kb];
-        const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
-        static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + G * pp]; rv[PP] = prow[tj + G * pp]; });
-        __builtin_amdgcn_sched_barrier(0);
-        singular_seen = singular_seen || (piv == 0.0);
-        // rows / columns of the LATER tile blocks (pp > kb) lie below / right of the pivot whatever the thread: only the
-        // pivot's own block needs the "strictly below / right of k" masks (one compare each instead of TP - kb)
-        const bool colk = tj == kk;
-        static_for<TP - kb>([&](auto PP) LCP_INL {
-          constexpr int pp = kb + PP;
-          const double l = lm[PP] * inv;
-          if constexpr (PP == 0) {
-            lm[0] = (ti > kk) ? l : 0.0;
-            rv[0] = (tj > kk) ? rv[0] : 0.0;
-            t[pp][kb] = (colk && ti > kk) ? l : t[pp][kb];
-          } else {
-            lm[PP] = l;
-            t[pp][kb] = colk ? l : t[pp][kb];
+      BIG_TICK(5)                                                             // (profile: W load + diagonal)
+      auto sync = [&]() { if constexpr (NT == 64) wsync(); else __syncthreads(); };
+      bool singular_seen = false;
+      // ---- panel pass over ONE tile per 16-lane row.  ROWS: lane = row `lo` of an L tile, d = its row of the diagonal tile.
+      auto panel_rows = [&](int k, int I, bool valid, bool keeper) LCP_INL {
+        double d[16], x[16], myinv = 1.0;
+        static_for<16>([&](auto C_) LCP_INL {
+          d[C_] = L.dt[lo * 17 + C_];
+          x[C_] = valid ? L.LU[(size_t)(16 * k + C_) * LDU + 16 * I + lo] : 0.0;
+        });
+        // Software-pipelined over the pivots: a step first updates column j + 1 - which holds the NEXT pivot - and starts that
+        // pivot's reciprocal chain, then sweeps the remaining columns in three phases (all broadcasts, then all FMAs), so
+        // that the dependent chains of a step overlap; the values are pinned once per step.
+        double piv = bc16<0>(d[0]);
+        double inv = fast_rcp(piv);
+        static_for<16>([&](auto J_) LCP_INL {
+          constexpr int j = J_;
+          singular_seen = singular_seen || (piv == 0.0);
+          const double ld = (lo > j) ? d[j] * inv : 0.0;
+          const double lx = x[j] * inv;
+          myinv = (lo == j) ? inv : myinv;
+          if constexpr (j < 15) {
+            const double u1 = bc16<j>(d[j + 1]);
+            d[j + 1] = fma(-ld, u1, d[j + 1]);
+            x[j + 1] = fma(-lx, u1, x[j + 1]);
+            piv = bc16<j + 1>(d[j + 1]);
+            inv = fast_rcp(piv);
           }
+          double uj[16];
+          static_for<(j < 14 ? 14 - j : 0)>([&](auto CC_) LCP_INL { constexpr int c = j + 2 + CC_; uj[c] = bc16<j>(d[c]); });
+          static_for<(j < 14 ? 14 - j : 0)>([&](auto CC_) LCP_INL {
+            constexpr int c = j + 2 + CC_;
+            d[c] = fma(-ld, uj[c], d[c]);
+            x[c] = fma(-lx, uj[c], x[c]);
+          });
+          static_for<15 - j>([&](auto CC_) LCP_INL { constexpr int c = j + 1 + CC_; pin(d[c]); pin(x[c]); });
+          d[j] = (lo > j) ? ld : d[j];
+          x[j] = lx;
         });
-        // border of the trailing tile: its first row and first column
-        static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb][kb + QQ] = fma(-lm[0], rv[QQ], t[kb][kb + QQ]); });
-        static_for<TP - kb - 1>([&](auto P1) LCP_INL { constexpr int PP = 1 + P1; t[kb + PP][kb] = fma(-lm[PP], rv[0], t[kb + PP][kb]); });
-        buf ^= 1;
-        if (kk + 1 < G) {                                                   // publish pivot k + 1 (same tile block)
-          double* nrow = L.prow + buf * NRD;
-          double* ncol = L.pcol + buf * NRD;
-          if (ti == kk + 1) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; nrow[tj + G * q] = t[kb][q]; });
-          if (tj == kk + 1) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; ncol[ti + G * pp] = t[pp][kb]; });
-          if (ti == kk + 1 && tj == kk + 1) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
+        if (valid) static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * k + C_) * LDU + 16 * I + lo] = x[C_]; });
+        if (keeper) {                                                         // one DPP row stores the factored diagonal tile
+          static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * k + C_) * LDU + 16 * k + lo] = d[C_]; });
+          L.dU[16 * k + lo] = myinv;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // interior
-        static_for<TP - kb - 1>([&](auto P1) LCP_INL {
-          constexpr int PP = 1 + P1;
-          static_for<TP - kb - 1>([&](auto Q1) LCP_INL { constexpr int QQ = 1 + Q1; t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); });
+      };
+      // COLS: lane = column `lo` of a U tile, dc = its column of the diagonal tile (same arithmetic, entry by entry)
+      auto panel_cols = [&](int k, int J, bool valid) LCP_INL {
+        double dc[16], y[16];
+        static_for<16>([&](auto R_) LCP_INL {
+          dc[R_] = L.dt[R_ * 17 + lo];
+          y[R_] = valid ? L.LU[(size_t)(16 * J + lo) * LDU + 16 * k + R_] : 0.0;
         });
-        sync();
+        double inv = fast_rcp(bc16<0>(dc[0]));
+        static_for<16>([&](auto J_) LCP_INL {
+          constexpr int j = J_;
+          const double invj = inv;
+          if constexpr (j < 15) {                                             // row j + 1 first: it holds the next pivot
+            const double l1 = bc16<j>(dc[j + 1] * invj);
+            dc[j + 1] = fma(-l1, dc[j], dc[j + 1]);                           // (columns <= j are dead from step j on: dc is never stored)
+            y[j + 1] = fma(-l1, y[j], y[j + 1]);
+            inv = fast_rcp(bc16<j + 1>(dc[j + 1]));
+          }
+          double m[16];
+          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL { constexpr int r = j + 2 + RR_; m[r] = dc[r] * invj; });     // (lane j: the multiplier l_rj)
+          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL { constexpr int r = j + 2 + RR_; m[r] = bc16<j>(m[r]); });
+          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL {
+            constexpr int r = j + 2 + RR_;
+            dc[r] = fma(-m[r], dc[j], dc[r]);
+            y[r] = fma(-m[r], y[j], y[r]);
+          });
+          static_for<15 - j>([&](auto RR_) LCP_INL { constexpr int r = j + 1 + RR_; pin(dc[r]); pin(y[r]); });
+        });
+        if (valid) static_for<16>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * J + lo) * LDU + 16 * k + R_] = y[R_]; });
+      };
+      // (3) trailing update of the owned tiles (I > k, J > k) = the local tiles [A0, 4) x [B0, 4): one straight-line
+      //     specialisation per (A0, B0), no branch between the MFMAs.  Operand reads, lane-linear in the finished panels:
+      //       lop[a][c] = -L[16 I + lo][16 k + 4 c + hg]       uop[b][c] = U[16 k + 4 c + hg][16 J + lo]
+      //     tile on / above the diagonal:  D -= L_Ik U_kJ       = mfma(A = lop, B = uop)
+      //     tile below (held transposed):  D^T -= U_kJ^T L_Ik^T = mfma(A = uop, B = lop)
+      //     local tiles a < b are above, a > b below; a == b is above iff wr <= wc (wave-uniform)
+      const bool dup = (NWV == 1) || (wr <= wc);
+      auto trailing = [&](auto A0_, auto B0_, int k) LCP_INL {
+        constexpr int A0 = A0_, B0 = B0_;
+        double lop[4][4], uop[4][4];
+        static_for<4 - A0>([&](auto AA_) LCP_INL {
+          constexpr int a = A0 + AA_;
+          const int I = gI(a);
+          static_for<4>([&](auto C_) LCP_INL { lop[a][C_] = -L.LU[(size_t)(16 * k + 4 * C_ + hg) * LDU + 16 * I + lo]; });
+        });
+        static_for<4 - B0>([&](auto BB_) LCP_INL {
+          constexpr int b = B0 + BB_;
+          const int J = gJ(b);
+          static_for<4>([&](auto C_) LCP_INL { uop[b][C_] = L.LU[(size_t)(16 * J + lo) * LDU + 16 * k + 4 * C_ + hg]; });
+        });
+        static_for<4>([&](auto C_) LCP_INL {                                  // chunk-outer: independent accumulators in flight
+          static_for<4 - A0>([&](auto AA_) LCP_INL { static_for<4 - B0>([&](auto BB_) LCP_INL {
+            constexpr int a = A0 + AA_, b = B0 + BB_;
+            double av, bv;
+            if constexpr (a < b) { av = lop[a][C_]; bv = uop[b][C_]; }
+            else if constexpr (a > b) { av = uop[b][C_]; bv = lop[a][C_]; }
+            else { av = dup ? lop[a][C_] : uop[b][C_]; bv = dup ? uop[b][C_] : lop[a][C_]; }
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[a][b], 0, 0, 0);
+          }); });
+        });
+        // publish panel k + 1 (its tiles are all among the ones just updated): local row A0 is tile row k + 1 iff rp,
+        // local column B0 is tile column k + 1 iff cp
+        const bool rp = gI(A0) == k + 1, cp = gJ(B0) == k + 1;
+        if (rp && cp) static_for<4>([&](auto R_) LCP_INL { L.dt[(hg + 4 * R_) * 17 + lo] = acc[A0][B0][(int)R_]; });
+        if (rp) static_for<4 - B0>([&](auto BB_) LCP_INL {
+          constexpr int b = B0 + BB_;
+          const int J = gJ(b);
+          if (J > k + 1) static_for<4>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * J + lo) * LDU + 16 * (k + 1) + hg + 4 * R_] = acc[A0][b][(int)R_]; });
+        });
+        if (cp) static_for<4 - A0>([&](auto AA_) LCP_INL {
+          constexpr int a = A0 + AA_;
+          const int I = gI(a);
+          if (I > k + 1) static_for<4>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * (k + 1) + hg + 4 * R_) * LDU + 16 * I + lo] = acc[a][B0][(int)R_]; });
+        });
+      };
+      // (1) publish the tiles of panel 0 (registers -> LDS; below the diagonal the registers hold the transpose); the
+      //     tiles of panel k + 1 are published by the trailing update of step k, straight from its accumulators
+      {
+        constexpr int k = 0;
+        static_for<4>([&](auto A_) LCP_INL { static_for<4>([&](auto B_) LCP_INL {
+          const int I = gI(A_), J = gJ(B_);
+          if (I == k && J == k) {
+            static_for<4>([&](auto R_) LCP_INL { L.dt[(hg + 4 * R_) * 17 + lo] = acc[A_][B_][(int)R_]; });
+          } else if (I == k && J > k) {
+            static_for<4>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * J + lo) * LDU + 16 * I + hg + 4 * R_] = acc[A_][B_][(int)R_]; });
+          } else if (J == k && I > k) {
+            static_for<4>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * J + hg + 4 * R_) * LDU + 16 * I + lo] = acc[A_][B_][(int)R_]; });
+          }
+        }); });
       }
-    });
-    if (singular_seen && tid == 0) L.flag[0] = 1;
-    BIG_TICK(6)                                                             // (profile: LU loop)
-    // park the factors: column-major, plus the reciprocals of U's diagonal
-    static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + G * Q) * LDU + ti + G * P] = t[P][Q]; }); });
-    if (ti == tj) static_for<TP>([&](auto P) LCP_INL { L.dU[ti + G * P] = 1.0 / t[P][P]; });
+#ifdef LCP_BIG_PROFILE
+      tm = clock64();
+#endif
+#pragma unroll 1
+      for (int k = 0; k < NTL; ++k) {
+        MF_TICK(4)
+        sync();
+        MF_TICK(0)
+        // (2) panel: L tiles k+1 .. on the first DPP rows, U tiles on the others
+        if constexpr (NWV == 4) {
+          const int slot = wave_u * 4 + hg;
+          if (wave_u < 2) panel_rows(k, k + 1 + slot, k + 1 + slot < NTL, slot == 0);
+          else panel_cols(k, k + 1 + (slot - 8), k + 1 + (slot - 8) < NTL);
+        } else {
+          panel_rows(k, k + 1 + hg, k + 1 + hg < NTL, hg == 0);
+          panel_cols(k, k + 1 + hg, k + 1 + hg < NTL);
+        }
+        MF_TICK(1)
+        sync();
+        MF_TICK(2)
+        // (3) trailing update of the owned tiles (I > k, J > k).  Operand reads, lane-linear in the finished panels:
+        //       lop[a][c] = -L[16 I + lo][16 k + 4 c + hg]       uop[b][c] = U[16 k + 4 c + hg][16 J + lo]
+        //     tile on / above the diagonal:  D -= L_Ik U_kJ       = mfma(A = lop, B = uop)
+        //     tile below (held transposed):  D^T -= U_kJ^T L_Ik^T = mfma(A = uop, B = lop)
+        {
+          const int a0 = (NWV == 4) ? ((k + 2 - wr) >> 1) : k + 1, b0 = (NWV == 4) ? ((k + 2 - wc) >> 1) : k + 1;
+          static_for<4>([&](auto A0_) LCP_INL { static_for<4>([&](auto B0_) LCP_INL {
+            constexpr int A0 = A0_, B0 = B0_;
+            if constexpr ((NWV == 4) ? (A0 - B0 <= 1 && B0 - A0 <= 1) : (A0 == B0)) {
+              if (a0 == A0 && b0 == B0) trailing(A0_, B0_, k);
+            }
+          }); });
+        }
+#ifdef LCP_BIG_PROFILE
+        static_for<4>([&](auto A_) LCP_INL { static_for<4>([&](auto B_) LCP_INL { double t_ = acc[A_][B_][0]; pin(t_); }); });   // (wait for the MFMAs)
+#endif
+        MF_TICK(3)
+      }
+#ifdef LCP_BIG_PROFILE
+      if (lane == 0) for (int i = 0; i < 5; ++i) L.prow[5 * wave_u + i] = (double)pcm[i];      // (prow is unused by the blocked LU)
+#endif
+      if (singular_seen && lo == 0) L.flag[0] = 1;
+      BIG_TICK(6)                                                             // (profile: LU loop)
+    } else {
+      double t[TP][TP];
+      static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { t[P][Q] = Wg[(size_t)(P * TP + Q) * NT + tid]; }); });
+      if (ti == tj) {
+        static_for<TH>([&](auto P) LCP_INL {
+          const int c = ti + G * P;
+          t[P][P] += L.add[c];                                              // (a_c, a_c)
+          t[P + TH][P] += L.add[LX + c];                                    // (u_c, a_c)
+          t[P + TH][P + TH] += L.add[2 * LX + c];                           // (u_c, u_c)
+        });
+      }
+      int buf = 0;
+      bool singular_seen = false;
+      BIG_TICK(5)                                                             // (profile: W load + diagonal)
+      const int nblk = (ncs + G - 1) >> GSH;                                  // G-pivot blocks that hold live contacts
+      auto sync = [&]() { if constexpr (NT == 64) wsync(); else __syncthreads(); };   // (one wave: the LDS is in order)
+      // Right-looking LU, no pivoting.  Pivot row, RAW multiplier column and (pivot, 1 / pivot) travel through LDS, double
+      // buffered.  The step is software-pipelined: it first updates the border of the trailing tile - which holds the NEXT
+      // pivot's row and column -, lets their owners publish them (and the owner of the diagonal entry run the reciprocal
+      // chain), and only then sweeps the interior: the LDS round trip and the reciprocal of step k + 1 run under the
+      // interior FMAs of step k, and one barrier per step remains.
+      static_for<TP>([&](auto KB) LCP_INL {
+        constexpr int kb = KB;
+        // rows / columns of contacts the scene does not have are identity: a block made of them only has nothing to eliminate
+        const int steps = ((kb % TH) < nblk) ? G : 0;
+        if (steps) {                                                          // prologue: the block's first pivot
+          double* prow = L.prow + buf * NRD;
+          double* pcol = L.pcol + buf * NRD;
+          if (ti == 0) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; prow[tj + G * q] = t[kb][q]; });
+          if (tj == 0) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; pcol[ti + G * pp] = t[pp][kb]; });
+          if (tid == 0) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
+          sync();
+        }
+#pragma unroll 1
+        for (int kk = 0; kk < steps; ++kk) {
+          const double* prow = L.prow + buf * NRD;                            // (pivot k = G * kb + kk)
+          const double* pcol = L.pcol + buf * NRD;
+          // every LDS read of the step is issued here, ahead of any use
+          // (unconditional loads, then selects: written as conditional loads they become sixteen exec-masked branches per step)
+          double lm[TP - kb], rv[TP - kb];
+          const double piv = L.pinv[2 * buf], inv = L.pinv[2 * buf + 1];       // (the reciprocal chain runs once, in the owner)
+          static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; lm[PP] = pcol[ti + G * pp]; rv[PP] = prow[tj + G * pp]; });
+          __builtin_amdgcn_sched_barrier(0);
+          singular_seen = singular_seen || (piv == 0.0);
+          // rows / columns of the LATER tile blocks (pp > kb) lie below / right of the pivot whatever the thread: only the
+          // pivot's own block needs the "strictly below / right of k" masks (one compare each instead of TP - kb)
+          const bool colk = tj == kk;
+          static_for<TP - kb>([&](auto PP) LCP_INL {
+            constexpr int pp = kb + PP;
+            const double l = lm[PP] * inv;
+            if constexpr (PP == 0) {
+              lm[0] = (ti > kk) ? l : 0.0;
+              rv[0] = (tj > kk) ? rv[0] : 0.0;
+              t[pp][kb] = (colk && ti > kk) ? l : t[pp][kb];
+            } else {
+              lm[PP] = l;
+              t[pp][kb] = colk ? l : t[pp][kb];
+            }
+          });
+          // border of the trailing tile: its first row and first column
+          static_for<TP - kb>([&](auto QQ) LCP_INL { t[kb][kb + QQ] = fma(-lm[0], rv[QQ], t[kb][kb + QQ]); });
+          static_for<TP - kb - 1>([&](auto P1) LCP_INL { constexpr int PP = 1 + P1; t[kb + PP][kb] = fma(-lm[PP], rv[0], t[kb + PP][kb]); });
+          buf ^= 1;
+          if (kk + 1 < G) {                                                   // publish pivot k + 1 (same tile block)
+            double* nrow = L.prow + buf * NRD;
+            double* ncol = L.pcol + buf * NRD;
+            if (ti == kk + 1) static_for<TP - kb>([&](auto QQ) LCP_INL { constexpr int q = kb + QQ; nrow[tj + G * q] = t[kb][q]; });
+            if (tj == kk + 1) static_for<TP - kb>([&](auto PP) LCP_INL { constexpr int pp = kb + PP; ncol[ti + G * pp] = t[pp][kb]; });
+            if (ti == kk + 1 && tj == kk + 1) { L.pinv[2 * buf] = t[kb][kb]; L.pinv[2 * buf + 1] = fast_rcp(t[kb][kb]); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // interior
+          static_for<TP - kb - 1>([&](auto P1) LCP_INL {
+            constexpr int PP = 1 + P1;
+            static_for<TP - kb - 1>([&](auto Q1) LCP_INL { constexpr int QQ = 1 + Q1; t[kb + PP][kb + QQ] = fma(-lm[PP], rv[QQ], t[kb + PP][kb + QQ]); });
+          });
+          sync();
+        }
+      });
+      if (singular_seen && tid == 0) L.flag[0] = 1;
+      BIG_TICK(6)                                                             // (profile: LU loop)
+      // park the factors: column-major, plus the reciprocals of U's diagonal
+      static_for<TP>([&](auto P) LCP_INL { static_for<TP>([&](auto Q) LCP_INL { L.LU[(size_t)(tj + G * Q) * LDU + ti + G * P] = t[P][Q]; }); });
+      if (ti == tj) static_for<TP>([&](auto P) LCP_INL { L.dU[ti + G * P] = 1.0 / t[P][P]; });
+    }
   };
 
   // ---- T^-1 hz through the reduced system (wave 0); rows: a_c = lane, u_c = 64 + lane --------------------------------------
@@ -786,7 +1067,8 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_BIG_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
-  if (tid == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap + (4 * ncap - 8); for (int i = 0; i < 4; ++i) o[i] = (float)pc[i]; o[4] = (float)pc_ts; o[5] = (float)pc[5]; o[6] = (float)pc[6]; }
+  if (tid == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap + (4 * ncap - 8); for (int i = 0; i < 4; ++i) o[i] = (float)pc[i]; o[4] = (float)pc_ts; o[5] = (float)pc[5]; o[6] = (float)pc[6];
+    if (SP.z) { float* oz = (float*)SP.z + (size_t)scene * 4 * ncap + (4 * ncap - 24); for (int i = 0; i < 20; ++i) oz[i] = (float)L.prow[i]; } }
 #endif
 }
 

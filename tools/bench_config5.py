@@ -35,10 +35,13 @@ import json
 print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts, nineq 256, nz 33, neq 3), forward (lcp_solve_dynamics_f32)",
                   "value": B / dt, "unit": "sim steps/s", "batch": B, "ms_per_step": dt * 1e3,
                   "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),
-                  "kernel": "lcp::big::lcp_fwd_big (one 256-thread workgroup per scene)"}))
+                  "kernel": "lcp::big::lcp_big_kernel<64> (one 256-thread workgroup per scene; blocked LU, trailing updates on v_mfma_f64_16x16x4_f64)"}))
 import os
 if "bigprof" in os.environ.get("LCP_HIP_LIB", ""):
     pc = out["s"][:, 248:255].double().mean(dim=0).tolist()
     print("factor split: W load + diag %.0f   LU loop %.0f" % (pc[5], pc[6]))
+    for w in range(4):
+        pm = out["z"][:, 232 + 5 * w:237 + 5 * w].double().mean(dim=0).tolist()
+        print("blocked LU, wave %d: publish %.0f  barrier %.0f   panel %.0f   barrier %.0f   trailing MFMA %.0f" % (w, pm[4], pm[0], pm[1], pm[2], pm[3]))
     tot = sum(pc[:4])
     print("cycles per scene: residuals %.0f  factor %.0f  steps+bookkeeping %.0f  solve_kkt %.0f (of which triangular sweeps %.0f)  total %.0f" % (pc[0], pc[1], pc[2], pc[3], pc[4], tot))
