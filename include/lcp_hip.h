@@ -43,6 +43,9 @@ extern "C" {
 /* May be OR-ed into any `compute` argument: serve this call from the generic workgroup-per-scene kernels whatever the
  * sizes (A/B and debugging aid; a backward must carry the same flag as its forward - they share the workspace layout). */
 #define LCP_PATH_GENERIC 0x200
+/* OR-ed into the `compute` argument of lcp_workspace_bytes by callers of the fp64-I/O entry points (lcp_pdipm_forward_f64 /
+ * lcp_pdipm_backward_f64): their workspace also keeps an fp64 copy of F. */
+#define LCP_IO_F64 0x400
 
 #define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
 #define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan  */

@@ -15,6 +15,7 @@ COMPUTE_F32 = 0
 COMPUTE_F64 = 1
 HINT_ALL_CONTACT = 0x100
 PATH_GENERIC = 0x200
+IO_F64 = 0x400
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2

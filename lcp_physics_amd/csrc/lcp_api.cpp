@@ -18,14 +18,14 @@ thread_local int g_path = 0;              // 0 = automatic, 1 = force the generi
 // workgroup-per-scene kernels
 inline int split_compute(int compute, bool* generic) {
   *generic = (compute & LCP_PATH_GENERIC) != 0 || g_path == 1;
-  return compute & ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT);
+  return compute & ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64);
 }
 
 // Which kernel family serves a problem.  Deterministic in (sizes, io type) so that forward and
 // backward of one op agree on the workspace layout.
 inline bool use_wave64(int io_f64, int nz, int m, int e, bool generic) {
-  if (io_f64 || generic) return false;
-  return lcp::wave64_supported(nz, m, e);
+  if (generic) return false;
+  return lcp::wave64_supported(nz, m, e);       // (fp64 I/O runs the same kernels with fp64 loads / stores)
 }
 
 // Kernel family of the contact-list entry points (lcp_step_fused_f32, lcp_solve_dynamics_f32, lcp_step_backward_f32):
@@ -41,24 +41,39 @@ inline StepFamily step_family(int nz, int m, int e, int compute, bool generic) {
 
 inline int csize_of(int io_f64, int compute) { return (io_f64 || compute == LCP_COMPUTE_F64) ? 8 : 4; }
 
-}  // namespace
-
-extern "C" {
-
-const char* lcp_version(void) { return "lcp_hip 0.1.0 gfx950"; }
-
-size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
-  if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return 0;
+// The dense entry points serve 17 .. 64 contact LCPs (nineq <= 256) from lcp_big.hip when the scene has the contact structure
+// (classified per scene on the device); the other scenes of the batch stay on the generic kernels.  Both families then share
+// ONE per-scene workspace stride, and the per-scene classes live behind the B scene blocks.
+inline bool use_big_dense(int io_f64, int nz, int m, int e, int compute, bool generic) {
+  return !io_f64 && !generic && compute == LCP_COMPUTE_F64 && !lcp::wave64_supported(nz, m, e) && lcp::big_dense_supported(nz, m, e);
+}
+inline size_t scene_bytes(int nz, int m, int e, int compute, int io_f64) {
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   size_t per_scene = pl.ws_stride * cs;
   if (lcp::wave64_supported(nz, m, e) || lcp::quad_step_supported(nz, m, e)) {   // (lcp_quad.hip uses the wave64 layout)
-    const size_t w = lcp::wave64_ws_bytes(compute);
+    const size_t w = lcp::wave64_ws_bytes(compute, io_f64);
     if (w > per_scene) per_scene = w;
   }
   if (!lcp::quad_step_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes(m) > per_scene)
     per_scene = lcp::big_ws_bytes(m);      // (the sizes the quad kernel takes never reach lcp_big.hip)
-  return (size_t)B * per_scene;
+  return (per_scene + 15) & ~(size_t)15;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lcp_version(void) { return "lcp_hip 0.2.0 gfx950"; }
+
+size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
+  if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return 0;
+  const int io_f64 = (compute & LCP_IO_F64) ? 1 : 0;
+  compute &= ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64);
+  if (io_f64) compute = LCP_COMPUTE_F64;
+  const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
+  const size_t cls_bytes = (((size_t)B * sizeof(int32_t)) + 255) & ~(size_t)255;     // per-scene classes of the dense lcp_big path
+  return (size_t)B * per_scene + cls_bytes;
 }
 
 // Debugging / A-B aid: 0 = automatic kernel selection, 1 = generic kernels only, 2 = wave64 when legal.
@@ -89,7 +104,14 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   P.x = x; P.y = y; P.z = z; P.s = s; P.iters = iters; P.status = status;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.eps = eps; P.max_iter = max_iter; P.lim = lim;
   P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds; P.trace = g_trace;
-  if (w64) return lcp::wave64_forward(P, compute, stream);
+  if (w64) return lcp::wave64_forward(P, compute, stream, io_f64);
+  if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
+    const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
+    int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
+    int rc = lcp::big_dense_forward(P, cls, per_scene, stream);          // classifies, then serves the scenes of class 2
+    if (rc) return rc;
+    P.cls = cls; P.ws_stride = per_scene / cs;                            // the rest of the batch, same stride
+  }
   return lcp::generic_forward(P, io_f64, compute, pl.lds_bytes, stream);
 }
 
@@ -128,7 +150,14 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  if (w64) return lcp::wave64_backward(P, compute, hint != 0, stream);
+  if (w64) return lcp::wave64_backward(P, compute, hint != 0, stream, io_f64);
+  if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
+    const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
+    int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
+    int rc = lcp::big_dense_backward(P, cls, per_scene, stream);
+    if (rc) return rc;
+    P.cls = cls; P.ws_stride = per_scene / cs;
+  }
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
 }
 

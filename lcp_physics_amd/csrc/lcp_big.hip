@@ -146,8 +146,8 @@ template <int NCB>
 __device__ __forceinline__ const float* jrow(const Lds& L, int r, int nzs) { return (r < NCB ? L.Jc + (size_t)r * nzs : L.Jt + (size_t)(r - NCB) * nzs); }
 
 // workspace per scene (doubles): W tiles, a 64-entry header (contact count), then the best iterate the backward needs:
-// x[64] y[8] z[4][64] s[4][64]
-template <int NCB> struct WsLayout { static constexpr int W = 4 * NCB * NCB, IT = W + 64, TOTAL = IT + 64 + 8 + 8 * LX; };
+// x[64] y[8] z[4][64] s[4][64], then mu[64] and diag(Q)[64] (what the dense backward cannot read from its arguments)
+template <int NCB> struct WsLayout { static constexpr int W = 4 * NCB * NCB, IT = W + 64, TOTAL = IT + 64 + 8 + 10 * LX; };
 
 // ---------------------------------------------------------------- the kernel
 // BWD = false: fused step (contact list in, v_new out; engines.py:26-78).
@@ -155,8 +155,11 @@ template <int NCB> struct WsLayout { static constexpr int W = 4 * NCB * NCB, IT 
 //              factorisation at the stored iterate, one KKT solve - lcp.py:37-64 - and the contraction of the rank-1
 //              LCP gradients through the engine assembly), reading W and the iterate the forward left in the workspace.
 // (second launch bound = waves per SIMD the register allocation must allow: the small classes share a CU)
-template <int NCB, bool BWD>
-__global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs) {
+// DENSE: the same solve behind the dense LCPFunction boundary (lcp.py:22-64): the scene's (Q, p, G, h, A, b, F) is read
+//        instead of a contact list (scenes lcp_classify_big marked contact-structured with diagonal Q), the outputs are
+//        x, y, z, s (forward) or the seven dense gradients of lcp.py:52-61 (backward).
+template <int NCB, bool BWD, bool DENSE>
+__global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kernel(StepArgs SP, StepBwdArgs Gd, int nzs, DenseIO DN) {
   constexpr int G = Grid<NCB>::G, NT = Grid<NCB>::NT, GSH = (G == 8) ? 3 : 4;
   constexpr int NRD = 2 * NCB, LDU = NRD + 1, TP = NRD / G, TH = TP / 2;
   constexpr int WS_W = WsLayout<NCB>::W, WS_IT = WsLayout<NCB>::IT, WS_TOTAL = WsLayout<NCB>::TOTAL;
@@ -167,7 +170,8 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   // SIMD while the other three idle.  Blocks 256 apart are the ones that tend to share a CU.
   const bool w0 = wave == ((NCB == 64 || NT == 64) ? 0 : (int)((blockIdx.x >> 8) & 3));
   const int ti = tid >> GSH, tj = tid & (G - 1);                          // tile coordinates of the matrix role
-  const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e;
+  if (DENSE && DN.cls[blockIdx.x] != 2) return;                            // (a general scene: the generic kernels serve it)
+  const int nb = SP.nb, nz = DENSE ? DN.nz : 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;
   carve<NCB>(L, smem, nzs);
   const int lc = lane < NCB ? lane : NCB - 1;                             // (lanes beyond the contact capacity read in bounds, results unused)
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   const int lo = lane & 15, hg = lane >> 4;
   auto gI = [&](int a) { return (NWV == 4) ? 2 * a + wr : a; };          // global tile row / column of a local index
   auto gJ = [&](int b) { return (NWV == 4) ? 2 * b + wc : b; };
-  double* Wg = (double*)SP.ws + (size_t)scene * WS_TOTAL;                 // W tiles: Wg[(p * 8 + q) * 256 + tid]
+  double* Wg = (double*)SP.ws + (size_t)scene * (DENSE ? DN.ws_scene / sizeof(double) : (size_t)WS_TOTAL);   // W tiles, header, iterate
   double* Wit = Wg + WS_IT;                                               // best iterate
   int ncs = ncap;
   if (BWD) ncs = (int)Wg[WS_W];                                           // the count the forward solved with
@@ -198,31 +202,60 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   for (int i = tid; i < EQB * nzs; i += NT) L.At[i] = 0.0f;
   if (tid < 4) L.flag[tid] = 0;
   __syncthreads();
-  const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
-  const float* vv = (const float*)SP.v + (size_t)scene * nz;
-  const float* ff = (const float*)SP.f + (size_t)scene * nz;
-  double mu_c = 0, hn = 0;
-  if (vc) {
-    const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
-                                                     (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
-                                                     SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
-                                                     (const float*)SP.fric + (size_t)scene * nb, vv, lane);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
-      L.Jc[(size_t)lane * nzs + col] = r.jn[q];
-      L.Jt[(size_t)lane * nzs + col] = r.jf[q];
+  const float* Md = DENSE ? nullptr : (const float*)SP.Mdiag + (size_t)scene * nz;
+  const float* vv = DENSE ? nullptr : (const float*)SP.v + (size_t)scene * nz;
+  const float* ff = DENSE ? nullptr : (const float*)SP.f + (size_t)scene * nz;
+  double mu_c = 0, hn = 0, p = 0, qd = 0, qid = 0, b_in = 0;
+  if constexpr (DENSE) {
+    // dense boundary: G = [Jc; Jf; 0] with Jf rows (+jt, -jt) (engines.py:67-68, world.py:191-192), F[3nc + c][c] = mu_c
+    // (engines.py:71), h = [h_n; 0; 0] (:74) - all verified per scene by lcp_classify_big
+    const int m = DN.m;
+    const float* Gs = DN.G + (size_t)scene * m * nz;
+    for (int i = tid; i < ncap * nz; i += NT) {
+      const int c = i / nz, k = i - c * nz;
+      L.Jc[(size_t)c * nzs + k] = Gs[(size_t)c * nz + k];
+      L.Jt[(size_t)c * nzs + k] = Gs[(size_t)(ncap + 2 * c) * nz + k];
     }
-    mu_c = (double)r.mu; hn = (double)r.h;
+    if (BWD) {                                                            // (lcp_pdipm_backward_f32 gets G, A and the cotangent only)
+      if (vc) mu_c = Wit[72 + 8 * LX + lane];
+      if (w0 && lane < nz) { qd = Wit[72 + 9 * LX + lane]; qid = 1.0 / qd; }
+    } else {
+      if (vc) {
+        mu_c = (double)DN.F[(size_t)scene * m * m + (size_t)(3 * ncap + lane) * m + lane];
+        hn = (double)DN.h[(size_t)scene * m + lane];
+      }
+      if (w0 && lane < nz) {
+        const float q = DN.Q[(size_t)scene * nz * nz + (size_t)lane * nz + lane];
+        qd = (double)q; qid = 1.0 / (double)q;
+        p = (double)DN.p[(size_t)scene * nz + lane];
+      }
+      if (w0 && lane < e) b_in = (double)DN.b[(size_t)scene * e + lane];
+      if (w0) { Wit[72 + 8 * LX + lane] = mu_c; Wit[72 + 9 * LX + lane] = qd; }
+    }
+    if (w0) L.qid[lane] = qid;
+    for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz; L.At[(size_t)a * nzs + k] = DN.A[(size_t)scene * e * nz + i]; }
+  } else {
+    if (vc) {
+      const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
+                                                       (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
+                                                       SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
+                                                       (const float*)SP.fric + (size_t)scene * nb, vv, lane);
+  #pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
+        L.Jc[(size_t)lane * nzs + col] = r.jn[q];
+        L.Jt[(size_t)lane * nzs + col] = r.jf[q];
+      }
+      mu_c = (double)r.mu; hn = (double)r.h;
+    }
+    if (w0 && lane < nz) {
+      const float q = Md[lane];
+      qd = (double)q; qid = 1.0 / (double)q;
+      p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
+    }
+    if (w0) L.qid[lane] = qid;
+    for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz; L.At[(size_t)a * nzs + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   }
-  double p = 0, qd = 0, qid = 0;
-  if (w0 && lane < nz) {
-    const float q = Md[lane];
-    qd = (double)q; qid = 1.0 / (double)q;
-    p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
-  }
-  if (w0) L.qid[lane] = qid;
-  for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz; L.At[(size_t)a * nzs + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   int status = truncated;
   __syncthreads();
 
@@ -861,6 +894,39 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     __syncthreads();
     factor();                                                               // lcp.py:46
     __syncthreads();
+    if constexpr (DENSE) {
+      // ---- LCPFunction.backward (lcp.py:37-64): one KKT solve with rhs (dl_dx, 0, 0, 0), then the outer products ----------------
+      double* V = L.LU;                                                     // staging area (the factors are dead after the solve)
+      double *X = V, *DX = V + 64, *NU = V + 128, *DNU = V + 136, *LAM = V + 144, *DLAM = V + 144 + 4 * NCB;
+      const int m = 4 * ncap;
+      if (w0) {
+        ua = L.dU[lc]; uu = L.dU[NCB + lc];
+        const double g = (lane < nz) ? (double)DN.dl_dx[(size_t)scene * nz + lane] : 0.0;
+        const M4<double> zero = m4<double>(0, 0, 0, 0);
+        solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu, false);         // lcp.py:47-50
+        const double nu = (lane < 8) ? Wit[64 + lane] : 0.0;
+        wsync();
+        X[lane] = x; DX[lane] = dx;
+        if (lane < 8) { NU[lane] = nu; DNU[lane] = dnu; }
+        if (lane < ncap) {                                                  // dense row order: [normal | friction pairs | cone]
+          LAM[lane] = z.n; LAM[ncap + 2 * lane] = z.f1; LAM[ncap + 2 * lane + 1] = z.f2; LAM[3 * ncap + lane] = z.g;
+          DLAM[lane] = dl.n; DLAM[ncap + 2 * lane] = dl.f1; DLAM[ncap + 2 * lane + 1] = dl.f2; DLAM[3 * ncap + lane] = dl.g;
+        }
+      }
+      __syncthreads();
+      if (DN.dp) for (int j = tid; j < nz; j += NT) DN.dp[(size_t)scene * nz + j] = (float)DX[j];                            // lcp.py:52
+      if (DN.dh) for (int i = tid; i < m; i += NT) DN.dh[(size_t)scene * m + i] = (float)(-DLAM[i]);                          // :56
+      if (DN.db) for (int a = tid; a < e; a += NT) DN.db[(size_t)scene * e + a] = (float)(-DNU[a]);                           // :58
+      if (DN.dQ) for (int i = tid; i < nz * nz; i += NT) { const int j = i / nz, k = i - j * nz;
+        DN.dQ[(size_t)scene * nz * nz + i] = (float)(0.5 * (DX[j] * X[k] + X[j] * DX[k])); }                                  // :59-60
+      if (DN.dA) for (int i = tid; i < e * nz; i += NT) { const int a = i / nz, k = i - a * nz;
+        DN.dA[(size_t)scene * e * nz + i] = (float)(DNU[a] * X[k] + NU[a] * DX[k]); }                                         // :57
+      if (DN.dG) for (int i = tid; i < m * nz; i += NT) { const int r = i / nz, k = i - r * nz;
+        DN.dG[(size_t)scene * m * nz + i] = (float)(DLAM[r] * X[k] + LAM[r] * DX[k]); }                                       // :53
+      if (DN.dF) { float* o = DN.dF + (size_t)scene * m * m;
+        for (int i = tid; i < m * m; i += NT) { const int r = i / m, c = i - r * m; o[i] = (float)(-DLAM[r] * LAM[c]); } }    // :54
+      return;
+    }
     if (!w0) return;
     ua = L.dU[lc]; uu = L.dU[NCB + lc];
     // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
@@ -934,7 +1000,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   const int max_iter = SP.max_iter, lim = SP.lim;
   const double eps = SP.eps;
   const double mf = (double)(4 * ncs);
-  double x = 0, y = 0, b = 0;
+  double x = 0, y = 0, b = DENSE ? b_in : 0.0;
   M4<double> s = m4<double>(1, 1, 1, 1), z = s, dinv = s;
   double bx = 0, by = 0;
   M4<double> bz = s, bs = s;
@@ -1055,7 +1121,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   }
   if (lane < e && SP.y) ((float*)SP.y)[(size_t)scene * e + lane] = (float)by;
   if (lane < nz) {
-    const double nv = -bx;                                                            // engines.py:76-77
+    const double nv = DENSE ? bx : -bx;                                               // engines.py:76-77 (dense boundary: zhats = x itself, lcp.py:35)
     ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)nv;
     if (SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
   }
@@ -1088,14 +1154,14 @@ size_t big_ws_bytes(int m) {
   return sizeof(double) * (size_t)total;
 }
 
-template <int NCB, bool BWD>
-static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
-  const int nz = 3 * SP.nb, nzs = nz | 1;
+template <int NCB, bool BWD, bool DENSE = false>
+static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, const DenseIO& DN = DenseIO{}) {
+  const int nz = DENSE ? DN.nz : 3 * SP.nb, nzs = nz | 1;
   big::Lds L;
   const size_t lds = big::carve<NCB>(L, nullptr, nzs);
-  auto k = big::lcp_big_kernel<NCB, BWD>;
+  auto k = big::lcp_big_kernel<NCB, BWD, DENSE>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return LCP_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::Grid<NCB>::NT), lds, (hipStream_t)stream, SP, Gd, nzs);
+  hipLaunchKernelGGL(k, dim3(SP.B), dim3(big::Grid<NCB>::NT), lds, (hipStream_t)stream, SP, Gd, nzs, DN);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 template <bool BWD>
@@ -1108,5 +1174,66 @@ static int big_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream)
 }
 int big_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return big_dispatch<false>(SP, Gd, stream); }
 int big_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return big_dispatch<true>(SP, Gd, stream); }
+
+// ---------------------------------------------------------------- dense boundary (LCPFunction sizes 17 .. 64 contacts)
+namespace big {
+// One workgroup per scene: is the dense LCP the mixed contact LCP of engines.py:50-74 with a diagonal Q ?
+//   G = [Jc; Jf; 0] with Jf rows in (+jt, -jt) pairs, F = [[0, 0, 0], [0, 0, E], [mu, -E^T, 0]], h = [h_n; 0; 0], Q diagonal.
+// cls[scene] = 2 if so (lcp_big_kernel<.., DENSE> serves it), else 0 (the generic kernels do).
+__global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e) {
+  const int scene = blockIdx.x, tid = threadIdx.x, nz = DN.nz, m = DN.m, nc = m >> 2;
+  const float* G = DN.G + (size_t)scene * m * nz;
+  const float* F = DN.F + (size_t)scene * m * m;
+  const float* Q = DN.Q + (size_t)scene * nz * nz;
+  const float* h = DN.h + (size_t)scene * m;
+  int good = 1;                                                            // (accumulated with &: no short-circuit between loads)
+  for (int i = tid; i < nc * nz; i += 256) { const int c = i / nz, k = i - c * nz; good &= (G[(size_t)(nc + 2 * c + 1) * nz + k] == -G[(size_t)(nc + 2 * c) * nz + k]) ? 1 : 0; }
+  for (int i = tid; i < nc * nz; i += 256) good &= (G[(size_t)3 * nc * nz + i] == 0.0f) ? 1 : 0;
+  for (int i = nc + tid; i < m; i += 256) good &= (h[i] == 0.0f) ? 1 : 0;
+  for (int i = tid; i < nz * nz; i += 256) { const int r = i / nz, c = i - r * nz; good &= (r == c || Q[i] == 0.0f) ? 1 : 0; }
+  for (int i = tid; i < m * m; i += 256) {
+    const int r = i / m, j = i - r * m;
+    const float v = F[i];
+    float want = 0.0f;
+    if (r >= nc && r < 3 * nc) want = (j == 3 * nc + ((r - nc) >> 1)) ? 1.0f : 0.0f;
+    else if (r >= 3 * nc) { const int cg = r - 3 * nc; if (j == cg) want = v; else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = -1.0f; }
+    good &= (v == want) ? 1 : 0;
+  }
+  const int all = __syncthreads_and(good);
+  if (tid == 0) DN.cls[scene] = all ? 2 : 0;
+}
+}  // namespace big
+
+bool big_dense_supported(int nz, int m, int e) {
+  if ((m % 4) != 0 || m / 4 <= 16 || !big_supported(nz, m, e)) return false;      // (<= 16 contacts: the wave-per-scene kernels)
+  return nz <= 64;
+}
+
+static void dense_io(DenseIO& DN, int nz, int m, int32_t* cls, size_t ws_scene) { DN = DenseIO{}; DN.nz = nz; DN.m = m; DN.cls = cls; DN.ws_scene = ws_scene; }
+
+int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
+  DenseIO DN;
+  dense_io(DN, P.nz, P.m, cls, ws_scene);
+  DN.Q = (const float*)P.Q; DN.p = (const float*)P.p; DN.G = (const float*)P.G; DN.h = (const float*)P.h;
+  DN.A = (const float*)P.A; DN.b = (const float*)P.b; DN.F = (const float*)P.F;
+  hipLaunchKernelGGL(big::lcp_classify_big, dim3(P.B), dim3(256), 0, (hipStream_t)stream, DN, P.e);
+  StepArgs SP = {};
+  SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;
+  SP.v_new = P.x; SP.z = P.z; SP.s = P.s; SP.y = P.y; SP.iters = P.iters; SP.status = P.status;
+  StepBwdArgs Gd = {};
+  return big_class(SP.nc) == 32 ? big_launch<32, false, true>(SP, Gd, stream, DN) : big_launch<64, false, true>(SP, Gd, stream, DN);
+}
+
+int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
+  DenseIO DN;
+  dense_io(DN, P.nz, P.m, cls, ws_scene);
+  DN.G = (const float*)P.G; DN.A = (const float*)P.A; DN.dl_dx = (const float*)P.dl_dx;
+  DN.dQ = (float*)P.dQ; DN.dp = (float*)P.dp; DN.dG = (float*)P.dG; DN.dh = (float*)P.dh; DN.dA = (float*)P.dA; DN.db = (float*)P.db; DN.dF = (float*)P.dF;
+  StepArgs SP = {};
+  SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  StepBwdArgs Gd = {};
+  return big_class(SP.nc) == 32 ? big_launch<32, true, true>(SP, Gd, stream, DN) : big_launch<64, true, true>(SP, Gd, stream, DN);
+}
 
 }  // namespace lcp

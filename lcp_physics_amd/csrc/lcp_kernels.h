@@ -28,6 +28,7 @@ struct FwdArgs {
   int max_iter, lim;
   int ldT, t_in_lds;
   double* trace;     // optional [B, max_iter, 4] (resid, mu, sigma, alpha) - debugging aid
+  const int32_t* cls;  // optional per-scene class (lcp_classify_big): the generic kernels leave scenes of class 2 alone
 };
 
 struct BwdArgs {
@@ -37,6 +38,19 @@ struct BwdArgs {
   void* ws;
   size_t ws_stride;
   int ldT, t_in_lds;
+  const int32_t* cls;  // as FwdArgs::cls
+};
+
+// dense (Q, p, G, h, A, b, F) boundary of lcp_big.hip: LCPFunction sizes beyond the wave-per-scene kernels (nineq <= 256)
+struct DenseIO {
+  int nz, m;
+  const float *Q, *p, *G, *h, *A, *b, *F;           // forward inputs
+  float *x, *y, *z, *s;                             // forward outputs
+  int32_t *iters, *status;
+  int32_t* cls;                                     // [B] class per scene (2 = contact-structured with diagonal Q)
+  size_t ws_scene;                                  // workspace bytes per scene (common to the kernel families of a batch)
+  const float* dl_dx;                               // backward: cotangent, then the seven gradients (any may be NULL)
+  float *dQ, *dp, *dG, *dh, *dA, *db, *dF;
 };
 
 struct StepArgs {
@@ -93,9 +107,9 @@ int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, 
 
 // wave-per-scene register-resident path (nz <= 16, nineq <= 64, neq <= 8, fp32 I/O) - lcp_wave64.hip
 bool wave64_supported(int nz, int m, int e);
-size_t wave64_ws_bytes(int compute);
-int wave64_forward(const FwdArgs& P, int compute, void* stream);
-int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream);
+size_t wave64_ws_bytes(int compute, int io_f64 = 0);
+int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64 = 0);
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64 = 0);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
 // four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
@@ -103,8 +117,8 @@ int wave64_step(const StepArgs& P, int compute, void* stream);
 // `accept`: classification flag value (workspace meta[0]) the launch serves
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
-int quad_forward(const FwdArgs& P, int compute, int accept, void* stream);
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream);
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
 int quad_step(const StepArgs& P, int compute, void* stream);
 int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream);
 
@@ -113,6 +127,10 @@ bool big_supported(int nz, int m, int e);
 size_t big_ws_bytes(int m);
 int big_step(const StepArgs& P, void* stream);
 int big_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
+// dense boundary (lcp_pdipm_forward_f32 / _backward_f32) for 16 < nineq / 4 <= 64 contacts: classification, then the same kernel
+bool big_dense_supported(int nz, int m, int e);
+int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
+int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
 
 // narrow-phase contact generation + position update - lcp_contacts.hip
 int contacts_launch(const ContactArgs& P, void* stream);

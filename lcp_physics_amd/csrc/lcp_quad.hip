@@ -1256,19 +1256,22 @@ bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <
 // land on four disjoint bank groups (a stride that is a multiple of 128 B - the unpadded 3456 B - puts them all on the
 // same banks).  Measured: SQ_LDS_BANK_CONFLICT 273 k -> 169 k cycles per launch; no change of the kernel time - the
 // single wave waits out the LDS latency either way.
-template <typename TC>
+template <typename TC, typename TI = float>
 static size_t q16_lds(bool with_w, int xh = 1) {
-  q16::LdsQ<float, TC> L;
-  size_t n = q16::carve_q<float, TC>(L, nullptr, with_w, xh);
+  q16::LdsQ<TI, TC> L;
+  size_t n = q16::carve_q<TI, TC>(L, nullptr, with_w, xh);
   while (n % 256 != 64) n += 16;
   return n;
 }
 
-int quad_forward(const FwdArgs& P, int compute, int accept, void* stream) {
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
-  if (compute == LCP_COMPUTE_F64) {
+  if (io_f64) {                                  // the reference's native dtype (physics/utils.py:34): fp64 loads / stores
+    const int ls = (int)q16_lds<double, double>(LCP_Q_LDSW != 0);
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<double, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+  } else if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else {
@@ -1295,10 +1298,13 @@ int quad_step(const StepArgs& SP, int compute, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream) {
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
-  if (compute == LCP_COMPUTE_F64) {
+  if (io_f64) {
+    const int ls = (int)q16_lds<double, double>(false);
+    hipLaunchKernelGGL((q16::lcp_bwd_quad<double, double>), grid, blk, 4 * ls, st, P, ls, accept);
+  } else if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double>), grid, blk, 4 * ls, st, P, ls, accept);
   } else {

@@ -1202,12 +1202,13 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
 // ---------------------------------------------------------------- host-side launchers
 bool wave64_supported(int nz, int m, int e) { return nz <= w64::NZP && m <= w64::MP && e <= w64::EP; }
 
-size_t wave64_ws_bytes(int compute) {
+size_t wave64_ws_bytes(int compute, int io_f64) {
+  if (io_f64) return w64::ws_bytes<double, double>();
   return compute == LCP_COMPUTE_F64 ? w64::ws_bytes<float, double>() : w64::ws_bytes<float, float>();
 }
 
-template <typename TC>
-static size_t w64_lds(bool with_panel = true) { w64::Lds<float, TC> L; return w64::carve<float, TC>(L, nullptr, with_panel); }
+template <typename TC, typename TI = float>
+static size_t w64_lds(bool with_panel = true) { w64::Lds<TI, TC> L; return w64::carve<TI, TC>(L, nullptr, with_panel); }
 
 static inline dim3 w64_grid(int B) { return dim3((B + w64::WPB - 1) / w64::WPB); }
 
@@ -1228,14 +1229,20 @@ static int w64_allow_lds(K kernel, size_t bytes) {
     hipLaunchKernelGGL(kfn, GRID, blk, (size_t)(LW) * w64::WPB, st, __VA_ARGS__);        \
   } while (0)
 
-int wave64_forward(const FwdArgs& P, int compute, void* stream) {
+int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
   // classify, then: quad kernel (structured + diagonal Q), wave64 structured kernel, general kernel -
   // every scene is picked up by exactly one of them.
-  if (compute == LCP_COMPUTE_F64) {
+  if (io_f64) {                                  // fp64 I/O (the reference's native dtype): same kernels, fp64 loads / stores
+    const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
+    hipLaunchKernelGGL((w64::lcp_classify_wave<double, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
+    if (quad) { int rc = quad_forward(P, compute, 2, stream, 1); if (rc) return rc; }
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<double, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave<double, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
+  } else if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
@@ -1266,12 +1273,16 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream) {
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
-  if (quad) { int rc = quad_backward(P, compute, 2, stream); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
-  if (compute == LCP_COMPUTE_F64) {
+  if (quad) { int rc = quad_backward(P, compute, 2, stream, io_f64); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
+  if (io_f64) {
+    const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<double, double, true, true>), w64_grid(P.B), ls, P, ls, quad);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave<double, double, true, false>), w64_grid(P.B), lw, P, lw, 0);
+  } else if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls, quad);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw, 0);

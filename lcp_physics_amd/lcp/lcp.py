@@ -65,7 +65,7 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
         _lib.require_gpu_tensor(b, "b", dtype)
     assert Q.shape == (B, nz, nz) and p.shape == (B, nz) and h.shape == (B, m) and F.shape == (B, m, m)
     comp = _lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]
-    need = _lib.workspace_bytes(B, nz, m, e, comp)
+    need = _lib.workspace_bytes(B, nz, m, e, comp | (_lib.IO_F64 if dtype == torch.float64 else 0))
     if need == 0:
         raise RuntimeError("invalid LCP sizes B=%d nz=%d nineq=%d neq=%d" % (B, nz, m, e))
     if ws is None or ws.numel() < need:

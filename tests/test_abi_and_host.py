@@ -34,7 +34,12 @@ def test_workspace_bytes_and_argument_checks_host_only():
     w64 = lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F64)
     w32 = lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F32)
     assert w64 > w32 and w64 >= 4096 * 8 * (64 * 64 + 15 * 15 + 64 * 3 + 9 + 15 + 128 + 3)
-    assert w64 % 4096 == 0 and (w64 // 4096) % 256 == 0        # per-scene stride keeps 256 B alignment
+    tail = (4096 * 4 + 255) & ~255                              # per-scene classes of the dense lcp_big path, behind the scene blocks
+    assert (w64 - tail) % 4096 == 0 and ((w64 - tail) // 4096) % 256 == 0        # per-scene stride keeps 256 B alignment
+    # fp64 I/O keeps an fp64 copy of F in the workspace: the caller says so with LCP_IO_F64
+    assert lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F64 | _lib.IO_F64) > w64
+    # config-5 sizes (nz 33, nineq 256): lcp_big.hip's layout (W tiles + iterate) or the generic one, whichever is larger
+    assert lib.lcp_workspace_bytes(8, 33, 256, 3, _lib.COMPUTE_F64) >= 8 * 8 * (4 * 64 * 64 + 64 + 72 + 10 * 64)
     assert lib.lcp_workspace_bytes(0, 15, 64, 3, 1) == 0
     # argument validation happens before any launch: NULL pointers / bad sizes -> LCP_E_BADARG
     N = None

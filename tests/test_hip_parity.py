@@ -362,8 +362,8 @@ def test_mixed_batch_every_scene_served_by_the_right_kernel(kernel_path):
         from lcp_physics_amd import _lib
         import ctypes
         # classification flags live in the workspace: meta[0] of each scene (see lcp_wave_common.h `Ws`)
-        stride = _lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) // B
-        flags = sol.ws.view(torch.float64).reshape(B, stride // 8)[:, 5080].cpu()
+        stride = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255)) // B     # (the tail holds lcp_big's classes)
+        flags = sol.ws[:B * stride].view(torch.float64).reshape(B, stride // 8)[:, 5080].cpu()
         assert flags.tolist() == [2.0] * 4 + [1.0] * 4 + [0.0] * 5
     cot = torch.randn(B, nz, generator=g, dtype=torch.float32)
     gref = O.lcp_backward(ref, *lcp64, cot.double())
@@ -548,3 +548,114 @@ def test_fused_engine_plugin_runs_both_branches_and_post_stabilization_on_the_de
           for c in world.contacts]
     ref = W.post_stabilization(Md, n("v"), cs, n("rest"), n("Je"))
     assert np.abs(dp - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (name, "post_stabilization", np.abs(dp - ref).max())
+
+
+# ------------------------------------------------------------------ the operator boundary at every size and dtype
+def test_fp64_io_takes_the_fast_kernels_and_agrees_with_the_generic_ones(kernel_path):
+    """`lcp_pdipm_forward_f64 / _backward_f64` (the reference's native dtype, physics/utils.py:34) run the wave / quad kernels
+    with fp64 loads and stores; the same inputs through the forced generic kernels give the same answer (two different
+    kernel families, both within 1e-7 of the oracle)."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    sc = scenes.make_stack_scenes(B=64, nbox=4, pts_per_interface=4, seed=4242, dtype=torch.float64)
+    lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    ref = O.lcp_forward(*lcp64)
+    sol = _solve(lcp64, torch.float64)
+    ex = parity.err_x(sol.x.cpu(), ref.x, lcp64[0], lcp64[1])
+    assert float(ex.max()) < 1e-7, (kernel_path, float(ex.max()))
+    dec = parity.decisive_rows(ref.z, ref.s)
+    assert bool(((parity.active_sets(sol.z.cpu(), sol.s.cpu()) == parity.active_sets(ref.z, ref.s)) | ~dec).all())
+    cot = torch.randn(64, lcp64[0].shape[1], generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    grads = lcp_backward(sol, cot.to(DEV))
+    gref = O.lcp_backward(ref, *lcp64, cot)
+    ok = parity.backward_well_posed(lcp64[0], lcp64[2], lcp64[4], lcp64[6], ref, cot, gref)
+    fl = parity.grad_floors(lcp64[0], lcp64[1], cot, ref.x, ref.z, ref.y)
+    errs = parity.err_grads({k: g.cpu() for k, g in zip("QpGhAbF", grads) if k in "QpAb"}, {k: gref["d" + k] for k in "QpAb"}, fl)
+    assert max(float(e[ok].max()) for e in errs.values()) < 1e-6, {k: float(v[ok].max()) for k, v in errs.items()}
+    if kernel_path != "generic":                      # the fast path really is a different kernel: its timing says so
+        big = scenes.make_stack_scenes(B=2048, nbox=4, pts_per_interface=4, seed=1, dtype=torch.float64)
+        lcpb = _gpu([None if t is None else t.double() for t in O.assemble_lcp(*big.assembly_args())], torch.float64)
+        from lcp_physics_amd.lcp import lcp_solve
+        def timed():
+            s0 = lcp_solve(*lcpb)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); lcp_solve(*lcpb, ws=s0.ws); e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        fast = timed()
+        _lib.set_path("generic")
+        try:
+            slow = timed()
+        finally:
+            _lib.set_path(kernel_path)
+        assert fast < 0.25 * slow, (fast, slow)
+
+
+def _pile_lcp(B, seed):
+    from lcp_physics_amd import scenes
+    sc = scenes.make_pile_scenes(B=B, seed=seed, dtype=torch.float32)
+    return sc, O.assemble_lcp(*sc.assembly_args())
+
+
+def test_dense_boundary_reaches_the_big_kernel_at_config5_sizes(kernel_path):
+    """`LCPFunction`-level inputs of BASELINE config 5 (nz 33, nineq 256, neq 3): the dense entry points classify every scene on
+    the device and serve the contact-structured ones from lcp_big.hip (blocked MFMA LU), the rest - here two scenes whose F was
+    perturbed - from the generic kernels, in ONE call.  Forward: err_x <= 1e-4 and index sets against the oracle; backward: the
+    well-defined gradients against the oracle and all seven against the generic kernels' (same multipliers, fp32 stores)."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.lcp import lcp_backward
+    B = 10
+    sc, lcp32 = _pile_lcp(B, 77)
+    lcp32 = [None if t is None else t.clone() for t in lcp32]
+    nc = sc.nc
+    lcp32[6][3, 5, 7] = 0.25                          # scenes 3 and 8 lose the contact structure: they are general LCPs now
+    lcp32[6][8, 3 * nc + 2, 2 * nc] = -0.5
+    lcp64 = [None if t is None else t.double() for t in lcp32]
+    ref = O.lcp_forward(*lcp64)
+    sol = _solve(lcp32, torch.float32)
+    _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, "config5 dense")
+    assert int(sol.status.cpu().max()) & ~4 == 0
+    cot = torch.randn(B, lcp32[0].shape[1], generator=torch.Generator().manual_seed(11), dtype=torch.float32)
+    grads = [None if g is None else g.double().cpu() for g in lcp_backward(sol, cot.to(DEV))]
+    torch.cuda.synchronize()
+    if kernel_path != "generic":
+        _lib.set_path("generic")
+        try:
+            solg = _solve(lcp32, torch.float32)
+            gg = [None if g is None else g.double().cpu() for g in lcp_backward(solg, cot.to(DEV))]
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_path(kernel_path)
+        assert float((sol.x.cpu() - solg.x.cpu()).abs().max()) <= 1e-5 * max(1.0, float(solg.x.abs().max()))
+        for k, a, b in zip("QpGhAbF", grads, gg):
+            if k in "QpAb":                           # (dG, dh, dF of redundant piles are rounding-determined: tests/parity.py)
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 1e-4 * max(scale, 1e-12), (k, float((a - b).abs().max()), scale)
+    gref = O.lcp_backward(ref, *lcp64, cot.double())
+    ok = parity.backward_well_posed(lcp64[0], lcp64[2], lcp64[4], lcp64[6], ref, cot.double(), gref)
+    fl = parity.grad_floors(lcp64[0], lcp64[1], cot.double(), ref.x, ref.z, ref.y)
+    errs = parity.err_grads({k: g for k, g in zip("QpGhAbF", grads) if k in "QpAb"}, {k: gref["d" + k] for k in "QpAb"}, fl)
+    if bool(ok.any()):
+        assert max(float(e[ok].max()) for e in errs.values()) < TOL_G32, {k: float(v[ok].max()) for k, v in errs.items()}
+    # the rank-1 structure of the dense gradients (lcp.py:53-56): dF = -dlam (x) lam, dh = -dlam
+    dF, dh = grads[6], grads[3]
+    lam = sol.z.double().cpu()
+    rebuilt = dh.unsqueeze(2) * lam.unsqueeze(1)
+    assert float((dF - rebuilt).abs().max()) <= 1e-5 * max(1.0, float(dF.abs().max()))
+
+
+def test_dense_boundary_speed_at_config5_sizes(kernel_path):
+    """The point of the routing: LCPFunction-level config 5 no longer runs at the generic kernels' 2.3 k sim steps/s."""
+    from lcp_physics_amd.lcp import lcp_solve
+    if kernel_path == "generic":
+        pytest.skip("forced generic kernels")
+    B = 1024
+    _, lcp32 = _pile_lcp(B, 5)
+    g = _gpu(lcp32, torch.float32)
+    s0 = lcp_solve(*g)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); lcp_solve(*g, ws=s0.ws); e1.record(); torch.cuda.synchronize()
+    rate = B / (e0.elapsed_time(e1) * 1e-3)
+    print("dense config-5 forward: %.0f sim steps/s" % rate)
+    assert rate > 1e5, rate
