@@ -330,4 +330,12 @@ int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, con
   return lcp::contacts_launch(P, stream);
 }
 
+int lcp_contact_frame_backward_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
+                                   const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
+                                   const float* g_p1, const float* g_p2, double* dp, void* stream) {
+  if (B <= 0 || nb <= 0 || maxc <= 0) return LCP_E_BADARG;
+  if (!kind || !radius || !p || !c_i1 || !c_i2 || !count || !g_n || !g_p1 || !g_p2 || !dp) return LCP_E_BADARG;
+  return lcp::contact_frame_backward_launch(B, nb, maxc, kind, radius, p, c_i1, c_i2, count, g_n, g_p1, g_p2, dp, stream);
+}
+
 }  // extern "C"

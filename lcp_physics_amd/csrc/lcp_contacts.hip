@@ -411,7 +411,56 @@ __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs 
   }
 }
 
+// ---------------------------------------------------------------- backward of the contact frame (circle / circle)
+// The reference builds the contact tuple with differentiable torch operations (DiffContactHandler, contacts.py:57-205), so
+// a loss after a roll-out reaches the poses through (normal, p1, p2).  This is that chain rule for the circle / circle
+// record of contacts.py:68-79, with d = pos1 - pos2, dist = |d|, n = d / dist, r = rad1 + rad2:
+//     normal = n        p1 = -n (rad1 - (r - dist) / 2)        p2 = n (rad2 - (r - dist) / 2)
+//     d(loss)/dd = (I - n n^T) / dist . (g_n - a1 g_p1 + a2 g_p2)  +  n (n . (g_p2 - g_p1)) / 2,   a_i = rad_i - (r - dist) / 2
+// and d(loss)/dpos1 = +that, d(loss)/dpos2 = -that (the rotations do not enter).  Contacts involving a hull are treated as
+// constants of the step (their frame backward is not implemented: gradients stop there).  One thread per scene walks the
+// scene's contact list in order: fixed summation order, no atomics.
+__global__ void __launch_bounds__(64) lcp_contact_frame_backward_kernel(int B, int nb, int maxc, const int32_t* kind, const double* radius,
+                                                                        const double* p, const int32_t* c_i1, const int32_t* c_i2,
+                                                                        const int32_t* count, const float* g_n, const float* g_p1,
+                                                                        const float* g_p2, double* dp) {
+  const int scene = blockIdx.x * 64 + threadIdx.x;
+  if (scene >= B) return;
+  double* out = dp + (size_t)scene * nb * 3;
+  for (int i = 0; i < nb * 3; ++i) out[i] = 0.0;
+  int n = count[scene];
+  n = n < 0 ? 0 : (n > maxc ? maxc : n);
+  for (int c = 0; c < n; ++c) {
+    const size_t o = (size_t)scene * maxc + c;
+    const int i1 = c_i1[o], i2 = c_i2[o];
+    if (kind[(size_t)scene * nb + i1] != 0 || kind[(size_t)scene * nb + i2] != 0) continue;
+    const double* q1 = p + ((size_t)scene * nb + i1) * 3;
+    const double* q2 = p + ((size_t)scene * nb + i2) * 3;
+    const double r1 = radius[(size_t)scene * nb + i1], r2 = radius[(size_t)scene * nb + i2];
+    const double dx = q1[1] - q2[1], dy = q1[2] - q2[2];
+    const double dist = sqrt(dx * dx + dy * dy), inv = 1.0 / dist;
+    const double nx = dx * inv, ny = dy * inv;
+    const double half = 0.5 * ((r1 + r2) - dist);
+    const double a1 = r1 - half, a2 = r2 - half;
+    const double gnx = g_n[o * 2], gny = g_n[o * 2 + 1], g1x = g_p1[o * 2], g1y = g_p1[o * 2 + 1], g2x = g_p2[o * 2], g2y = g_p2[o * 2 + 1];
+    const double wx = gnx - a1 * g1x + a2 * g2x, wy = gny - a1 * g1y + a2 * g2y;
+    const double wn = wx * nx + wy * ny;
+    const double k = 0.5 * (nx * (g2x - g1x) + ny * (g2y - g1y));
+    const double gx = (wx - nx * wn) * inv + nx * k, gy = (wy - ny * wn) * inv + ny * k;
+    out[i1 * 3 + 1] += gx; out[i1 * 3 + 2] += gy;
+    out[i2 * 3 + 1] -= gx; out[i2 * 3 + 2] -= gy;
+  }
+}
+
 }  // namespace ct
+
+int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
+                                  const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
+                                  const float* g_p1, const float* g_p2, double* dp, void* stream) {
+  hipLaunchKernelGGL(ct::lcp_contact_frame_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, maxc, kind,
+                     radius, p, c_i1, c_i2, count, g_n, g_p1, g_p2, dp);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
 
 int contacts_launch(const ContactArgs& P, void* stream) {
   if (P.nb > ct::MAXB) return LCP_E_TOOLARGE;

@@ -364,8 +364,9 @@ class ContactWorld:
 
     State: `p` [B,nb,3] float64 (rot, x, y), `v` [B,nb,3] float32, `t` [B] float64 (scenes advance by their own
     accepted dt, world.py:122), `contacts` (`contacts.ContactBuffers`: padded records + `count`).
-    Restrictions: forces are constant (gravity-like), joints have a constant Jacobian `Je` (Total/X/Y/Rot
-    constraints); at most 16 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the
+    Forces: a constant `f` or `force_fn(t)` (time-dependent, `forces.py:29-48`).  `step(differentiable=True)` records the
+    step in torch's autograd graph (roll-out gradients, `demos/grad_demo.py`).  Restrictions: joints have a constant
+    Jacobian `Je` (Total/X/Y/Rot constraints); at most 16 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the
     four-scenes-per-wave solver, anything else on the workgroup-per-scene kernels (slower).
     `post_stab=True` (off by default, as in the reference: utils.py:30) adds the two launches of world.py:109-121 to a
     step: `lcp_post_stabilization_f32` (frictionless LCP + correction move) and a contact re-detection.
@@ -373,9 +374,14 @@ class ContactWorld:
 
     def __init__(self, geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1.0 / 30, eps=0.1, tol=1e-6,
                  strict_no_penetration=True, maxc=16, max_iter=10, compute="f64", solver_eps=1e-12,
-                 not_improved_lim=3, max_trials=64, check=True, post_stab=False):
+                 not_improved_lim=3, max_trials=64, check=True, post_stab=False, force_fn=None):
         from . import contacts as _contacts
         self.post_stab = bool(post_stab)
+        # `force_fn(t) -> f [B,nb,3] float32` replaces the constant force: the batched form of the reference's
+        # `ExternalForce(force_func)` (forces.py:29-48, `force_func(t)` evaluated at the world's clock every step,
+        # world.py:135-137); `t` is the per-scene clock [B] float64 on the device - build f with tensor operations
+        # (e.g. `torch.where(t < 0.1, ...)`), no host synchronisation.
+        self.force_fn = force_fn
         self._ps_out = self._ps_ws = None
         self._phase, self._graphs = 0, {}
         self._contacts_mod = _contacts
@@ -449,11 +455,48 @@ class ContactWorld:
         if self.check:
             self.assert_not_truncated()                                    # one synchronisation per run, none per step
 
-    def step(self):
+    def step_autograd(self):
+        """`step()` as a node of torch's autograd graph, for losses evaluated after a roll-out (`demos/grad_demo.py:45-50`,
+        `experiments/inference.py:55-61`).  Same two launches; the graph of one step is
+
+            frame   = ContactFrameFunction(p)                         backward: lcp_contact_frame_backward_f64
+            v_new   = SolveDynamicsFunction(Mdiag, v, f(t), rest, fric, frame, ...)   backward: lcp_step_backward_f32
+            p_new   = p + v_new dt_used                               (bodies.py:80-82; dt_used: the dt the step_dt loop accepted)
+
+        `Mdiag, f, rest, fric, v, p` (and what `force_fn` closes over) may require grad.  State tensors are replaced, not
+        overwritten, and every step keeps its own workspace and contact snapshot for the backward.  Contacts that involve a
+        hull are constants of the step (see `contacts.contact_frame_backward`); post-stabilisation is not differentiated."""
+        if self.post_stab:
+            raise RuntimeError("step_autograd: post-stabilisation is not differentiable here")
+        ct = self._contacts_mod
+        cb = self.contacts
+        frame = ct.snapshot_frame(cb)
+        c_n, c_p1, c_p2 = ct.ContactFrameFunction.apply(self.p, self.geom, frame)
+        f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
+        opts = {"max_iter": self.max_iter, "eps": self.solver_eps, "not_improved_lim": self.lim, "compute": self.compute}
+        v_new = SolveDynamicsFunction.apply(self.Mdiag, self.v.contiguous(), f, self.rest, self.fric, c_n, c_p1, c_p2, frame.c_i1,
+                                            frame.c_i2, frame.count, self.Je, self.dt, opts)
+        out = opts["last"]
+        torch.bitwise_or(self.sticky_status, out["status"], out=self.sticky_status)
+        p_start = self.p
+        ct.move_and_find_contacts(self.geom, p_start.detach(), v_new.detach(), self.dt, eps=self.eps, tol=self.tol,
+                                  strict=self.strict, dt_floor=self.dt / 4, max_trials=self.max_trials, t=self.t, out=cb)
+        # the accepted pose: the kernel's value, the gradient of p + v dt_used
+        p_lin = p_start + v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
+        self.p = p_lin + (cb.p_out - p_lin).detach()
+        self.v = v_new
+        ret = dict(out)
+        ret["v_new"] = v_new
+        return ret
+
+    def step(self, differentiable=False):
         """`World.step()` = `step_dt(self.dt)` (`world.py:72-122`) for every scene."""
+        if differentiable:
+            return self.step_autograd()
         self._phase ^= 1
         cb = self.contacts
-        out = solve_dynamics(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, self.f, self.rest,
+        f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
+        out = solve_dynamics(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, f, self.rest,
                              self.fric, cb, self.Je, self.dt, eps=self.solver_eps, not_improved_lim=self.lim,
                              max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
         self._ws, self._out = out["ws"], out

@@ -125,3 +125,55 @@ def move_and_find_contacts(geom, p_start, v, dt, maxc=16, eps=EPSILON, tol=TOL, 
 def find_contacts(geom, p, maxc=16, eps=EPSILON, out=None):
     """`World.find_contacts` (`world.py:139-142`) for every scene at pose `p` [B,nb,3] (float64)."""
     return move_and_find_contacts(geom, p, None, 0.0, maxc=maxc, eps=eps, out=out, max_trials=1)
+
+
+def contact_frame_backward(geom, p, cb, g_n, g_p1, g_p2):
+    """d(loss)/d(pose) through the contact frame (`lcp_contact_frame_backward_f64`): the chain rule of the reference's
+    differentiable contact handler (`contacts.py:57-205`) for the contacts in `cb` detected at pose `p` [B,nb,3] float64.
+    Circle / circle contacts only - a contact that involves a hull contributes nothing."""
+    lib = _lib.load()
+    B, nb = geom.B, geom.nb
+    dev = p.device
+    for name, t in (("g_n", g_n), ("g_p1", g_p1), ("g_p2", g_p2)):
+        _lib.require_gpu_tensor(t, name, torch.float32)
+    _lib.require_gpu_tensor(p, "p", torch.float64)
+    dp = torch.empty(B, nb, 3, dtype=torch.float64, device=dev)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_contact_frame_backward_f64(B, nb, cb.c_n.shape[1], P(geom.kind), P(geom.radius), P(p), P(cb.c_i1), P(cb.c_i2),
+                                                P(cb.count), P(g_n), P(g_p1), P(g_p2), P(dp), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_contact_frame_backward_f64")
+    return dp
+
+
+class _FrameSnapshot:
+    __slots__ = ("c_n", "c_p1", "c_p2", "c_i1", "c_i2", "count")
+
+
+class ContactFrameFunction(torch.autograd.Function):
+    """The contact list as a differentiable function of the poses: forward hands out the records the detection kernel
+    found at `p` (their values are constants of the launch), backward is `lcp_contact_frame_backward_f64`.
+
+        c_n, c_p1, c_p2 = ContactFrameFunction.apply(p, geom, frame)        # frame: a snapshot of the ContactBuffers"""
+
+    @staticmethod
+    def forward(ctx, p, geom, frame):
+        ctx.geom, ctx.frame = geom, frame
+        ctx.save_for_backward(p)
+        return frame.c_n.clone(), frame.c_p1.clone(), frame.c_p2.clone()
+
+    @staticmethod
+    def backward(ctx, g_n, g_p1, g_p2):
+        (p,) = ctx.saved_tensors
+        z = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous()
+        fr = ctx.frame
+        dp = contact_frame_backward(ctx.geom, p, fr, z(g_n, fr.c_n), z(g_p1, fr.c_p1), z(g_p2, fr.c_p2))
+        return dp, None, None
+
+
+def snapshot_frame(cb):
+    """Copies of the contact records in `cb` (the buffers are re-used by the next detection launch)."""
+    fr = _FrameSnapshot()
+    fr.c_n, fr.c_p1, fr.c_p2 = cb.c_n.clone(), cb.c_p1.clone(), cb.c_p2.clone()
+    fr.c_i1, fr.c_i2, fr.count = cb.c_i1.clone(), cb.c_i2.clone(), cb.count.clone()
+    return fr

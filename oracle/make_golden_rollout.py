@@ -1,0 +1,86 @@
+"""Generate tests/golden/rollout_grad.npz: gradients the UNMODIFIED reference obtains by back-propagating through many
+`World.step`s (what `demos/grad_demo.py:19-83` does: `dist = (target.pos - c.pos).norm(); dist.backward()` after a
+roll-out, gradient with respect to a force applied for the first 0.1 s; `experiments/inference.py:26-89` has the same
+shape).  TEST INFRASTRUCTURE ONLY; needs /root/reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_rollout.py
+
+Scene = grad_demo's `make_world` (three circles of radius 30: a target that collides with nothing, a pushed ball c1 and the
+ball c2 it has to send towards the target), with geometry / force magnitudes chosen so that the collision happens inside
+a 36-step roll-out.  For each of several initial forces the fixture stores the final state, the loss and
+d(loss)/d(initial_force) from the reference's autograd - through `PdipmEngine.solve_dynamics`, `LCPFunction.backward`,
+`DiffContactHandler` (circle / circle: physics/contacts.py:67-80) and `Body.move` (bodies.py:80-96) - plus what a batched
+world needs to rebuild the scene.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+NSTEPS = 36
+T_PUSH = 0.1
+MULT = 100.0
+FORCES = [[0.0, 30.0, 8.0], [0.0, 34.0, 9.5], [0.0, 27.0, 6.0], [0.5, 31.0, 8.8], [0.0, 36.0, 11.0], [-0.4, 29.0, 7.1],
+          [0.0, 32.5, 10.2], [0.2, 28.0, 8.0]]
+
+
+def make_world(force_fn):
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.forces import ExternalForce
+    from lcp_physics.physics.world import World
+    target = Circle([500, 300], 30)
+    c1 = Circle([250, 210], 30)
+    c1.add_force(ExternalForce(force_fn, multiplier=MULT))
+    c1.add_no_contact(target)
+    c2 = Circle([345, 236], 30, restitution=0.4, fric_coeff=0.3)
+    c2.add_no_contact(target)
+    world = World([target, c1, c2], [], dt=1.0 / 30)
+    return world, c2, target
+
+
+def run(force0):
+    from lcp_physics.physics.forces import ExternalForce
+    f0 = torch.tensor(force0, dtype=torch.float64, requires_grad=True)
+    fn = lambda t: f0 if t < T_PUSH else ExternalForce.ZEROS
+    world, c, target = make_world(fn)
+    nb = len(world.bodies)
+    rec = dict(Mdiag=torch.diagonal(world.M()).reshape(nb, 3).detach().numpy().copy(),
+               rest=np.array([float(b.restitution) for b in world.bodies]),
+               fric=np.array([float(b.fric_coeff) for b in world.bodies]),
+               rad=np.array([float(b.rad) for b in world.bodies]),
+               p0=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
+               v0=world.get_v().reshape(nb, 3).detach().numpy().copy())
+    ncs, ts = [], []
+    for _ in range(NSTEPS):
+        world.step()
+        ncs.append(len(world.contacts)); ts.append(float(world.t))
+    dist = (target.pos - c.pos).norm()
+    dist.backward()
+    rec.update(p_final=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
+               v_final=world.get_v().reshape(nb, 3).detach().numpy().copy(),
+               loss=np.float64(float(dist)), grad=f0.grad.numpy().copy(), ncontacts=np.array(ncs), t=np.array(ts))
+    return rec
+
+
+def main():
+    ref_shim.load_reference()
+    torch.set_default_dtype(torch.float64)
+    recs = [run(f) for f in FORCES]
+    out = {k: np.stack([r[k] for r in recs]) for k in recs[0]}
+    out.update(force0=np.array(FORCES), nsteps=np.int64(NSTEPS), t_push=np.float64(T_PUSH), mult=np.float64(MULT),
+               dt=np.float64(1.0 / 30), no_contact=np.array([[0, 1], [0, 2]]), pushed_body=np.int64(1), loss_bodies=np.array([0, 2]))
+    for i, r in enumerate(recs):
+        print("force", FORCES[i], "loss %.4f" % r["loss"], "grad", np.array2string(r["grad"], precision=5),
+              "steps with contact", int((r["ncontacts"] > 0).sum()), "halved", int((np.diff(np.concatenate([[0.0], r["t"]])) < 0.99 / 30).sum()))
+    np.savez_compressed(os.path.join(OUT, "rollout_grad.npz"), **out)
+    print("wrote", os.path.join(OUT, "rollout_grad.npz"))
+
+
+if __name__ == "__main__":
+    main()

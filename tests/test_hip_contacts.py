@@ -6,6 +6,8 @@ Tolerances: contact index lists, counts, trial counts: exact.  Penetration (fp64
 Contact frame (normal, arms): the kernel computes them in fp64 and rounds to fp32 for the LCP kernels, so they
 are compared at fp32 resolution of their magnitude (|arm| <= ~500 -> 1e-4 absolute; normals 1e-6).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -621,3 +623,96 @@ def test_singular_pivot_scenes_of_a_settled_world_match_the_oracle():
             checked += 1
     print("scenes with status bit 4 over the sampled steps:", flagged_total, "checked against the oracle:", checked)
     assert checked >= 6, "the settled world no longer produces singular-pivot scenes: drop or re-seed this test"
+
+
+def _rollout_world(d, rep, requires_grad=True):
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    nv = d["force0"].shape[0]
+    B = nv * rep
+    rp = lambda a, dt_: torch.tensor(np.repeat(a, rep, axis=0), dtype=dt_, device=DEV)
+    nb = d["rad"].shape[1]
+    geom = GeometryBatch.from_shapes([("circle", float(r)) for r in d["rad"][0]], B)
+    nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
+    for i, j in d["no_contact"].tolist():
+        nocon[:, i, j] = nocon[:, j, i] = 1
+    geom.no_contact = nocon
+    geom = geom.to(DEV)
+    force0 = rp(d["force0"], torch.float32).requires_grad_(requires_grad)
+    mult, t_push, pushed = float(d["mult"]), float(d["t_push"]), int(d["pushed_body"])
+
+    def force_fn(t):                                    # ExternalForce(lambda t: force0 if t < 0.1 else ZEROS, multiplier) on body `pushed`
+        on = (t < t_push).to(torch.float32).unsqueeze(1)
+        z = torch.zeros(B, 1, 3, dtype=torch.float32, device=DEV)
+        parts = [z] * nb
+        parts[pushed] = (force0 * mult * on).unsqueeze(1)
+        return torch.cat(parts, dim=1)
+
+    world = ContactWorld(geom, rp(d["p0"], torch.float64), rp(d["v0"], torch.float32), rp(d["Mdiag"], torch.float32),
+                         torch.zeros(B, nb, 3, device=DEV), rp(d["rest"], torch.float32), rp(d["fric"], torch.float32), Je=None,
+                         dt=float(d["dt"]), maxc=2, force_fn=force_fn)
+    return world, force0
+
+
+def test_contact_frame_backward_matches_autograd_of_the_circle_record():
+    """`lcp_contact_frame_backward_f64` against torch autograd of the circle / circle contact tuple (contacts.py:68-79)."""
+    from lcp_physics_amd.physics import contacts as ct
+    B, nb = 64, 4
+    g = torch.Generator().manual_seed(12)
+    rad = 20.0 + 10.0 * torch.rand(nb, generator=g, dtype=torch.float64)
+    geom = ct.GeometryBatch.from_shapes([("circle", float(r)) for r in rad], B).to(DEV)
+    p = torch.zeros(B, nb, 3, dtype=torch.float64)
+    p[:, :, 1] = torch.arange(nb, dtype=torch.float64) * 48.0 + 4.0 * torch.rand(B, nb, generator=g, dtype=torch.float64)
+    p[:, :, 2] = 10.0 * torch.rand(B, nb, generator=g, dtype=torch.float64)
+    pg = p.to(DEV)
+    cb = ct.find_contacts(geom, pg, maxc=6, eps=30.0)
+    cnt = cb.count.cpu()
+    assert int(cnt.min()) >= 2
+    gn, g1, g2 = [torch.randn(B, 6, 2, generator=g).to(DEV) for _ in range(3)]
+    dp = ct.contact_frame_backward(geom, pg, cb, gn, g1, g2).cpu()
+    pt = p.clone().requires_grad_(True)
+    loss = 0.0
+    i1, i2 = cb.c_i1.cpu().long(), cb.c_i2.cpu().long()
+    for b in range(B):
+        for c in range(int(cnt[b])):
+            a, o = int(i1[b, c]), int(i2[b, c])
+            d = pt[b, a, 1:] - pt[b, o, 1:]
+            dist = d.norm(); n = d / dist; pen = rad[a] + rad[o] - dist
+            c1, c2 = -n * (rad[a] - pen / 2), n * (rad[o] - pen / 2)
+            loss = loss + (n * gn[b, c].double().cpu()).sum() + (c1 * g1[b, c].double().cpu()).sum() + (c2 * g2[b, c].double().cpu()).sum()
+            assert float((n.detach().float() - cb.c_n[b, c].cpu()).abs().max()) < 1e-6      # same record the kernel produced
+    loss.backward()
+    assert float((dp - pt.grad).abs().max()) <= 1e-12 * max(1.0, float(pt.grad.abs().max()))
+
+
+def test_rollout_gradient_matches_the_reference_autograd():
+    """A batched `grad_demo` (demos/grad_demo.py:19-83): B = 1024 scenes of three balls, 36 `ContactWorld.step(differentiable=
+    True)` each, loss = |target - ball| after the roll-out, back-propagated to the force that pushed the first ball for
+    0.1 s.  Final poses, losses and d(loss)/d(force) against what the UNMODIFIED reference produced for the same eight
+    scenes by its own autograd (tests/golden/rollout_grad.npz, oracle/make_golden_rollout.py): 1e-4."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    rep = 128
+    world, force0 = _rollout_world(d, rep)
+    nsteps = int(d["nsteps"])
+    ncs = []
+    for _ in range(nsteps):
+        world.step(differentiable=True)
+        ncs.append(world.contacts.count.clone())
+    a, b = [int(i) for i in d["loss_bodies"]]
+    pos = world.p[:, :, 1:]
+    loss = (pos[:, a] - pos[:, b]).norm(dim=1)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    # same trajectory: clocks (dt halving), contact counts, final poses
+    assert np.abs(world.t.cpu().numpy()[::rep] - d["t"][:, -1]).max() < 1e-12
+    assert (torch.stack(ncs, 1).cpu().numpy()[::rep] == d["ncontacts"]).all()
+    pf = world.p.detach().cpu().numpy()[::rep]
+    assert np.abs(pf - d["p_final"]).max() <= 1e-4, np.abs(pf - d["p_final"]).max()
+    ls = loss.detach().cpu().numpy()[::rep]
+    assert np.abs(ls - d["loss"]).max() <= 1e-5 * np.abs(d["loss"]).max()
+    gr = force0.grad.cpu().numpy()
+    assert np.abs(gr.reshape(-1, rep, 3) - gr[::rep][:, None]).max() == 0.0          # replicas are bitwise replicas
+    ref = d["grad"]
+    err = np.abs(gr[::rep] - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print("roll-out gradient: worst relative error", err.max(), "per scene", np.array2string(err, precision=2))
+    assert err.max() <= 1e-4, err
