@@ -234,6 +234,21 @@ int lcp_move_find_contacts_f64(int B, int nb, int maxc,
                                int32_t* c_i1, int32_t* c_i2, int32_t* count, double* max_pen,
                                double* dt_used, double* t, int32_t* trials, void* stream);
 
+/* Replaces World.Je (physics/world.py:156-170) over the joints' J() (physics/constraints.py:13-217) and Joint.move /
+ * update_pos (constraints.py:39-50) for B scenes: joints whose Jacobian follows the pose.
+ *   jtype[B,nj]: 1 Joint (revolute, 2 rows)  2 FixedJoint (3 rows)  3 XConstraint  4 YConstraint  5 RotConstraint (1 row each)
+ *                6 TotalConstraint (3 rows)  0 empty;   jb1 / jb2 [B,nj] body indices (jb2 = -1: no second body)
+ *   jr1 / jrot1 [B,nj]: polar coordinates of a Joint's anchor relative to body 1 (cart_to_polar with the positive-angle rule,
+ *                utils.py:75-82); jrot1 is state: with `v` != NULL it is first advanced by vscale * v[body1][0] * dt_k,
+ *                dt_k = dt_scene[k] (NULL: `dt`) - the dt the scene's step accepted (world.py:88-107 restores the joints before
+ *                every retry); vscale = 1 for the dynamics move, 0.5 for the post-stabilisation move (world.py:112).
+ *   p[B,nb,3] the pose the Jacobian is wanted at;  out: Je[B,e,3 nb] float32, e = the rows the joint list adds up to. */
+int lcp_joint_jacobian_f64(int B, int nb, int nj, int e,
+                           const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                           const double* jr1, double* jrot1, const double* p,
+                           const float* v, const double* dt_scene, double dt, double vscale,
+                           float* Je, void* stream);
+
 /* Backward of the contact frame with respect to the poses: what the reference obtains by autograd through
  * DiffContactHandler (physics/contacts.py:57-205, every operation of the contact tuple is a differentiable torch op), needed
  * to back-propagate through a roll-out (demos/grad_demo.py:45-50, experiments/inference.py:55-61).  Implemented for the

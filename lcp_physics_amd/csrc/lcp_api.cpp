@@ -330,6 +330,14 @@ int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, con
   return lcp::contacts_launch(P, stream);
 }
 
+int lcp_joint_jacobian_f64(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                           const double* jr1, double* jrot1, const double* p, const float* v, const double* dt_scene, double dt,
+                           double vscale, float* Je, void* stream) {
+  if (B <= 0 || nb <= 0 || nj <= 0 || e <= 0) return LCP_E_BADARG;
+  if (!jtype || !jb1 || !jb2 || !jr1 || !jrot1 || !p || !Je) return LCP_E_BADARG;
+  return lcp::joint_jacobian_launch(B, nb, nj, e, jtype, jb1, jb2, jr1, jrot1, p, v, dt_scene, dt, vscale, Je, stream);
+}
+
 int lcp_contact_frame_backward_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
                                    const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
                                    const float* g_p1, const float* g_p2, double* dp, void* stream) {

@@ -452,7 +452,64 @@ __global__ void __launch_bounds__(64) lcp_contact_frame_backward_kernel(int B, i
   }
 }
 
+// ---------------------------------------------------------------- joints whose Jacobian follows the pose
+// World.Je (world.py:156-170) over the joints' J() and Joint.move (constraints.py:13-217) for B scenes; one thread per scene.
+//   jtype: 1 Joint (revolute, 2 rows; anchor = body1.pos + r1 (cos rot1, sin rot1), constraints.py:13-50)
+//          2 FixedJoint (3 rows, :56-92)   3 XConstraint   4 YConstraint   5 RotConstraint (1 row each, :95-172)
+//          6 TotalConstraint (3 rows, :175-192)   0 empty slot
+// With `v`: first rot1 += vscale * v[body1][0] * dt_k (Joint.move :39-43; dt_k = the dt the scene's step accepted - the
+// retry loop of world.py:88-107 restores rot1 before every trial, so only the accepted dt counts), then Je at pose p.
+__global__ void __launch_bounds__(64) lcp_joint_jacobian_kernel(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1,
+                                                                const int32_t* jb2, const double* jr1, double* jrot1, const double* p,
+                                                                const float* v, const double* dt_scene, double dt, double vscale, float* Je) {
+  const int scene = blockIdx.x * 64 + threadIdx.x;
+  if (scene >= B) return;
+  const int nz = 3 * nb;
+  float* J = Je + (size_t)scene * e * nz;
+  for (int i = 0; i < e * nz; ++i) J[i] = 0.0f;
+  const double* q = p + (size_t)scene * nb * 3;
+  const double dtk = dt_scene ? dt_scene[scene] : dt;
+  int row = 0;
+  for (int k = 0; k < nj; ++k) {
+    const size_t o = (size_t)scene * nj + k;
+    const int t = jtype[o], b1 = jb1[o], b2 = jb2[o];
+    if (t == 1 || t == 2) {
+      double p1x = 0, p1y = 0;
+      if (t == 1) {
+        double rot = jrot1[o];
+        if (v) { rot += vscale * (double)v[((size_t)scene * nb + b1) * 3] * dtk; jrot1[o] = rot; }
+        p1x = jr1[o] * cos(rot); p1y = jr1[o] * sin(rot);                          // polar_to_cart (utils.py:85-90)
+      }
+      if (row + 1 < e) {
+        J[(size_t)row * nz + 3 * b1] = (float)(-p1y); J[(size_t)row * nz + 3 * b1 + 1] = 1.0f;
+        J[(size_t)(row + 1) * nz + 3 * b1] = (float)p1x; J[(size_t)(row + 1) * nz + 3 * b1 + 2] = 1.0f;
+        if (b2 >= 0) {
+          const double p2x = q[b1 * 3 + 1] + p1x - q[b2 * 3 + 1], p2y = q[b1 * 3 + 2] + p1y - q[b2 * 3 + 2];
+          J[(size_t)row * nz + 3 * b2] = (float)p2y; J[(size_t)row * nz + 3 * b2 + 1] = -1.0f;
+          J[(size_t)(row + 1) * nz + 3 * b2] = (float)(-p2x); J[(size_t)(row + 1) * nz + 3 * b2 + 2] = -1.0f;
+        }
+      }
+      row += 2;
+      if (t == 2) {
+        if (row < e) { J[(size_t)row * nz + 3 * b1] = 1.0f; if (b2 >= 0) J[(size_t)row * nz + 3 * b2] = -1.0f; }
+        row += 1;
+      }
+    } else if (t == 3) { if (row < e) J[(size_t)row * nz + 3 * b1 + 1] = 1.0f; row += 1; }
+    else if (t == 4) { if (row < e) J[(size_t)row * nz + 3 * b1 + 2] = 1.0f; row += 1; }
+    else if (t == 5) { if (row < e) J[(size_t)row * nz + 3 * b1] = 1.0f; row += 1; }
+    else if (t == 6) { if (row + 2 < e) for (int i = 0; i < 3; ++i) J[(size_t)(row + i) * nz + 3 * b1 + i] = 1.0f; row += 3; }
+  }
+}
+
 }  // namespace ct
+
+int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2, const double* jr1,
+                          double* jrot1, const double* p, const float* v, const double* dt_scene, double dt, double vscale, float* Je,
+                          void* stream) {
+  hipLaunchKernelGGL(ct::lcp_joint_jacobian_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, nj, e, jtype, jb1, jb2,
+                     jr1, jrot1, p, v, dt_scene, dt, vscale, Je);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
 
 int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
                                   const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,

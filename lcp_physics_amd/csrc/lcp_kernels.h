@@ -134,6 +134,9 @@ int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* st
 
 // narrow-phase contact generation + position update - lcp_contacts.hip
 int contacts_launch(const ContactArgs& P, void* stream);
+int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2, const double* jr1,
+                          double* jrot1, const double* p, const float* v, const double* dt_scene, double dt, double vscale, float* Je,
+                          void* stream);
 int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
                                   const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
                                   const float* g_p1, const float* g_p2, double* dp, void* stream);

@@ -374,7 +374,7 @@ class ContactWorld:
 
     def __init__(self, geom, p, v, Mdiag, f, rest, fric, Je=None, dt=1.0 / 30, eps=0.1, tol=1e-6,
                  strict_no_penetration=True, maxc=16, max_iter=10, compute="f64", solver_eps=1e-12,
-                 not_improved_lim=3, max_trials=64, check=True, post_stab=False, force_fn=None):
+                 not_improved_lim=3, max_trials=64, check=True, post_stab=False, force_fn=None, joints=None):
         from . import contacts as _contacts
         self.post_stab = bool(post_stab)
         # `force_fn(t) -> f [B,nb,3] float32` replaces the constant force: the batched form of the reference's
@@ -383,6 +383,7 @@ class ContactWorld:
         # (e.g. `torch.where(t < 0.1, ...)`), no host synchronisation.
         self.force_fn = force_fn
         self._ps_out = self._ps_ws = None
+        self._Je_spare = None
         self._phase, self._graphs = 0, {}
         self._contacts_mod = _contacts
         self.geom = geom
@@ -391,8 +392,18 @@ class ContactWorld:
         self.p = p.to(dtype=torch.float64).contiguous()
         self.v, self.Mdiag, self.f, self.rest, self.fric = f32(v), f32(Mdiag), f32(f), f32(rest), f32(fric)
         self.B, self.nb = self.p.shape[0], self.p.shape[1]
-        self.e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
-        self.Je = f32(Je) if self.e else None
+        # `joints` (a `joints.JointSet`): joints whose Jacobian follows the pose - the reference's revolute `Joint` and
+        # `FixedJoint` (constraints.py:13-92) next to the X / Y / Rot / Total constraints; Je is then rebuilt on the device
+        # after every move (`lcp_joint_jacobian_f64`).  `Je`: a constant Jacobian instead.
+        self.joints = joints
+        if joints is not None:
+            if Je is not None:
+                raise ValueError("give either a constant Je or a JointSet")
+            self.e = joints.e
+            self.Je = joints.jacobian(self.p)
+        else:
+            self.e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+            self.Je = f32(Je) if self.e else None
         self.dt, self.eps, self.tol, self.strict = float(dt), float(eps), float(tol), bool(strict_no_penetration)
         self.maxc, self.max_iter, self.compute = int(maxc), int(max_iter), compute
         self.solver_eps, self.lim, self.max_trials = solver_eps, not_improved_lim, max_trials
@@ -485,6 +496,8 @@ class ContactWorld:
         p_lin = p_start + v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
         self.p = p_lin + (cb.p_out - p_lin).detach()
         self.v = v_new
+        if self.joints is not None:                                        # (the joint Jacobian is a constant of the backward)
+            self.Je = self.joints.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
         ret = dict(out)
         ret["v_new"] = v_new
         return ret
@@ -506,6 +519,9 @@ class ContactWorld:
                                                   strict=self.strict, dt_floor=self.dt / 4,
                                                   max_trials=self.max_trials, t=self.t, out=cb)
         self.p, cb.p_out = cb.p_out, self.p                              # accepted pose becomes the state (double buffer)
+        if self.joints is not None:                                      # joint.move(dt) + the Jacobian at the new pose (world.py:91-92)
+            self._Je_spare = self.joints.jacobian(self.p, v=self.v, dt_scene=cb.dt_used, out=self._Je_spare)
+            self.Je, self._Je_spare = self._Je_spare, self.Je
         if self.post_stab:                                               # world.py:109-121
             # the engine's defaults here (engines.py:114 `self.lcp_solver()`), not the dynamics solve's settings;
             # the pose is corrected in place (every thread reads and writes its own entry)
@@ -513,6 +529,9 @@ class ContactWorld:
                                     self.Je, p=self.p, dt_scene=cb.dt_used, dt=self.dt, p_out=self.p,
                                     compute=self.compute, ws=self._ps_ws, out=self._ps_out)
             self._ps_ws, self._ps_out = ps["ws"], ps
+            if self.joints is not None:                                  # the joints follow the correction move too (world.py:112-116)
+                self._Je_spare = self.joints.jacobian(self.p, v=ps["dp"], dt_scene=cb.dt_used, vscale=0.5, out=self._Je_spare)
+                self.Je, self._Je_spare = self._Je_spare, self.Je
             self._contacts_mod.find_contacts(self.geom, self.p, maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
             out["post_stab"] = ps
         ret = dict(out)

@@ -1,0 +1,97 @@
+"""Joints of a batched world (`physics/constraints.py:13-217` of the reference), evaluated on the device.
+
+The reference's `World.Je()` (`world.py:156-170`) asks every joint for its Jacobian blocks at the current pose
+(`Joint.J()`, `FixedJoint.J()`, the X / Y / Rot / Total constraints) and `step_dt` moves the joints with the bodies
+(`Joint.move`, `world.py:91-92,102-107`).  `JointSet` is that state for B scenes, `JointSet.jacobian()` one launch of
+`lcp_joint_jacobian_f64` (include/lcp_hip.h).  No CPU fallback.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from .. import _lib
+
+JOINT, FIXED, XCON, YCON, ROTCON, TOTAL = 1, 2, 3, 4, 5, 6
+ROWS = {JOINT: 2, FIXED: 3, XCON: 1, YCON: 1, ROTCON: 1, TOTAL: 3}
+_NAMES = {"joint": JOINT, "fixed": FIXED, "x": XCON, "y": YCON, "rot": ROTCON, "total": TOTAL}
+
+
+@dataclass
+class JointSet:
+    """jtype, jb1, jb2 [B,nj] int32; jr1, jrot1 [B,nj] float64 (polar coordinates of a `Joint`'s anchor relative to body 1;
+    `jrot1` is state, advanced with the bodies); `e` = number of equality rows."""
+    jtype: torch.Tensor
+    jb1: torch.Tensor
+    jb2: torch.Tensor
+    jr1: torch.Tensor
+    jrot1: torch.Tensor
+    e: int
+
+    @property
+    def pose_dependent(self):
+        return bool(((self.jtype == JOINT) | (self.jtype == FIXED)).any())
+
+    def to(self, device):
+        mv = lambda t: t.to(device).contiguous()
+        return JointSet(mv(self.jtype), mv(self.jb1), mv(self.jb2), mv(self.jr1), mv(self.jrot1), self.e)
+
+    @staticmethod
+    def from_list(joints, p0, B=1):
+        """`joints`: [("joint", b1, b2_or_None, (x, y)), ("fixed", b1, b2), ("x", b), ("y", b), ("rot", b), ("total", b)];
+        `p0` [nb,3] (or [B,nb,3]) the poses the joints are created at (`Joint.__init__`: pos1 = pos - body1.pos, polar
+        coordinates with the positive-angle rule, constraints.py:21-23, utils.py:75-82).  Replicated over B scenes."""
+        p0 = torch.as_tensor(p0, dtype=torch.float64)
+        if p0.dim() == 2:
+            p0 = p0.unsqueeze(0).expand(B, -1, -1)
+        B = p0.shape[0]
+        nj = len(joints)
+        jtype = torch.zeros(B, nj, dtype=torch.int32)
+        jb1 = torch.zeros(B, nj, dtype=torch.int32)
+        jb2 = torch.full((B, nj), -1, dtype=torch.int32)
+        jr1 = torch.zeros(B, nj, dtype=torch.float64)
+        jrot1 = torch.zeros(B, nj, dtype=torch.float64)
+        e = 0
+        for k, j in enumerate(joints):
+            t = _NAMES[j[0]]
+            jtype[:, k], jb1[:, k] = t, int(j[1])
+            if t in (JOINT, FIXED) and j[2] is not None:
+                jb2[:, k] = int(j[2])
+            if t == JOINT:
+                d = torch.tensor(j[3], dtype=torch.float64).unsqueeze(0) - p0[:, int(j[1]), 1:]
+                jr1[:, k] = d.norm(dim=1)
+                th = torch.atan2(d[:, 1], d[:, 0])
+                jrot1[:, k] = torch.where(th < 0, th + 2 * math.pi, th)
+            e += ROWS[t]
+        return JointSet(jtype, jb1, jb2, jr1, jrot1, e)
+
+    @staticmethod
+    def from_arrays(jtype, jb1, jb2, jr1, jrot1, B):
+        """The encoding itself (what oracle/make_golden_world.py records), replicated over B scenes."""
+        rep = lambda a, dt_: torch.as_tensor(a).to(dt_).reshape(1, -1).repeat(B, 1).contiguous()
+        e = sum(ROWS[int(t)] for t in torch.as_tensor(jtype).tolist())
+        return JointSet(rep(jtype, torch.int32), rep(jb1, torch.int32), rep(jb2, torch.int32), rep(jr1, torch.float64),
+                        rep(jrot1, torch.float64), e)
+
+    def jacobian(self, p, v=None, dt_scene=None, dt=0.0, vscale=1.0, out=None):
+        """Je [B,e,3nb] float32 at pose `p` [B,nb,3] float64.  With `v` the revolute joints are moved first
+        (`rot1 += vscale v[body1][0] dt`, dt per scene from `dt_scene` when given)."""
+        lib = _lib.load()
+        B, nb = p.shape[0], p.shape[1]
+        _lib.require_gpu_tensor(p, "p", torch.float64)
+        for name, t, dt_ in (("jtype", self.jtype, torch.int32), ("jb1", self.jb1, torch.int32), ("jb2", self.jb2, torch.int32),
+                             ("jr1", self.jr1, torch.float64), ("jrot1", self.jrot1, torch.float64)):
+            _lib.require_gpu_tensor(t, name, dt_)
+        if v is not None:
+            _lib.require_gpu_tensor(v, "v", torch.float32)
+        if dt_scene is not None:
+            _lib.require_gpu_tensor(dt_scene, "dt_scene", torch.float64)
+        if out is None:
+            out = torch.empty(B, self.e, 3 * nb, dtype=torch.float32, device=p.device)
+        P = _lib.ptr
+        with torch.cuda.device(p.device):
+            rc = lib.lcp_joint_jacobian_f64(B, nb, self.jtype.shape[1], self.e, P(self.jtype), P(self.jb1), P(self.jb2), P(self.jr1),
+                                            P(self.jrot1), P(p), P(v), P(dt_scene), float(dt), float(vscale), P(out),
+                                            _lib.stream_ptr(p.device))
+        _lib.check(rc, "lcp_joint_jacobian_f64")
+        return out

@@ -65,7 +65,41 @@ def _scenes():
         a.add_force(Gravity(g=100))
         return [fl, a], [j], 45, True
 
+    def chain():
+        # tests/test_demos.py:76-100 (testChain), five links: a pinned link, revolute `Joint`s whose Jacobian follows the pose
+        # (constraints.py:13-53), a constant pull on the last link and a projectile pushed by a force that stops at t = 0.1
+        # (forces.py:14-18 hor_impulse)
+        from lcp_physics.physics.constraints import Joint, XConstraint, YConstraint
+        from lcp_physics.physics.forces import ExternalForce, down_force, hor_impulse
+        bodies, joints = [], []
+        r = Rect([300, 50], [20, 60])
+        bodies.append(r)
+        joints.append(XConstraint(r))
+        joints.append(YConstraint(r))
+        for i in range(1, 5):
+            r = Rect([300, 50 + 50 * i], [20, 60])
+            bodies.append(r)
+            joints.append(Joint(bodies[-1], bodies[-2], [300, 25 + 50 * i]))
+            bodies[-1].add_no_contact(bodies[-2])
+        bodies[-1].add_force(ExternalForce(down_force, multiplier=100))
+        c = Circle([183.7, 240], 20, restitution=1)          # (not a multiple of the step: no exactly-touching pose)
+        bodies.append(c)
+        c.add_force(ExternalForce(hor_impulse, multiplier=1000))
+        return bodies, joints, 60, True
+
+    def welded():
+        # two boxes welded by a FixedJoint (constraints.py:56-92) tumbling onto the floor
+        from lcp_physics.physics.constraints import FixedJoint
+        fl, j = floor()
+        a = Rect([0.3, 470, 430], [50, 30], vel=[0.5, 10, 0])
+        b = Rect([0.3, 520, 445.5], [50, 30])
+        for x in (a, b):
+            x.add_force(Gravity(g=100))
+        a.add_no_contact(b)
+        return [fl, a, b], [j, FixedJoint(a, b)], 40, True
+
     return dict(ball_floor=ball_floor, stack3=stack3, mixed=mixed(True), mixed_nonstrict=mixed(False), tumble=tumble,
+                chain=chain, welded=welded,
                 # the same scenes with post-stabilisation switched on (world.py:109-121, engines.py:80-116)
                 stack3_poststab=stack3, mixed_poststab=mixed(True), tumble_poststab=tumble)
 
@@ -88,7 +122,15 @@ def record(name, make):
                rest=np.array([float(b.restitution) for b in bodies]),
                fric=np.array([float(b.fric_coeff) for b in bodies]),
                Je=world.Je().numpy().copy())
-    P, V, T, NC, DP, PMID = [], [], [], [], [], []
+    # joints as a batched world needs them (constraints.py): type, bodies, and for `Joint` the polar coordinates of the anchor
+    from lcp_physics.physics import constraints as C_
+    jt = {C_.Joint: 1, C_.FixedJoint: 2, C_.XConstraint: 3, C_.YConstraint: 4, C_.RotConstraint: 5, C_.TotalConstraint: 6}
+    rec.update(jtype=np.array([jt[type(j[0])] for j in world.joints]),
+               jb1=np.array([j[1] for j in world.joints]), jb2=np.array([-1 if j[2] is None else j[2] for j in world.joints]),
+               jr1=np.array([float(j[0].r1) if isinstance(j[0], C_.Joint) else 0.0 for j in world.joints]),
+               jrot1=np.array([float(j[0].rot1) if isinstance(j[0], C_.Joint) else 0.0 for j in world.joints]),
+               no_contact=np.array([[i, k] for i, b in enumerate(bodies) for k, o in enumerate(bodies) if o.geom in b.geom.no_contact]).reshape(-1, 2))
+    P, V, T, NC, DP, PMID, FT, JE = [], [], [], [], [], [], [], []
     if post_stab:
         # per step: the engine's post_stabilization output and the pose it was computed at (the pose before the
         # post-stabilisation move) - lets the test pin that solve step by step on identical inputs.  The engine INSTANCE
@@ -124,10 +166,13 @@ def record(name, make):
     p, v = snap()
     P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
     for _ in range(nsteps):
+        FT.append(world.apply_forces(world.t).reshape(nb, 3).detach().numpy().copy())     # the force the step's solve sees
+        JE.append(world.Je().detach().numpy().copy())                                     # ... and its joint Jacobian
         world.step()
         p, v = snap()
         P.append(p); V.append(v); T.append(float(world.t)); NC.append(len(world.contacts))
-    rec.update(p=np.stack(P), v=np.stack(V), t=np.array(T), ncontacts=np.array(NC))
+    JE.append(world.Je().detach().numpy().copy())
+    rec.update(p=np.stack(P), v=np.stack(V), t=np.array(T), ncontacts=np.array(NC), f_t=np.stack(FT), Je_t=np.stack(JE))
     if post_stab:
         rec.update(dp=np.stack(DP), p_mid=np.stack(PMID))
         cap = max(1, max(l[1].shape[0] for l in LCPS))

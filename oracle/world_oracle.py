@@ -16,8 +16,11 @@ It is composed from the two oracles that are pinned on reference outputs by them
 `World` (`tests/golden/world_traj.npz`, made by `oracle/make_golden_world.py`) in
 `tests/test_world_oracle.py`.
 
-Restrictions (same as the device path it checks): joints must have a constant Jacobian
-(TotalConstraint / XConstraint / YConstraint / RotConstraint rows - `constraints.py`), forces are constant.
+  constraints.py:13-217, world.py:156-170  the joints' J() / move() and World.Je -> `joint_jacobian`, `joints_move`
+
+Joints: either a constant `Je`, or a `joints` dict (jtype, jb1, jb2, jr1, jrot1 - the encoding of
+`lcp_joint_jacobian_f64`) whose Jacobian follows the pose: `Joint` (revolute), `FixedJoint`, X / Y / Rot / Total
+constraints.  Forces: one array per call (the caller evaluates `force_func(t)`, forces.py:29-48).
 """
 import numpy as np
 import torch
@@ -118,14 +121,81 @@ def move_and_find(shapes, p_start, v, dt, eps=0.1, tol=1e-6, strict=True, dt_flo
     return p, contacts, dt, trials
 
 
+JOINT, FIXED, XCON, YCON, ROTCON, TOTAL = 1, 2, 3, 4, 5, 6
+JOINT_ROWS = {JOINT: 2, FIXED: 3, XCON: 1, YCON: 1, ROTCON: 1, TOTAL: 3}
+
+
+def joint_rows(jtype):
+    return int(sum(JOINT_ROWS[int(t)] for t in jtype))
+
+
+def joint_jacobian(joints, p):
+    """World.Je (world.py:156-170) over the joints' J() (constraints.py): [e, 3 nb] for pose p [nb,3] = (rot, x, y).
+    `Joint` (:13-36): pos1 = r1 (cos rot1, sin rot1) (polar_to_cart, utils.py:85-90), pos2 = body1.pos + pos1 - body2.pos,
+    J1 = [[-pos1_y, 1, 0], [pos1_x, 0, 1]], J2 = [[pos2_y, -1, 0], [-pos2_x, 0, -1]];  `FixedJoint` (:56-79): pos1 = 0,
+    pos2 = body1.pos - body2.pos, the same two rows plus [1, 0, 0] / [-1, 0, 0];  X / Y / Rot constraints (:95-172): one unit
+    row;  TotalConstraint (:175-192): the 3 x 3 identity."""
+    p = np.asarray(p, dtype=np.float64)
+    nb = p.shape[0]
+    Je = np.zeros((joint_rows(joints["jtype"]), 3 * nb))
+    row = 0
+    for k, t in enumerate(joints["jtype"]):
+        t, b1, b2 = int(t), int(joints["jb1"][k]), int(joints["jb2"][k])
+        if t in (JOINT, FIXED):
+            pos1 = joints["jr1"][k] * np.array([np.cos(joints["jrot1"][k]), np.sin(joints["jrot1"][k])]) if t == JOINT else np.zeros(2)
+            Je[row, 3 * b1:3 * b1 + 3] = [-pos1[1], 1, 0]
+            Je[row + 1, 3 * b1:3 * b1 + 3] = [pos1[0], 0, 1]
+            if b2 >= 0:
+                pos2 = p[b1, 1:] + pos1 - p[b2, 1:]
+                Je[row, 3 * b2:3 * b2 + 3] = [pos2[1], -1, 0]
+                Je[row + 1, 3 * b2:3 * b2 + 3] = [-pos2[0], 0, -1]
+            if t == FIXED:
+                Je[row + 2, 3 * b1] = 1
+                if b2 >= 0:
+                    Je[row + 2, 3 * b2] = -1
+        elif t == XCON:
+            Je[row, 3 * b1 + 1] = 1
+        elif t == YCON:
+            Je[row, 3 * b1 + 2] = 1
+        elif t == ROTCON:
+            Je[row, 3 * b1] = 1
+        elif t == TOTAL:
+            Je[row:row + 3, 3 * b1:3 * b1 + 3] = np.eye(3)
+        row += JOINT_ROWS[t]
+    return Je
+
+
+def joints_move(joints, v, dt):
+    """Joint.move (constraints.py:39-43): rot1 += body1.v[0] dt, from the rot1 the step started with (world.py:84,102-107 reset
+    it before every retry).  Returns a new joints dict."""
+    out = dict(joints)
+    rot = np.array(joints["jrot1"], dtype=np.float64).copy()
+    for k, t in enumerate(joints["jtype"]):
+        if int(t) == JOINT:
+            rot[k] = rot[k] + np.asarray(v, dtype=np.float64)[int(joints["jb1"][k]), 0] * dt
+    out["jrot1"] = rot
+    return out
+
+
 def step_dt(shapes, p, v, contacts, Mdiag, f, rest, fric, Je, dt, eps=0.1, tol=1e-6, strict=True, max_iter=10,
-            no_contact=(), post_stab=False):
-    """world.py:83-122.  Returns (p_new, v_new, contacts_new, dt_used, trials)."""
+            no_contact=(), post_stab=False, joints=None):
+    """world.py:83-122.  Returns (p_new, v_new, contacts_new, dt_used, trials) - and the moved joints as a sixth item when
+    `joints` (pose-dependent Jacobian) is given instead of a constant `Je`."""
+    if joints is not None:
+        Je = joint_jacobian(joints, p)
     new_v = solve_dynamics(Mdiag, v, f, dt, contacts, rest, fric, Je, max_iter=max_iter)
     p_new, cs, dt_used, trials = move_and_find(shapes, p, new_v, dt, eps=eps, tol=tol, strict=strict,
                                                dt_floor=dt / 4, no_contact=no_contact)
+    if joints is not None:
+        joints = joints_move(joints, new_v, dt_used)
     if post_stab:                                                                # :109-121
+        if joints is not None:
+            Je = joint_jacobian(joints, p_new)
         dp = post_stabilization(Mdiag, new_v, cs, rest, Je) / 2
         p_new = p_new + dp * dt_used
+        if joints is not None:
+            joints = joints_move(joints, dp, dt_used)
         cs = C.find_contacts(bodies_at(shapes, p_new), eps=eps, no_contact=no_contact)
+    if joints is not None:
+        return p_new, new_v, cs, dt_used, trials, joints
     return p_new, new_v, cs, dt_used, trials

@@ -391,13 +391,36 @@ def test_contact_world_follows_reference_trajectory(name):
     B = 5                                                        # replicas (a wave holds 4 scenes: exercises the tail too)
     geom = _geom([shapes] * B)
     rep = lambda a, dt_: torch.tensor(np.broadcast_to(a, (B,) + a.shape).copy(), dtype=dt_, device=DEV)
+    nb = len(shapes)
+    if rec["no_contact"].size:                                  # Body.add_no_contact (bodies.py:104-106)
+        nocon = torch.zeros(B, nb, nb, dtype=torch.uint8, device=DEV)
+        for i, j in rec["no_contact"].tolist():
+            nocon[:, i, j] = 1
+        geom.no_contact = nocon
+    # joints: a revolute `Joint` / `FixedJoint` needs the Jacobian that follows the pose (constraints.py:13-92) - a JointSet;
+    # the constant-Jacobian records keep handing over the recorded Je
+    kw = {}
+    if any(int(x) in (1, 2) for x in rec["jtype"]):
+        from lcp_physics_amd.physics.joints import JointSet
+        kw["joints"] = JointSet.from_arrays(rec["jtype"], rec["jb1"], rec["jb2"], rec["jr1"], rec["jrot1"], B).to(DEV)
+    else:
+        kw["Je"] = rep(rec["Je"], torch.float32)
+    # forces: a time-dependent ExternalForce (forces.py:14-18,29-48) is replayed from the recorded f(t) of every step
+    f_t = torch.tensor(rec["f_t"], dtype=torch.float32, device=DEV)
+    if float(np.abs(rec["f_t"] - rec["f_t"][0]).max()) > 0:
+        step_of = {"k": 0}
+        kw["force_fn"] = lambda t: f_t[step_of["k"]].unsqueeze(0).expand(B, -1, -1)
     world = ContactWorld(geom, rep(rec["p"][0], torch.float64), rep(rec["v"][0], torch.float32),
                          rep(rec["Mdiag"], torch.float32), rep(rec["f"], torch.float32), rep(rec["rest"], torch.float32),
-                         rep(rec["fric"], torch.float32), Je=rep(rec["Je"], torch.float32), dt=float(rec["dt"]),
-                         eps=float(rec["eps"]), tol=float(rec["tol"]), strict_no_penetration=bool(rec["strict"]), maxc=8)
+                         rep(rec["fric"], torch.float32), dt=float(rec["dt"]),
+                         eps=float(rec["eps"]), tol=float(rec["tol"]), strict_no_penetration=bool(rec["strict"]), maxc=8, **kw)
     assert world.contacts.count.cpu().tolist() == [int(rec["ncontacts"][0])] * B
     worst_p = worst_v = 0.0
     for k in range(1, len(rec["t"])):
+        if "force_fn" in kw:
+            step_of["k"] = k - 1
+        if "joints" in kw:                                       # World.Je() at the pose the step starts from
+            assert float((world.Je[0].double().cpu() - torch.tensor(rec["Je_t"][k - 1])).abs().max()) < 1e-4, (name, k, "Je")
         world.step()
         t = world.t.cpu().numpy()
         assert np.abs(t - rec["t"][k]).max() < 1e-12, (name, k, "t", t, rec["t"][k])

@@ -16,7 +16,10 @@ def test_world_oracle_follows_reference_trajectory(name):
     shapes = shapes_of(rec)
     dt, strict = float(rec["dt"]), bool(rec["strict"])
     p, v, t = rec["p"][0].copy(), rec["v"][0].copy(), 0.0
-    contacts = C.find_contacts(W.bodies_at(shapes, p), eps=float(rec["eps"]))          # World.__init__ (world.py:65-66)
+    nocon = [tuple(x) for x in rec["no_contact"].tolist()]
+    # records with a revolute `Joint` / `FixedJoint` follow the pose with their Jacobian (constraints.py:13-92)
+    joints = {k: rec[k] for k in ("jtype", "jb1", "jb2", "jr1", "jrot1")} if any(int(x) in (1, 2) for x in rec["jtype"]) else None
+    contacts = C.find_contacts(W.bodies_at(shapes, p), eps=float(rec["eps"]), no_contact=nocon)   # World.__init__ (world.py:65-66)
     assert len(contacts) == int(rec["ncontacts"][0])
     halved = 0
     # Post-stabilisation solves a frictionless LCP whose right-hand side is ~0 for resting contacts (engines.py:86-89):
@@ -26,10 +29,16 @@ def test_world_oracle_follows_reference_trajectory(name):
     # step on identical inputs in `test_post_stabilization_matches_reference_per_step`.
     p_atol = 2e-5 if bool(rec["post_stab"]) else 1e-6
     for k in range(1, len(rec["t"])):
-        p, v, contacts, dt_used, trials = W.step_dt(shapes, p, v, contacts, rec["Mdiag"], rec["f"], rec["rest"],
-                                                    rec["fric"], rec["Je"], dt, eps=float(rec["eps"]),
-                                                    tol=float(rec["tol"]), strict=strict,
-                                                    post_stab=bool(rec["post_stab"]))
+        if joints is not None:
+            assert np.abs(W.joint_jacobian(joints, p) - rec["Je_t"][k - 1]).max() < 1e-9, (name, k, "Je")
+        else:
+            assert np.abs(rec["Je_t"][k - 1] - rec["Je"]).max() == 0.0                 # a constant Jacobian really is one
+        out = W.step_dt(shapes, p, v, contacts, rec["Mdiag"], rec["f_t"][k - 1], rec["rest"], rec["fric"], rec["Je"], dt,
+                        eps=float(rec["eps"]), tol=float(rec["tol"]), strict=strict, post_stab=bool(rec["post_stab"]),
+                        no_contact=nocon, joints=joints)
+        p, v, contacts, dt_used, trials = out[:5]
+        if joints is not None:
+            joints = out[5]
         t += dt_used
         halved += trials > 1
         assert abs(t - rec["t"][k]) < 1e-12, (name, k, "t")
