@@ -18,6 +18,7 @@
 // Served through lcp_solve_dynamics_f32 (forward) and lcp_step_backward_f32 (gradients w.r.t. the physical inputs of the
 // step); the workspace it leaves is its own (W tiles + the best iterate), not the dense LCPFunction backward's.
 #include "lcp_wave_common.h"
+#include "lcp_big_dpp.h"
 
 namespace lcp {
 namespace big {
@@ -503,76 +504,54 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
       BIG_TICK(5)                                                             // (profile: W load + diagonal)
       auto sync = [&]() { if constexpr (NT == 64) wsync(); else __syncthreads(); };
       bool singular_seen = false;
-      // ---- panel pass over ONE tile per 16-lane row.  ROWS: lane = row `lo` of an L tile, d = its row of the diagonal tile.
-      auto panel_rows = [&](int k, int I, bool valid, bool keeper) LCP_INL {
-        double d[16], x[16], myinv = 1.0;
+      // ---- panel pass over ONE tile per 16-lane row.  Lane = row `lo`: d = its row of the diagonal tile (every DPP row factors
+      // that tile redundantly, bit-identically), x = its row of an L tile (I, k), y = its row of a U tile (k, J).  Per pivot j:
+      //     l = d[j] / u_jj (rows below j) ;  d[c] -= l u_jc, x[c] -= (x[j] / u_jj) u_jc  (c > j) ;  y[c] -= l y_j[c]  (all c)
+      // i.e. L_Ik = A_Ik U_kk^-1 and U_kJ = L_kk^-1 A_kJ by substitution, the pivot row (u_jc, y_j[c]) arriving through
+      // row_newbcast folded into the FMA (lcp_big_dpp.h).  Software-pipelined over the pivots: a step first updates column j + 1 -
+      // it holds the NEXT pivot - and starts that pivot's reciprocal chain, then sweeps the remaining columns.
+      auto panel = [&](int k, int I, bool vL, int J, bool vU, bool keeper, auto HASL_, auto HASU_) LCP_INL {
+        constexpr bool HASL = HASL_, HASU = HASU_;
+        double d[16], x[16], y[16], myinv = 1.0;
+        // (unconditional loads - a row without a tile re-reads the diagonal tile's place - then selects: written as conditional
+        //  loads they become eight exec-masked branches, each waiting out its own LDS round trip)
+        const int Ie = vL ? I : k, Je = vU ? J : k;
         static_for<16>([&](auto C_) LCP_INL {
           d[C_] = L.dt[lo * 17 + C_];
-          x[C_] = valid ? L.LU[(size_t)(16 * k + C_) * LDU + 16 * I + lo] : 0.0;
+          if constexpr (HASL) x[C_] = L.LU[(size_t)(16 * k + C_) * LDU + 16 * Ie + lo];
+          if constexpr (HASU) y[C_] = L.LU[(size_t)(16 * Je + C_) * LDU + 16 * k + lo];
         });
-        // Software-pipelined over the pivots: a step first updates column j + 1 - which holds the NEXT pivot - and starts that
-        // pivot's reciprocal chain, then sweeps the remaining columns in three phases (all broadcasts, then all FMAs), so
-        // that the dependent chains of a step overlap; the values are pinned once per step.
+        static_for<16>([&](auto C_) LCP_INL {
+          if constexpr (HASL) x[C_] = vL ? x[C_] : 0.0;
+          if constexpr (HASU) y[C_] = vU ? y[C_] : 0.0;
+        });
         double piv = bc16<0>(d[0]);
         double inv = fast_rcp(piv);
         static_for<16>([&](auto J_) LCP_INL {
           constexpr int j = J_;
           singular_seen = singular_seen || (piv == 0.0);
           const double ld = (lo > j) ? d[j] * inv : 0.0;
-          const double lx = x[j] * inv;
+          double lx = 0.0;
+          if constexpr (HASL) lx = x[j] * inv;
           myinv = (lo == j) ? inv : myinv;
           if constexpr (j < 15) {
             const double u1 = bc16<j>(d[j + 1]);
             d[j + 1] = fma(-ld, u1, d[j + 1]);
-            x[j + 1] = fma(-lx, u1, x[j + 1]);
+            if constexpr (HASL) x[j + 1] = fma(-lx, u1, x[j + 1]);
             piv = bc16<j + 1>(d[j + 1]);
             inv = fast_rcp(piv);
+            if constexpr (HASL) panel_dx<j, j + 2>(d, x, ld, lx); else panel_d<j, j + 2>(d, ld);
+            if constexpr (HASU) panel_y<j>(y, ld);
           }
-          double uj[16];
-          static_for<(j < 14 ? 14 - j : 0)>([&](auto CC_) LCP_INL { constexpr int c = j + 2 + CC_; uj[c] = bc16<j>(d[c]); });
-          static_for<(j < 14 ? 14 - j : 0)>([&](auto CC_) LCP_INL {
-            constexpr int c = j + 2 + CC_;
-            d[c] = fma(-ld, uj[c], d[c]);
-            x[c] = fma(-lx, uj[c], x[c]);
-          });
-          static_for<15 - j>([&](auto CC_) LCP_INL { constexpr int c = j + 1 + CC_; pin(d[c]); pin(x[c]); });
           d[j] = (lo > j) ? ld : d[j];
-          x[j] = lx;
+          if constexpr (HASL) x[j] = lx;
         });
-        if (valid) static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * k + C_) * LDU + 16 * I + lo] = x[C_]; });
+        if constexpr (HASL) { if (vL) static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * k + C_) * LDU + 16 * I + lo] = x[C_]; }); }
+        if constexpr (HASU) { if (vU) static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * J + C_) * LDU + 16 * k + lo] = y[C_]; }); }
         if (keeper) {                                                         // one DPP row stores the factored diagonal tile
           static_for<16>([&](auto C_) LCP_INL { L.LU[(size_t)(16 * k + C_) * LDU + 16 * k + lo] = d[C_]; });
           L.dU[16 * k + lo] = myinv;
         }
-      };
-      // COLS: lane = column `lo` of a U tile, dc = its column of the diagonal tile (same arithmetic, entry by entry)
-      auto panel_cols = [&](int k, int J, bool valid) LCP_INL {
-        double dc[16], y[16];
-        static_for<16>([&](auto R_) LCP_INL {
-          dc[R_] = L.dt[R_ * 17 + lo];
-          y[R_] = valid ? L.LU[(size_t)(16 * J + lo) * LDU + 16 * k + R_] : 0.0;
-        });
-        double inv = fast_rcp(bc16<0>(dc[0]));
-        static_for<16>([&](auto J_) LCP_INL {
-          constexpr int j = J_;
-          const double invj = inv;
-          if constexpr (j < 15) {                                             // row j + 1 first: it holds the next pivot
-            const double l1 = bc16<j>(dc[j + 1] * invj);
-            dc[j + 1] = fma(-l1, dc[j], dc[j + 1]);                           // (columns <= j are dead from step j on: dc is never stored)
-            y[j + 1] = fma(-l1, y[j], y[j + 1]);
-            inv = fast_rcp(bc16<j + 1>(dc[j + 1]));
-          }
-          double m[16];
-          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL { constexpr int r = j + 2 + RR_; m[r] = dc[r] * invj; });     // (lane j: the multiplier l_rj)
-          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL { constexpr int r = j + 2 + RR_; m[r] = bc16<j>(m[r]); });
-          static_for<(j < 14 ? 14 - j : 0)>([&](auto RR_) LCP_INL {
-            constexpr int r = j + 2 + RR_;
-            dc[r] = fma(-m[r], dc[j], dc[r]);
-            y[r] = fma(-m[r], y[j], y[r]);
-          });
-          static_for<15 - j>([&](auto RR_) LCP_INL { constexpr int r = j + 1 + RR_; pin(dc[r]); pin(y[r]); });
-        });
-        if (valid) static_for<16>([&](auto R_) LCP_INL { L.LU[(size_t)(16 * J + lo) * LDU + 16 * k + R_] = y[R_]; });
       };
       // (3) trailing update of the owned tiles (I > k, J > k) = the local tiles [A0, 4) x [B0, 4): one straight-line
       //     specialisation per (A0, B0), no branch between the MFMAs.  Operand reads, lane-linear in the finished panels:
@@ -645,11 +624,12 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
         // (2) panel: L tiles k+1 .. on the first DPP rows, U tiles on the others
         if constexpr (NWV == 4) {
           const int slot = wave_u * 4 + hg;
-          if (wave_u < 2) panel_rows(k, k + 1 + slot, k + 1 + slot < NTL, slot == 0);
-          else panel_cols(k, k + 1 + (slot - 8), k + 1 + (slot - 8) < NTL);
+          using T_ = std::integral_constant<bool, true>; using F_ = std::integral_constant<bool, false>;
+          if (wave_u < 2) panel(k, k + 1 + slot, k + 1 + slot < NTL, 0, false, slot == 0, T_{}, F_{});      // L tiles k+1 .. on waves 0, 1
+          else panel(k, 0, false, k + 1 + (slot - 8), k + 1 + (slot - 8) < NTL, false, F_{}, T_{});        // U tiles on waves 2, 3
         } else {
-          panel_rows(k, k + 1 + hg, k + 1 + hg < NTL, hg == 0);
-          panel_cols(k, k + 1 + hg, k + 1 + hg < NTL);
+          using T_ = std::integral_constant<bool, true>;
+          panel(k, k + 1 + hg, k + 1 + hg < NTL, k + 1 + hg, k + 1 + hg < NTL, hg == 0, T_{}, T_{});       // one wave: both tiles of index k+1+hg
         }
         MF_TICK(1)
         sync();

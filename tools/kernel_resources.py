@@ -1,0 +1,51 @@
+"""Register / scratch / occupancy report of every kernel in lcp_physics_amd/csrc, from the compiler itself
+(`hipcc -Rpass-analysis=kernel-resource-usage`; the vgpr / agpr columns of a rocprofv3 kernel trace are not the allocation).
+Runs without a GPU.    python tools/kernel_resources.py > profiles/r02_kernel_resources.json"""
+import json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
+FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
+KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+        "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_static_bytes",
+        "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills", "TotalSGPRs": "sgpr"}
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return dict(zip(names, out))
+
+
+def main():
+    table = {}
+    for f, extra in FILES.items():
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+               "-x", "hip", "-c", os.path.join(CSRC, f), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + extra
+        err = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
+        cur = None
+        for line in err.splitlines():
+            m = re.search(r"remark: (?:\s*)Function Name: (\S+)", line)
+            if m:
+                cur = m.group(1); table[cur] = {"file": f}
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+            if m and cur and m.group(1).strip() in KEYS:
+                table[cur][KEYS[m.group(1).strip()]] = int(m.group(2))
+    names = demangle(list(table))
+    nice = {names[k]: v for k, v in table.items()}
+    pick = lambda sub: next((dict(v, kernel=k) for k, v in nice.items() if sub in k), None)
+    out = {
+        # the keys bench.py quotes in its roofline object
+        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1>"),
+        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1>"),
+        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1>"),
+        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1>"),
+        "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
+        "all_kernels": nice,
+        "source": "hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py)",
+    }
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
