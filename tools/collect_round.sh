@@ -1,0 +1,27 @@
+#!/bin/bash
+# One GPU call that refreshes every measured artefact of a round: bench lines of all BASELINE configs, the worlds with contact
+# detection, config 5 through both boundaries, rocprofv3 kernel trace + PMC passes (profile_all.sh / profile_config5.sh).
+# Outputs land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+O=$ROOT/gpurun_out
+mkdir -p $O
+cd $ROOT
+run() { name=$1; shift; timeout 300 "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err; tail -1 $O/${TAG}_$name.json | cut -c1-200; }
+run bench_fused python bench.py
+run bench_dense python bench.py --mode dense --no-cpu-baseline
+run bench_fused_physical_bwd python bench.py --bwd physical --no-cpu-baseline
+run bench_config2_fwd_only python bench.py --batch 1024 --nbox 2 --fwd-only --no-cpu-baseline
+run bench_config4_on_1gpu python bench.py --batch 32768 --no-cpu-baseline
+run bench_fused_8contacts python bench.py --pts 2 --no-cpu-baseline
+run bench_config5 python tools/bench_config5.py
+run bench_config5_dense python tools/bench_config5.py 4096 dense
+run bench_midsize_24 python tools/bench_midsize.py 6 4
+run bench_midsize_32 python tools/bench_midsize.py 8 4
+run bench_world python tools/bench_world.py --cpu-scenes 2
+run bench_world_graph python tools/bench_world.py --cpu-scenes 0 --graph
+run bench_world_11bodies python tools/bench_world.py --nbox 10 --box 24 --maxc 32 --cpu-scenes 0
+run bench_world_6bodies python tools/bench_world.py --nbox 5 --box 40 --cpu-scenes 0
+EXTRA="" bash tools/profile_all.sh $TAG > $O/${TAG}_profile_all.log 2>&1
+bash tools/profile_config5.sh $TAG > $O/${TAG}_profile_config5.log 2>&1
+ls $O | grep "^prof_${TAG}\|^${TAG}_" | head -60
