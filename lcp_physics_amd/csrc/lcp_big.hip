@@ -560,8 +560,9 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
       //     tile below (held transposed):  D^T -= U_kJ^T L_Ik^T = mfma(A = uop, B = lop)
       //     local tiles a < b are above, a > b below; a == b is above iff wr <= wc (wave-uniform)
       const bool dup = (NWV == 1) || (wr <= wc);
-      auto trailing = [&](auto A0_, auto B0_, int k) LCP_INL {
+      auto trailing = [&](auto A0_, auto B0_, int k, bool upd, bool pub) LCP_INL {
         constexpr int A0 = A0_, B0 = B0_;
+        if (upd) {
         double lop[4][4], uop[4][4];
         static_for<4 - A0>([&](auto AA_) LCP_INL {
           constexpr int a = A0 + AA_;
@@ -583,9 +584,10 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[a][b], 0, 0, 0);
           }); });
         });
+        }
         // publish panel k + 1 (its tiles are all among the ones just updated): local row A0 is tile row k + 1 iff rp,
-        // local column B0 is tile column k + 1 iff cp
-        const bool rp = gI(A0) == k + 1, cp = gJ(B0) == k + 1;
+        // local column B0 is tile column k + 1 iff cp.  (Not for a panel without live contacts: nobody reads it.)
+        const bool rp = pub && gI(A0) == k + 1, cp = pub && gJ(B0) == k + 1;
         if (rp && cp) static_for<4>([&](auto R_) LCP_INL { L.dt[(hg + 4 * R_) * 17 + lo] = acc[A0][B0][(int)R_]; });
         if (rp) static_for<4 - B0>([&](auto BB_) LCP_INL {
           constexpr int b = B0 + BB_;
@@ -616,9 +618,14 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
 #ifdef LCP_BIG_PROFILE
       tm = clock64();
 #endif
+      // A panel whose 16 pivots all belong to contacts the scene does not have is the identity: nothing to eliminate, nothing
+      // to update with, and `tsolve` never reads its columns - the step is skipped (per-scene counts: ContactWorld).
+      auto live_step = [&](int k) { return 16 * (k % (NTL / 2)) < ncs; };
 #pragma unroll 1
       for (int k = 0; k < NTL; ++k) {
+        const bool live = live_step(k);
         MF_TICK(4)
+        if (live) {
         sync();
         MF_TICK(0)
         // (2) panel: L tiles k+1 .. on the first DPP rows, U tiles on the others
@@ -633,6 +640,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
         }
         MF_TICK(1)
         sync();
+        } else if (wave_u == 0 && hg == 0) L.dU[16 * k + lo] = 1.0;           // (1 / U_ii of identity rows: `tsolve` scales by it)
         MF_TICK(2)
         // (3) trailing update of the owned tiles (I > k, J > k).  Operand reads, lane-linear in the finished panels:
         //       lop[a][c] = -L[16 I + lo][16 k + 4 c + hg]       uop[b][c] = U[16 k + 4 c + hg][16 J + lo]
@@ -643,7 +651,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
           static_for<4>([&](auto A0_) LCP_INL { static_for<4>([&](auto B0_) LCP_INL {
             constexpr int A0 = A0_, B0 = B0_;
             if constexpr ((NWV == 4) ? (A0 - B0 <= 1 && B0 - A0 <= 1) : (A0 == B0)) {
-              if (a0 == A0 && b0 == B0) trailing(A0_, B0_, k);
+              if (a0 == A0 && b0 == B0) trailing(A0_, B0_, k, live, k + 1 < NTL && live_step(k + 1));
             }
           }); });
         }
@@ -1121,7 +1129,9 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
 }  // namespace big
 
 // capacity class of a scene batch: 16, 32 or 64 contacts
-static inline int big_class(int nc) { return nc <= 16 ? 16 : (nc <= 32 ? 32 : 64); }
+// (up to 16 contacts with more than ten bodies - beyond lcp_quad.hip - run in the 32-contact class: its panel steps without live
+//  contacts are skipped; the 256-thread 16-contact instantiation of the rank-1 form only exists in LCP_BIG_MFMA = 0 builds)
+static inline int big_class(int nc) { return (LCP_BIG_MFMA != 0) ? (nc <= 32 ? 32 : 64) : (nc <= 16 ? 16 : (nc <= 32 ? 32 : 64)); }
 // 64 contacts: nz <= 43 (the two 64 x nz Jacobians have to fit next to the 129 KB of factors in the 160 KB of LDS);
 // smaller classes: nz <= 48 (16 bodies, the contact kernel's limit)
 bool big_supported(int nz, int m, int e) {
@@ -1147,7 +1157,9 @@ static int big_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, c
 template <bool BWD>
 static int big_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   switch (big_class(SP.nc)) {
+#if !LCP_BIG_MFMA
     case 16: return big_launch<16, BWD>(SP, Gd, stream);
+#endif
     case 32: return big_launch<32, BWD>(SP, Gd, stream);
     default: return big_launch<64, BWD>(SP, Gd, stream);
   }
