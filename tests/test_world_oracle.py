@@ -105,3 +105,21 @@ def test_post_stabilization_matches_reference_per_step(name):
         assert np.allclose(dp, rec["dp"][k - 1], atol=1e-6, rtol=1e-7), (name, k, np.abs(dp - rec["dp"][k - 1]).max())
         dt_used = rec["t"][k] - rec["t"][k - 1]
         assert np.allclose(rec["p_mid"][k - 1] + rec["dp"][k - 1] / 2 * dt_used, rec["p"][k], atol=1e-9, rtol=0), (name, k)
+
+
+def test_jointset_host_encoding_matches_the_recorded_reference_joints():
+    """`JointSet.from_list` (host side, no GPU): anchors given in world coordinates become the polar state the reference keeps in
+    `Joint.r1 / .rot1` (constraints.py:21-23, cart_to_polar with the positive-angle rule) - compared with what the reference's
+    own joints of the chain scene held, and with the row count of its `World.Je()`."""
+    from lcp_physics_amd.physics.joints import JointSet
+    rec = TRAJ["chain"]
+    p0 = rec["p"][0]
+    joints = [("x", 0), ("y", 0)] + [("joint", i, i - 1, (300.0, 25.0 + 50.0 * i)) for i in range(1, 5)]
+    js = JointSet.from_list(joints, p0, B=3)
+    assert js.e == rec["Je_t"].shape[1] == W.joint_rows(rec["jtype"])
+    assert js.jtype[1].tolist() == rec["jtype"].tolist() and js.jb1[2].tolist() == rec["jb1"].tolist() and js.jb2[0].tolist() == rec["jb2"].tolist()
+    assert np.abs(js.jr1[0].numpy() - rec["jr1"]).max() < 1e-12 and np.abs(js.jrot1[2].numpy() - rec["jrot1"]).max() < 1e-12
+    w = TRAJ["welded"]
+    js2 = JointSet.from_list([("total", 0), ("fixed", 1, 2)], w["p"][0])
+    assert js2.e == 6 and js2.jtype[0].tolist() == w["jtype"].tolist() and js2.jb2[0].tolist() == w["jb2"].tolist()
+    assert js2.pose_dependent and not JointSet.from_list([("total", 0), ("rot", 1)], w["p"][0]).pose_dependent
