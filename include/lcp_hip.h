@@ -250,16 +250,17 @@ int lcp_joint_jacobian_f64(int B, int nb, int nj, int e,
                            float* Je, void* stream);
 
 /* Backward of the contact frame with respect to the poses: what the reference obtains by autograd through
- * DiffContactHandler (physics/contacts.py:57-205, every operation of the contact tuple is a differentiable torch op), needed
- * to back-propagate through a roll-out (demos/grad_demo.py:45-50, experiments/inference.py:55-61).  Implemented for the
- * circle / circle record (contacts.py:68-79); contacts that involve a hull contribute nothing (their frame is a constant of the
- * step here).
- *   in : kind[B,nb] radius[B,nb] p[B,nb,3] (the pose the contacts were detected at), the contact list indices and counts,
- *        g_n / g_p1 / g_p2 [B,maxc,2] = d(loss)/d(c_n, c_p1, c_p2) (what lcp_step_backward_f32 returns)
- *   out: dp[B,nb,3] = d(loss)/d(pose) through the contact frame (overwritten) */
+ * DiffContactHandler (physics/contacts.py:57-352 - every operation of the contact tuple is a differentiable torch op,
+ * including the rotated hull vertices of bodies.py:211-214), needed to back-propagate through a roll-out
+ * (demos/grad_demo.py:45-50, experiments/inference.py:55-61).  Every record type: circle / circle, circle / hull (GJK or
+ * SAT), hull / hull (SAT, incident edge, clipping); the derivative follows the branches the detection took (as autograd does).
+ *   in : the geometry and the pose `p` lcp_move_find_contacts_f64 detected the contact list at (its p_out), its `eps`,
+ *        count[B], and g_n / g_p1 / g_p2 [B,maxc,2] = d(loss)/d(c_n, c_p1, c_p2) (what lcp_step_backward_f32 returns)
+ *   out: dp[B,nb,3] = d(loss)/d(pose) through the contact frame (overwritten).   nb <= 16. */
 int lcp_contact_frame_backward_f64(int B, int nb, int maxc,
-                                   const int32_t* kind, const double* radius, const double* p,
-                                   const int32_t* c_i1, const int32_t* c_i2, const int32_t* count,
+                                   const int32_t* kind, const double* radius, const double* verts_local,
+                                   const int32_t* nverts, const uint8_t* no_contact,
+                                   const double* p, double eps, const int32_t* count,
                                    const float* g_n, const float* g_p1, const float* g_p2,
                                    double* dp, void* stream);
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "lcp_move_find_contacts_f64": (_I, [_I] * 3 + [_P] * 7 + [_c.c_double, _c.c_double, _I, _I, _c.c_double,
                                                           _c.c_double] + [_P] * 12 + [_P]),
     "lcp_joint_jacobian_f64": (_I, [_I] * 4 + [_P] * 8 + [_c.c_double, _c.c_double, _P, _P]),
-    "lcp_contact_frame_backward_f64": (_I, [_I] * 3 + [_P] * 10 + [_P]),
+    "lcp_contact_frame_backward_f64": (_I, [_I] * 3 + [_P] * 6 + [_c.c_double] + [_P] * 5 + [_P]),
     "lcp_debug_set_trace": (None, [_P]),
     "lcp_debug_set_path": (None, [_I]),
 }

@@ -338,12 +338,14 @@ int lcp_joint_jacobian_f64(int B, int nb, int nj, int e, const int32_t* jtype, c
   return lcp::joint_jacobian_launch(B, nb, nj, e, jtype, jb1, jb2, jr1, jrot1, p, v, dt_scene, dt, vscale, Je, stream);
 }
 
-int lcp_contact_frame_backward_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
-                                   const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
-                                   const float* g_p1, const float* g_p2, double* dp, void* stream) {
+int lcp_contact_frame_backward_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* verts_local,
+                                   const int32_t* nverts, const uint8_t* no_contact, const double* p, double eps,
+                                   const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,
+                                   void* stream) {
   if (B <= 0 || nb <= 0 || maxc <= 0) return LCP_E_BADARG;
-  if (!kind || !radius || !p || !c_i1 || !c_i2 || !count || !g_n || !g_p1 || !g_p2 || !dp) return LCP_E_BADARG;
-  return lcp::contact_frame_backward_launch(B, nb, maxc, kind, radius, p, c_i1, c_i2, count, g_n, g_p1, g_p2, dp, stream);
+  if (!kind || !radius || !verts_local || !nverts || !p || !count || !g_n || !g_p1 || !g_p2 || !dp) return LCP_E_BADARG;
+  return lcp::contact_frame_backward_launch(B, nb, maxc, kind, radius, verts_local, nverts, no_contact, p, eps, count, g_n, g_p1, g_p2,
+                                            dp, stream);
 }
 
 }  // extern "C"

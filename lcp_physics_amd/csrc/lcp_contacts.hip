@@ -31,234 +31,35 @@ namespace ct {
 constexpr int NV = 8;          // max vertices of a hull
 constexpr int MAXB = 16;       // max bodies per scene handled by this kernel
 
-struct V2 { double x, y; };
-__device__ __forceinline__ V2 v2(double x, double y) { V2 r; r.x = x; r.y = y; return r; }
-__device__ __forceinline__ V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ V2 operator-(V2 a) { return v2(-a.x, -a.y); }
-__device__ __forceinline__ V2 operator*(V2 a, double s) { return v2(a.x * s, a.y * s); }
-__device__ __forceinline__ V2 operator*(double s, V2 a) { return v2(a.x * s, a.y * s); }
-__device__ __forceinline__ double dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
-__device__ __forceinline__ double norm(V2 a) { return sqrt(a.x * a.x + a.y * a.y); }
-__device__ __forceinline__ V2 left_orth(V2 v) { return v2(v.y, -v.x); }              // utils.py:99-102
+#define LCP_S double
+#include "lcp_contacts_geom.inc"
+#undef LCP_S
 
-struct Body {             // world frame
-  int kind;               // 0 circle, 1 hull
-  V2 pos;
-  double rad;
-  int nv;
-  const V2* verts;        // hull vertices relative to pos, rotated (LDS)
-  const V2* nrm;          // outward unit normal of edge k = (verts[k], verts[k+1])  (LDS, formed once per trial pose)
-  const double* elen;     // length of edge k
+// ---- forward-mode derivative of the same geometry: value + ONE directional derivative ---------------------------------
+// (the reference builds the contact tuple with differentiable torch operations, contacts.py:57-352; its autograd follows the
+//  branches the forward pass took - so does this: every comparison looks at the values only)
+namespace ad {
+struct Dual {
+  double v, d;
+  __device__ __forceinline__ Dual() {}
+  __device__ __forceinline__ Dual(double a) : v(a), d(0.0) {}
+  __device__ __forceinline__ Dual(double a, double b) : v(a), d(b) {}
 };
-
-struct Pt { V2 n, p1, p2; double pen; };
-
-// contacts.py:207-217 (`>=`: last maximiser wins)
-__device__ __forceinline__ int support(const V2* pts, int n, V2 dir) {
-  int best = -1; double bn = -1.0;
-  for (int i = 0; i < n; ++i) { const double c = dot(pts[i], dir); if (c >= bn) { bn = c; best = i; } }
-  return best;
-}
-
-__device__ __forceinline__ int circle_circle(const Body& b1, const Body& b2, double eps, Pt& out0) {   // contacts.py:68-79
-  const double r = b1.rad + b2.rad;
-  V2 n = b1.pos - b2.pos;
-  const double dist = norm(n);
-  const double pen = r - dist;
-  if (pen < -eps) return 0;
-  n = n * (1.0 / dist);
-  out0.n = n; out0.p1 = -n * (b1.rad - pen / 2); out0.p2 = n * (b2.rad - pen / 2); out0.pen = pen;
-  return 1;
-}
-
-__device__ __forceinline__ void bary2(V2 p, V2 a, V2 b, double& u, double& v) {        // contacts.py:334-340
-  const V2 d = b - a;
-  const double n = norm(d);
-  const V2 nd = d * (1.0 / n);
-  u = dot(b - p, nd) / n; v = dot(p - a, nd) / n;
-}
-__device__ __forceinline__ void bary3(V2 p, V2 a, V2 b, V2 c, double& u, double& v, double& w) {   // contacts.py:341-350
-  // inverse of [[ax,bx,cx],[ay,by,cy],[1,1,1]] applied to (px,py,1)
-  const double det = a.x * (b.y - c.y) - b.x * (a.y - c.y) + c.x * (a.y - b.y);
-  const double id = 1.0 / det;
-  u = ((b.y - c.y) * p.x + (c.x - b.x) * p.y + (b.x * c.y - c.x * b.y)) * id;
-  v = ((c.y - a.y) * p.x + (a.x - c.x) * p.y + (c.x * a.y - a.x * c.y)) * id;
-  w = ((a.y - b.y) * p.x + (b.x - a.x) * p.y + (a.x * b.y - b.x * a.y)) * id;
-}
-
-// (no private arrays anywhere below: dynamically indexed locals live in scratch memory on this target, and a scratch
-//  round trip costs as much as the whole arithmetic of a pair - the simplex, clip and manifold buffers are named scalars)
-struct Simplex { V2 a, b, c; int ia, ib, ic; int n; };     // up to 3 points with their vertex indices
-
-// contacts.py:295-330: closest point of the simplex to p; `keep` = the sub-simplex that supports it (the reference's
-// `ids_used`, in its order), keep.n == 3 means p is inside the triangle
-__device__ __forceinline__ V2 closest(V2 p, const Simplex& sx, Simplex& keep) {
-  keep = sx;
-  if (sx.n == 1) return sx.a;
-  if (sx.n == 2) {
-    double u, v; bary2(p, sx.a, sx.b, u, v);
-    if (u <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.n = 1; return sx.b; }
-    if (v <= 0) { keep.n = 1; return sx.a; }
-    return u * sx.a + v * sx.b;
-  }
-  double uAB, vAB, uBC, vBC, uCA, vCA, uABC, vABC, wABC;
-  bary2(p, sx.a, sx.b, uAB, vAB); bary2(p, sx.b, sx.c, uBC, vBC); bary2(p, sx.c, sx.a, uCA, vCA);
-  bary3(p, sx.a, sx.b, sx.c, uABC, vABC, wABC);
-  if (vAB <= 0 && uCA <= 0) { keep.n = 1; return sx.a; }
-  if (vBC <= 0 && uAB <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.n = 1; return sx.b; }
-  if (vCA <= 0 && uBC <= 0) { keep.a = sx.c; keep.ia = sx.ic; keep.n = 1; return sx.c; }
-  if (uAB > 0 && vAB > 0 && wABC <= 0) { keep.n = 2; return uAB * sx.a + vAB * sx.b; }
-  if (uBC > 0 && vBC > 0 && uABC <= 0) { keep.a = sx.b; keep.ia = sx.ib; keep.b = sx.c; keep.ib = sx.ic; keep.n = 2; return uBC * sx.b + vBC * sx.c; }
-  if (uCA > 0 && vCA > 0 && vABC <= 0) { keep.a = sx.c; keep.ia = sx.ic; keep.b = sx.a; keep.ib = sx.ia; keep.n = 2; return uCA * sx.c + vCA * sx.a; }
-  return p;                                                      // inside (the reference raises if nothing matched)
-}
-
-// contacts.py:80-141: `circ` plays b1, `hull` b2
-__device__ __forceinline__ int circle_hull(const Body& circ, const Body& hull, double eps, bool circle_is_g2, Pt& out0) {
-  const V2* verts = hull.verts;
-  const int nv = hull.nv;
-  const V2 tp = circ.pos - hull.pos;
-  Simplex sx, keep;
-  sx.a = verts[0]; sx.ia = 0; sx.b = sx.a; sx.c = sx.a; sx.ib = -1; sx.ic = -1; sx.n = 1;
-  keep = sx;
-  V2 cl = sx.a;
-  for (int iter = 0; iter < 4 * NV; ++iter) {
-    cl = closest(tp, sx, keep);
-    if (keep.n == 3) break;
-    V2 sd;
-    if (keep.n == 2) {
-      sd = left_orth(keep.a - keep.b);
-      if (dot(sd, tp - keep.a) < 0) sd = -sd;
-    } else {
-      sd = tp - cl;
-    }
-    if (sd.x == 0 && sd.y == 0) break;
-    const int si = support(verts, nv, sd);
-    const bool in_simplex = (si == sx.ia) || (sx.n > 1 && si == sx.ib) || (sx.n > 2 && si == sx.ic);
-    if (in_simplex) break;
-    sx = keep;                                                   // the used points, then the new support point
-    if (keep.n == 1) { sx.b = verts[si]; sx.ib = si; } else { sx.c = verts[si]; sx.ic = si; }
-    sx.n = keep.n + 1;
-  }
-  V2 bn, bp1, bp2; double bd;
-  if (keep.n < 3) {
-    bp2 = cl;
-    const V2 cw = cl + hull.pos;
-    bp1 = cw - circ.pos;
-    bd = norm(cw - circ.pos) - circ.rad;
-    if (bd > eps) return 0;
-    bn = -bp1 * (1.0 / norm(bp1));
-  } else {                                     // centre inside the hull: SAT, contacts.py:114-137
-    bd = -1e10; bn = v2(0, 0); bp1 = bn; bp2 = bn;
-    for (int idx = 0; idx < nv; ++idx) {
-      const V2 nrm = hull.nrm[idx];
-      const V2 center = circ.pos - hull.pos;
-      const double dist = dot(nrm, center - verts[idx]) - circ.rad;
-      if (dist > bd) {
-        if (dist > eps) return 0;
-        bd = dist; bn = nrm;
-        bp2 = center + nrm * -(dist + circ.rad);
-        bp1 = bp2 + hull.pos - circ.pos;
-      }
-    }
-  }
-  if (circle_is_g2) { bn = -bn; const V2 t = bp1; bp1 = bp2; bp2 = t; }
-  out0.n = bn; out0.p1 = bp1; out0.p2 = bp2; out0.pen = -bd;
-  return 1;
-}
-
-struct Sep { double dist; V2 normal; int vertex; double edge_norm; int edge; };
-
-__device__ __forceinline__ Sep test_separations(const Body& h1, const Body& h2, double eps) {      // contacts.py:220-250
-  Sep best; best.dist = -1e10; best.normal = v2(0, 0); best.vertex = -1; best.edge_norm = 0; best.edge = 0;
-  for (int idx = 0; idx < h1.nv; ++idx) {
-    const double en = h1.elen[idx];
-    const V2 nrm = h1.nrm[idx];
-    const int si = support(h2.verts, h2.nv, -nrm);
-    const V2 sp = h2.verts[si] + h2.pos - h1.pos;
-    const double dist = dot(nrm, sp - h1.verts[idx]);
-    if (dist > best.dist) {
-      if (dist > eps) { best.dist = dist; best.edge = idx; return best; }
-      best.dist = dist; best.normal = -nrm; best.vertex = si; best.edge_norm = en; best.edge = idx;
-    }
-  }
-  return best;
-}
-
-__device__ __forceinline__ int incident_edge(V2 ref_normal, const Body& inc, int inc_vertex) {      // contacts.py:253-268
-  double min_dot = 1e10; int best = -1;
-  const int e0 = (inc_vertex - 1 + inc.nv) % inc.nv;
-  for (int q = 0; q < 2; ++q) {
-    const int i = q == 0 ? e0 : inc_vertex;
-    const V2 inrm = inc.nrm[i];
-    const double d = dot(ref_normal, inrm);
-    if (d < min_dot) { min_dot = d; best = i; }
-  }
-  return best;
-}
-
-__device__ __forceinline__ int clip(V2 in0, V2 in1, V2 nrm, double offset, V2& o0, V2& o1) {       // contacts.py:270-292
-  int n = 0;
-  const double d0 = dot(nrm, in0) + offset, d1 = dot(nrm, in1) + offset;
-  o0 = in0; o1 = in1;
-  if (d0 >= 0.0) { o0 = in0; n = 1; }
-  if (d1 >= 0.0) { if (n == 0) o0 = in1; else o1 = in1; ++n; }
-  if (d0 * d1 < 0.0 || n < 2) {
-    const double interp = d0 / (d0 - d1);
-    const V2 x = in0 + interp * (in1 - in0);
-    if (n == 0) o0 = x; else if (n == 1) o1 = x;             // (never a third point: two kept vertices imply d0 d1 >= 0)
-    ++n;
-  }
-  return n;
-}
-
-__device__ __forceinline__ int hull_hull(const Body& b1, const Body& b2, double eps, Pt& out0, Pt& out1) {  // contacts.py:142-201
-  const Sep c1 = test_separations(b1, b2, eps);
-  if (c1.dist > eps) return 0;
-  const Sep c2 = test_separations(b2, b1, eps);
-  if (c2.dist > eps) return 0;
-  const bool ref_is_b2 = c2.dist > c1.dist;
-  const Body& ref = ref_is_b2 ? b2 : b1;
-  const Body& inc = ref_is_b2 ? b1 : b2;
-  const Sep& c = ref_is_b2 ? c2 : c1;
-  const V2 nrm = -c.normal;
-  const double half_edge = c.edge_norm / 2;
-  const int ie = incident_edge(nrm, inc, c.vertex);
-  const V2 iv0 = inc.verts[ie] + inc.pos - ref.pos;
-  const V2 iv1 = inc.verts[(ie + 1) % inc.nv] + inc.pos - ref.pos;
-  const V2 plane = left_orth(nrm);
-  V2 a0, a1, q0, q1;
-  const int n1 = clip(iv0, iv1, plane, half_edge, a0, a1);
-  if (n1 < 2) return 0;
-  const int n2 = clip(a0, a1, -plane, half_edge, q0, q1);
-  int n = 0;
-  const V2 refv = ref.verts[c.edge];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const V2 cq = q == 0 ? q0 : q1;
-    const double dist = dot(nrm, cq - refv);
-    if (q < n2 && dist <= eps) {
-      const V2 pt1 = cq + nrm * -dist;
-      const V2 pt2 = pt1 + ref.pos - inc.pos;
-      Pt r;
-      if (ref_is_b2) { r.n = nrm; r.p1 = pt2; r.p2 = pt1; }                        // contacts.py:170-175
-      else { r.n = -nrm; r.p1 = pt1; r.p2 = pt2; }                                 // contacts.py:198-201
-      r.pen = -dist;
-      if (n == 0) out0 = r; else out1 = r;
-      ++n;
-    }
-  }
-  return n;
-}
-
-__device__ __forceinline__ int collide_pair(const Body& b1, const Body& b2, double eps, Pt& out0, Pt& out1) {   // contacts.py:57-205
-  const bool c1 = b1.kind == 0, c2 = b2.kind == 0;
-  if (c1 && c2) return circle_circle(b1, b2, eps, out0);
-  if (c1) return circle_hull(b1, b2, eps, false, out0);
-  if (c2) return circle_hull(b2, b1, eps, true, out0);
-  return hull_hull(b1, b2, eps, out0, out1);
-}
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return Dual(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ Dual sqrt(Dual a) { const double r = ::sqrt(a.v); return Dual(r, 0.5 * a.d / r); }
+__device__ __forceinline__ bool operator<(Dual a, Dual b) { return a.v < b.v; }
+__device__ __forceinline__ bool operator<=(Dual a, Dual b) { return a.v <= b.v; }
+__device__ __forceinline__ bool operator>(Dual a, Dual b) { return a.v > b.v; }
+__device__ __forceinline__ bool operator>=(Dual a, Dual b) { return a.v >= b.v; }
+__device__ __forceinline__ bool operator==(Dual a, Dual b) { return a.v == b.v; }
+#define LCP_S Dual
+#include "lcp_contacts_geom.inc"
+#undef LCP_S
+}  // namespace ad
 
 // One launch = the whole position update of World.step_dt (world.py:88-101) for every scene: try the step with
 // the current dt (Body.move), detect contacts, accept when no contact penetrates by more than `tol`, otherwise
@@ -411,44 +212,73 @@ __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs 
   }
 }
 
-// ---------------------------------------------------------------- backward of the contact frame (circle / circle)
-// The reference builds the contact tuple with differentiable torch operations (DiffContactHandler, contacts.py:57-205), so
-// a loss after a roll-out reaches the poses through (normal, p1, p2).  This is that chain rule for the circle / circle
-// record of contacts.py:68-79, with d = pos1 - pos2, dist = |d|, n = d / dist, r = rad1 + rad2:
-//     normal = n        p1 = -n (rad1 - (r - dist) / 2)        p2 = n (rad2 - (r - dist) / 2)
-//     d(loss)/dd = (I - n n^T) / dist . (g_n - a1 g_p1 + a2 g_p2)  +  n (n . (g_p2 - g_p1)) / 2,   a_i = rad_i - (r - dist) / 2
-// and d(loss)/dpos1 = +that, d(loss)/dpos2 = -that (the rotations do not enter).  Contacts involving a hull are treated as
-// constants of the step (their frame backward is not implemented: gradients stop there).  One thread per scene walks the
-// scene's contact list in order: fixed summation order, no atomics.
+// ---------------------------------------------------------------- backward of the contact frame
+// The reference builds the contact tuple with differentiable torch operations (DiffContactHandler, contacts.py:57-205), so a
+// loss after a roll-out reaches the poses through (normal, p1, p2) - `demos/grad_demo.py:45-50`, `experiments/inference.py`.
+// This is that chain rule for every record type (circle / circle, circle / hull by GJK or SAT, hull / hull by SAT + clipping):
+//     d(loss)/d(pose_b,q) = sum over the contacts of   g_n . dn/d(pose_b,q) + g_p1 . dp1/d(..) + g_p2 . dp2/d(..)
+// with the partial derivatives of a pair's records taken in FORWARD mode: the pair's geometry code (lcp_contacts_geom.inc) is
+// re-run on dual numbers, once per pose coordinate of its two bodies (6 passes), from the same pose the detection kernel saw.
+// Hull vertices are R(rot) v_local, so d/d(rot) reaches normals, incident edges and clipped points the way the reference's
+// incrementally rotated `verts` do (bodies.py:211-214).  One thread per scene walks the body pairs in the detection kernel's
+// order (so the running contact index is the list's), pairs without a contact cost one value-only pass; fixed summation order.
 __global__ void __launch_bounds__(64) lcp_contact_frame_backward_kernel(int B, int nb, int maxc, const int32_t* kind, const double* radius,
-                                                                        const double* p, const int32_t* c_i1, const int32_t* c_i2,
+                                                                        const double* verts_local, const int32_t* nverts,
+                                                                        const uint8_t* no_contact, const double* p, double eps,
                                                                         const int32_t* count, const float* g_n, const float* g_p1,
                                                                         const float* g_p2, double* dp) {
+  using V2 = ad::V2; using Body = ad::Body; using Pt = ad::Pt; using Dual = ad::Dual;      // (functions: found through their arguments)
   const int scene = blockIdx.x * 64 + threadIdx.x;
   if (scene >= B) return;
   double* out = dp + (size_t)scene * nb * 3;
   for (int i = 0; i < nb * 3; ++i) out[i] = 0.0;
-  int n = count[scene];
-  n = n < 0 ? 0 : (n > maxc ? maxc : n);
-  for (int c = 0; c < n; ++c) {
-    const size_t o = (size_t)scene * maxc + c;
-    const int i1 = c_i1[o], i2 = c_i2[o];
-    if (kind[(size_t)scene * nb + i1] != 0 || kind[(size_t)scene * nb + i2] != 0) continue;
-    const double* q1 = p + ((size_t)scene * nb + i1) * 3;
-    const double* q2 = p + ((size_t)scene * nb + i2) * 3;
-    const double r1 = radius[(size_t)scene * nb + i1], r2 = radius[(size_t)scene * nb + i2];
-    const double dx = q1[1] - q2[1], dy = q1[2] - q2[2];
-    const double dist = sqrt(dx * dx + dy * dy), inv = 1.0 / dist;
-    const double nx = dx * inv, ny = dy * inv;
-    const double half = 0.5 * ((r1 + r2) - dist);
-    const double a1 = r1 - half, a2 = r2 - half;
-    const double gnx = g_n[o * 2], gny = g_n[o * 2 + 1], g1x = g_p1[o * 2], g1y = g_p1[o * 2 + 1], g2x = g_p2[o * 2], g2y = g_p2[o * 2 + 1];
-    const double wx = gnx - a1 * g1x + a2 * g2x, wy = gny - a1 * g1y + a2 * g2y;
-    const double wn = wx * nx + wy * ny;
-    const double k = 0.5 * (nx * (g2x - g1x) + ny * (g2y - g1y));
-    const double gx = (wx - nx * wn) * inv + nx * k, gy = (wy - ny * wn) * inv + ny * k;
-    out[i1 * 3 + 1] += gx; out[i1 * 3 + 2] += gy;
-    out[i2 * 3 + 1] -= gx; out[i2 * 3 + 2] -= gy;
+  int ntot = count[scene];
+  ntot = ntot < 0 ? 0 : (ntot > maxc ? maxc : ntot);
+  const double* q = p + (size_t)scene * nb * 3;
+  int base = 0;
+  // one body of the pair at pose q with the derivative seeded on coordinate `seed` (0 rot, 1 x, 2 y; -1: none)
+  auto build = [&](int b, int seed, V2* verts, V2* nrm, Dual* elen, Body& body) {
+    body.kind = kind[(size_t)scene * nb + b];
+    body.rad = Dual(radius[(size_t)scene * nb + b]);
+    body.nv = nverts[(size_t)scene * nb + b];
+    body.pos = v2(Dual(q[b * 3 + 1], seed == 1 ? 1.0 : 0.0), Dual(q[b * 3 + 2], seed == 2 ? 1.0 : 0.0));
+    body.verts = verts; body.nrm = nrm; body.elen = elen;
+    if (body.kind != 0) {
+      const double rot = q[b * 3], sn = sin(rot), cs = cos(rot), dr = seed == 0 ? 1.0 : 0.0;
+      const Dual S(sn, cs * dr), C(cs, -sn * dr);
+      const double* vl = verts_local + ((size_t)scene * nb + b) * NV * 2;
+      for (int k = 0; k < body.nv; ++k) { const Dual lx(vl[2 * k]), ly(vl[2 * k + 1]); verts[k] = v2(C * lx - S * ly, S * lx + C * ly); }    // utils.py:105-112
+      for (int k = 0; k < body.nv; ++k) {
+        const V2 edge = verts[(k + 1) % body.nv] - verts[k];
+        const Dual en = norm(edge);
+        elen[k] = en; nrm[k] = left_orth(edge) * (Dual(1.0) / en);
+      }
+    }
+  };
+  for (int bi = 0; bi < nb && base < ntot; ++bi) {
+    for (int bj = bi + 1; bj < nb && base < ntot; ++bj) {
+      if (no_contact && no_contact[((size_t)scene * nb + bi) * nb + bj]) continue;
+      V2 v1[NV], n1[NV], v2_[NV], n2[NV];
+      Dual e1[NV], e2[NV];
+      Body b1, b2;
+      Pt pt0, pt1;
+      build(bi, -1, v1, n1, e1, b1); build(bj, -1, v2_, n2, e2, b2);
+      const int cnt = collide_pair(b1, b2, eps, pt0, pt1);
+      if (cnt == 0) continue;
+      for (int s = 0; s < 6; ++s) {                                           // the six pose coordinates of the pair
+        build(bi, s < 3 ? s : -1, v1, n1, e1, b1); build(bj, s >= 3 ? s - 3 : -1, v2_, n2, e2, b2);
+        const int c2 = collide_pair(b1, b2, eps, pt0, pt1);                   // (same values, hence the same branches and count)
+        double acc = 0.0;
+        for (int c = 0; c < c2 && base + c < ntot; ++c) {
+          const Pt& pt = c == 0 ? pt0 : pt1;
+          const size_t o = ((size_t)scene * maxc + base + c) * 2;
+          acc += (double)g_n[o] * pt.n.x.d + (double)g_n[o + 1] * pt.n.y.d + (double)g_p1[o] * pt.p1.x.d + (double)g_p1[o + 1] * pt.p1.y.d
+               + (double)g_p2[o] * pt.p2.x.d + (double)g_p2[o + 1] * pt.p2.y.d;
+        }
+        out[(s < 3 ? bi : bj) * 3 + (s % 3)] += acc;
+      }
+      base += cnt;
+    }
   }
 }
 
@@ -511,11 +341,13 @@ int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, co
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
-                                  const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
-                                  const float* g_p1, const float* g_p2, double* dp, void* stream) {
+int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* verts_local,
+                                  const int32_t* nverts, const uint8_t* no_contact, const double* p, double eps,
+                                  const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,
+                                  void* stream) {
+  if (nb > ct::MAXB) return LCP_E_TOOLARGE;
   hipLaunchKernelGGL(ct::lcp_contact_frame_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, maxc, kind,
-                     radius, p, c_i1, c_i2, count, g_n, g_p1, g_p2, dp);
+                     radius, verts_local, nverts, no_contact, p, eps, count, g_n, g_p1, g_p2, dp);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 

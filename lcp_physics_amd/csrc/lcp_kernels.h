@@ -137,8 +137,9 @@ int contacts_launch(const ContactArgs& P, void* stream);
 int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2, const double* jr1,
                           double* jrot1, const double* p, const float* v, const double* dt_scene, double dt, double vscale, float* Je,
                           void* stream);
-int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* p,
-                                  const int32_t* c_i1, const int32_t* c_i2, const int32_t* count, const float* g_n,
-                                  const float* g_p1, const float* g_p2, double* dp, void* stream);
+int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* verts_local,
+                                  const int32_t* nverts, const uint8_t* no_contact, const double* p, double eps,
+                                  const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,
+                                  void* stream);
 
 }  // namespace lcp

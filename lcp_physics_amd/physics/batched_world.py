@@ -475,14 +475,19 @@ class ContactWorld:
             p_new   = p + v_new dt_used                               (bodies.py:80-82; dt_used: the dt the step_dt loop accepted)
 
         `Mdiag, f, rest, fric, v, p` (and what `force_fn` closes over) may require grad.  State tensors are replaced, not
-        overwritten, and every step keeps its own workspace and contact snapshot for the backward.  Contacts that involve a
-        hull are constants of the step (see `contacts.contact_frame_backward`); post-stabilisation is not differentiated."""
+        overwritten, and every step keeps its own workspace and contact snapshot for the backward.  The joint Jacobian is a
+        constant of the backward; post-stabilisation is not differentiated."""
         if self.post_stab:
             raise RuntimeError("step_autograd: post-stabilisation is not differentiable here")
         ct = self._contacts_mod
         cb = self.contacts
         frame = ct.snapshot_frame(cb)
-        c_n, c_p1, c_p2 = ct.ContactFrameFunction.apply(self.p, self.geom, frame)
+        # the pose the GEOMETRY is differentiated at: the same values as self.p, but a rotation increment that is exactly
+        # zero carries no gradient - the reference turns its hulls' vertices by the increment and skips the turn when the
+        # increment is zero (bodies.py:199-202 `if rot.item() != 0: self.rotate_verts(rot)`), so its autograd has no
+        # vertex path through such a step (a hull in free fall with no torque on it, for instance)
+        p_geo = self._p_geom if getattr(self, "_p_geom_src", None) is self.p else self.p
+        c_n, c_p1, c_p2 = ct.ContactFrameFunction.apply(p_geo, self.geom, frame, self.eps)
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
         opts = {"max_iter": self.max_iter, "eps": self.solver_eps, "not_improved_lim": self.lim, "compute": self.compute}
         v_new = SolveDynamicsFunction.apply(self.Mdiag, self.v.contiguous(), f, self.rest, self.fric, c_n, c_p1, c_p2, frame.c_i1,
@@ -493,8 +498,12 @@ class ContactWorld:
         ct.move_and_find_contacts(self.geom, p_start.detach(), v_new.detach(), self.dt, eps=self.eps, tol=self.tol,
                                   strict=self.strict, dt_floor=self.dt / 4, max_trials=self.max_trials, t=self.t, out=cb)
         # the accepted pose: the kernel's value, the gradient of p + v dt_used
-        p_lin = p_start + v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
+        dp = v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
+        p_lin = p_start + dp
         self.p = p_lin + (cb.p_out - p_lin).detach()
+        turned = (dp[..., :1] != 0).to(dp.dtype)
+        g_lin = p_geo + torch.cat([dp[..., :1] * turned + (dp[..., :1] * (1 - turned)).detach(), dp[..., 1:]], dim=-1)
+        self._p_geom, self._p_geom_src = g_lin + (cb.p_out - g_lin).detach(), self.p
         self.v = v_new
         if self.joints is not None:                                        # (the joint Jacobian is a constant of the backward)
             self.Je = self.joints.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)

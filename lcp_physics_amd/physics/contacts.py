@@ -127,10 +127,10 @@ def find_contacts(geom, p, maxc=16, eps=EPSILON, out=None):
     return move_and_find_contacts(geom, p, None, 0.0, maxc=maxc, eps=eps, out=out, max_trials=1)
 
 
-def contact_frame_backward(geom, p, cb, g_n, g_p1, g_p2):
+def contact_frame_backward(geom, p, cb, g_n, g_p1, g_p2, eps=EPSILON):
     """d(loss)/d(pose) through the contact frame (`lcp_contact_frame_backward_f64`): the chain rule of the reference's
-    differentiable contact handler (`contacts.py:57-205`) for the contacts in `cb` detected at pose `p` [B,nb,3] float64.
-    Circle / circle contacts only - a contact that involves a hull contributes nothing."""
+    differentiable contact handler (`contacts.py:57-352`) for the contacts in `cb` detected at pose `p` [B,nb,3] float64 with
+    margin `eps` - every record type (circle / circle, circle / hull, hull / hull)."""
     lib = _lib.load()
     B, nb = geom.B, geom.nb
     dev = p.device
@@ -140,8 +140,9 @@ def contact_frame_backward(geom, p, cb, g_n, g_p1, g_p2):
     dp = torch.empty(B, nb, 3, dtype=torch.float64, device=dev)
     P = _lib.ptr
     with torch.cuda.device(dev):
-        rc = lib.lcp_contact_frame_backward_f64(B, nb, cb.c_n.shape[1], P(geom.kind), P(geom.radius), P(p), P(cb.c_i1), P(cb.c_i2),
-                                                P(cb.count), P(g_n), P(g_p1), P(g_p2), P(dp), _lib.stream_ptr(dev))
+        rc = lib.lcp_contact_frame_backward_f64(B, nb, cb.c_n.shape[1], P(geom.kind), P(geom.radius), P(geom.verts_local),
+                                                P(geom.nverts), P(geom.no_contact), P(p), float(eps), P(cb.count), P(g_n), P(g_p1),
+                                                P(g_p2), P(dp), _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_contact_frame_backward_f64")
     return dp
 
@@ -157,8 +158,8 @@ class ContactFrameFunction(torch.autograd.Function):
         c_n, c_p1, c_p2 = ContactFrameFunction.apply(p, geom, frame)        # frame: a snapshot of the ContactBuffers"""
 
     @staticmethod
-    def forward(ctx, p, geom, frame):
-        ctx.geom, ctx.frame = geom, frame
+    def forward(ctx, p, geom, frame, eps=EPSILON):
+        ctx.geom, ctx.frame, ctx.eps = geom, frame, eps
         ctx.save_for_backward(p)
         return frame.c_n.clone(), frame.c_p1.clone(), frame.c_p2.clone()
 
@@ -167,8 +168,8 @@ class ContactFrameFunction(torch.autograd.Function):
         (p,) = ctx.saved_tensors
         z = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous()
         fr = ctx.frame
-        dp = contact_frame_backward(ctx.geom, p, fr, z(g_n, fr.c_n), z(g_p1, fr.c_p1), z(g_p2, fr.c_p2))
-        return dp, None, None
+        dp = contact_frame_backward(ctx.geom, p, fr, z(g_n, fr.c_n), z(g_p1, fr.c_p1), z(g_p2, fr.c_p2), eps=ctx.eps)
+        return dp, None, None, None
 
 
 def snapshot_frame(cb):

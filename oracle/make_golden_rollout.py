@@ -68,11 +68,74 @@ def run(force0):
     return rec
 
 
+# ---- second scene: contacts that involve hulls (circle / hull by GJK, hull / hull by SAT + clipping) ------------------------
+# a floor (TotalConstraint), a ball and a box, both under gravity, both pushed for the first 0.1 s by learnable forces; the ball
+# lands on the floor, rolls into the box, the box slides and tips.  loss = |ball - box| after the roll-out.
+# (In three of the scenes the box carries no torque and stays flat, |rot| ~ 1e-17: the steps in which its rotation increment is
+#  exactly zero contribute no vertex-rotation path to the reference's gradient - bodies.py:199-202 skips `rotate_verts` then -
+#  which shows up in d(loss)/d(box torque); `box_rot_max` is recorded to tell those scenes apart.)
+H_NSTEPS = 40
+H_FORCES = [([0.0, 6.0, 0.0], [0.0, -2.0, 0.0]), ([0.0, 8.0, 1.0], [0.3, -3.0, 0.0]), ([0.0, 5.0, -1.0], [0.0, -1.0, 0.5]),
+            ([0.2, 7.0, 0.5], [-0.2, -2.5, 0.0]), ([0.0, 9.0, 0.0], [0.0, -4.0, 1.0]), ([-0.1, 6.5, 2.0], [0.1, -1.5, -0.5])]
+
+
+def make_world_hulls(f_ball, f_box):
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import TotalConstraint
+    from lcp_physics.physics.forces import ExternalForce, Gravity
+    from lcp_physics.physics.world import World
+    floor = Rect([500, 500], [900, 10])
+    ball = Circle([380, 468], 20, restitution=0.3, fric_coeff=0.6)
+    box = Rect([470, 474.5], [40, 40], restitution=0.2, fric_coeff=0.4)
+    for b, fn in ((ball, f_ball), (box, f_box)):
+        b.add_force(Gravity(g=100))
+        b.add_force(ExternalForce(fn, multiplier=MULT))
+    world = World([floor, ball, box], [TotalConstraint(floor)], dt=1.0 / 30)
+    return world, ball, box
+
+
+def run_hulls(fb, fx):
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.forces import ExternalForce
+    f1 = torch.tensor(fb, dtype=torch.float64, requires_grad=True)
+    f2 = torch.tensor(fx, dtype=torch.float64, requires_grad=True)
+    world, ball, box = make_world_hulls(lambda t: f1 if t < T_PUSH else ExternalForce.ZEROS,
+                                        lambda t: f2 if t < T_PUSH else ExternalForce.ZEROS)
+    nb = len(world.bodies)
+    rec = dict(Mdiag=torch.diagonal(world.M()).reshape(nb, 3).detach().numpy().copy(),
+               rest=np.array([float(b.restitution) for b in world.bodies]),
+               fric=np.array([float(b.fric_coeff) for b in world.bodies]),
+               kind=np.array([0 if isinstance(b, Circle) else 1 for b in world.bodies]),
+               size=np.array([[float(b.rad), 0.0] if isinstance(b, Circle) else b.dims.numpy().tolist() for b in world.bodies]),
+               gravity=np.stack([np.zeros(3)] + [np.array([0.0, 0.0, 100.0 * float(b.mass)]) for b in world.bodies[1:]]),
+               Je=world.Je().detach().numpy().copy(),
+               p0=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
+               v0=world.get_v().reshape(nb, 3).detach().numpy().copy())
+    ncs, ts, rot_max = [], [], 0.0
+    for _ in range(H_NSTEPS):
+        world.step()
+        ncs.append(len(world.contacts)); ts.append(float(world.t))
+        rot_max = max(rot_max, abs(float(box.p[0])))
+    dist = (ball.pos - box.pos).norm()
+    dist.backward()
+    rec.update(p_final=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(), loss=np.float64(float(dist)),
+               grad_ball=f1.grad.numpy().copy(), grad_box=f2.grad.numpy().copy(), ncontacts=np.array(ncs), t=np.array(ts), box_rot_max=np.float64(rot_max))
+    return rec
+
+
 def main():
     ref_shim.load_reference()
     torch.set_default_dtype(torch.float64)
+    hrecs = [run_hulls(a, b) for a, b in H_FORCES]
+    hout = {"h_" + k: np.stack([r[k] for r in hrecs]) for k in hrecs[0]}
+    hout.update(h_force_ball=np.array([a for a, _ in H_FORCES]), h_force_box=np.array([b for _, b in H_FORCES]), h_nsteps=np.int64(H_NSTEPS))
+    for i, r in enumerate(hrecs):
+        print("hulls", H_FORCES[i], "loss %.4f" % r["loss"], "grad ball", np.array2string(r["grad_ball"], precision=4), "grad box",
+              np.array2string(r["grad_box"], precision=4), "max |box rot| %.1e" % r["box_rot_max"], "contacts", r["ncontacts"].tolist(), "halved",
+              int((np.diff(np.concatenate([[0.0], r["t"]])) < 0.99 / 30).sum()))
     recs = [run(f) for f in FORCES]
     out = {k: np.stack([r[k] for r in recs]) for k in recs[0]}
+    out.update(hout)
     out.update(force0=np.array(FORCES), nsteps=np.int64(NSTEPS), t_push=np.float64(T_PUSH), mult=np.float64(MULT),
                dt=np.float64(1.0 / 30), no_contact=np.array([[0, 1], [0, 2]]), pushed_body=np.int64(1), loss_bodies=np.array([0, 2]))
     for i, r in enumerate(recs):

@@ -692,7 +692,7 @@ def test_contact_frame_backward_matches_autograd_of_the_circle_record():
     cnt = cb.count.cpu()
     assert int(cnt.min()) >= 2
     gn, g1, g2 = [torch.randn(B, 6, 2, generator=g).to(DEV) for _ in range(3)]
-    dp = ct.contact_frame_backward(geom, pg, cb, gn, g1, g2).cpu()
+    dp = ct.contact_frame_backward(geom, pg, cb, gn, g1, g2, eps=30.0).cpu()
     pt = p.clone().requires_grad_(True)
     loss = 0.0
     i1, i2 = cb.c_i1.cpu().long(), cb.c_i2.cpu().long()
@@ -739,3 +739,54 @@ def test_rollout_gradient_matches_the_reference_autograd():
     err = np.abs(gr[::rep] - ref).max(axis=1) / np.abs(ref).max(axis=1)
     print("roll-out gradient: worst relative error", err.max(), "per scene", np.array2string(err, precision=2))
     assert err.max() <= 1e-4, err
+
+
+def test_rollout_gradient_through_hull_contacts_matches_the_reference_autograd():
+    """The same, with contacts that involve hulls: a ball landing on a fixed floor (circle / hull, GJK), rolling into a box that
+    slides and tips on the floor (hull / hull: SAT, incident edge, clipping), both pushed for 0.1 s by learnable forces, 40 steps,
+    loss = |ball - box|.  d(loss)/d(both forces) - through `lcp_step_backward_f32` and the forward-mode contact-frame
+    derivative `lcp_contact_frame_backward_f64` - against the unmodified reference's autograd on six scenes."""
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    nv, rep = d["h_force_ball"].shape[0], 32
+    B = nv * rep
+    rp = lambda a, dt_: torch.tensor(np.repeat(a, rep, axis=0), dtype=dt_, device=DEV)
+    shapes = [("circle", float(s[0])) if int(k) == 0 else ("rect", (float(s[0]), float(s[1]))) for k, s in zip(d["h_kind"][0], d["h_size"][0])]
+    geom = GeometryBatch.from_shapes(shapes, B).to(DEV)
+    fb = rp(d["h_force_ball"], torch.float32).requires_grad_(True)
+    fx = rp(d["h_force_box"], torch.float32).requires_grad_(True)
+    grav = rp(d["h_gravity"], torch.float32)
+    mult, t_push = float(d["mult"]), float(d["t_push"])
+
+    def force_fn(t):
+        on = (t < t_push).to(torch.float32).unsqueeze(1)
+        z = torch.zeros(B, 1, 3, dtype=torch.float32, device=DEV)
+        return grav + torch.cat([z, (fb * mult * on).unsqueeze(1), (fx * mult * on).unsqueeze(1)], dim=1)
+
+    world = ContactWorld(geom, rp(d["h_p0"], torch.float64), rp(d["h_v0"], torch.float32), rp(d["h_Mdiag"], torch.float32),
+                         torch.zeros(B, 3, 3, device=DEV), rp(d["h_rest"], torch.float32), rp(d["h_fric"], torch.float32),
+                         Je=rp(d["h_Je"], torch.float32), dt=float(d["dt"]), maxc=8, force_fn=force_fn)
+    ncs = []
+    for _ in range(int(d["h_nsteps"])):
+        world.step(differentiable=True)
+        ncs.append(world.contacts.count.clone())
+    pos = world.p[:, :, 1:]
+    loss = (pos[:, 1] - pos[:, 2]).norm(dim=1)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    t_ok = np.abs(world.t.cpu().numpy()[::rep] - d["h_t"][:, -1]) < 1e-12
+    n_ok = (torch.stack(ncs, 1).cpu().numpy()[::rep] == d["h_ncontacts"]).all(axis=1)
+    same = t_ok & n_ok                                 # scenes whose every dt-halving / contact-count decision matched the reference's
+    print("scenes on the reference's trajectory:", same.tolist())
+    assert same.sum() >= nv - 1
+    pf = world.p.detach().cpu().numpy()[::rep]
+    assert np.abs(pf - d["h_p_final"])[same].max() <= 5e-4, np.abs(pf - d["h_p_final"])[same].max()
+    gb, gx = fb.grad.cpu().numpy()[::rep], fx.grad.cpu().numpy()[::rep]
+    ref = np.concatenate([d["h_grad_ball"], d["h_grad_box"]], axis=1)
+    got = np.concatenate([gb, gx], axis=1)
+    err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print("hull roll-out gradient: relative error per scene", np.array2string(err, precision=2))
+    if os.environ.get("LCP_TEST_VERBOSE"):
+        print(np.array2string(got, precision=5)); print(np.array2string(ref, precision=5))
+    assert err[same].max() <= 1e-5, err
