@@ -12,7 +12,8 @@ namespace {
 // debugging aids below are per calling thread (thread_local), and the kernel family can also be forced per call with
 // LCP_PATH_GENERIC in the `compute` word.
 thread_local double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
-thread_local int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels
+thread_local int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels,
+                                          // 3 = contact-space lcp_big.hip instead of the body-space lcp_primal.hip (A/B aid)
 
 // `compute` word of an entry point -> arithmetic type; *generic = the caller (or this thread's debug setting) forces the
 // workgroup-per-scene kernels
@@ -30,10 +31,11 @@ inline bool use_wave64(int io_f64, int nz, int m, int e, bool generic) {
 
 // Kernel family of the contact-list entry points (lcp_step_fused_f32, lcp_solve_dynamics_f32, lcp_step_backward_f32):
 // ONE function of (sizes, arithmetic, forced path), so that a backward always reads the workspace layout its forward wrote.
-enum StepFamily { FAM_QUAD, FAM_BIG, FAM_WAVE64, FAM_GENERIC };
+enum StepFamily { FAM_QUAD, FAM_PRIMAL, FAM_BIG, FAM_WAVE64, FAM_GENERIC };
 inline StepFamily step_family(int nz, int m, int e, int compute, bool generic) {
   if (generic) return FAM_GENERIC;
   if (lcp::quad_step_supported(nz, m, e)) return FAM_QUAD;                     // <= 16 contacts, <= 10 bodies, e <= 4
+  if (compute == LCP_COMPUTE_F64 && g_path != 3 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // <= 64 contacts, body-space systems
   if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e)) return FAM_BIG;   // <= 64 contacts (fp64 arithmetic)
   if (lcp::wave64_supported(nz, m, e)) return FAM_WAVE64;                      // nz <= 16, e 5..8
   return FAM_GENERIC;
@@ -242,6 +244,7 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
   // the same family decision as the forward entry points (launch_step): the workspace layout is the family's
   switch (step_family(3 * nb, 4 * nc, e, compute, generic)) {
     case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream);
+    case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream);
     case FAM_BIG: return lcp::big_step_backward(P, G, stream);
     default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read
   }
@@ -251,6 +254,7 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
 static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream) {
   switch (step_family(nz, m, e, compute, generic)) {
     case FAM_QUAD: return lcp::quad_step(P, compute, stream);
+    case FAM_PRIMAL: return lcp::primal_step(P, stream);
     case FAM_BIG: return lcp::big_step(P, stream);
     case FAM_WAVE64: if (!P.c_count) return lcp::wave64_step(P, compute, stream);   // (its kernel takes full lists only)
     default: break;

@@ -112,6 +112,12 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64 = 0);
 int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64 = 0);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
+// body-space (primal) contact-structured path: one wave per scene, <= 64 contacts, nz + neq <= 56 - lcp_primal.hip
+bool primal_supported(int nz, int m, int e);
+size_t primal_ws_bytes();
+int primal_step(const StepArgs& P, void* stream);
+int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
+
 // four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
 // list) - lcp_quad.hip
 // `accept`: classification flag value (workspace meta[0]) the launch serves

@@ -1,0 +1,545 @@
+// lcp_primal.hip - contact-structured PDIPM for scenes of up to 64 contacts with the KKT systems solved in BODY space:
+// one wavefront per scene, lane c = contact c, lane j = row j of an (nz + neq)-square system.
+//
+// The reference eliminates x first and factors T = G Q^-1 G^T + F + D^-1 in contact space (pdipm.py:325-454: nineq = 4 nc
+// rows; lcp_quad.hip / lcp_big.hip reduce that exactly to 2 nc).  The same Newton step can be had by eliminating the
+// inequality block first - the block (F + D^-1) of the mixed contact LCP (engines.py:67-73) is block diagonal, one 4 x 4 block
+//        [ Dn  0   0   0 ]     rows / columns: normal, friction +, friction -, cone        D = s / z
+//    M = [ 0   D1  0   1 ]     (F = [[0, 0, 0], [0, 0, E], [mu, -E^T, 0]])
+//        [ 0   0   D2  1 ]
+//        [ mu  -1  -1  Dg ]
+// per contact, inverted in closed form inside the contact's lane:
+//    G dx - M dz = q,  q = rs / d - rz                 (the inequality rows of the step equations behind pdipm.py:325-354)
+//    (Q + G^T M^-1 G) dx + A^T dy = -rx + G^T M^-1 q,  A dx = -ry
+//    dz = M^-1 (G dx - q),   ds = (-rs - dz) / d
+// With G = [Jc; +Jt; -Jt; 0] only a 2 x 2 matrix per contact enters G^T M^-1 G (B00 Jc^T Jc + B10 Jt^T Jc + B11 Jt^T Jt), and a
+// contact touches two bodies: its contribution is a 6 x 6 block.  The system is (nz + neq) square - 36 for BASELINE config 5
+// (11 bodies, 64 contacts, nineq 256) instead of 256 (reference) or 128 (reduced contact space): 45 x fewer LU flops, and
+// the whole scene fits one wavefront's registers.  Same iterates as the reference in exact arithmetic; in fp64 the final
+// velocities agree with the contact-space solve to ~1e-12 (tools/experiments/primal_numerics.py, the parity tests).
+//
+// Mapping: lane c holds the contact's rows of Jc / Jt in compressed form (six entries each + the two body indices) and the
+// four inequality components of every m-space vector; lane r < nz + neq holds entry r of the x / y vectors and ROW r of the
+// system matrix in registers.  Formation: the lanes add their 6 x 6 blocks into an LDS image of the matrix with ds_add_f64
+// (one wave owns the image, so the order of the additions - and the result - is the same on every run), rows then move to
+// registers.  LU without pivoting (x rows first: Q + G^T M^-1 G has a positive definite symmetric part; then the equality
+// rows, whose Schur complement -A S^-1 A^T is negative definite), pivot rows broadcast with v_readlane.
+// Kernels: forward of the fused step (engines.py:26-78) and its backward w.r.t. the physical inputs (lcp.py:37-64 contracted
+// through the assembly), behind lcp_solve_dynamics_f32 / lcp_step_backward_f32.
+#include "lcp_wave_scene.h"
+
+namespace lcp {
+namespace primal {
+
+using namespace w64;
+using namespace wsc;
+
+constexpr int LX = 64;           // lanes = stride of the stored iterate
+constexpr int EQB = 4;           // padded neq
+// workspace per scene (doubles): a 64-entry header (contact count), then the best iterate the backward needs, in the layout
+// lcp_big.hip uses: x[64] y[8] z[4][64] s[4][64] mu[64] diag(Q)[64]
+struct WsLayout { static constexpr int IT = 64, TOTAL = IT + 64 + 8 + 10 * LX; };
+
+#ifdef LCP_PRIMAL_PROFILE
+#define PR_TICK(i) { const long long now_ = clock64(); pc[i] += now_ - tk; tk = now_; }
+#else
+#define PR_TICK(i)
+#endif
+
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ds_add_f64 (no return)
+}
+
+// NCOL: capacity of the system (nz + neq <= NCOL <= 64), a multiple of 8
+template <int NCOL, bool BWD>
+__global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
+  constexpr int LDK = NCOL + 1;
+  __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];   // image of the system matrix (formation); backward: staging
+  __shared__ double xv[LX];                                        // x-space exchange / accumulation
+  __shared__ float At[EQB * LX];                                   // A rows
+  __shared__ int B12[2 * LX];
+  const int scene = blockIdx.x, lane = threadIdx.x;
+  const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
+  double* Wg = (double*)SP.ws + (size_t)scene * (size_t)WsLayout::TOTAL;
+  double* Wit = Wg + WsLayout::IT;
+  int ncs = ncap;
+  if (BWD) ncs = (int)Wg[0];                                               // the count the forward solved with
+  else if (SP.c_count) ncs = SP.c_count[scene];
+  const int truncated = (ncs > ncap) ? LCP_ST_TRUNCATED : 0;               // more contacts found than the list holds
+  ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
+  if (!BWD && lane == 0) Wg[0] = (double)ncs;
+  const bool vc = lane < ncs;                                              // this lane owns a live contact
+  const bool vx = lane < nz, ve = lane >= nz && lane < n;                  // ... an x entry, an equality multiplier
+
+  // ---- assembly (engines.py:31-32,50-74; world.py:144-234) ----------------------------------------------------------
+  const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
+  const float* vv = (const float*)SP.v + (size_t)scene * nz;
+  const float* ff = (const float*)SP.f + (size_t)scene * nz;
+  double jn[6] = {0, 0, 0, 0, 0, 0}, jf[6] = {0, 0, 0, 0, 0, 0};
+  int c0 = 0, c1 = 0;                                                      // first columns of the contact's two bodies
+  double mu_c = 0, hn = 0;
+  if (vc) {
+    const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
+                                                     (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
+                                                     SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
+                                                     (const float*)SP.fric + (size_t)scene * nb, vv, lane);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { jn[q] = (double)r.jn[q]; jf[q] = (double)r.jf[q]; }
+    c0 = 3 * r.b1; c1 = 3 * r.b2;
+    mu_c = (double)r.mu; hn = (double)r.h;
+  }
+  auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
+  double qd = 0, p = 0;
+  if (vx) {
+    qd = (double)Md[lane];
+    p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
+  }
+  for (int i = lane; i < EQB * LX; i += 64) At[i] = 0.0f;
+  wsync();
+  for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  wsync();
+  int status = truncated;
+  if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
+  // the lane's column / row of A: x lanes hold A[:, lane], the equality lane nz + a holds nothing extra (its row is read from At)
+  double acol[EQB];
+#pragma unroll
+  for (int a = 0; a < EQB; ++a) acol[a] = (vx && a < e) ? (double)At[a * LX + lane] : 0.0;
+
+  // ---- products ------------------------------------------------------------------------------------------------------
+  auto Gv = [&](double v, double& gn, double& gt) {                       // m-space <- x-space (v on the x lanes)
+    xv[lane] = vx ? v : 0.0; wsync();
+    gn = 0; gt = 0;
+    if (vc) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const double xq = xv[colq(q)]; gn = fma(jn[q], xq, gn); gt = fma(jf[q], xq, gt); }
+    }
+    wsync();
+  };
+  auto Gtw = [&](double wn, double wt) -> double {                        // x-space <- m-space (Jc^T wn + Jt^T wt)
+    xv[lane] = 0.0; wsync();
+    if (vc) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) lds_add(&xv[colq(q)], fma(jf[q], wt, jn[q] * wn));
+    }
+    wsync();
+    const double r = vx ? xv[lane] : 0.0;
+    wsync();
+    return r;
+  };
+  auto Av = [&](double v) -> double {                                     // equality lanes <- x lanes
+    double out = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol[a] * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+    return out;
+  };
+  auto Aty = [&](double y) -> double {                                    // x lanes <- equality lanes
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol[a], bcast_lane(y, nz + a), acc); }
+    return acc;
+  };
+
+  // ---- the contact's 4 x 4 block M = F_c + diag(s / z), inverted in closed form ------------------------------------------------
+  double idn = 1, i1 = 1, i2 = 1, kap = 1.0 / 3.0;                         // 1 / Dn, 1 / D1, 1 / D2, 1 / (Dg + 1 / D1 + 1 / D2)
+  double b00 = 0, b10 = 0, b11 = 0;                                        // the 2 x 2 matrix of G^T M^-1 G in (Jc, Jt) coordinates
+  auto block_setup = [&](const M4<double>& D) {                           // D = 1 / d = s / z
+    idn = 1.0 / D.n; i1 = 1.0 / D.f1; i2 = 1.0 / D.f2;
+    kap = 1.0 / (D.g + (i1 + i2));
+    b00 = idn;
+    b10 = kap * (i1 - i2) * (mu_c * idn);
+    b11 = kap * fma(i1 + i2, D.g, 4.0 * (i1 * i2));                        // = (i1 + i2) - kap (i1 - i2)^2, without the cancellation
+  };
+  auto minv = [&](const M4<double>& t) -> M4<double> {                    // M^-1 t
+    M4<double> o;
+    o.n = idn * t.n;
+    o.g = kap * ((t.g - mu_c * o.n) + fma(i1, t.f1, i2 * t.f2));
+    o.f1 = i1 * (t.f1 - o.g);
+    o.f2 = i2 * (t.f2 - o.g);
+    return o;
+  };
+
+#ifdef LCP_PRIMAL_PROFILE
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = clock64();
+#endif
+  // ---- formation + LU of K = [[Q + G^T M^-1 G, A^T], [A, 0]]: row `lane` in t[], 1 / U[lane][lane] in udinv ---------------------
+  double t[NCOL];
+  double udinv = 1.0;
+  bool singular = false;
+  auto factor = [&]() LCP_INL {
+    for (int i = lane; i < NCOL * LDK; i += 64) Kl[i] = 0.0;
+    wsync();
+    if (lane < NCOL) Kl[lane * LDK + lane] = vx ? qd : (ve ? 0.0 : 1.0);   // rows beyond the system: identity
+    if (vx) {
+#pragma unroll
+      for (int a = 0; a < EQB; ++a) { if (a < e) { Kl[lane * LDK + nz + a] = acol[a]; Kl[(nz + a) * LDK + lane] = acol[a]; } }
+    }
+    wsync();
+    if (vc) {
+      double p0[6], p1[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { p0[q] = b00 * jn[q]; p1[q] = fma(b10, jn[q], b11 * jf[q]); }
+#pragma unroll
+      for (int pq = 0; pq < 6; ++pq) {
+        double* row = Kl + colq(pq) * LDK;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) lds_add(row + colq(q), fma(jf[pq], p1[q], jn[pq] * p0[q]));
+      }
+    }
+    wsync();
+    PR_TICK(1)
+    {
+      const double* row = Kl + (lane < NCOL ? lane : 0) * LDK;
+      static_for<NCOL>([&](auto J) LCP_INL { t[J] = row[J]; });
+      if (lane >= NCOL) static_for<NCOL>([&](auto J) LCP_INL { t[J] = 0.0; });
+    }
+    wsync();
+    singular = false;
+    static_for<NCOL / 8>([&](auto G8) LCP_INL {
+      if (8 * G8 < n) {
+        static_for<8>([&](auto KK) LCP_INL {
+          constexpr int k = 8 * G8 + KK;
+          const double pk = bcast_lane(t[k], k);
+          singular = singular || !(pk != 0.0) || (pk != pk);
+          const double inv = fast_rcp(pk);
+          if (lane == k) udinv = inv;
+          const double l = (lane > k) ? t[k] * inv : 0.0;
+          if (lane > k) t[k] = l;
+          static_for<NCOL - 1 - k>([&](auto JJ) LCP_INL {
+            constexpr int j = k + 1 + JJ;
+            t[j] = fma(-l, bcast_lane(t[j], k), t[j]);
+          });
+        });
+      }
+    });
+  };
+  // K^-1 w (w: entry `lane` of the right-hand side)
+  auto ksolve = [&](double w) -> double {
+    static_for<NCOL / 8>([&](auto G8) LCP_INL {
+      if (8 * G8 < n) {
+        static_for<8>([&](auto KK) LCP_INL {
+          constexpr int k = 8 * G8 + KK;
+          const double yk = bcast_lane(w, k);
+          w = fma(-((lane > k) ? t[k] : 0.0), yk, w);
+        });
+      }
+    });
+    static_for<NCOL / 8>([&](auto GR) LCP_INL {
+      constexpr int g8 = NCOL / 8 - 1 - GR;
+      if (8 * g8 < n) {
+        static_for<8>([&](auto KR) LCP_INL {
+          constexpr int k = 8 * g8 + 7 - KR;
+          const double xk = bcast_lane(w * udinv, k);
+          w = fma(-((lane < k) ? t[k] : 0.0), xk, w);
+        });
+      }
+    });
+    return w * udinv;
+  };
+
+  // solve_kkt (pdipm.py:325-354) in body space; di = 1 / d.  rx / ox: x lanes, ry / oy: equality lanes
+  auto solve_kkt = [&](const M4<double>& di, double rx, const M4<double>& rs, const M4<double>& rz, double ry,
+                       double& ox, M4<double>& os, M4<double>& oz, double& oy) {
+    M4<double> q = m4<double>(rs.n * di.n - rz.n, rs.f1 * di.f1 - rz.f1, rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);
+    if (!vc) q = m4<double>(0, 0, 0, 0);
+    const M4<double> u = minv(q);
+    const double gu = Gtw(vc ? u.n : 0.0, vc ? u.f1 - u.f2 : 0.0);
+    const double rhs = vx ? (gu - rx) : (ve ? -ry : 0.0);
+    const double sol = ksolve(rhs);
+    ox = vx ? sol : 0.0; oy = ve ? sol : 0.0;
+    double gn, gt;
+    Gv(ox, gn, gt);
+    oz = minv(m4<double>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+    if (!vc) oz = m4<double>(0, 0, 0, 0);
+    os = m4<double>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
+    if (!vc) os = m4<double>(0, 0, 0, 0);
+  };
+
+  // get_step for (z, dz), (s, ds) (pdipm.py:182-186), NaN semantics as in lcp_quad.hip step_pair_q
+  auto step_pair = [&](const M4<double>& z, const M4<double>& dz, const M4<double>& s, const M4<double>& ds) -> double {
+    const double ninf = -inf_of<double>(), pinf = inf_of<double>();
+    const M4<double> az = m4<double>(-z.n / dz.n, -z.f1 / dz.f1, -z.f2 / dz.f2, -z.g / dz.g);
+    const M4<double> as = m4<double>(-s.n / ds.n, -s.f1 / ds.f1, -s.f2 / ds.f2, -s.g / ds.g);
+    auto key4 = [&](const M4<double>& a) { return umax(umax(nan_key(a.n), nan_key(a.f1)), umax(nan_key(a.f2), nan_key(a.g))); };
+    auto max4 = [&](const M4<double>& a) { return __builtin_fmax(__builtin_fmax(a.n, a.f1), __builtin_fmax(a.f2, a.g)); };
+    auto min4 = [&](const M4<double>& a) { return __builtin_fmin(__builtin_fmin(a.n, a.f1), __builtin_fmin(a.f2, a.g)); };
+    const uint32_t kmz = wave_umax(vc ? key4(az) : 0u), kms = wave_umax(vc ? key4(as) : 0u);
+    const double mz = wave_max(vc ? max4(az) : ninf), ms = wave_max(vc ? max4(as) : ninf);
+    const double fz = key_is_nan(kmz) ? 1.0 : __builtin_fmax(mz, 1.0), fs = key_is_nan(kms) ? 1.0 : __builtin_fmax(ms, 1.0);
+    auto pick = [&](double dv, double a, double fill) { return (dv > 0.0) ? fill : a; };
+    const M4<double> pz = m4<double>(pick(dz.n, az.n, fz), pick(dz.f1, az.f1, fz), pick(dz.f2, az.f2, fz), pick(dz.g, az.g, fz));
+    const M4<double> ps = m4<double>(pick(ds.n, as.n, fs), pick(ds.f1, as.f1, fs), pick(ds.f2, as.f2, fs), pick(ds.g, as.g, fs));
+    const uint32_t kl = wave_umax(vc ? umax(key4(pz), key4(ps)) : 0u);
+    const double l = wave_min(vc ? __builtin_fmin(min4(pz), min4(ps)) : pinf);
+    return key_is_nan(kl) ? nan_of<double>() : l;
+  };
+
+  if (BWD) {
+    // ---- backward: d(loss)/d(v_new) -> d(loss)/d(Mdiag, v, f, rest, fric, contact normal / arms) ----------------------------
+    double x = vx ? Wit[lane] : 0.0, dx = 0, dnu = 0;
+    M4<double> z = m4<double>(1, 1, 1, 1), s = z, dinv = z, ds, dl;
+    if (vc) {
+      z = m4<double>(Wit[72 + lane], Wit[72 + LX + lane], Wit[72 + 2 * LX + lane], Wit[72 + 3 * LX + lane]);
+      s = m4<double>(Wit[72 + 4 * LX + lane], Wit[72 + 5 * LX + lane], Wit[72 + 6 * LX + lane], Wit[72 + 7 * LX + lane]);
+      dinv = m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                 // 1 / d, d = z / s (lcp.py:44)
+    }
+    // At a converged iterate the ratios D = s / z of the active rows underflow against Q (1e-12 and below), and Q + G^T M^-1 G
+    // would lose Q.  The factorisation therefore uses D floored at BWD_FLOOR x (the row's effective inverse mass
+    // j Q^-1 j^T) - a perturbation of 1e-9 of the diagonal of the contact-space matrix - and one step of iterative refinement on
+    // the UNREDUCED equations (residuals formed with M, not M^-1) takes the perturbation out again: 1e-8 of the natural scale
+    // |g| / min Q against the contact-space solve (tools/experiments/primal_numerics.py).  The forward needs neither: its
+    // right-hand sides keep the error of the stiff directions benign (same experiment).
+    constexpr double BWD_FLOOR = 1e-9;
+    M4<double> dfl = dinv;
+    {
+      xv[lane] = vx ? 1.0 / qd : 0.0; wsync();
+      double wn = 0, wt = 0;
+      if (vc) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const double qi = xv[colq(q)]; wn = fma(jn[q] * jn[q], qi, wn); wt = fma(jf[q] * jf[q], qi, wt); }
+        dfl.n = __builtin_fmax(dinv.n, BWD_FLOOR * wn);
+        dfl.f1 = __builtin_fmax(dinv.f1, BWD_FLOOR * wt);
+        dfl.f2 = __builtin_fmax(dinv.f2, BWD_FLOOR * wt);
+      }
+      wsync();
+    }
+    block_setup(dfl);
+    factor();                                                               // lcp.py:46
+    // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
+    const double g = vx ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
+    const M4<double> zero = m4<double>(0, 0, 0, 0);
+    solve_kkt(dfl, g, zero, zero, 0.0, dx, ds, dl, dnu);                     // lcp.py:47-50
+    {
+      // residuals of  Q dx + G^T dl + A^T dnu = -g ,  G dx - M dl = 0 ,  A dx = 0  with the TRUE D
+      double r1 = -g - (qd * dx + Gtw(vc ? dl.n : 0.0, vc ? dl.f1 - dl.f2 : 0.0));
+      if (e > 0) r1 -= Aty(dnu);
+      if (!vx) r1 = 0.0;
+      double gn, gt;
+      Gv(dx, gn, gt);
+      M4<double> r3 = m4<double>(-(gn - dinv.n * dl.n), -(gt - (dinv.f1 * dl.f1 + dl.g)), -(-gt - (dinv.f2 * dl.f2 + dl.g)),
+                                 (mu_c * dl.n - (dl.f1 + dl.f2)) + dinv.g * dl.g);
+      if (!vc) r3 = zero;
+      const double r2 = (e > 0) ? -Av(dx) : 0.0;
+      double cx, cnu;
+      M4<double> cs, cl;
+      solve_kkt(dfl, -r1, zero, m4<double>(-r3.n, -r3.f1, -r3.f2, -r3.g), -r2, cx, cs, cl, cnu);
+      dx += cx; dnu += cnu;
+      dl = m4<double>(dl.n + cl.n, dl.f1 + cl.f1, dl.f2 + cl.f2, dl.g + cl.g);
+    }
+    // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
+    double* X = Kl; double* DX = Kl + LX; double* CR = Kl + 2 * LX; double* CF = Kl + 3 * LX;
+    X[lane] = x; DX[lane] = dx; wsync();
+    double gh_rbar = 0;
+    {
+      double cr = 0, cf = 0, dnx = 0, dny = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+      int b1 = 0, b2 = 0;
+      if (vc) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        const double nx = ((const float*)SP.c_n)[cb * 2], ny = ((const float*)SP.c_n)[cb * 2 + 1];
+        const double p1x = ((const float*)SP.c_p1)[cb * 2], p1y = ((const float*)SP.c_p1)[cb * 2 + 1];
+        const double p2x = ((const float*)SP.c_p2)[cb * 2], p2y = ((const float*)SP.c_p2)[cb * 2 + 1];
+        b1 = SP.c_i1[cb]; b2 = SP.c_i2[cb];
+        const double rbar = 0.5 * ((double)((const float*)SP.rest)[(size_t)scene * nb + b1] + (double)((const float*)SP.rest)[(size_t)scene * nb + b2]);
+        const double jnd[6] = {p1x * ny - p1y * nx, nx, ny, -(p2x * ny - p2y * nx), -nx, -ny};     // world.py:177-183
+        const double gh = -dl.n;                                              // dh = -dlam (lcp.py:56)
+        const double af = dl.f1 - dl.f2, lf = z.f1 - z.f2;                    // Jf rows are +jt, -jt (world.py:191-192)
+        double gjn[6], gjf[6], jnv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
+          const double xq = X[col], dxq = DX[col], vq = (double)vv[col];
+          jnv = fma(jnd[q], vq, jnv);
+          gjn[q] = dl.n * xq + z.n * dxq + gh * rbar * vq;                    // dG row n (lcp.py:53) + h = (Jc v) rbar
+          gjf[q] = af * xq + lf * dxq;
+        }
+        gh_rbar = gh * rbar;
+        cr = 0.5 * gh * jnv;                                                  // rbar = (rest_b1 + rest_b2) / 2 (world.py:144-151)
+        cf = 0.5 * (-dl.g * z.n);                                             // dF[gamma_c, n_c] = -dlam_g lam_n (lcp.py:54), F = mu there
+        dnx = -gjn[0] * p1y + gjn[1] + gjn[3] * p2y - gjn[4] - gjf[0] * p1x - gjf[2] + gjf[3] * p2x + gjf[5];
+        dny = gjn[0] * p1x + gjn[2] - gjn[3] * p2x - gjn[5] - gjf[0] * p1y + gjf[1] + gjf[3] * p2y - gjf[4];
+        d1x = gjn[0] * ny - gjf[0] * nx; d1y = -gjn[0] * nx - gjf[0] * ny;
+        d2x = -gjn[3] * ny + gjf[3] * nx; d2y = gjn[3] * nx + gjf[3] * ny;
+      }
+      wsync();
+      CR[lane] = cr; CF[lane] = cf; B12[lane] = b1; B12[LX + lane] = b2;
+      if (lane < ncap) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        if (Gd.dcn) { ((float*)Gd.dcn)[cb * 2] = (float)dnx; ((float*)Gd.dcn)[cb * 2 + 1] = (float)dny; }
+        if (Gd.dcp1) { ((float*)Gd.dcp1)[cb * 2] = (float)d1x; ((float*)Gd.dcp1)[cb * 2 + 1] = (float)d1y; }
+        if (Gd.dcp2) { ((float*)Gd.dcp2)[cb * 2] = (float)d2x; ((float*)Gd.dcp2)[cb * 2 + 1] = (float)d2y; }
+      }
+    }
+    const double dv_h = Gtw(gh_rbar, 0.0);                                   // Jc^T (dh rbar)
+    if (vx) {
+      const size_t o = (size_t)scene * nz + lane;
+      const double md = (double)Md[lane], v = (double)vv[lane];
+      if (Gd.dMdiag) ((float*)Gd.dMdiag)[o] = (float)(dx * x + dx * v);      // Q = diag(M) (dQ, lcp.py:59-60) and p = M v + dt f
+      if (Gd.dv) ((float*)Gd.dv)[o] = (float)(dx * md + dv_h);
+      if (Gd.df) ((float*)Gd.df)[o] = (float)(dx * (double)SP.dt);
+    }
+    if (lane < nb) {                                                          // per-body sums over the contacts, fixed order
+      double ar = 0, af = 0;
+      for (int c = 0; c < ncs; ++c) {
+        const double w = ((B12[c] == lane) ? 1.0 : 0.0) + ((B12[LX + c] == lane) ? 1.0 : 0.0);
+        if (w != 0.0) { ar += w * CR[c]; af += w * CF[c]; }
+      }
+      if (Gd.drest) ((float*)Gd.drest)[(size_t)scene * nb + lane] = (float)ar;
+      if (Gd.dfric) ((float*)Gd.dfric)[(size_t)scene * nb + lane] = (float)af;
+    }
+    return;
+  }
+
+  // ---- the PDIPM loop (pdipm.py:49-179) -----------------------------------------------------------------------------------
+  const int max_iter = SP.max_iter, lim = SP.lim;
+  const double eps = SP.eps;
+  const double mf = (double)(4 * ncs);
+  double x = 0, y = 0;                                                       // x on the x lanes, y on the equality lanes
+  M4<double> s = m4<double>(1, 1, 1, 1), z = s, dinv = s;
+  double bx = 0, by = 0;
+  M4<double> bz = s, bs = s;
+  double best_resid = inf_of<double>();
+  bool have_best = false, done = false;
+  int n_not = 0, iters = 0;
+  for (int it = -1; it < max_iter; ++it) {
+    double rx = 0, ry = 0, mu = 0, resid = 0;
+    M4<double> rs = m4<double>(0, 0, 0, 0), rz = rs;
+    if (it < 0) {                                                           // init: (p, 0, -h, -b), d = 1 (:57-63); b = 0 (engines.py:74)
+      rx = p; ry = 0.0; rz = m4<double>(-hn, 0, 0, 0); dinv = m4<double>(1, 1, 1, 1);
+    } else {                                                                // residuals (:82-96)
+      rx = Gtw(vc ? z.n : 0.0, vc ? z.f1 - z.f2 : 0.0) + qd * x + p;
+      if (e > 0) rx += Aty(y);
+      if (!vx) rx = 0.0;
+      rs = z;
+      double gn, gt;
+      Gv(x, gn, gt);
+      rz = m4<double>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (mu_c * z.n - (z.f1 + z.f2)));
+      if (!vc) rz = m4<double>(0, 0, 0, 0);
+      ry = (e > 0) ? Av(x) : 0.0;
+      const double n_rx = wave_sum(rx * rx);
+      const double n_rz = wave_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
+      const double n_ry = wave_sum(ry * ry);
+      const double sz = wave_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : 0.0);
+      mu = sz / mf; mu = mu < 0 ? -mu : mu;                                 // (:91)
+      resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;               // (:92-96)
+      dinv = vc ? m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<double>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
+    }
+    block_setup(dinv);
+    PR_TICK(0)                                                              // residuals
+    factor();                                                               // (:99-100)
+    PR_TICK(2)                                                              // LU
+    if (it >= 0 && !done) {
+      ++iters;
+      if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
+      else {
+        const bool improved = !have_best || (resid < best_resid);             // (:107-132)
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; by = y; bz = z; bs = s; }
+        else ++n_not;
+        if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;   // (:133)
+      }
+    }
+    // (the iterate the last pass would produce is never evaluated - pdipm.py:176-179 - so its solves are skipped)
+    if (it >= 0 && it == max_iter - 1) done = true;
+    if (done) break;
+    double ax = 0, ay = 0;
+    M4<double> as_ = m4<double>(0, 0, 0, 0), az = as_;
+    const int npass = (it < 0) ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
+      double ox, oy;
+      M4<double> os, oz;
+      PR_TICK(3)
+      solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+      PR_TICK(4)                                                            // solve_kkt
+      if (it < 0) {
+        x = ox; s = os; z = oz; y = oy;                                     // (:60-63)
+        auto min4 = [&](const M4<double>& a) { return pmin(pmin(a.n, a.f1), pmin(a.f2, a.g)); };
+        const uint32_t ks = wave_umax(vc ? umax(umax(nan_key(s.n), nan_key(s.f1)), umax(nan_key(s.f2), nan_key(s.g))) : 0u);
+        const uint32_t kz = wave_umax(vc ? umax(umax(nan_key(z.n), nan_key(z.f1)), umax(nan_key(z.f2), nan_key(z.g))) : 0u);
+        double smin = wave_min(vc ? min4(s) : inf_of<double>()), zmin = wave_min(vc ? min4(z) : inf_of<double>());
+        if (key_is_nan(ks)) smin = nan_of<double>();
+        if (key_is_nan(kz)) zmin = nan_of<double>();
+        if (smin <= 0.0) { const double sh = 1.0 - smin; s = m4<double>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
+        if (zmin <= 0.0) { const double sh = 1.0 - zmin; z = m4<double>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
+        if (!vc) { s = m4<double>(1, 1, 1, 1); z = s; }
+        if (ncs == 0) { bx = x; by = y; done = true; }                      // engines.py:36-50: x = P^-1 u, no LCP
+      } else if (pass == 0) {
+        ax = ox; ay = oy; as_ = os; az = oz;                                // affine direction (:138-139)
+        const double alpha = pmin(step_pair(z, az, s, as_), 1.0);          // (:142-144)
+        auto sc = [&](double sv, double dsv, double zv, double dzv) { return (sv + alpha * dsv) * (zv + alpha * dzv); };
+        const double t3 = wave_sum(vc ? (sc(s.n, as_.n, z.n, az.n) + sc(s.f1, as_.f1, z.f1, az.f1)) + (sc(s.f2, as_.f2, z.f2, az.f2) + sc(s.g, as_.g, z.g, az.g)) : 0.0);
+        const double t4 = wave_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : 0.0);
+        const double r3 = t3 / t4, sig = r3 * r3 * r3;                      // (:146-150)
+        const double ms = -mu * sig;
+        rx = 0; ry = 0; rz = m4<double>(0, 0, 0, 0);
+        rs = vc ? m4<double>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
+                : m4<double>(0, 0, 0, 0);                                   // (:153)
+      } else {
+        const double cx = ox + ax, cy = oy + ay;                            // (:160-163)
+        const M4<double> cs = m4<double>(os.n + as_.n, os.f1 + as_.f1, os.f2 + as_.f2, os.g + as_.g);
+        const M4<double> cz = m4<double>(oz.n + az.n, oz.f1 + az.f1, oz.f2 + az.f2, oz.g + az.g);
+        const double alpha = pmin(0.999 * step_pair(z, cz, s, cs), 1.0);   // (:164-166)
+        x += alpha * cx; y += alpha * cy;                                   // (:171-174)
+        if (vc) {
+          s = m4<double>(s.n + alpha * cs.n, s.f1 + alpha * cs.f1, s.f2 + alpha * cs.f2, s.g + alpha * cs.g);
+          z = m4<double>(z.n + alpha * cz.n, z.f1 + alpha * cz.f1, z.f2 + alpha * cz.f2, z.g + alpha * cz.g);
+        }
+      }
+      PR_TICK(5)                                                            // step lengths, update
+    }
+    if (done) break;
+  }
+
+  // ---- outputs (row layout of a capacity-sized LCP, padded slots 0) ---------------------------------------------------------
+  bool bad = vx && (bx != bx);
+  if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
+                (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
+  if (__any(bad)) status |= LCP_ST_NAN;
+  const int m = 4 * ncap;
+  if (lane < ncap) {
+    const float k = vc ? 1.0f : 0.0f;
+    if (SP.z) { float* o = (float*)SP.z + (size_t)scene * m; o[lane] = k * (float)bz.n; o[ncap + 2 * lane] = k * (float)bz.f1; o[ncap + 2 * lane + 1] = k * (float)bz.f2; o[3 * ncap + lane] = k * (float)bz.g; }
+    if (SP.s) { float* o = (float*)SP.s + (size_t)scene * m; o[lane] = k * (float)bs.n; o[ncap + 2 * lane] = k * (float)bs.f1; o[ncap + 2 * lane + 1] = k * (float)bs.f2; o[3 * ncap + lane] = k * (float)bs.g; }
+  }
+  if (ve && SP.y) ((float*)SP.y)[(size_t)scene * e + (lane - nz)] = (float)by;
+  if (vx) {
+    const double nv = -bx;                                                            // engines.py:76-77
+    ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)nv;
+    if (SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
+  }
+  // the iterate the backward starts from (lcp.py:29 keeps nus, lams, slacks on the op)
+  Wit[lane] = vx ? bx : 0.0;
+  {
+    const double ys = bcast_lane(by, nz) , y1 = bcast_lane(by, nz + 1 < 64 ? nz + 1 : 63), y2 = bcast_lane(by, nz + 2 < 64 ? nz + 2 : 63), y3 = bcast_lane(by, nz + 3 < 64 ? nz + 3 : 63);
+    if (lane < 8) Wit[64 + lane] = (lane >= e) ? 0.0 : (lane == 0 ? ys : (lane == 1 ? y1 : (lane == 2 ? y2 : y3)));
+  }
+  Wit[72 + lane] = bz.n; Wit[72 + LX + lane] = bz.f1; Wit[72 + 2 * LX + lane] = bz.f2; Wit[72 + 3 * LX + lane] = bz.g;
+  Wit[72 + 4 * LX + lane] = bs.n; Wit[72 + 5 * LX + lane] = bs.f1; Wit[72 + 6 * LX + lane] = bs.f2; Wit[72 + 7 * LX + lane] = bs.g;
+  if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+#ifdef LCP_PRIMAL_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && SP.s) { float* o = (float*)SP.s + (size_t)scene * 4 * ncap + (4 * ncap - 8); for (int i = 0; i < 6; ++i) o[i] = (float)pc[i]; }
+#endif
+}
+
+}  // namespace primal
+
+// nz + neq rows on the lanes of one wave, a contact per lane
+bool primal_supported(int nz, int m, int e) {
+  return (m % 4) == 0 && m / 4 <= 64 && e <= primal::EQB && (nz % 3) == 0 && nz + e <= 56;
+}
+size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOTAL; }
+
+template <int NCOL, bool BWD>
+static int primal_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
+  hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+template <bool BWD>
+static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
+  const int n = 3 * SP.nb + SP.e;
+  if (n <= 24) return primal_launch<24, BWD>(SP, Gd, stream);
+  if (n <= 40) return primal_launch<40, BWD>(SP, Gd, stream);
+  return primal_launch<56, BWD>(SP, Gd, stream);
+}
+int primal_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_dispatch<false>(SP, Gd, stream); }
+int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_dispatch<true>(SP, Gd, stream); }
+
+}  // namespace lcp
