@@ -46,18 +46,21 @@ struct WsLayout { static constexpr int IT = 64, TOTAL = IT + 64 + 8 + 10 * LX; }
 #define PR_TICK(i)
 #endif
 
+// keeps a wave-uniform value in scalar registers at this point (the batches of pivot-row broadcasts stay batches)
+__device__ __forceinline__ void sgpr_pin(double& v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ds_add_f64 (no return)
 }
 
 // NCOL: capacity of the system (nz + neq <= NCOL <= 64), a multiple of 8
 template <int NCOL, bool BWD>
-__global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
+__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
   constexpr int LDK = NCOL + 1;
   __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];   // image of the system matrix (formation); backward: staging
   __shared__ double xv[LX];                                        // x-space exchange / accumulation
   __shared__ float At[EQB * LX];                                   // A rows
   __shared__ int B12[2 * LX];
+  __shared__ double stash[8 * LX];                                 // the affine direction, parked during the corrector solve
   const int scene = blockIdx.x, lane = threadIdx.x;
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
   double* Wg = (double*)SP.ws + (size_t)scene * (size_t)WsLayout::TOTAL;
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
   const float* vv = (const float*)SP.v + (size_t)scene * nz;
   const float* ff = (const float*)SP.f + (size_t)scene * nz;
-  double jn[6] = {0, 0, 0, 0, 0, 0}, jf[6] = {0, 0, 0, 0, 0, 0};
+  float jn[6] = {0, 0, 0, 0, 0, 0}, jf[6] = {0, 0, 0, 0, 0, 0};            // (fp32 inputs: exact, half the registers)
   int c0 = 0, c1 = 0;                                                      // first columns of the contact's two bodies
   double mu_c = 0, hn = 0;
   if (vc) {
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
                                                      SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
                                                      (const float*)SP.fric + (size_t)scene * nb, vv, lane);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { jn[q] = (double)r.jn[q]; jf[q] = (double)r.jf[q]; }
+    for (int q = 0; q < 6; ++q) { jn[q] = r.jn[q]; jf[q] = r.jf[q]; }
     c0 = 3 * r.b1; c1 = 3 * r.b2;
     mu_c = (double)r.mu; hn = (double)r.h;
   }
@@ -101,9 +104,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   int status = truncated;
   if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
   // the lane's column / row of A: x lanes hold A[:, lane], the equality lane nz + a holds nothing extra (its row is read from At)
-  double acol[EQB];
-#pragma unroll
-  for (int a = 0; a < EQB; ++a) acol[a] = (vx && a < e) ? (double)At[a * LX + lane] : 0.0;
+  auto acol = [&](int a) -> double { return (double)At[a * LX + lane]; };    // (zero beyond nz: At is cleared)
 
   // ---- products ------------------------------------------------------------------------------------------------------
   auto Gv = [&](double v, double& gn, double& gt) {                       // m-space <- x-space (v on the x lanes)
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
     gn = 0; gt = 0;
     if (vc) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { const double xq = xv[colq(q)]; gn = fma(jn[q], xq, gn); gt = fma(jf[q], xq, gt); }
+      for (int q = 0; q < 6; ++q) { const double xq = xv[colq(q)]; gn = fma((double)jn[q], xq, gn); gt = fma((double)jf[q], xq, gt); }
     }
     wsync();
   };
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
     xv[lane] = 0.0; wsync();
     if (vc) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) lds_add(&xv[colq(q)], fma(jf[q], wt, jn[q] * wn));
+      for (int q = 0; q < 6; ++q) lds_add(&xv[colq(q)], fma((double)jf[q], wt, (double)jn[q] * wn));
     }
     wsync();
     const double r = vx ? xv[lane] : 0.0;
@@ -129,13 +130,13 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   auto Av = [&](double v) -> double {                                     // equality lanes <- x lanes
     double out = 0;
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol[a] * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
     return out;
   };
   auto Aty = [&](double y) -> double {                                    // x lanes <- equality lanes
     double acc = 0;
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol[a], bcast_lane(y, nz + a), acc); }
+    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
     return acc;
   };
 
@@ -166,23 +167,26 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   double udinv = 1.0;
   bool singular = false;
   auto factor = [&]() LCP_INL {
+    // (the lane compares below are invariant over the PDIPM loop: hoisted, their ~100 masks overflow the scalar file and come
+    //  back through v_readlane spills - an opaque copy of the lane index keeps them local to the factorisation)
+    int ln = lane; asm volatile("" : "+v"(ln));
     for (int i = lane; i < NCOL * LDK; i += 64) Kl[i] = 0.0;
     wsync();
     if (lane < NCOL) Kl[lane * LDK + lane] = vx ? qd : (ve ? 0.0 : 1.0);   // rows beyond the system: identity
     if (vx) {
 #pragma unroll
-      for (int a = 0; a < EQB; ++a) { if (a < e) { Kl[lane * LDK + nz + a] = acol[a]; Kl[(nz + a) * LDK + lane] = acol[a]; } }
+      for (int a = 0; a < EQB; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
     }
     wsync();
     if (vc) {
       double p0[6], p1[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { p0[q] = b00 * jn[q]; p1[q] = fma(b10, jn[q], b11 * jf[q]); }
+      for (int q = 0; q < 6; ++q) { p0[q] = b00 * (double)jn[q]; p1[q] = fma(b10, (double)jn[q], b11 * (double)jf[q]); }
 #pragma unroll
       for (int pq = 0; pq < 6; ++pq) {
         double* row = Kl + colq(pq) * LDK;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) lds_add(row + colq(q), fma(jf[pq], p1[q], jn[pq] * p0[q]));
+        for (int q = 0; q < 6; ++q) lds_add(row + colq(q), fma((double)jf[pq], p1[q], (double)jn[pq] * p0[q]));
       }
     }
     wsync();
@@ -201,12 +205,18 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
           const double pk = bcast_lane(t[k], k);
           singular = singular || !(pk != 0.0) || (pk != pk);
           const double inv = fast_rcp(pk);
-          if (lane == k) udinv = inv;
-          const double l = (lane > k) ? t[k] * inv : 0.0;
-          if (lane > k) t[k] = l;
-          static_for<NCOL - 1 - k>([&](auto JJ) LCP_INL {
-            constexpr int j = k + 1 + JJ;
-            t[j] = fma(-l, bcast_lane(t[j], k), t[j]);
+          if (ln == k) udinv = inv;
+          const double l = (ln > k) ? t[k] * inv : 0.0;
+          if (ln > k) t[k] = l;
+          // pivot-row entries in batches of 8 scalar pairs, then the 8 FMAs: back to back, every v_readlane -> v_fma pair
+          // costs two wait states more and the pairs serialise on one scalar register
+          constexpr int NJ = NCOL - 1 - k;
+          static_for<(NJ + 7) / 8>([&](auto C8) LCP_INL {
+            constexpr int j0 = k + 1 + 8 * C8, nj = (NJ - 8 * C8) < 8 ? (NJ - 8 * C8) : 8;
+            double pv[8];
+            static_for<nj>([&](auto I) LCP_INL { pv[I] = bcast_lane(t[j0 + I], k); });
+            static_for<nj>([&](auto I) LCP_INL { sgpr_pin(pv[I]); });
+            static_for<nj>([&](auto I) LCP_INL { t[j0 + I] = fma(-l, pv[I], t[j0 + I]); });
           });
         });
       }
@@ -214,12 +224,13 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   };
   // K^-1 w (w: entry `lane` of the right-hand side)
   auto ksolve = [&](double w) -> double {
+    int ln = lane; asm volatile("" : "+v"(ln));
     static_for<NCOL / 8>([&](auto G8) LCP_INL {
       if (8 * G8 < n) {
         static_for<8>([&](auto KK) LCP_INL {
           constexpr int k = 8 * G8 + KK;
           const double yk = bcast_lane(w, k);
-          w = fma(-((lane > k) ? t[k] : 0.0), yk, w);
+          w = fma(-((ln > k) ? t[k] : 0.0), yk, w);
         });
       }
     });
@@ -229,7 +240,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
         static_for<8>([&](auto KR) LCP_INL {
           constexpr int k = 8 * g8 + 7 - KR;
           const double xk = bcast_lane(w * udinv, k);
-          w = fma(-((lane < k) ? t[k] : 0.0), xk, w);
+          w = fma(-((ln < k) ? t[k] : 0.0), xk, w);
         });
       }
     });
@@ -295,7 +306,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
       double wn = 0, wt = 0;
       if (vc) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const double qi = xv[colq(q)]; wn = fma(jn[q] * jn[q], qi, wn); wt = fma(jf[q] * jf[q], qi, wt); }
+        for (int q = 0; q < 6; ++q) { const double qi = xv[colq(q)]; wn = fma((double)jn[q] * (double)jn[q], qi, wn); wt = fma((double)jf[q] * (double)jf[q], qi, wt); }
         dfl.n = __builtin_fmax(dinv.n, BWD_FLOOR * wn);
         dfl.f1 = __builtin_fmax(dinv.f1, BWD_FLOOR * wt);
         dfl.f2 = __builtin_fmax(dinv.f2, BWD_FLOOR * wt);
@@ -394,8 +405,14 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   const double mf = (double)(4 * ncs);
   double x = 0, y = 0;                                                       // x on the x lanes, y on the equality lanes
   M4<double> s = m4<double>(1, 1, 1, 1), z = s, dinv = s;
-  double bx = 0, by = 0;
-  M4<double> bz = s, bs = s;
+  // the best iterate lives in the workspace block the backward reads (18 doubles per lane that would otherwise hold
+  // registers for the whole loop): stored when an iterate improves, read back once for the outputs
+  auto keep_best = [&](double x_, double y_, const M4<double>& z_, const M4<double>& s_) {
+    if (vx) Wit[lane] = x_;
+    if (ve) Wit[64 + (lane - nz)] = y_;
+    Wit[72 + lane] = z_.n; Wit[72 + LX + lane] = z_.f1; Wit[72 + 2 * LX + lane] = z_.f2; Wit[72 + 3 * LX + lane] = z_.g;
+    Wit[72 + 4 * LX + lane] = s_.n; Wit[72 + 5 * LX + lane] = s_.f1; Wit[72 + 6 * LX + lane] = s_.f2; Wit[72 + 7 * LX + lane] = s_.g;
+  };
   double best_resid = inf_of<double>();
   bool have_best = false, done = false;
   int n_not = 0, iters = 0;
@@ -431,7 +448,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
       else {
         const bool improved = !have_best || (resid < best_resid);             // (:107-132)
-        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; by = y; bz = z; bs = s; }
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; keep_best(x, y, z, s); }
         else ++n_not;
         if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;   // (:133)
       }
@@ -459,7 +476,7 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
         if (smin <= 0.0) { const double sh = 1.0 - smin; s = m4<double>(s.n + sh, s.f1 + sh, s.f2 + sh, s.g + sh); }   // (:66-75)
         if (zmin <= 0.0) { const double sh = 1.0 - zmin; z = m4<double>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
         if (!vc) { s = m4<double>(1, 1, 1, 1); z = s; }
-        if (ncs == 0) { bx = x; by = y; done = true; }                      // engines.py:36-50: x = P^-1 u, no LCP
+        if (ncs == 0) { keep_best(x, y, z, s); done = true; }               // engines.py:36-50: x = P^-1 u, no LCP
       } else if (pass == 0) {
         ax = ox; ay = oy; as_ = os; az = oz;                                // affine direction (:138-139)
         const double alpha = pmin(step_pair(z, az, s, as_), 1.0);          // (:142-144)
@@ -471,8 +488,12 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
         rx = 0; ry = 0; rz = m4<double>(0, 0, 0, 0);
         rs = vc ? m4<double>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
                 : m4<double>(0, 0, 0, 0);                                   // (:153)
+        stash[lane] = as_.n; stash[LX + lane] = as_.f1; stash[2 * LX + lane] = as_.f2; stash[3 * LX + lane] = as_.g;
+        stash[4 * LX + lane] = az.n; stash[5 * LX + lane] = az.f1; stash[6 * LX + lane] = az.f2; stash[7 * LX + lane] = az.g;
       } else {
         const double cx = ox + ax, cy = oy + ay;                            // (:160-163)
+        as_ = m4<double>(stash[lane], stash[LX + lane], stash[2 * LX + lane], stash[3 * LX + lane]);
+        az = m4<double>(stash[4 * LX + lane], stash[5 * LX + lane], stash[6 * LX + lane], stash[7 * LX + lane]);
         const M4<double> cs = m4<double>(os.n + as_.n, os.f1 + as_.f1, os.f2 + as_.f2, os.g + as_.g);
         const M4<double> cz = m4<double>(oz.n + az.n, oz.f1 + az.f1, oz.f2 + az.f2, oz.g + az.g);
         const double alpha = pmin(0.999 * step_pair(z, cz, s, cs), 1.0);   // (:164-166)
@@ -488,6 +509,10 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
   }
 
   // ---- outputs (row layout of a capacity-sized LCP, padded slots 0) ---------------------------------------------------------
+  if (!have_best && ncs > 0) keep_best(x, y, z, s);                         // (max_iter = 0: the initial point)
+  const double bx = vx ? Wit[lane] : 0.0, by = ve ? Wit[64 + (lane - nz)] : 0.0;
+  const M4<double> bz = m4<double>(Wit[72 + lane], Wit[72 + LX + lane], Wit[72 + 2 * LX + lane], Wit[72 + 3 * LX + lane]);
+  const M4<double> bs = m4<double>(Wit[72 + 4 * LX + lane], Wit[72 + 5 * LX + lane], Wit[72 + 6 * LX + lane], Wit[72 + 7 * LX + lane]);
   bool bad = vx && (bx != bx);
   if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
                 (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
@@ -504,14 +529,6 @@ __global__ void __launch_bounds__(64) lcp_primal_kernel(StepArgs SP, StepBwdArgs
     ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)nv;
     if (SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
   }
-  // the iterate the backward starts from (lcp.py:29 keeps nus, lams, slacks on the op)
-  Wit[lane] = vx ? bx : 0.0;
-  {
-    const double ys = bcast_lane(by, nz) , y1 = bcast_lane(by, nz + 1 < 64 ? nz + 1 : 63), y2 = bcast_lane(by, nz + 2 < 64 ? nz + 2 : 63), y3 = bcast_lane(by, nz + 3 < 64 ? nz + 3 : 63);
-    if (lane < 8) Wit[64 + lane] = (lane >= e) ? 0.0 : (lane == 0 ? ys : (lane == 1 ? y1 : (lane == 2 ? y2 : y3)));
-  }
-  Wit[72 + lane] = bz.n; Wit[72 + LX + lane] = bz.f1; Wit[72 + 2 * LX + lane] = bz.f2; Wit[72 + 3 * LX + lane] = bz.g;
-  Wit[72 + 4 * LX + lane] = bs.n; Wit[72 + 5 * LX + lane] = bs.f1; Wit[72 + 6 * LX + lane] = bs.f2; Wit[72 + 7 * LX + lane] = bs.g;
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_PRIMAL_PROFILE
   __builtin_amdgcn_s_waitcnt(0);

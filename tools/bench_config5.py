@@ -27,11 +27,23 @@ print("max |v_new|", float(ref["v_new"].abs().max()), "max |z|", float(ref["z"].
       "max |s - s_generic|", float((out["s"][:nchk] - ref["s"]).abs().max()))
 print("nb", sc.nb, "nc", sc.nc, "max |v_new - generic| on %d scenes: %.3e" % (nchk, float(d)), "iters", float(out["iters"].float().mean()), float(ref["iters"].float().mean()),
       "status!=0", int((out["status"] != 0).sum()))
-t = time.perf_counter()
-for _ in range(5): out = run(out)
+if len(sys.argv) > 2 and sys.argv[2] == "big":      # contact-space lcp_big.hip instead of the body-space lcp_primal.hip (A/B)
+    _lib.set_path("big")
+    out = run(); torch.cuda.synchronize()
+for _ in range(3): out = run(out)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t) / 5
+t = time.perf_counter()
+for _ in range(10): out = run(out)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 10
 import json
+from lcp_physics_amd.physics.batched_world import fused_step_backward
+cot = torch.randn(B, sc.nb, 3, device='cuda')
+pg = fused_step_backward(sc, out, cot); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(10): pg = fused_step_backward(sc, out, cot)
+torch.cuda.synchronize()
+dtb = (time.perf_counter() - t) / 10
 if len(sys.argv) > 2 and sys.argv[2] == "dense":
     # the same piles through the dense LCPFunction boundary (lcp_pdipm_forward_f32 / _backward_f32): classification on the
     # device, then lcp_big.hip for the contact-structured scenes
@@ -57,8 +69,15 @@ if len(sys.argv) > 2 and sys.argv[2] == "dense":
     sys.exit(0)
 print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts, nineq 256, nz 33, neq 3), forward (lcp_solve_dynamics_f32)",
                   "value": B / dt, "unit": "sim steps/s", "batch": B, "ms_per_step": dt * 1e3,
+                  "backward_ms": dtb * 1e3, "fwd_bwd_value": B / (dt + dtb),
                   "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),
-                  "kernel": "lcp::big::lcp_big_kernel<64> (one 256-thread workgroup per scene; blocked LU, trailing updates on v_mfma_f64_16x16x4_f64)"}))
+                  "kernel": "lcp::big::lcp_big_kernel<64> (contact space, 128 x 128: blocked LU, trailing updates on v_mfma_f64_16x16x4_f64)"
+                            if len(sys.argv) > 2 and sys.argv[2] == "big" else
+                            "lcp::primal::lcp_primal_kernel<40> (body space, 36 x 36 systems, one wave per scene)"}))
+if "primalprof" in os.environ.get("LCP_HIP_LIB", ""):
+    pc = out["s"][:, 248:254].double().mean(dim=0).tolist()
+    print("cycles per scene: residuals %.0f  formation %.0f  LU %.0f  bookkeeping %.0f  solve_kkt %.0f  steps + update %.0f  total %.0f"
+          % (pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], sum(pc)))
 import os
 if "bigprof" in os.environ.get("LCP_HIP_LIB", ""):
     pc = out["s"][:, 248:255].double().mean(dim=0).tolist()
