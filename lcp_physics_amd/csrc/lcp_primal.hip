@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
           const double l = (ln > k) ? t[k] * inv : 0.0;
           if (ln > k) t[k] = l;
           // pivot-row entries in batches of 8 scalar pairs, then the 8 FMAs: back to back, every v_readlane -> v_fma pair
-          // costs two wait states more and the pairs serialise on one scalar register
+          // costs two wait states more and the pairs serialise on one scalar register.  (Measured and dropped: the pivot row
+          // through LDS - lane k stores it with ds_write_b128, every lane reads it back at a uniform address.  Fewer
+          // instructions, but every read moves 1 KB through the CU's one LDS port and eight waves share it: 3.8 M against
+          // 6.5 M sim steps/s on config 5.)
           constexpr int NJ = NCOL - 1 - k;
           static_for<(NJ + 7) / 8>([&](auto C8) LCP_INL {
             constexpr int j0 = k + 1 + 8 * C8, nj = (NJ - 8 * C8) < 8 ? (NJ - 8 * C8) : 8;

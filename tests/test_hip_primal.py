@@ -1,0 +1,129 @@
+"""GPU parity of the body-space PDIPM kernel (`lcp_primal.hip`: the Newton systems of a contact scene solved in nz + neq unknowns,
+one wavefront per scene) against the contact-space kernels it replaces behind `lcp_solve_dynamics_f32` /
+`lcp_step_backward_f32` (`lcp_big.hip`, forced with the debug path "big") and against the fp64 oracle.  The two formulations
+take the same Newton steps in exact arithmetic (pdipm.py:325-454 eliminates x first, the body-space kernel the inequality block),
+so new_v has to agree far below the fp32 outputs' resolution."""
+import pytest
+import torch
+
+from oracle import pdipm_oracle as O
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _solve(sc, count, path="auto"):
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(sc.B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    e = 0 if sc.Je is None else sc.Je.shape[1]
+    _lib.set_path(path)
+    try:
+        out = solve_dynamics(sc.B, sc.nb, sc.nc, e, count.to(DEV), scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_path("auto")
+    return scg, out
+
+
+def _scenes(kind, B):
+    from lcp_physics_amd import scenes
+    if kind == "pile":                                    # BASELINE config 5: 11 bodies, 64 contacts -> 36 x 36 systems
+        return scenes.make_pile_scenes(B=B, seed=33, dtype=torch.float32)
+    nbox, pts = kind
+    return scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=500 + 7 * nbox + pts, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("kind", ["pile", (6, 4), (11, 1), (11, 2), (15, 2), (7, 4)])
+def test_forward_matches_the_contact_space_kernels(kind):
+    """Piles (system capacity 40), 7 bodies / 24 contacts (24), 12 bodies / 11 and 22 contacts (40), 16 bodies / 30 contacts (56),
+    8 bodies / 28 contacts (40), with ragged contact counts: new_v, the iteration counts and the status words of both kernels."""
+    B = 48
+    sc = _scenes(kind, B)
+    g = torch.Generator().manual_seed(3)
+    count = torch.randint(0, sc.nc + 1, (B,), generator=g, dtype=torch.int32)
+    count[: B // 2] = sc.nc
+    _, a = _solve(sc, count)
+    _, b = _solve(sc, count, "big")
+    va, vb = a["v_new"].double().cpu(), b["v_new"].double().cpu()
+    scale = vb.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    err = (va - vb).abs().reshape(B, -1).max(dim=1)[0] / scale
+    print(kind, "worst scaled |v_new - v_new(contact space)|", float(err.max()), "iteration counts differ in",
+          int((a["iters"] != b["iters"]).sum()), "of", B)
+    assert float(err.max()) <= 2e-6
+    assert int(((a["status"] & 8) != 0).sum()) == 0
+    # (iteration counts may differ where the solve converges to rounding - towers with one contact per interface: the exit
+    #  tests of pdipm.py:133 are then met a rounding apart; the answers above are the criterion)
+    full = (count == sc.nc).to(DEV)
+    assert int(((a["iters"] != b["iters"]) & (a["iters"] == 10) & (b["iters"] == 10) & full).sum()) == 0
+
+
+def test_forward_matches_the_oracle_on_piles():
+    B = 8
+    sc = _scenes("pile", B)
+    count = torch.tensor([64, 64, 40, 64, 9, 64, 64, 23], dtype=torch.int32)
+    _, out = _solve(sc, count)
+    got = out["v_new"].double().cpu()
+    for k in range(B):
+        n = int(count[k])
+        one = lambda t: t[k:k + 1]
+        args = (one(sc.Mdiag), one(sc.v), one(sc.f), sc.dt, sc.c_n[k:k + 1, :n], sc.c_p1[k:k + 1, :n], sc.c_p2[k:k + 1, :n],
+                sc.c_i1[k:k + 1, :n], sc.c_i2[k:k + 1, :n], one(sc.rest), one(sc.fric), one(sc.Je))
+        lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*args)]
+        rs = O.lcp_forward(*lcp64)
+        ex = float(parity.err_x(-got[k].reshape(1, -1), rs.x, lcp64[0], lcp64[1]).max())
+        assert ex <= 1e-5, (k, n, ex)
+
+
+def test_results_are_bitwise_reproducible():
+    """The matrix and the products G^T w are accumulated with LDS atomics (ds_add_f64) by the one wave that owns the scene: the
+    order of the additions is a function of the instruction stream, so two launches give the same bits."""
+    sc = _scenes("pile", 256)
+    count = torch.full((256,), sc.nc, dtype=torch.int32)
+    _, a = _solve(sc, count)
+    a = {k: a[k].clone() for k in ("v_new", "z", "s")}
+    for _ in range(3):
+        _, b = _solve(sc, count)
+        for k in a:
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+
+
+@pytest.mark.parametrize("kind", ["pile", (6, 4), (11, 1), (15, 2)])
+def test_backward_matches_the_contact_space_backward(kind):
+    """`lcp_step_backward_f32` from both kernels on the same scenes (each from its own forward).  (11, 1) is a tower whose solve
+    converges to machine precision - the ratios s / z underflow against the masses there, which is what the floored factorisation
+    and the refinement step of the body-space backward are for."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import fused_step_backward
+    B = 32
+    sc = _scenes(kind, B)
+    count = torch.full((B,), sc.nc, dtype=torch.int32)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(5), dtype=torch.float32).to(DEV)
+    grads = {}
+    for path in ("auto", "big"):
+        scg, out = _solve(sc, count, path)
+        _lib.set_path(path)
+        try:
+            grads[path] = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot).items()}
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_path("auto")
+    # Mdiag, v, f: defined whatever the multipliers (tests/parity.py::err_physical); the per-contact keys depend on how the load is
+    # shared between redundant contacts, which the two eliminations resolve differently at the level of s / z ~ 1e-12
+    worst = 0.0
+    for k in ("Mdiag", "v", "f"):
+        a, b = grads["auto"][k], grads["big"][k]
+        # scale: the scene's largest entry, but not below 1e-3 of the batch's - a stack pinned by friction answers a push with
+        # its contact compliances s / z ~ 1e-10 only, and a gradient of 1e-8 next to 1e-2 is zero, not a number to match to 1e-3
+        scale = b.abs().reshape(B, -1).max(dim=1)[0]
+        scale = torch.maximum(scale, 1e-3 * scale.max())
+        err = (a - b).abs().reshape(B, -1).max(dim=1)[0] / scale
+        worst = max(worst, float(err.max()))
+        assert float(err.max()) <= 1e-3, (k, float(err.max()))
+    for k in ("rest", "fric", "c_n", "c_p1", "c_p2"):
+        assert bool(torch.isfinite(grads["auto"][k]).all()), k
+    print(kind, "worst gradient difference, Mdiag / v / f (relative to the scene's largest entry)", worst)
