@@ -110,8 +110,12 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
     const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
-    int rc = lcp::big_dense_forward(P, cls, per_scene, stream);          // classifies, then serves the scenes of class 2
+    // classes per scene: 3 = contact structure, at most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure
+    // (lcp_big.hip); 0 = anything else (the generic kernels)
+    const int primal_ok = (g_path != 3 && (nz % 3) == 0 && lcp::primal_supported(nz, m, e)) ? 1 : 0;
+    int rc = lcp::big_dense_forward(P, cls, per_scene, primal_ok, stream);
     if (rc) return rc;
+    if (primal_ok) { rc = lcp::primal_dense_forward(P, cls, per_scene, stream); if (rc) return rc; }
     P.cls = cls; P.ws_stride = per_scene / cs;                            // the rest of the batch, same stride
   }
   return lcp::generic_forward(P, io_f64, compute, pl.lds_bytes, stream);
@@ -156,8 +160,9 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
     const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
-    int rc = lcp::big_dense_backward(P, cls, per_scene, stream);
+    int rc = lcp::big_dense_backward(P, cls, per_scene, stream);           // (the classes the forward left behind the scene blocks)
     if (rc) return rc;
+    if ((nz % 3) == 0 && lcp::primal_supported(nz, m, e)) { rc = lcp::primal_dense_backward(P, cls, per_scene, stream); if (rc) return rc; }
     P.cls = cls; P.ws_stride = per_scene / cs;
   }
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);

@@ -1122,7 +1122,9 @@ namespace big {
 // One workgroup per scene: is the dense LCP the mixed contact LCP of engines.py:50-74 with a diagonal Q ?
 //   G = [Jc; Jf; 0] with Jf rows in (+jt, -jt) pairs, F = [[0, 0, 0], [0, 0, E], [mu, -E^T, 0]], h = [h_n; 0; 0], Q diagonal.
 // cls[scene] = 2 if so (lcp_big_kernel<.., DENSE> serves it), else 0 (the generic kernels do).
-__global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e) {
+// ... and 3 if, in addition, `primal_ok` (the sizes fit lcp_primal.hip) and no contact's rows touch more than two bodies (columns in
+// body triples): the body-space kernel takes those.
+__global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e, int primal_ok) {
   const int scene = blockIdx.x, tid = threadIdx.x, nz = DN.nz, m = DN.m, nc = m >> 2;
   const float* G = DN.G + (size_t)scene * m * nz;
   const float* F = DN.F + (size_t)scene * m * m;
@@ -1141,8 +1143,20 @@ __global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e) {
     else if (r >= 3 * nc) { const int cg = r - 3 * nc; if (j == cg) want = v; else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = -1.0f; }
     good &= (v == want) ? 1 : 0;
   }
+  int two = 1;
+  if (primal_ok && tid < nc) {
+    const float* gc = G + (size_t)tid * nz; const float* gt = G + (size_t)(nc + 2 * tid) * nz;
+    int blocks = 0;
+    for (int bq = 0; bq < nz / 3; ++bq) {
+      const bool nzb = (gc[3 * bq] != 0.0f) || (gc[3 * bq + 1] != 0.0f) || (gc[3 * bq + 2] != 0.0f) ||
+                       (gt[3 * bq] != 0.0f) || (gt[3 * bq + 1] != 0.0f) || (gt[3 * bq + 2] != 0.0f);
+      blocks += nzb ? 1 : 0;
+    }
+    two = blocks <= 2 ? 1 : 0;
+  }
   const int all = __syncthreads_and(good);
-  if (tid == 0) DN.cls[scene] = all ? 2 : 0;
+  const int sparse = __syncthreads_and(two);
+  if (tid == 0) DN.cls[scene] = all ? ((primal_ok && sparse) ? 3 : 2) : 0;
 }
 }  // namespace big
 
@@ -1153,12 +1167,12 @@ bool big_dense_supported(int nz, int m, int e) {
 
 static void dense_io(DenseIO& DN, int nz, int m, int32_t* cls, size_t ws_scene) { DN = DenseIO{}; DN.nz = nz; DN.m = m; DN.cls = cls; DN.ws_scene = ws_scene; }
 
-int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
+int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int primal_ok, void* stream) {
   DenseIO DN;
   dense_io(DN, P.nz, P.m, cls, ws_scene);
   DN.Q = (const float*)P.Q; DN.p = (const float*)P.p; DN.G = (const float*)P.G; DN.h = (const float*)P.h;
   DN.A = (const float*)P.A; DN.b = (const float*)P.b; DN.F = (const float*)P.F;
-  hipLaunchKernelGGL(big::lcp_classify_big, dim3(P.B), dim3(256), 0, (hipStream_t)stream, DN, P.e);
+  hipLaunchKernelGGL(big::lcp_classify_big, dim3(P.B), dim3(256), 0, (hipStream_t)stream, DN, P.e, primal_ok);
   StepArgs SP = {};
   SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
   SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;

@@ -619,7 +619,7 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_fwd_kernel(FwdArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x;
-  if (P.cls && P.cls[scene] == 2) return;              // served by lcp_big.hip (contact-structured, diagonal Q)
+  if (P.cls && P.cls[scene] >= 2) return;              // served by lcp_big.hip / lcp_primal.hip (contact-structured, diagonal Q)
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
   Scene<TC> S;
@@ -762,7 +762,7 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x;
-  if (P.cls && P.cls[scene] == 2) return;
+  if (P.cls && P.cls[scene] >= 2) return;
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
   Scene<TC> S;

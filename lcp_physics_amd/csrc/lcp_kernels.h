@@ -117,6 +117,8 @@ bool primal_supported(int nz, int m, int e);
 size_t primal_ws_bytes();
 int primal_step(const StepArgs& P, void* stream);
 int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
+int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);      // scenes of class 3
+int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
 
 // four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
 // list) - lcp_quad.hip
@@ -135,7 +137,7 @@ int big_step(const StepArgs& P, void* stream);
 int big_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
 // dense boundary (lcp_pdipm_forward_f32 / _backward_f32) for 16 < nineq / 4 <= 64 contacts: classification, then the same kernel
 bool big_dense_supported(int nz, int m, int e);
-int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
+int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int primal_ok, void* stream);   // (classifies: 0 / 2 / 3)
 int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
 
 // narrow-phase contact generation + position update - lcp_contacts.hip

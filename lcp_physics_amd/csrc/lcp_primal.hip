@@ -53,17 +53,23 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 }
 
 // NCOL: capacity of the system (nz + neq <= NCOL <= 64), a multiple of 8
-template <int NCOL, bool BWD>
-__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
+// DENSE: the same solve behind the dense LCPFunction boundary (lcp.py:22-64): the scene's (Q, p, G, h, A, b, F) is read instead of
+//        a contact list - scenes lcp_classify_big marked 3: the mixed contact LCP of engines.py:50-74 with a diagonal Q whose
+//        Jacobian rows touch at most two bodies -, the outputs are x, y, z, s (forward) or the seven dense gradients of
+//        lcp.py:52-61 (backward).
+template <int NCOL, bool BWD, bool DENSE>
+__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd, DenseIO DN) {
   constexpr int LDK = NCOL + 1;
-  __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];   // image of the system matrix (formation); backward: staging
+  constexpr int KSZ = (NCOL * LDK > 11 * LX) ? NCOL * LDK : 11 * LX;    // (the dense backward stages 144 + 8 nc <= 656 doubles here)
+  __shared__ __attribute__((aligned(16))) double Kl[KSZ];          // image of the system matrix (formation); backward: staging
   __shared__ double xv[LX];                                        // x-space exchange / accumulation
   __shared__ float At[EQB * LX];                                   // A rows
   __shared__ int B12[2 * LX];
   __shared__ double stash[8 * LX];                                 // the affine direction, parked during the corrector solve
   const int scene = blockIdx.x, lane = threadIdx.x;
+  if (DENSE && DN.cls[scene] != 3) return;                                 // (another family serves the scene)
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
-  double* Wg = (double*)SP.ws + (size_t)scene * (size_t)WsLayout::TOTAL;
+  double* Wg = (double*)SP.ws + (size_t)scene * (DENSE ? DN.ws_scene / sizeof(double) : (size_t)WsLayout::TOTAL);
   double* Wit = Wg + WsLayout::IT;
   int ncs = ncap;
   if (BWD) ncs = (int)Wg[0];                                               // the count the forward solved with
@@ -75,31 +81,67 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   const bool vx = lane < nz, ve = lane >= nz && lane < n;                  // ... an x entry, an equality multiplier
 
   // ---- assembly (engines.py:31-32,50-74; world.py:144-234) ----------------------------------------------------------
-  const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
-  const float* vv = (const float*)SP.v + (size_t)scene * nz;
-  const float* ff = (const float*)SP.f + (size_t)scene * nz;
+  const float* Md = DENSE ? nullptr : (const float*)SP.Mdiag + (size_t)scene * nz;
+  const float* vv = DENSE ? nullptr : (const float*)SP.v + (size_t)scene * nz;
+  const float* ff = DENSE ? nullptr : (const float*)SP.f + (size_t)scene * nz;
   float jn[6] = {0, 0, 0, 0, 0, 0}, jf[6] = {0, 0, 0, 0, 0, 0};            // (fp32 inputs: exact, half the registers)
   int c0 = 0, c1 = 0;                                                      // first columns of the contact's two bodies
   double mu_c = 0, hn = 0;
-  if (vc) {
-    const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
-                                                     (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
-                                                     SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
-                                                     (const float*)SP.fric + (size_t)scene * nb, vv, lane);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { jn[q] = r.jn[q]; jf[q] = r.jf[q]; }
-    c0 = 3 * r.b1; c1 = 3 * r.b2;
-    mu_c = (double)r.mu; hn = (double)r.h;
-  }
-  auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
-  double qd = 0, p = 0;
-  if (vx) {
-    qd = (double)Md[lane];
-    p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
-  }
+  double qd = 0, p = 0, b_in = 0;
   for (int i = lane; i < EQB * LX; i += 64) At[i] = 0.0f;
   wsync();
-  for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  if constexpr (DENSE) {
+    // dense boundary: G = [Jc; Jf; 0] with Jf rows (+jt, -jt) (engines.py:67-68, world.py:191-192), F[3nc + c][c] = mu_c
+    // (engines.py:71), h = [h_n; 0; 0] (:74), at most two bodies per contact - all verified per scene by lcp_classify_big
+    const int m = DN.m;
+    if (vc) {
+      const float* gc = DN.G + ((size_t)scene * m + lane) * nz;
+      const float* gt = DN.G + ((size_t)scene * m + ncap + 2 * lane) * nz;
+      int bf = -1, bl = -1;                                                // first / last body with a nonzero entry
+      for (int bq = 0; bq < nb; ++bq) {
+        const bool nzb = (gc[3 * bq] != 0.0f) || (gc[3 * bq + 1] != 0.0f) || (gc[3 * bq + 2] != 0.0f) ||
+                         (gt[3 * bq] != 0.0f) || (gt[3 * bq + 1] != 0.0f) || (gt[3 * bq + 2] != 0.0f);
+        if (nzb) { if (bf < 0) bf = bq; bl = bq; }
+      }
+      if (bf < 0) { bf = 0; bl = 0; }
+      c0 = 3 * bf; c1 = 3 * bl;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { jn[q] = gc[c0 + q]; jf[q] = gt[c0 + q]; }
+      if (bl != bf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { jn[3 + q] = gc[c1 + q]; jf[3 + q] = gt[c1 + q]; }
+      }
+      if (BWD) mu_c = Wit[72 + 8 * LX + lane];                              // (lcp_pdipm_backward_f32 gets G, A and the cotangent only)
+      else {
+        mu_c = (double)DN.F[(size_t)scene * m * m + (size_t)(3 * ncap + lane) * m + lane];
+        hn = (double)DN.h[(size_t)scene * m + lane];
+      }
+    }
+    if (BWD) { if (vx) qd = Wit[72 + 9 * LX + lane]; }
+    else {
+      if (vx) { qd = (double)DN.Q[(size_t)scene * nz * nz + (size_t)lane * nz + lane]; p = (double)DN.p[(size_t)scene * nz + lane]; }
+      if (ve) b_in = (double)DN.b[(size_t)scene * e + (lane - nz)];
+      Wit[72 + 8 * LX + lane] = mu_c; Wit[72 + 9 * LX + lane] = qd;
+    }
+    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = DN.A[(size_t)scene * e * nz + i]; }
+  } else {
+    if (vc) {
+      const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
+                                                       (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
+                                                       SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
+                                                       (const float*)SP.fric + (size_t)scene * nb, vv, lane);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { jn[q] = r.jn[q]; jf[q] = r.jf[q]; }
+      c0 = 3 * r.b1; c1 = 3 * r.b2;
+      mu_c = (double)r.mu; hn = (double)r.h;
+    }
+    if (vx) {
+      qd = (double)Md[lane];
+      p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
+    }
+    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  }
+  auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
   wsync();
   int status = truncated;
   if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
@@ -319,7 +361,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
     block_setup(dfl);
     factor();                                                               // lcp.py:46
     // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
-    const double g = vx ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
+    const double g = !vx ? 0.0 : (DENSE ? (double)DN.dl_dx[(size_t)scene * nz + lane] : -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane]);
     const M4<double> zero = m4<double>(0, 0, 0, 0);
     solve_kkt(dfl, g, zero, zero, 0.0, dx, ds, dl, dnu);                     // lcp.py:47-50
     {
@@ -338,6 +380,33 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       solve_kkt(dfl, -r1, zero, m4<double>(-r3.n, -r3.f1, -r3.f2, -r3.g), -r2, cx, cs, cl, cnu);
       dx += cx; dnu += cnu;
       dl = m4<double>(dl.n + cl.n, dl.f1 + cl.f1, dl.f2 + cl.f2, dl.g + cl.g);
+    }
+    if constexpr (DENSE) {
+      // ---- LCPFunction.backward (lcp.py:52-61): the outer products of (x, dx), (nu, dnu), (lam, dlam) --------------------------------
+      double *X = Kl, *DX = Kl + 64, *NU = Kl + 128, *DNU = Kl + 136, *LAM = Kl + 144, *DLAM = Kl + 144 + 4 * LX;
+      const int m = 4 * ncap;
+      wsync();
+      X[lane] = x; DX[lane] = vx ? dx : 0.0;
+      if (lane < 8) { NU[lane] = (lane < e) ? Wit[64 + lane] : 0.0; DNU[lane] = 0.0; }
+      wsync();
+      if (ve) DNU[lane - nz] = dnu;
+      if (lane < ncap) {                                                    // dense row order: [normal | friction pairs | cone]
+        LAM[lane] = z.n; LAM[ncap + 2 * lane] = z.f1; LAM[ncap + 2 * lane + 1] = z.f2; LAM[3 * ncap + lane] = z.g;
+        DLAM[lane] = dl.n; DLAM[ncap + 2 * lane] = dl.f1; DLAM[ncap + 2 * lane + 1] = dl.f2; DLAM[3 * ncap + lane] = dl.g;
+      }
+      wsync();
+      if (DN.dp) for (int j = lane; j < nz; j += 64) DN.dp[(size_t)scene * nz + j] = (float)DX[j];                            // lcp.py:52
+      if (DN.dh) for (int i = lane; i < m; i += 64) DN.dh[(size_t)scene * m + i] = (float)(-DLAM[i]);                          // :56
+      if (DN.db) for (int a = lane; a < e; a += 64) DN.db[(size_t)scene * e + a] = (float)(-DNU[a]);                           // :58
+      if (DN.dQ) for (int i = lane; i < nz * nz; i += 64) { const int j = i / nz, k = i - j * nz;
+        DN.dQ[(size_t)scene * nz * nz + i] = (float)(0.5 * (DX[j] * X[k] + X[j] * DX[k])); }                                  // :59-60
+      if (DN.dA) for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz;
+        DN.dA[(size_t)scene * e * nz + i] = (float)(DNU[a] * X[k] + NU[a] * DX[k]); }                                         // :57
+      if (DN.dG) for (int i = lane; i < m * nz; i += 64) { const int r = i / nz, k = i - r * nz;
+        DN.dG[(size_t)scene * m * nz + i] = (float)(DLAM[r] * X[k] + LAM[r] * DX[k]); }                                       // :53
+      if (DN.dF) { float* o = DN.dF + (size_t)scene * m * m;
+        for (int i = lane; i < m * m; i += 64) { const int r = i / m, c = i - r * m; o[i] = (float)(-DLAM[r] * LAM[c]); } }   // :54
+      return;
     }
     // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
     double* X = Kl; double* DX = Kl + LX; double* CR = Kl + 2 * LX; double* CF = Kl + 3 * LX;
@@ -422,8 +491,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   for (int it = -1; it < max_iter; ++it) {
     double rx = 0, ry = 0, mu = 0, resid = 0;
     M4<double> rs = m4<double>(0, 0, 0, 0), rz = rs;
-    if (it < 0) {                                                           // init: (p, 0, -h, -b), d = 1 (:57-63); b = 0 (engines.py:74)
-      rx = p; ry = 0.0; rz = m4<double>(-hn, 0, 0, 0); dinv = m4<double>(1, 1, 1, 1);
+    if (it < 0) {                                                           // init: (p, 0, -h, -b), d = 1 (:57-63); b = 0 from a contact list (engines.py:74)
+      rx = p; ry = -b_in; rz = m4<double>(-hn, 0, 0, 0); dinv = m4<double>(1, 1, 1, 1);
     } else {                                                                // residuals (:82-96)
       rx = Gtw(vc ? z.n : 0.0, vc ? z.f1 - z.f2 : 0.0) + qd * x + p;
       if (e > 0) rx += Aty(y);
@@ -433,7 +502,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       Gv(x, gn, gt);
       rz = m4<double>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (mu_c * z.n - (z.f1 + z.f2)));
       if (!vc) rz = m4<double>(0, 0, 0, 0);
-      ry = (e > 0) ? Av(x) : 0.0;
+      ry = (e > 0) ? Av(x) - b_in : 0.0;
       const double n_rx = wave_sum(rx * rx);
       const double n_rz = wave_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
       const double n_ry = wave_sum(ry * ry);
@@ -528,9 +597,9 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   }
   if (ve && SP.y) ((float*)SP.y)[(size_t)scene * e + (lane - nz)] = (float)by;
   if (vx) {
-    const double nv = -bx;                                                            // engines.py:76-77
+    const double nv = DENSE ? bx : -bx;                                               // engines.py:76-77 (dense boundary: zhats = x itself, lcp.py:35)
     ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)nv;
-    if (SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
+    if (!DENSE && SP.p_new) ((float*)SP.p_new)[(size_t)scene * nz + lane] = (float)((double)((const float*)SP.pos)[(size_t)scene * nz + lane] + nv * SP.dt);   // bodies.py:81
   }
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 #ifdef LCP_PRIMAL_PROFILE
@@ -547,19 +616,43 @@ bool primal_supported(int nz, int m, int e) {
 }
 size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOTAL; }
 
-template <int NCOL, bool BWD>
-static int primal_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
-  hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd);
+template <int NCOL, bool BWD, bool DENSE = false>
+static int primal_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, const DenseIO& DN = DenseIO{}) {
+  hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD, DENSE>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd, DN);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
-template <bool BWD>
-static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
+template <bool BWD, bool DENSE = false>
+static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, const DenseIO& DN = DenseIO{}) {
   const int n = 3 * SP.nb + SP.e;
-  if (n <= 24) return primal_launch<24, BWD>(SP, Gd, stream);
-  if (n <= 40) return primal_launch<40, BWD>(SP, Gd, stream);
-  return primal_launch<56, BWD>(SP, Gd, stream);
+  if (n <= 24) return primal_launch<24, BWD, DENSE>(SP, Gd, stream, DN);
+  if (n <= 40) return primal_launch<40, BWD, DENSE>(SP, Gd, stream, DN);
+  return primal_launch<56, BWD, DENSE>(SP, Gd, stream, DN);
 }
 int primal_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_dispatch<false>(SP, Gd, stream); }
 int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_dispatch<true>(SP, Gd, stream); }
+
+// dense boundary: the scenes lcp_classify_big marked 3 (launched next to the contact-space and generic kernels, which take 2 and 0)
+int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
+  DenseIO DN = {};
+  DN.nz = P.nz; DN.m = P.m; DN.cls = cls; DN.ws_scene = ws_scene;
+  DN.Q = (const float*)P.Q; DN.p = (const float*)P.p; DN.G = (const float*)P.G; DN.h = (const float*)P.h;
+  DN.A = (const float*)P.A; DN.b = (const float*)P.b; DN.F = (const float*)P.F;
+  StepArgs SP = {};
+  SP.B = P.B; SP.nb = P.nz / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;
+  SP.v_new = P.x; SP.z = P.z; SP.s = P.s; SP.y = P.y; SP.iters = P.iters; SP.status = P.status;
+  StepBwdArgs Gd = {};
+  return primal_dispatch<false, true>(SP, Gd, stream, DN);
+}
+int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
+  DenseIO DN = {};
+  DN.nz = P.nz; DN.m = P.m; DN.cls = cls; DN.ws_scene = ws_scene;
+  DN.G = (const float*)P.G; DN.A = (const float*)P.A; DN.dl_dx = (const float*)P.dl_dx;
+  DN.dQ = (float*)P.dQ; DN.dp = (float*)P.dp; DN.dG = (float*)P.dG; DN.dh = (float*)P.dh; DN.dA = (float*)P.dA; DN.db = (float*)P.db; DN.dF = (float*)P.dF;
+  StepArgs SP = {};
+  SP.B = P.B; SP.nb = P.nz / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  StepBwdArgs Gd = {};
+  return primal_dispatch<true, true>(SP, Gd, stream, DN);
+}
 
 }  // namespace lcp

@@ -127,3 +127,48 @@ def test_backward_matches_the_contact_space_backward(kind):
     for k in ("rest", "fric", "c_n", "c_p1", "c_p2"):
         assert bool(torch.isfinite(grads["auto"][k]).all()), k
     print(kind, "worst gradient difference, Mdiag / v / f (relative to the scene's largest entry)", worst)
+
+
+def test_dense_boundary_routes_every_scene_to_its_kernel():
+    """`lcp_pdipm_forward_f32 / _backward_f32` at config-5 sizes: one call serves contact-structured scenes whose rows touch two
+    bodies (class 3: lcp_primal.hip), contact-structured scenes that do not (class 2: lcp_big.hip - here a normal row with an entry
+    on a third body) and general LCPs (class 0: the generic kernels - here a perturbed F).  The classes the device wrote are read
+    back from the tail of the workspace; answers and gradients against the generic kernels forced on every scene."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+    B = 12
+    sc = scenes.make_pile_scenes(B=B, seed=91, dtype=torch.float32)
+    lcp = [None if t is None else t.clone() for t in O.assemble_lcp(*sc.assembly_args())]
+    nc, nz, m = sc.nc, 3 * sc.nb, 4 * sc.nc
+    lcp[2][2, 5, 3 * 9 + 1] = 0.125                       # scene 2: contact 5 (bodies 0 and 2) also pushes on body 9
+    lcp[2][7, 40, 3 * 1 + 2] = -0.25                      # scene 7: likewise
+    lcp[6][4, 5, 7] = 0.25                                # scene 4: F is not the contact F any more
+    g = [None if t is None else t.to(DEV).contiguous() for t in lcp]
+    cot = torch.randn(B, nz, generator=torch.Generator().manual_seed(2), dtype=torch.float32).to(DEV)
+
+    def run(path):
+        _lib.set_path(path)
+        try:
+            sol = lcp_solve(*g)
+            grads = [None if t is None else t.double().cpu() for t in lcp_backward(sol, cot)]
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_path("auto")
+        return sol, grads
+
+    sol, grads = run("auto")
+    per_scene = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255)) // B
+    cls = sol.ws[B * per_scene: B * per_scene + 4 * B].view(torch.int32).cpu().tolist()
+    want = [3] * B
+    want[2] = want[7] = 2
+    want[4] = 0
+    assert cls == want, cls
+    solg, gg = run("generic")
+    solb, gb = run("big")                                  # (contact-space kernel on the classes 2 AND 3)
+    for other, go, name in ((solg, gg, "generic"), (solb, gb, "big")):
+        scale = max(1.0, float(other.x.abs().max()))
+        assert float((sol.x - other.x).abs().max()) <= 1e-5 * scale, name
+        for k, a, b in zip("QpGhAbF", grads, go):
+            if k in "QpAb":                                # (dG, dh, dF of redundant piles are rounding-determined: tests/parity.py)
+                sk = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 1e-4 * max(sk, 1e-12), (name, k, float((a - b).abs().max()), sk)
