@@ -1,6 +1,6 @@
 #!/bin/bash
 # BASELINE config 5 (4096 scenes x 64 contacts) on the GPU box: rocprofv3 kernel trace + stats, PMC counters in their own
-# passes (never combined with tracing domains), and - when tools/liblcp_bigprof.so exists - the in-kernel phase profile.
+# passes (never combined with tracing domains), and - when tools/liblcp_primalprof.so exists - the in-kernel phase profile.
 # Summaries land in gpurun_out/prof_<tag>_config5.*; copy them into profiles/ by hand.
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
@@ -20,8 +20,9 @@ f=$(find $OUT/prof_${TAG}_c5_trace -name "*.db" | head -1)
 python tools/rocprof_summary.py $f > $OUT/prof_${TAG}_config5_kernel_stats.txt
 python tools/pmc_summary.py $OUT/prof_${TAG}_c5_pmc_* > $OUT/prof_${TAG}_config5_pmc.txt
 rm -rf $OUT/prof_${TAG}_c5_*/
-if [ -f tools/liblcp_bigprof.so ]; then
-  LCP_HIP_LIB=$ROOT/tools/liblcp_bigprof.so timeout 200 python tools/bench_config5.py ${BATCH:-4096} > $OUT/prof_${TAG}_config5_phases.txt 2>&1
+if [ -f tools/liblcp_primalprof.so ]; then      # lcp_primal.hip built with -DLCP_PRIMAL_PROFILE: cycles per phase
+  LCP_HIP_LIB=$ROOT/tools/liblcp_primalprof.so timeout 200 python tools/bench_config5.py ${BATCH:-4096} > $OUT/prof_${TAG}_config5_phases.txt 2>&1
 fi
+timeout 200 python tools/bench_config5.py ${BATCH:-4096} big > $OUT/prof_${TAG}_config5_contact_space.txt 2>&1
 tail -4 $OUT/prof_${TAG}_config5_phases.txt
 head -6 $OUT/prof_${TAG}_config5_kernel_stats.txt
