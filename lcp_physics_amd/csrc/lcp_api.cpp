@@ -258,7 +258,7 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
 // forward of the contact-list entry points, by family
 static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream) {
   switch (step_family(nz, m, e, compute, generic)) {
-    case FAM_QUAD: return lcp::quad_step(P, compute, stream);
+    case FAM_QUAD: return lcp::quad_step(P, compute, stream, g_path != 3);
     case FAM_PRIMAL: return lcp::primal_step(P, stream);
     case FAM_BIG: return lcp::big_step(P, stream);
     case FAM_WAVE64: if (!P.c_count) return lcp::wave64_step(P, compute, stream);   // (its kernel takes full lists only)

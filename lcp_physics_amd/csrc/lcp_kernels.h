@@ -127,7 +127,7 @@ bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
-int quad_step(const StepArgs& P, int compute, void* stream);
+int quad_step(const StepArgs& P, int compute, void* stream, int body_space = 1);
 int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream);
 
 // workgroup-per-scene contact-structured forward for up to 64 contacts (fused step, forward only) - lcp_big.hip

@@ -592,6 +592,187 @@ __device__ __forceinline__ void solve_kkt_q(const SceneQ<TI, TC, XH>& S, const T
   LCP_QTICK(pr, 5)                                                         // solve_kkt: products after
 }
 
+// ---------------------------------------------------------------- asm blocks of the body-space variant
+// (same rules as the LU blocks above: every statement opens with `s_nop 1`, no DPP source is written inside a statement)
+// LU trailing update over the lane's x-row (xr) and equality row (er), 20 columns: the LuColsA pattern on 20-entry arrays
+template <int K, int J0, int N> struct LuColsP;
+#define LCP_LUP_DEF(N)                                                                                                   \
+  template <int K, int J0> struct LuColsP<K, J0, N> {                                                                    \
+    static __device__ __forceinline__ void run(double (&ta)[20], double (&tu)[20], double la, double lu) {               \
+      asm("s_nop 1\n\t" LCP_LUA_S##N : LCP_LUA_O##N : [la] "v"(la), [lu] "v"(lu), [k] "n"(K));                           \
+    }                                                                                                                    \
+  };
+LCP_LUP_DEF(1) LCP_LUP_DEF(2) LCP_LUP_DEF(3) LCP_LUP_DEF(4) LCP_LUP_DEF(5) LCP_LUP_DEF(6) LCP_LUP_DEF(7)
+LCP_LUP_DEF(8) LCP_LUP_DEF(9) LCP_LUP_DEF(10) LCP_LUP_DEF(11) LCP_LUP_DEF(12) LCP_LUP_DEF(13) LCP_LUP_DEF(14)
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_p(double (&xr)[20], double (&er)[20], double lx, double le) {
+  if constexpr (N > 14) { LuColsP<K, J0, 14>::run(xr, er, lx, le); lu_cols_p<K, J0 + 14, N - 14>(xr, er, lx, le); }
+  else if constexpr (N > 0) LuColsP<K, J0, N>::run(xr, er, lx, le);
+}
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_p(float (&xr)[20], float (&er)[20], float lx, float le) {
+  static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; const float sj = bc<K>(xr[j]); er[j] = fmaf(-le, sj, er[j]); xr[j] = fmaf(-lx, sj, xr[j]); });
+}
+// formation: xr[j] += a * (lane K's p0[j]) + b * (lane K's p1[j]) for eight columns
+// (the eight p0 terms first, then the eight p1 terms: the two updates of a column are eight instructions apart)
+#define LCP_PQF_ONE(X, P, M) "v_fmac_f64_dpp %[" #X "], %[" #P "], %[" #M "] row_newbcast:%[k] " LCP_DPP_FULL "\n\t"
+template <int K, int J0> __device__ __forceinline__ void pq_form8(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x4, p4, a) LCP_PQF_ONE(x5, p5, a) LCP_PQF_ONE(x6, p6, a) LCP_PQF_ONE(x7, p7, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) LCP_PQF_ONE(x4, q4, b) LCP_PQF_ONE(x5, q5, b) LCP_PQF_ONE(x6, q6, b) LCP_PQF_ONE(x7, q7, b)
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3]), [x4] "+v"(xr[J0 + 4]), [x5] "+v"(xr[J0 + 5]), [x6] "+v"(xr[J0 + 6]), [x7] "+v"(xr[J0 + 7])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [p4] "v"(p0[J0 + 4]), [q4] "v"(p1[J0 + 4]), [p5] "v"(p0[J0 + 5]), [q5] "v"(p1[J0 + 5]), [p6] "v"(p0[J0 + 6]), [q6] "v"(p1[J0 + 6]), [p7] "v"(p0[J0 + 7]), [q7] "v"(p1[J0 + 7]), [a] "v"(a), [b] "v"(b), [k] "n"(K));
+}
+template <int K, int J0> __device__ __forceinline__ void pq_form8(float (&xr)[20], const float (&p0)[16], const float (&p1)[16], float a, float b) {
+  static_for<8>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; xr[j] = fmaf(bc<K>(p0[j]), a, xr[j]); xr[j] = fmaf(bc<K>(p1[j]), b, xr[j]); });
+}
+
+// ---------------------------------------------------------------- body-space variant of factor / solve (ALG = 1, nz <= 16)
+// The same Newton step with the inequality block eliminated first (lcp_primal.hip has the algebra): per contact the 4 x 4 block
+// M = F_c + diag(s / z) is inverted in closed form in the contact's lane, and what is factored is
+//     K = [[Q + G^T M^-1 G, A^T], [A, 0]]      (nz + neq <= 20 rows instead of the 2 nc = 32 of the reduced contact-space system)
+// Lane i holds x-row i in xr[] and (lanes < neq) equality row i in er[]; columns 0..15 <-> x, 16..19 <-> y.  G^T M^-1 G is
+// accumulated contact by contact, the contact's 2 x 16 block P = B [jc; jt] broadcast from its lane with row_newbcast.
+template <typename TC>
+struct PrimQ {
+  TC idn, i1, i2, kap;               // 1 / Dn, 1 / D1, 1 / D2, 1 / (Dg + 1 / D1 + 1 / D2) of this lane's contact
+  TC udx, ude;                       // 1 / U[i][i] of the lane's x-row and equality row
+};
+template <typename TI, typename TC>
+__device__ __forceinline__ M4<TC> minv_pq(const PrimQ<TC>& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& t) {   // M^-1 t
+  M4<TC> o;
+  o.n = R.idn * t.n;
+  o.g = R.kap * ((t.g - S.mu * o.n) + fma(R.i1, t.f1, R.i2 * t.f2));
+  o.f1 = R.i1 * (t.f1 - o.g);
+  o.f2 = R.i2 * (t.f2 - o.g);
+  return o;
+}
+template <typename TI, typename TC>
+__device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& D,
+                                          bool valid LCP_QPROF_ARG) {
+  const int l16 = launder(S.l16), ncw = __builtin_amdgcn_readfirstlane(S.ncw);
+  const int nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
+  R.idn = fast_rcp(D.n); R.i1 = fast_rcp(D.f1); R.i2 = fast_rcp(D.f2);
+  R.kap = fast_rcp(D.g + (R.i1 + R.i2));
+  const TC b00 = valid ? R.idn : (TC)0;
+  const TC b10 = valid ? R.kap * (R.i1 - R.i2) * (S.mu * R.idn) : (TC)0;
+  const TC b11 = valid ? R.kap * fma(R.i1 + R.i2, D.g, (TC)4 * (R.i1 * R.i2)) : (TC)0;   // = (i1 + i2) - kap (i1 - i2)^2, no cancellation
+  TC p0[16], p1[16];
+  static_for<16>([&](auto J) LCP_INL { const TC c = (TC)launder(S.jc[J]), t = (TC)launder(S.jt[J]); p0[J] = b00 * c; p1[J] = fma(b10, c, b11 * t); });
+  const int oz = lds_opaque_zero();
+  {
+    const TI* at = S.L.AtL + oz;
+    static_for<16>([&](auto J) LCP_INL {
+      xr[J] = (l16 == J) ? ((l16 < nz) ? S.qd[0] : (TC)1) : (TC)0;
+      er[J] = (l16 < EQ) ? (TC)at[(l16 & (EQ - 1)) * 16 + J] : (TC)0;
+    });
+    static_for<EQ>([&](auto A) LCP_INL {
+      xr[16 + A] = (TC)at[A * 16 + l16];
+      er[16 + A] = (l16 == A && A >= e) ? (TC)1 : (TC)0;
+    });
+  }
+  {
+    const TI* gl = S.L.GL + l16 + oz;
+    const TI* gtl = S.L.GTL + l16 + oz;
+    static_for<2>([&](auto Hh) LCP_INL {
+      constexpr int C0 = 8 * Hh;
+      if (C0 < ncw) {
+        TI gv[8], tv[8];
+        static_for<8>([&](auto I) LCP_INL { gv[I] = gl[(C0 + I) * 16]; tv[I] = gtl[(C0 + I) * 16]; });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8>([&](auto I) LCP_INL {
+          constexpr int C = C0 + I;
+          const TC a = (TC)gv[I], b = (TC)tv[I];
+          pq_form8<C, 0>(xr, p0, p1, a, b);
+          pq_form8<C, 8>(xr, p0, p1, a, b);
+        });
+      }
+    });
+  }
+  LCP_QTICK(pr, 1)                                                               // formation
+  bool singular = false;
+  R.udx = 1; R.ude = 1;
+  // (as in factor_q: each step updates the NEXT pivot column first and launches that pivot's reciprocal before the block of
+  //  the remaining columns - the wave is alone on its SIMD and nothing else hides the broadcast -> v_rcp_f64 -> Newton chain)
+  TC pivv = bc<0>(xr[0]);
+  TC inv = fast_rcp(pivv);
+  static_for<16>([&](auto K) LCP_INL {                                           // x pivots
+    constexpr int k = K;
+    if (k < nz) {
+      singular = singular || (pivv == (TC)0);
+      const TC lx = (l16 > k) ? xr[k] * inv : (TC)0;
+      const TC le = er[k] * inv;
+      xr[k] = (l16 > k) ? lx : xr[k];
+      er[k] = le;
+      R.udx = (l16 == k) ? inv : R.udx;
+      fnmac_bc<k>(er[k + 1], xr[k + 1], le);                                     // (reads row k's xr[j] before it is updated below)
+      fnmac_bc<k>(xr[k + 1], xr[k + 1], lx);
+      if constexpr (k + 1 < 16) { pivv = bc<(k + 1) & 15>(xr[k + 1]); inv = fast_rcp(pivv); }
+      lu_cols_p<k, k + 2, 18 - k>(xr, er, lx, le);
+    }
+  });
+  static_for<EQ>([&](auto A_) LCP_INL {                                          // equality pivots
+    constexpr int a = A_, k = 16 + A_;
+    if (a < e) {
+      const TC pivv = bc<a>(er[k]);
+      singular = singular || (pivv == (TC)0);
+      const TC inv = fast_rcp(pivv);
+      const TC le = (l16 > a) ? er[k] * inv : (TC)0;
+      er[k] = (l16 > a) ? le : er[k];
+      R.ude = (l16 == a) ? inv : R.ude;
+      static_for<EQ - 1 - a>([&](auto JJ) LCP_INL { constexpr int j = k + 1 + JJ; fnmac_bc<a>(er[j], er[j], le); });
+    }
+  });
+  LCP_QTICK(pr, 2)                                                               // LU
+  return singular;
+}
+
+// solve_kkt (pdipm.py:325-354) in body space:  q = rs / d - rz,  K [dx; dy] = [-rx + G^T M^-1 q; -ry],
+// dz = M^-1 (G dx - q),  ds = (-rs - dz) / d
+template <typename TI, typename TC>
+__device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const TC (&xr)[20], const TC (&er)[20], const PrimQ<TC>& R,
+                                             const M4<TC>& di, bool valid, const XV<TC, 1>& rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
+                                             XV<TC, 1>& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
+  const int l16 = S.l16, nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
+  M4<TC> q = m4<TC>(rs.n * di.n - rz.n, rs.f1 * di.f1 - rz.f1, rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);
+  if (!valid) q = m4<TC>(0, 0, 0, 0);
+  const M4<TC> u = minv_pq<TI, TC>(R, S, q);
+  const XV<TC, 1> gu = S.Gtw(valid ? u.n : (TC)0, valid ? u.f1 - u.f2 : (TC)0);
+  TC wx = (l16 < nz) ? gu.v[0] - rx.v[0] : (TC)0;
+  TC we = (l16 < e) ? -ry : (TC)0;
+  LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
+  static_for<4>([&](auto Gq) LCP_INL {                                     // L y = rhs
+    if (4 * Gq < nz) static_for<4>([&](auto Kq) LCP_INL {
+      constexpr int k = 4 * Gq + Kq;
+      fnmac_bc<k>(we, wx, er[k]);
+      fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k));
+    });
+  });
+  if (e > 0) {
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; fnmac_bc<a>(we, we, keep_if(er[16 + a], l16 > a)); });
+    static_for<EQ>([&](auto AR) LCP_INL {                                  // U x = y
+      constexpr int a = EQ - 1 - AR;
+      const TC xs = we * R.ude;
+      fnmac_bc<a>(wx, xs, xr[16 + a]);
+      fnmac_bc<a>(we, xs, keep_if(er[16 + a], l16 < a));
+    });
+  }
+  static_for<4>([&](auto GR) LCP_INL {
+    constexpr int Gq = 3 - GR;
+    if (4 * Gq < nz) static_for<4>([&](auto KR) LCP_INL {
+      constexpr int k = 4 * Gq + 3 - KR;
+      const TC xs = wx * R.udx;
+      fnmac_bc<k>(wx, xs, keep_if(xr[k], l16 < k));
+    });
+  });
+  LCP_QTICK(pr, 4)                                                         // triangular sweeps
+  ox.v[0] = (l16 < nz) ? wx * R.udx : (TC)0;
+  oy = (l16 < e) ? we * R.ude : (TC)0;
+  TC gn, gt;
+  S.Gv(ox, gn, gt);
+  oz = minv_pq<TI, TC>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+  if (!valid) oz = m4<TC>(0, 0, 0, 0);
+  os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
+  if (!valid) os = m4<TC>(0, 0, 0, 0);
+  LCP_QTICK(pr, 5)                                                         // solve_kkt: products after
+}
+
 // get_step for (z,dz),(s,ds) of one scene (pdipm.py:182-186): min(step(z,dz), step(s,ds)), NaN semantics kept
 template <typename TC>
 __device__ __forceinline__ TC step_pair_q(const M4<TC>& z, const M4<TC>& dz, const M4<TC>& s, const M4<TC>& ds, bool valid) {
@@ -785,9 +966,11 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC, XH>& S, const Ws<TI, T
 // ---------------------------------------------------------------- forward kernel
 // `accept`: value of the classification flag (meta[0]) this kernel serves for dense inputs.
 // XH: x-space halves (1: nz <= 16; 2: nz <= 32, fused inputs only)
-template <typename TI, typename TC, bool FUSED, int XH>
+// ALG: 0 = the reduced contact-space system (32 x 32), 1 = the body-space system (nz + neq <= 20 rows; XH = 1 only)
+template <typename TI, typename TC, bool FUSED, int XH, int ALG = 0>
 __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
   static_assert(XH == 1 || FUSED, "the dense loader is written for nz <= 16");
+  static_assert(ALG == 0 || XH == 1, "the body-space variant holds one x-row per lane");
   using XVt = XV<TC, XH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
@@ -827,8 +1010,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   int status = prefactor_q<TI, TC, XH>(S, W, live) | truncated;
   TC* const wsx = ws_x<XH>(W);
 
-  TC ta[32], tu[32];
-  RedQ<TC> R;
+  TC ta[ALG == 0 ? 32 : 20], tu[ALG == 0 ? 32 : 20];                    // ALG 1: x-rows and equality rows of the body-space system
+  std::conditional_t<ALG == 0, RedQ<TC>, PrimQ<TC>> R;
   XVt x;
   static_for<XH>([&](auto HX) LCP_INL { x.v[HX] = 0; });
   TC y = 0;
@@ -876,7 +1059,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
     }
     LCP_QTICK(pr, 0)                                                       // residuals, d
-    const bool singular = row_any(factor_q<TI, TC, LCP_Q_LDSW != 0, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS));     // (:99-100)
+    bool sing_;
+    if constexpr (ALG == 0) sing_ = factor_q<TI, TC, LCP_Q_LDSW != 0, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);            // (:99-100)
+    else sing_ = factor_pq<TI, TC>(ta, tu, R, S, dinv, vc LCP_QPROF_PASS);
+    const bool singular = row_any(sing_);
     if (it >= 0 && !done) {
       ++iters;
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
@@ -904,7 +1090,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       XVt ox;
       TC oy;
       M4<TC> os, oz;
-      solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy, pass == 1 LCP_QPROF_PASS);
+      if constexpr (ALG == 0) solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy, pass == 1 LCP_QPROF_PASS);
+      else solve_kkt_pq<TI, TC>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
         const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());       // (once per solve)
@@ -996,6 +1183,24 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   }
 }
 
+// Backward at an iterate whose T = W + diag(s / z) has an exact zero (or NaN) pivot.  A forward in contact space never leaves one
+// (pdipm.py:99-102: an iterate whose factorisation fails is not recorded), the body-space forward factors another matrix and can
+// run a step further into convergence, where s / z underflows against a W that redundant contacts make singular.  Then - and
+// only then - the factorisation is repeated with s / z floored at 1e-9 x the row's diagonal of W (the perturbation
+// lcp_primal.hip's backward applies always): a gradient of the converged solution instead of NaN.
+template <typename TI, typename TC, int XH>
+__device__ __forceinline__ void factor_bwd_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC>& R, const SceneQ<TI, TC, XH>& S, const TC* W2q,
+                                             M4<TC>& dinv, bool vc LCP_QPROF_ARG) {
+  const bool sing = factor_q<TI, TC, false, XH>(ta, tu, R, S, W2q, dinv, vc LCP_QPROF_PASS);
+  if (!__any(row_any(sing))) return;
+  const int l16 = S.l16;
+  const TC waa = W2q[((((size_t)(l16 >> 1)) * 2 + 0) * 16 + l16) * 2 + (l16 & 1)];
+  const TC wuu = W2q[((((size_t)((16 + l16) >> 1)) * 2 + 1) * 16 + l16) * 2 + (l16 & 1)];
+  const TC fa = (TC)1e-9 * waa, fu = (TC)1e-9 * wuu;
+  if (vc && row_any(sing)) { dinv.n = fmax_(dinv.n, fa); dinv.f1 = fmax_(dinv.f1, fu); dinv.f2 = fmax_(dinv.f2, fu); }
+  factor_q<TI, TC, false, XH>(ta, tu, R, S, W2q, dinv, vc LCP_QPROF_PASS);
+}
+
 // ---------------------------------------------------------------- backward kernel (lcp.py:37-64)
 template <typename TI, typename TC>
 __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene, int accept) {
@@ -1041,13 +1246,13 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   XV<TC, 1> g;
   g.v[0] = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
-  const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);            // 1 / d, d = z / s (lcp.py:44)
+  M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                  // 1 / d, d = z / s (lcp.py:44)
   TC ta[32], tu[32];
   RedQ<TC> R;
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_q<TI, TC, false, 1>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);             // lcp.py:46
+  factor_bwd_q<TI, TC, 1>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
   XV<TC, 1> dxv;
   TC dnu;
   M4<TC> ds, dl;
@@ -1160,13 +1365,13 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   });
   const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  const M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
+  M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
   TC ta[32], tu[32];
   RedQ<TC> R;
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_q<TI, TC, false, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);            // lcp.py:46
+  factor_bwd_q<TI, TC, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);               // lcp.py:46
   XVt dx;
   TC dnu;
   M4<TC> ds, dl;
@@ -1264,6 +1469,14 @@ static size_t q16_lds(bool with_w, int xh = 1) {
   return n;
 }
 
+// The dense LCPFunction boundary keeps the contact-space factorisation: it is the reference's own formulation, and with it the
+// exit tests of pdipm.py:133 fall where the reference's fall (iteration counts equal to the oracle's even where a solve converges
+// to rounding - tests/test_hip_parity.py).  The body-space variant takes the same Newton steps to ~1e-12 but can leave a converged
+// solve one iteration later; it serves the contact-list entry points (1 builds it here too, for profiling: the phase trace of
+// LCP_Q_PROFILE is written by the dense forward).
+#ifndef LCP_Q_DENSE_BODY_SPACE
+#define LCP_Q_DENSE_BODY_SPACE 0
+#endif
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
@@ -1273,7 +1486,7 @@ int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io
     hipLaunchKernelGGL((q16::lcp_fwd_quad<double, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1, LCP_Q_DENSE_BODY_SPACE>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else {
     const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
@@ -1281,7 +1494,8 @@ int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_step(const StepArgs& SP, int compute, void* stream) {
+// `body_space`: factor / solve the (nz + neq)-row body-space system instead of the 32-row contact-space one (fp64 arithmetic, nz <= 16)
+int quad_step(const StepArgs& SP, int compute, void* stream, int body_space) {
   FwdArgs P = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
@@ -1289,6 +1503,7 @@ int quad_step(const StepArgs& SP, int compute, void* stream) {
   if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0, wide ? 2 : 1);
     if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    else if (body_space) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
     else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {
     const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0, wide ? 2 : 1);
