@@ -20,7 +20,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   formulation, lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by
                   its average launch duration measured with HIP events on the launch stream inside the timed
                   region, over the FP64 vector rate (the kernel issues no MFMA: `bound` says "valu_fp64");
-                  `frac_executed` = the FLOPs the structure-exploiting kernel really executes (reduced 2nc
+                  `frac_executed` = the FLOPs the structure-exploiting kernel really executes (body-space system / reduced 2nc
                   system) over the same peak; counters / registers quoted from the committed rocprof and
                   compiler reports under profiles/.
   cpu_baseline  - the oracle (a port, torch CPU fp64) timed on this host's cores on the same workload (rank 0,
@@ -325,7 +325,11 @@ class HipStackWorkload:
         status = (self.sol.status if a.mode == "dense" else self.step_out["status"])
         it_list = iters.cpu().tolist()
         fl_fwd = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
-        fl_exec = float(sum(flops.flops_forward_executed(nz, nc, e, it) for it in it_list))
+        # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic), the dense
+        # boundary the contact-space one
+        body_space = a.mode == "fused" and a.compute == "f64" and nz <= 16
+        fl_exec = float(sum((flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)(nz, nc, e, it)
+                            for it in it_list))
         fl_bwd = flops.flops_backward(nz, m, e) * B
         achieved = fl_fwd / (fwd_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.compute]
@@ -337,15 +341,15 @@ class HipStackWorkload:
         tj = _quoted("traffic", key)
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
-        rj = _quoted("kernel_resources", "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))
+        rj = _quoted("kernel_resources", "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))   # (the variant this mode runs)
         # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
         cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
             (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
         what = "forward only" if a.fwd_only else "forward + backward (implicit diff)"
         st = status.cpu()
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
-                "kernel": "lcp_fwd_quad<float,%s,%s> (PDIPM forward%s)" % (
-                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false",
+                "kernel": "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
+                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 1 if body_space else 0,
                     ", fused assembly + integrate" if a.mode == "fused" else "; the event-timed forward call also contains the classify launch"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "executed_flops_per_launch": fl_exec,
@@ -357,7 +361,8 @@ class HipStackWorkload:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_frac_algorithmic": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "frac = SURVEY 8d dense-formulation FLOPs / time / FP64 vector peak (no MFMA is issued by this kernel); "
-                        "frac_executed counts the reduced 2nc system the kernel really factors"}
+                        "frac_executed counts what the kernel really executes: " +
+                        ("the body-space system of nz + neq rows (formation + LU per iteration)" if body_space else "the reduced 2nc contact-space system")}
         if cj:
             roof.update({"valu_active": cj.get("valu_active"), "wait_frac": cj.get("wait_frac"), "counters_source": cj["source"]})
         if rj:

@@ -33,6 +33,21 @@ def flops_forward_executed(nz, nc, e, it):
     return P + Fk + S_full + it * I
 
 
+def flops_forward_executed_body_space(nz, nc, e, it):
+    """FLOPs the body-space variant executes per scene (lcp_quad.hip ALG = 1, lcp_primal.hip): per factorisation the formation of
+    Q + G^T M^-1 G (dense over the nz columns in the quad kernel: 2 rank-1 updates of an nz x nz block per contact) and the LU
+    of the (nz + e)-square system; per KKT solve one J^T w, one J v, the two triangular sweeps and the closed-form 4 x 4 block
+    inverses; W = J P J^T is still formed once (the backward kernels read it)."""
+    n = nz + e
+    P = 2 * (2 * nc) ** 2 * nz                          # prefactor of the contact-space W, kept for the backward
+    Fk = 4 * nc * nz * nz + 6 * nc * nz + (2.0 / 3) * n ** 3 + 30 * nc
+    prod = 4 * nc * nz                                  # one J v or J^T w product (dense rows)
+    S = 2 * prod + 2 * n * n + 60 * nc + 2 * nz
+    Rk = 2 * prod + (4 * e * nz if e > 0 else 0) + 2 * nz + 30 * nc
+    I = Fk + 2 * S + Rk + 60 * nc
+    return P + Fk + S + it * I
+
+
 def flops_backward(nz, m, e):
     k = e + m
     Fk = (2.0 / 3) * m ** 3 + m

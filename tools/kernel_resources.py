@@ -5,7 +5,7 @@ import json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
-FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
+FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
 KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
         "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_static_bytes",
         "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills", "TotalSGPRs": "sgpr"}
@@ -36,11 +36,14 @@ def main():
     pick = lambda sub: next((dict(v, kernel=k) for k, v in nice.items() if sub in k), None)
     out = {
         # the keys bench.py quotes in its roofline object
-        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1>"),
-        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1>"),
-        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1>"),
-        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1>"),
+        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 1>"),        # body-space variant (contact-list entries)
+        "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0>"),
+        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 0>"),
+        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0>"),
+        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0>"),
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
+        "lcp_primal_kernel_40_fwd": pick("lcp_primal_kernel<40, false, false>"),
+        "lcp_primal_kernel_40_bwd": pick("lcp_primal_kernel<40, true, false>"),
         "all_kernels": nice,
         "source": "hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py)",
     }
