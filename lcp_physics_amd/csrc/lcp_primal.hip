@@ -254,7 +254,10 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
           // costs two wait states more and the pairs serialise on one scalar register.  (Measured and dropped: the pivot row
           // through LDS - lane k stores it with ds_write_b128, every lane reads it back at a uniform address.  Fewer
           // instructions, but every read moves 1 KB through the CU's one LDS port and eight waves share it: 3.8 M against
-          // 6.5 M sim steps/s on config 5.)
+          // 6.5 M sim steps/s on config 5.  Also measured and dropped: skipping the 3 x 3 column blocks a pivot row cannot reach
+          // - block masks from the contact graph, symbolic elimination on scalars, bodies in reverse order to keep the fill
+          // low (31 of 66 block visits on a config-5 pile) - with scalar branches between batches of three columns: the
+          // shorter batches and the branches cost more than the skipped work saves, 6.3 M against 6.5 M; towers gained 3-5 %.)
           constexpr int NJ = NCOL - 1 - k;
           static_for<(NJ + 7) / 8>([&](auto C8) LCP_INL {
             constexpr int j0 = k + 1 + 8 * C8, nj = (NJ - 8 * C8) < 8 ? (NJ - 8 * C8) : 8;
