@@ -268,7 +268,10 @@ int lcp_contact_frame_backward_f64(int B, int nb, int maxc,
  * lcp_debug_set_trace: when non-NULL, the dense forward writes trace[B, max_iter, 4] =
  *   (resid, mu, sigma, alpha) per PDIPM iteration (device pointer to doubles).
  * lcp_debug_set_path : 0 = automatic kernel selection, 1 = generic (workgroup-per-scene) kernels only,
- *   2 = wave-per-scene kernels whenever the sizes allow (the default behaviour of 0 today).
+ *   2 = wave-per-scene kernels whenever the sizes allow (the default behaviour of 0 today),
+ *   3 = contact-space factorisation everywhere: lcp_big.hip instead of lcp_primal.hip for 17..64 contacts, the 32-row reduced
+ *       system instead of the body-space one in lcp_quad.hip's contact-list forward (the formulation of pdipm.py:325-454;
+ *       same answers).  A forward and its backward must run under the same setting.
  * Both settings are thread_local: they affect the calls of the thread that made them, nobody else's. */
 void lcp_debug_set_trace(double* device_trace);
 void lcp_debug_set_path(int path);
