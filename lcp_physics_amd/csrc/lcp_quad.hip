@@ -611,6 +611,22 @@ template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_p(double
 template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_p(float (&xr)[20], float (&er)[20], float lx, float le) {
   static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; const float sj = bc<K>(xr[j]); er[j] = fmaf(-le, sj, er[j]); xr[j] = fmaf(-lx, sj, xr[j]); });
 }
+// single-row form (pinned variant: no equality rows), the LuColsU pattern on a 20-entry array
+template <int K, int J0, int N> struct LuColsX;
+#define LCP_LUX_DEF(N)                                                                                                   \
+  template <int K, int J0> struct LuColsX<K, J0, N> {                                                                    \
+    static __device__ __forceinline__ void run(double (&tu)[20], double lu) {                                            \
+      asm("s_nop 1\n\t" LCP_LUU_S##N : LCP_LUU_O##N : [lu] "v"(lu), [k] "n"(K));                                         \
+    }                                                                                                                    \
+  };
+LCP_LUX_DEF(1) LCP_LUX_DEF(2) LCP_LUX_DEF(3) LCP_LUX_DEF(4) LCP_LUX_DEF(5) LCP_LUX_DEF(6) LCP_LUX_DEF(7)
+LCP_LUX_DEF(8) LCP_LUX_DEF(9) LCP_LUX_DEF(10) LCP_LUX_DEF(11) LCP_LUX_DEF(12) LCP_LUX_DEF(13) LCP_LUX_DEF(14)
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_x(double (&xr)[20], double lx) {
+  if constexpr (N > 0) LuColsX<K, J0, N>::run(xr, lx);
+}
+template <int K, int J0, int N> __device__ __forceinline__ void lu_cols_x(float (&xr)[20], float lx) {
+  static_for<N>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; xr[j] = fmaf(-lx, bc<K>(xr[j]), xr[j]); });
+}
 // formation: xr[j] += a * (lane K's p0[j]) + b * (lane K's p1[j]) for eight columns
 // (the eight p0 terms first, then the eight p1 terms: the two updates of a column are eight instructions apart)
 #define LCP_PQF_ONE(X, P, M) "v_fmac_f64_dpp %[" #X "], %[" #P "], %[" #M "] row_newbcast:%[k] " LCP_DPP_FULL "\n\t"
@@ -633,7 +649,16 @@ template <typename TC>
 struct PrimQ {
   TC idn, i1, i2, kap;               // 1 / Dn, 1 / D1, 1 / D2, 1 / (Dg + 1 / D1 + 1 / D2) of this lane's contact
   TC udx, ude;                       // 1 / U[i][i] of the lane's x-row and equality row
+  bool pin;                          // (wave-uniform) the equality rows pin the first neq coordinates: A = [I 0], b = 0
+  TC sp[EQ];                         // pinned variant: the lane's entries in the pinned columns, S[i][a] (taken out of xr[], where
+                                     // zeros make the sweep steps of the pinned coordinates exact no-ops)
 };
+// PINNED COORDINATES.  Every world of the reference's demos fixes its floor with a TotalConstraint on body 0 (constraints.py:175-192,
+// A = [I_3 0]).  Then A dx = -ry IS dx_a = -ry_a for a < neq, the rows of K that belong to the other coordinates close over
+// themselves (S_ff dx_f = rhs_f - S_fp dx_p) and dy_a = rhs_a - (S dx)_a is read off row a afterwards: the LU runs over
+// nz - neq rows of ONE row per lane (66 row updates instead of 360 on the headline config), the rows of the pinned coordinates
+// are never touched by it and stay S.  Same equations, fewer of them; detected per wave (all four scenes), any other A takes
+// the general path.
 template <typename TI, typename TC>
 __device__ __forceinline__ M4<TC> minv_pq(const PrimQ<TC>& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& t) {   // M^-1 t
   M4<TC> o;
@@ -688,6 +713,30 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>&
   LCP_QTICK(pr, 1)                                                               // formation
   bool singular = false;
   R.udx = 1; R.ude = 1;
+  if (R.pin) {
+    // x pivots e .. nz-1 only, one row per lane, columns k+1 .. 15
+    TC pivv = bc<0>(xr[0]);                                                      // (placeholder until the first live step)
+    TC inv = (TC)1;
+    bool primed = false;
+    static_for<16>([&](auto K) LCP_INL {
+      constexpr int k = K;
+      if (k >= e && k < nz) {
+        if (!primed) { pivv = bc<k>(xr[k]); inv = fast_rcp(pivv); primed = true; }
+        singular = singular || (pivv == (TC)0);
+        const TC lx = (l16 > k) ? xr[k] * inv : (TC)0;
+        xr[k] = (l16 > k) ? lx : xr[k];
+        R.udx = (l16 == k) ? inv : R.udx;
+        if constexpr (k + 1 < 16) {
+          fnmac_bc<k>(xr[k + 1], xr[k + 1], lx);
+          pivv = bc<(k + 1) & 15>(xr[k + 1]); inv = fast_rcp(pivv);
+          lu_cols_x<k, k + 2, 14 - k>(xr, lx);
+        }
+      }
+    });
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; R.sp[a] = xr[a]; xr[a] = (a < e) ? (TC)0 : xr[a]; });
+    LCP_QTICK(pr, 2)                                                             // LU
+    return singular;
+  }
   // (as in factor_q: each step updates the NEXT pivot column first and launches that pivot's reciprocal before the block of
   //  the remaining columns - the wave is alone on its SIMD and nothing else hides the broadcast -> v_rcp_f64 -> Newton chain)
   TC pivv = bc<0>(xr[0]);
@@ -737,6 +786,36 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
   TC wx = (l16 < nz) ? gu.v[0] - rx.v[0] : (TC)0;
   TC we = (l16 < e) ? -ry : (TC)0;
   LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
+  if (R.pin) {
+    // dx_p = -ry on the pinned lanes; the free rows solve S_ff dx_f = rhs_f - S_fp dx_p; the pinned lanes, whose rows are still
+    // S, ride along in the backward sweep and end up with rhs_a - (S dx)_a = dy_a
+    if (e > 0) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; fnmac_bc<a>(wx, we, keep_if(R.sp[a], a < e)); });
+    static_for<4>([&](auto Gq) LCP_INL {                                   // L y = rhs (the steps of the pinned columns meet zeros)
+      if (4 * Gq < nz) static_for<4>([&](auto Kq) LCP_INL {
+        constexpr int k = 4 * Gq + Kq;
+        fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k));
+      });
+    });
+    static_for<4>([&](auto GR) LCP_INL {                                   // U x = y
+      constexpr int Gq = 3 - GR;
+      if (4 * Gq < nz) static_for<4>([&](auto KR) LCP_INL {
+        constexpr int k = 4 * Gq + 3 - KR;
+        const TC xs = wx * R.udx;
+        fnmac_bc<k>(wx, xs, keep_if(xr[k], l16 < k));
+      });
+    });
+    LCP_QTICK(pr, 4)                                                       // triangular sweeps
+    ox.v[0] = (l16 < e) ? we : ((l16 < nz) ? wx * R.udx : (TC)0);
+    oy = (l16 < e) ? wx : (TC)0;
+    TC gn, gt;
+    S.Gv(ox, gn, gt);
+    oz = minv_pq<TI, TC>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+    if (!valid) oz = m4<TC>(0, 0, 0, 0);
+    os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
+    if (!valid) os = m4<TC>(0, 0, 0, 0);
+    LCP_QTICK(pr, 5)                                                       // solve_kkt: products after
+    return;
+  }
   static_for<4>([&](auto Gq) LCP_INL {                                     // L y = rhs
     if (4 * Gq < nz) static_for<4>([&](auto Kq) LCP_INL {
       constexpr int k = 4 * Gq + Kq;
@@ -1012,6 +1091,12 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
 
   TC ta[ALG == 0 ? 32 : 20], tu[ALG == 0 ? 32 : 20];                    // ALG 1: x-rows and equality rows of the body-space system
   std::conditional_t<ALG == 0, RedQ<TC>, PrimQ<TC>> R;
+  if constexpr (ALG == 1) {
+    // do the equality rows pin the first neq coordinates (A = [I 0], b = 0) in all four scenes of the wave ?  (or are there none)
+    bool okl = (l16 >= e) || (b == (TC)0);
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; if (a < e) okl = okl && ((TC)S.L.AtL[a * 16 + l16] == ((l16 == a) ? (TC)1 : (TC)0)); });
+    R.pin = __all(okl) != 0;
+  }
   XVt x;
   static_for<XH>([&](auto HX) LCP_INL { x.v[HX] = 0; });
   TC y = 0;
