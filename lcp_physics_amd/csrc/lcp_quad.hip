@@ -683,14 +683,14 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>&
   const int oz = lds_opaque_zero();
   {
     const TI* at = S.L.AtL + oz;
-    static_for<16>([&](auto J) LCP_INL {
-      xr[J] = (l16 == J) ? ((l16 < nz) ? S.qd[0] : (TC)1) : (TC)0;
-      er[J] = (l16 < EQ) ? (TC)at[(l16 & (EQ - 1)) * 16 + J] : (TC)0;
-    });
-    static_for<EQ>([&](auto A) LCP_INL {
-      xr[16 + A] = (TC)at[A * 16 + l16];
-      er[16 + A] = (l16 == A && A >= e) ? (TC)1 : (TC)0;
-    });
+    static_for<16>([&](auto J) LCP_INL { xr[J] = (l16 == J) ? ((l16 < nz) ? S.qd[0] : (TC)1) : (TC)0; });
+    if (!R.pin) {                                                               // (the pinned variant has no equality rows / columns)
+      static_for<16>([&](auto J) LCP_INL { er[J] = (l16 < EQ) ? (TC)at[(l16 & (EQ - 1)) * 16 + J] : (TC)0; });
+      static_for<EQ>([&](auto A) LCP_INL {
+        xr[16 + A] = (TC)at[A * 16 + l16];
+        er[16 + A] = (l16 == A && A >= e) ? (TC)1 : (TC)0;
+      });
+    }
   }
   {
     const TI* gl = S.L.GL + l16 + oz;
@@ -1118,27 +1118,34 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   for (int it = -1; it < max_iter; ++it) {
     if (!__any(!done)) break;
     XVt rx;
-    TC ry, mu = 0, resid = 0;
+    TC ry, mu = 0, resid = 0, szsum = 0;
     M4<TC> rs, rz;
     if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63)
       rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); dinv = m4<TC>(1, 1, 1, 1);
     } else {                                                               // residuals (:82-96)
       rx = S.Gtw(z.n, z.f1 - z.f2);
       static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = rx.v[HX] + S.qd[HX] * x.v[HX] + p.v[HX]; });
-      if (e > 0) { const XVt ay_ = S.Aty(y); static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] += ay_.v[HX]; }); }
+      if (e > 0) {
+        if constexpr (ALG == 1) {
+          if (R.pin) rx.v[0] += (l16 < e) ? y : (TC)0;                        // A = [I 0]: A^T y is y on the pinned lanes (the product's exact value)
+          else { const XVt ay_ = S.Aty(y); rx.v[0] += ay_.v[0]; }
+        } else { const XVt ay_ = S.Aty(y); static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] += ay_.v[HX]; }); }
+      }
       rs = z;
       TC gn, gt;
       S.Gv(x, gn, gt);
       // F z is lane-local for the contact structure (engines.py:69-73)
       rz = m4<TC>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (S.mu * z.n - (z.f1 + z.f2)));
       if (!vc) rz = m4<TC>(0, 0, 0, 0);
-      ry = (e > 0) ? (S.Av(x) - b) : (TC)0;
+      if constexpr (ALG == 1) ry = (e > 0) ? (R.pin ? ((l16 < e) ? x.v[0] : (TC)0) : (S.Av(x) - b)) : (TC)0;   // (pinned: A x = x_p, b = 0)
+      else ry = (e > 0) ? (S.Av(x) - b) : (TC)0;
       TC rx2 = 0;
       static_for<XH>([&](auto HX) LCP_INL { rx2 += (16 * HX + l16 < nz) ? rx.v[HX] * rx.v[HX] : (TC)0; });
       const TC n_rx = row_sum(rx2);
       const TC n_rz = row_sum(rz.n * rz.n + rz.f1 * rz.f1 + rz.f2 * rz.f2 + rz.g * rz.g);
       const TC n_ry = row_sum((l16 < e) ? ry * ry : (TC)0);
       const TC sz = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
+      szsum = sz;
       mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
       dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
@@ -1193,7 +1200,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         const TC alpha = pmin(step_pair_q(z, az, s, as_, vc), (TC)1);        // (:142-144)
         auto sc = [&](TC sv, TC dsv, TC zv, TC dzv) { return (sv + alpha * dsv) * (zv + alpha * dzv); };
         const TC t3 = row_sum(vc ? (sc(s.n, as_.n, z.n, az.n) + sc(s.f1, as_.f1, z.f1, az.f1)) + (sc(s.f2, as_.f2, z.f2, az.f2) + sc(s.g, as_.g, z.g, az.g)) : (TC)0);
-        const TC t4 = row_sum(vc ? (s.n * z.n + s.f1 * z.f1) + (s.f2 * z.f2 + s.g * z.g) : (TC)0);
+        const TC t4 = szsum;                                                  // sum(s z) of this iterate: formed with the residuals (:91)
         const TC r3 = t3 / t4, sig = r3 * r3 * r3;                            // (:146-150)
         const TC ms = -mu * sig;
         static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = 0; });
