@@ -349,8 +349,10 @@ class HipStackWorkload:
         st = status.cpu()
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
                 "kernel": "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
-                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 1 if body_space else 0,
-                    ", fused assembly + integrate" if a.mode == "fused" else "; the event-timed forward call also contains the classify launch"),
+                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
+                    ", fused assembly + integrate; the event-timed forward also contains the (empty) second pass lcp_fwd_quad<...,1,1> for "
+                    "scenes whose equality rows do not pin the leading coordinates" if a.mode == "fused"
+                    else "; the event-timed forward call also contains the classify launch"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "executed_flops_per_launch": fl_exec,
                 "achieved_executed": fl_exec / (fwd_ms * 1e-3) / 1e12,

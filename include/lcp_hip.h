@@ -272,6 +272,7 @@ int lcp_contact_frame_backward_f64(int B, int nb, int maxc,
  *   3 = contact-space factorisation everywhere: lcp_big.hip instead of lcp_primal.hip for 17..64 contacts, the 32-row reduced
  *       system instead of the body-space one in lcp_quad.hip's contact-list forward (the formulation of pdipm.py:325-454;
  *       same answers).  A forward and its backward must run under the same setting.
+ *   4 = lcp_primal.hip (one wave per scene) also where lcp_quad.hip would serve (A/B: small batches).
  * Both settings are thread_local: they affect the calls of the thread that made them, nobody else's. */
 void lcp_debug_set_trace(double* device_trace);
 void lcp_debug_set_path(int path);

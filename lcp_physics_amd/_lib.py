@@ -102,7 +102,7 @@ def require_gpu_tensor(t, name, dtype=None):
 
 def set_path(path):
     """A/B aid: 'auto' | 'generic' | 'wave64' kernel family."""
-    load().lcp_debug_set_path({"auto": 0, "generic": 1, "wave64": 2, "big": 3}[path])
+    load().lcp_debug_set_path({"auto": 0, "generic": 1, "wave64": 2, "big": 3, "primal": 4}[path])
 
 
 def workspace_bytes(B, nz, m, e, compute):

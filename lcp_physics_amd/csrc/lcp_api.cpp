@@ -34,6 +34,7 @@ inline bool use_wave64(int io_f64, int nz, int m, int e, bool generic) {
 enum StepFamily { FAM_QUAD, FAM_PRIMAL, FAM_BIG, FAM_WAVE64, FAM_GENERIC };
 inline StepFamily step_family(int nz, int m, int e, int compute, bool generic) {
   if (generic) return FAM_GENERIC;
+  if (g_path == 4 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // (A/B: one wave per scene at every size)
   if (lcp::quad_step_supported(nz, m, e)) return FAM_QUAD;                     // <= 16 contacts, <= 10 bodies, e <= 4
   if (compute == LCP_COMPUTE_F64 && g_path != 3 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // <= 64 contacts, body-space systems
   if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e)) return FAM_BIG;   // <= 64 contacts (fp64 arithmetic)

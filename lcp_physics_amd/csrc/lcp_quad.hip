@@ -645,11 +645,13 @@ template <int K, int J0> __device__ __forceinline__ void pq_form8(float (&xr)[20
 //     K = [[Q + G^T M^-1 G, A^T], [A, 0]]      (nz + neq <= 20 rows instead of the 2 nc = 32 of the reduced contact-space system)
 // Lane i holds x-row i in xr[] and (lanes < neq) equality row i in er[]; columns 0..15 <-> x, 16..19 <-> y.  G^T M^-1 G is
 // accumulated contact by contact, the contact's 2 x 16 block P = B [jc; jt] broadcast from its lane with row_newbcast.
-template <typename TC>
+// PINC: the kernel is the pinned variant ALONE (ALG = 2; `pin_rt` then only says whether the wave qualified)
+template <typename TC, bool PINC = false>
 struct PrimQ {
   TC idn, i1, i2, kap;               // 1 / Dn, 1 / D1, 1 / D2, 1 / (Dg + 1 / D1 + 1 / D2) of this lane's contact
   TC udx, ude;                       // 1 / U[i][i] of the lane's x-row and equality row
-  bool pin;                          // (wave-uniform) the equality rows pin the first neq coordinates: A = [I 0], b = 0
+  bool pin_rt;                       // (wave-uniform) the equality rows pin the first neq coordinates: A = [I 0], b = 0
+  __device__ __forceinline__ bool pin() const { return PINC || pin_rt; }
   TC sp[EQ];                         // pinned variant: the lane's entries in the pinned columns, S[i][a] (taken out of xr[], where
                                      // zeros make the sweep steps of the pinned coordinates exact no-ops)
 };
@@ -659,8 +661,8 @@ struct PrimQ {
 // nz - neq rows of ONE row per lane (66 row updates instead of 360 on the headline config), the rows of the pinned coordinates
 // are never touched by it and stay S.  Same equations, fewer of them; detected per wave (all four scenes), any other A takes
 // the general path.
-template <typename TI, typename TC>
-__device__ __forceinline__ M4<TC> minv_pq(const PrimQ<TC>& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& t) {   // M^-1 t
+template <typename TI, typename TC, typename PQ>
+__device__ __forceinline__ M4<TC> minv_pq(const PQ& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& t) {   // M^-1 t
   M4<TC> o;
   o.n = R.idn * t.n;
   o.g = R.kap * ((t.g - S.mu * o.n) + fma(R.i1, t.f1, R.i2 * t.f2));
@@ -668,8 +670,8 @@ __device__ __forceinline__ M4<TC> minv_pq(const PrimQ<TC>& R, const SceneQ<TI, T
   o.f2 = R.i2 * (t.f2 - o.g);
   return o;
 }
-template <typename TI, typename TC>
-__device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& D,
+template <typename TI, typename TC, typename PQ>
+__device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& D,
                                           bool valid LCP_QPROF_ARG) {
   const int l16 = launder(S.l16), ncw = __builtin_amdgcn_readfirstlane(S.ncw);
   const int nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
@@ -684,7 +686,7 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>&
   {
     const TI* at = S.L.AtL + oz;
     static_for<16>([&](auto J) LCP_INL { xr[J] = (l16 == J) ? ((l16 < nz) ? S.qd[0] : (TC)1) : (TC)0; });
-    if (!R.pin) {                                                               // (the pinned variant has no equality rows / columns)
+    if (!R.pin()) {                                                               // (the pinned variant has no equality rows / columns)
       static_for<16>([&](auto J) LCP_INL { er[J] = (l16 < EQ) ? (TC)at[(l16 & (EQ - 1)) * 16 + J] : (TC)0; });
       static_for<EQ>([&](auto A) LCP_INL {
         xr[16 + A] = (TC)at[A * 16 + l16];
@@ -713,7 +715,7 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>&
   LCP_QTICK(pr, 1)                                                               // formation
   bool singular = false;
   R.udx = 1; R.ude = 1;
-  if (R.pin) {
+  if (R.pin()) {
     // x pivots e .. nz-1 only, one row per lane, columns k+1 .. 15
     TC pivv = bc<0>(xr[0]);                                                      // (placeholder until the first live step)
     TC inv = (TC)1;
@@ -774,19 +776,19 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PrimQ<TC>&
 
 // solve_kkt (pdipm.py:325-354) in body space:  q = rs / d - rz,  K [dx; dy] = [-rx + G^T M^-1 q; -ry],
 // dz = M^-1 (G dx - q),  ds = (-rs - dz) / d
-template <typename TI, typename TC>
-__device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const TC (&xr)[20], const TC (&er)[20], const PrimQ<TC>& R,
+template <typename TI, typename TC, typename PQ>
+__device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const TC (&xr)[20], const TC (&er)[20], const PQ& R,
                                              const M4<TC>& di, bool valid, const XV<TC, 1>& rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
                                              XV<TC, 1>& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
   const int l16 = S.l16, nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
   M4<TC> q = m4<TC>(rs.n * di.n - rz.n, rs.f1 * di.f1 - rz.f1, rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);
   if (!valid) q = m4<TC>(0, 0, 0, 0);
-  const M4<TC> u = minv_pq<TI, TC>(R, S, q);
+  const M4<TC> u = minv_pq<TI, TC, PQ>(R, S, q);
   const XV<TC, 1> gu = S.Gtw(valid ? u.n : (TC)0, valid ? u.f1 - u.f2 : (TC)0);
   TC wx = (l16 < nz) ? gu.v[0] - rx.v[0] : (TC)0;
   TC we = (l16 < e) ? -ry : (TC)0;
   LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
-  if (R.pin) {
+  if (R.pin()) {
     // dx_p = -ry on the pinned lanes; the free rows solve S_ff dx_f = rhs_f - S_fp dx_p; the pinned lanes, whose rows are still
     // S, ride along in the backward sweep and end up with rhs_a - (S dx)_a = dy_a
     if (e > 0) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; fnmac_bc<a>(wx, we, keep_if(R.sp[a], a < e)); });
@@ -809,7 +811,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
     oy = (l16 < e) ? wx : (TC)0;
     TC gn, gt;
     S.Gv(ox, gn, gt);
-    oz = minv_pq<TI, TC>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+    oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
     if (!valid) oz = m4<TC>(0, 0, 0, 0);
     os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
     if (!valid) os = m4<TC>(0, 0, 0, 0);
@@ -845,7 +847,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
   oy = (l16 < e) ? we * R.ude : (TC)0;
   TC gn, gt;
   S.Gv(ox, gn, gt);
-  oz = minv_pq<TI, TC>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+  oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
   if (!valid) oz = m4<TC>(0, 0, 0, 0);
   os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
   if (!valid) os = m4<TC>(0, 0, 0, 0);
@@ -1045,11 +1047,16 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC, XH>& S, const Ws<TI, T
 // ---------------------------------------------------------------- forward kernel
 // `accept`: value of the classification flag (meta[0]) this kernel serves for dense inputs.
 // XH: x-space halves (1: nz <= 16; 2: nz <= 32, fused inputs only)
-// ALG: 0 = the reduced contact-space system (32 x 32), 1 = the body-space system (nz + neq <= 20 rows; XH = 1 only)
+// ALG: 0 = the reduced contact-space system (32 x 32), 1 = the body-space system (nz + neq <= 20 rows; XH = 1 only),
+//      2 = the body-space system for waves whose equality rows pin the leading coordinates, ALONE in the kernel (contact-list
+//          inputs): without the general path's equality rows the kernel needs 47 instead of 95 accumulation registers and runs
+//          6 % faster.  A wave that does not qualify marks its scenes (meta[21]) and leaves; the ALG = 1 kernel, launched right
+//          behind with accept = 3, serves exactly the marked scenes - on the usual worlds it finds none and is gone in 2-3 us.
 template <typename TI, typename TC, bool FUSED, int XH, int ALG = 0>
 __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
   static_assert(XH == 1 || FUSED, "the dense loader is written for nz <= 16");
   static_assert(ALG == 0 || XH == 1, "the body-space variant holds one x-row per lane");
+  static_assert(ALG != 2 || FUSED, "the pinned-only kernel is launched by the contact-list entry points");
   using XVt = XV<TC, XH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
@@ -1063,6 +1070,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   Ws<TI, TC> W(FUSED ? SP.ws : P.ws, scene);
   bool live = scene_raw < Btot;
   if (!FUSED) live = live && ((int)W.meta[0] == accept);
+  if (FUSED && ALG == 1 && accept == 3) live = live && ((int)W.meta[21] == 1);   // second pass: the scenes the pinned-only kernel left
   if (!__any(live)) return;
   SceneQ<TI, TC, XH> S;
   carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0, XH);
@@ -1086,17 +1094,22 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     load_dense_q<TI, TC>(S, P, W, scene, p, hn, b);
   }
   if (live && l16 == 0) W.meta[19] = (TC)ncs;
+  std::conditional_t<ALG == 0, RedQ<TC>, PrimQ<TC, ALG == 2>> R;
+  if constexpr (ALG != 0) {
+    // do the equality rows pin the first neq coordinates (A = [I 0], b = 0) in all four scenes of the wave ?  (or are there none)
+    __syncthreads();                                                     // (the A rows the loaders put into LDS)
+    bool okl = (l16 >= e) || (b == (TC)0);
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; if (a < e) okl = okl && ((TC)S.L.AtL[a * 16 + l16] == ((l16 == a) ? (TC)1 : (TC)0)); });
+    R.pin_rt = __all(okl) != 0;
+    if constexpr (ALG == 2) {
+      if (live && l16 == 0) W.meta[21] = R.pin_rt ? (TC)0 : (TC)1;
+      if (!R.pin_rt) return;                                             // the general kernel behind this one takes the wave
+    }
+  }
   int status = prefactor_q<TI, TC, XH>(S, W, live) | truncated;
   TC* const wsx = ws_x<XH>(W);
 
-  TC ta[ALG == 0 ? 32 : 20], tu[ALG == 0 ? 32 : 20];                    // ALG 1: x-rows and equality rows of the body-space system
-  std::conditional_t<ALG == 0, RedQ<TC>, PrimQ<TC>> R;
-  if constexpr (ALG == 1) {
-    // do the equality rows pin the first neq coordinates (A = [I 0], b = 0) in all four scenes of the wave ?  (or are there none)
-    bool okl = (l16 >= e) || (b == (TC)0);
-    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; if (a < e) okl = okl && ((TC)S.L.AtL[a * 16 + l16] == ((l16 == a) ? (TC)1 : (TC)0)); });
-    R.pin = __all(okl) != 0;
-  }
+  TC ta[ALG == 0 ? 32 : 20], tu[ALG == 0 ? 32 : 20];                    // ALG 1, 2: x-rows and equality rows of the body-space system
   XVt x;
   static_for<XH>([&](auto HX) LCP_INL { x.v[HX] = 0; });
   TC y = 0;
@@ -1126,8 +1139,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       rx = S.Gtw(z.n, z.f1 - z.f2);
       static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = rx.v[HX] + S.qd[HX] * x.v[HX] + p.v[HX]; });
       if (e > 0) {
-        if constexpr (ALG == 1) {
-          if (R.pin) rx.v[0] += (l16 < e) ? y : (TC)0;                        // A = [I 0]: A^T y is y on the pinned lanes (the product's exact value)
+        if constexpr (ALG != 0) {
+          if (R.pin()) rx.v[0] += (l16 < e) ? y : (TC)0;                        // A = [I 0]: A^T y is y on the pinned lanes (the product's exact value)
           else { const XVt ay_ = S.Aty(y); rx.v[0] += ay_.v[0]; }
         } else { const XVt ay_ = S.Aty(y); static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] += ay_.v[HX]; }); }
       }
@@ -1137,7 +1150,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       // F z is lane-local for the contact structure (engines.py:69-73)
       rz = m4<TC>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (S.mu * z.n - (z.f1 + z.f2)));
       if (!vc) rz = m4<TC>(0, 0, 0, 0);
-      if constexpr (ALG == 1) ry = (e > 0) ? (R.pin ? ((l16 < e) ? x.v[0] : (TC)0) : (S.Av(x) - b)) : (TC)0;   // (pinned: A x = x_p, b = 0)
+      if constexpr (ALG != 0) ry = (e > 0) ? (R.pin() ? ((l16 < e) ? x.v[0] : (TC)0) : (S.Av(x) - b)) : (TC)0;   // (pinned: A x = x_p, b = 0)
       else ry = (e > 0) ? (S.Av(x) - b) : (TC)0;
       TC rx2 = 0;
       static_for<XH>([&](auto HX) LCP_INL { rx2 += (16 * HX + l16 < nz) ? rx.v[HX] * rx.v[HX] : (TC)0; });
@@ -1153,7 +1166,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     LCP_QTICK(pr, 0)                                                       // residuals, d
     bool sing_;
     if constexpr (ALG == 0) sing_ = factor_q<TI, TC, LCP_Q_LDSW != 0, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);            // (:99-100)
-    else sing_ = factor_pq<TI, TC>(ta, tu, R, S, dinv, vc LCP_QPROF_PASS);
+    else sing_ = factor_pq<TI, TC, decltype(R)>(ta, tu, R, S, dinv, vc LCP_QPROF_PASS);
     const bool singular = row_any(sing_);
     if (it >= 0 && !done) {
       ++iters;
@@ -1183,7 +1196,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       TC oy;
       M4<TC> os, oz;
       if constexpr (ALG == 0) solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy, pass == 1 LCP_QPROF_PASS);
-      else solve_kkt_pq<TI, TC>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
+      else solve_kkt_pq<TI, TC, decltype(R)>(S, ta, tu, R, dinv, vc, rx, rs, rz, ry, ox, os, oz, oy LCP_QPROF_PASS);
       if (it < 0) {
         x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
         const TC smin = row_pmin(vc ? pmin(pmin(s.n, s.f1), pmin(s.f2, s.g)) : inf_of<TC>());       // (once per solve)
@@ -1595,7 +1608,10 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space) {
   if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0, wide ? 2 : 1);
     if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
-    else if (body_space) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
+    else if (body_space) {
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);   // pinned leading coordinates
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 3);   // whatever that one left
+    }
     else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {
     const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0, wide ? 2 : 1);

@@ -172,3 +172,46 @@ def test_dense_boundary_routes_every_scene_to_its_kernel():
             if k in "QpAb":                                # (dG, dh, dF of redundant piles are rounding-determined: tests/parity.py)
                 sk = float(b.abs().max())
                 assert float((a - b).abs().max()) <= 1e-4 * max(sk, 1e-12), (name, k, float((a - b).abs().max()), sk)
+
+
+def test_quad_body_space_takes_any_equality_rows():
+    """The four-scenes-per-wave forward of the contact-list entry points runs a kernel that assumes the equality rows pin the leading
+    coordinates (A = [I 0]: the TotalConstraint on the floor) and, behind it, the general body-space kernel for the waves that do
+    not qualify.  Here: every fourth wave keeps the floor pin, the others get rows that pin ANOTHER body, a row with general
+    entries, or fewer rows - in one batch, so that one call exercises both kernels.  Against the contact-space kernel (forced
+    path) and the oracle."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    B = 64
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=17, dtype=torch.float32)
+    Je = sc.Je.clone()
+    nz = 3 * sc.nb
+    for k in range(B):
+        kind = (k // 4) % 4                                   # per wave of four scenes
+        if kind == 1:                                         # the joint pins body 1 instead of the floor; the floor is heavy
+            Je[k].zero_()
+            Je[k, 0, 3] = Je[k, 1, 4] = Je[k, 2, 5] = 1.0
+        elif kind == 2:                                       # a general row: the floor's x follows body 1's rotation
+            Je[k, 1, 3] = 0.25
+        elif kind == 3:                                       # scaled rows (same constraint, A is not [I 0])
+            Je[k] *= 2.0
+    sc.Je = Je
+    scg = sc.to(device=DEV)
+    out = fused_step(scg)
+    _lib.set_path("big")
+    try:
+        ref_cs = fused_step(scg)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_path("auto")
+    va, vb = out["v_new"].double().cpu(), ref_cs["v_new"].double().cpu()
+    scale = vb.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    err = (va - vb).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(err.max()) <= 2e-6, err.tolist()
+    assert int((out["status"] & 8).sum()) == 0
+    lcp = [None if t is None else t.double().cpu() for t in assemble_contacts(scg)]
+    ref = O.lcp_forward(*lcp)
+    ex = parity.err_x(-va.reshape(B, -1), ref.x, lcp[0], lcp[1])
+    assert float(ex.max()) <= 1e-4, float(ex.max())
+    ey = (out["y"].double().cpu() - ref.y).abs().max(dim=1)[0] / ref.y.abs().max(dim=1)[0].clamp_min(1.0)
+    assert float(ey.max()) <= 1e-4, ey.tolist()

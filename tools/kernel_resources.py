@@ -36,7 +36,8 @@ def main():
     pick = lambda sub: next((dict(v, kernel=k) for k, v in nice.items() if sub in k), None)
     out = {
         # the keys bench.py quotes in its roofline object
-        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 1>"),        # body-space variant (contact-list entries)
+        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 2>"),        # body-space, pinned leading coordinates (contact-list entries)
+        "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1>"),
         "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0>"),
         "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 0>"),
         "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0>"),

@@ -5,7 +5,7 @@ writes profiles/r02_traffic.json (FETCH_SIZE / WRITE_SIZE, KB per launch of the 
 import json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1E", "dense_B4096_nc16_f64": "lcp_fwd_quadIfdLb0ELi1E"}
+KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E", "dense_B4096_nc16_f64": "lcp_fwd_quadIfdLb0ELi1E"}
 
 
 def main(path, tag):
