@@ -215,3 +215,43 @@ def test_quad_body_space_takes_any_equality_rows():
     assert float(ex.max()) <= 1e-4, float(ex.max())
     ey = (out["y"].double().cpu() - ref.y).abs().max(dim=1)[0] / ref.y.abs().max(dim=1)[0].clamp_min(1.0)
     assert float(ey.max()) <= 1e-4, ey.tolist()
+
+
+def test_quad_body_space_without_equality_rows():
+    """neq = 0 (a heavy free floor instead of a pinned one) on the four-scenes-per-wave contact-list path: nothing to pin, the
+    pinned-variant kernel factors all nz rows; against the contact-space kernel and the oracle, with ragged contact counts."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 32
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=29, dtype=torch.float32)
+    sc.Mdiag[:, 0] *= 1e4
+    sc.f[:, 0] = 0
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.randint(0, sc.nc + 1, (B,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
+    count[::3] = sc.nc
+    run = lambda: solve_dynamics(B, sc.nb, sc.nc, 0, count.to(DEV), scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, None, sc.dt)
+    a = run()
+    _lib.set_path("big")
+    try:
+        b = run()
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_path("auto")
+    va, vb = a["v_new"].double().cpu(), b["v_new"].double().cpu()
+    scale = vb.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    assert float(((va - vb).abs().reshape(B, -1).max(dim=1)[0] / scale).max()) <= 2e-6
+    assert int((a["status"] & 8).sum()) == 0
+    for k in range(0, B, 5):
+        n = int(count[k])
+        if n == 0:
+            continue
+        one = lambda t: t[k:k + 1]
+        args = (one(sc.Mdiag), one(sc.v), one(sc.f), sc.dt, sc.c_n[k:k + 1, :n], sc.c_p1[k:k + 1, :n], sc.c_p2[k:k + 1, :n],
+                sc.c_i1[k:k + 1, :n], sc.c_i2[k:k + 1, :n], one(sc.rest), one(sc.fric), None)
+        lcp64 = [None if t is None else t.double() for t in O.assemble_lcp(*args)]
+        rs = O.lcp_forward(*lcp64)
+        ex = float(parity.err_x(-va[k].reshape(1, -1), rs.x, lcp64[0], lcp64[1]).max())
+        assert ex <= 1e-4, (k, n, ex)
