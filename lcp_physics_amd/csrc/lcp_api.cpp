@@ -309,14 +309,16 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   if (!c_count || !dp || !ws || max_iter < 0) return LCP_E_BADARG;
   if ((p_out != nullptr) != (p != nullptr)) return LCP_E_BADARG;
   const int nz = 3 * nb, m = 4 * maxc;
-  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
-  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
-  if (!pl.ok) return LCP_E_TOOLARGE;
   P.c_count = c_count;
   P.dt = dt;
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = dp; P.iters = iters; P.status = status;
   P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
+  // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
+  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
   return lcp::generic_post_stab(P, compute, pl.lds_bytes, stream);
 }

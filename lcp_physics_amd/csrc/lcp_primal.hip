@@ -611,6 +611,267 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
 #endif
 }
 
+
+// ---------------------------------------------------------------- post-stabilisation (engines.py:80-116; world.py:109-117)
+// The frictionless LCP of PdipmEngine.post_stabilization - Q = M, p = 0, G = Jc, h = gc = Jc v + Jc v * -restitutions, A = Je,
+// b = ge = Je v, F = 0: ONE inequality row per contact - solved in body space like the step above (the block M is the scalar
+// D = s / z), then dp = -x and, when poses are given, the correction move p_out = p + (dp / 2) dt_scene.  No contact: the direct
+// KKT solve of :92-103, which is what the initialisation solve computes.  One wave per scene; replaces the generic
+// workgroup-per-scene kernel on this path (4.2 ms for 4096 x 16 contacts).
+template <int NCOL>
+__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_kernel(StepArgs SP) {
+  constexpr int LDK = NCOL + 1;
+  __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];
+  __shared__ double xv[LX];
+  __shared__ float At[EQB * LX];
+  const int scene = blockIdx.x, lane = threadIdx.x;
+  const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
+  int ncs = ncap;
+  if (SP.c_count) ncs = SP.c_count[scene];
+  const int truncated = (ncs > ncap) ? LCP_ST_TRUNCATED : 0;
+  ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
+  const bool vc = lane < ncs, vx = lane < nz, ve = lane >= nz && lane < n;
+  const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
+  const float* vv = (const float*)SP.v + (size_t)scene * nz;
+  float jn[6] = {0, 0, 0, 0, 0, 0};
+  int c0 = 0, c1 = 0;
+  double hn = 0;
+  if (vc) {
+    const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
+                                                     (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
+                                                     SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
+                                                     (const float*)SP.rest + (size_t)scene * nb, vv, lane);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) jn[q] = r.jn[q];
+    c0 = 3 * r.b1; c1 = 3 * r.b2;
+    hn = (double)r.jv + (double)r.jv * -(double)r.rbar;                      // engines.py:87-89
+  }
+  auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
+  const double qd = vx ? (double)Md[lane] : 0.0;
+  for (int i = lane; i < EQB * LX; i += 64) At[i] = 0.0f;
+  wsync();
+  for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  wsync();
+  int status = truncated;
+  if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
+  auto acol = [&](int a) -> double { return (double)At[a * LX + lane]; };
+  auto Gv = [&](double v) -> double {                                     // (Jc v)_c
+    xv[lane] = vx ? v : 0.0; wsync();
+    double gn = 0;
+    if (vc) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gn = fma((double)jn[q], xv[colq(q)], gn);
+    }
+    wsync();
+    return gn;
+  };
+  auto Gtw = [&](double wn) -> double {                                   // (Jc^T w)_j
+    xv[lane] = 0.0; wsync();
+    if (vc) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) lds_add(&xv[colq(q)], (double)jn[q] * wn);
+    }
+    wsync();
+    const double r = vx ? xv[lane] : 0.0;
+    wsync();
+    return r;
+  };
+  auto Av = [&](double v) -> double {
+    double out = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+    return out;
+  };
+  auto Aty = [&](double y) -> double {
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
+    return acc;
+  };
+  const double b_in = (e > 0) ? Av(vx ? (double)vv[lane] : 0.0) : 0.0;    // ge = Je v (engines.py:86), on the equality lanes
+
+  double t[NCOL];
+  double udinv = 1.0, idn = 1.0;
+  bool singular = false;
+  auto factor = [&]() LCP_INL {
+    int ln = lane; asm volatile("" : "+v"(ln));
+    for (int i = lane; i < NCOL * LDK; i += 64) Kl[i] = 0.0;
+    wsync();
+    if (lane < NCOL) Kl[lane * LDK + lane] = vx ? qd : (ve ? 0.0 : 1.0);
+    if (vx) {
+#pragma unroll
+      for (int a = 0; a < EQB; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
+    }
+    wsync();
+    if (vc) {
+#pragma unroll
+      for (int pq = 0; pq < 6; ++pq) {
+        double* row = Kl + colq(pq) * LDK;
+        const double a = idn * (double)jn[pq];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) lds_add(row + colq(q), a * (double)jn[q]);
+      }
+    }
+    wsync();
+    {
+      const double* row = Kl + (lane < NCOL ? lane : 0) * LDK;
+      static_for<NCOL>([&](auto J) LCP_INL { t[J] = row[J]; });
+      if (lane >= NCOL) static_for<NCOL>([&](auto J) LCP_INL { t[J] = 0.0; });
+    }
+    wsync();
+    singular = false;
+    static_for<NCOL / 8>([&](auto G8) LCP_INL {
+      if (8 * G8 < n) {
+        static_for<8>([&](auto KK) LCP_INL {
+          constexpr int k = 8 * G8 + KK;
+          const double pk = bcast_lane(t[k], k);
+          singular = singular || !(pk != 0.0) || (pk != pk);
+          const double inv = fast_rcp(pk);
+          if (ln == k) udinv = inv;
+          const double l = (ln > k) ? t[k] * inv : 0.0;
+          if (ln > k) t[k] = l;
+          constexpr int NJ = NCOL - 1 - k;
+          static_for<(NJ + 7) / 8>([&](auto C8) LCP_INL {
+            constexpr int j0 = k + 1 + 8 * C8, nj = (NJ - 8 * C8) < 8 ? (NJ - 8 * C8) : 8;
+            double pv[8];
+            static_for<nj>([&](auto I) LCP_INL { pv[I] = bcast_lane(t[j0 + I], k); });
+            static_for<nj>([&](auto I) LCP_INL { sgpr_pin(pv[I]); });
+            static_for<nj>([&](auto I) LCP_INL { t[j0 + I] = fma(-l, pv[I], t[j0 + I]); });
+          });
+        });
+      }
+    });
+  };
+  auto ksolve = [&](double w) -> double {
+    int ln = lane; asm volatile("" : "+v"(ln));
+    static_for<NCOL / 8>([&](auto G8) LCP_INL {
+      if (8 * G8 < n) {
+        static_for<8>([&](auto KK) LCP_INL {
+          constexpr int k = 8 * G8 + KK;
+          const double yk = bcast_lane(w, k);
+          w = fma(-((ln > k) ? t[k] : 0.0), yk, w);
+        });
+      }
+    });
+    static_for<NCOL / 8>([&](auto GR) LCP_INL {
+      constexpr int g8 = NCOL / 8 - 1 - GR;
+      if (8 * g8 < n) {
+        static_for<8>([&](auto KR) LCP_INL {
+          constexpr int k = 8 * g8 + 7 - KR;
+          const double xk = bcast_lane(w * udinv, k);
+          w = fma(-((ln < k) ? t[k] : 0.0), xk, w);
+        });
+      }
+    });
+    return w * udinv;
+  };
+  // solve_kkt (pdipm.py:325-354) in body space: q = rs / d - rz, K [dx; dy] = [-rx + Jc^T (q / D); -ry], dz = (Jc dx - q) / D
+  auto solve_kkt = [&](double di, double rx, double rs, double rz, double ry, double& ox, double& os, double& oz, double& oy) {
+    const double q = vc ? rs * di - rz : 0.0;
+    const double gu = Gtw(vc ? idn * q : 0.0);
+    const double sol = ksolve(vx ? (gu - rx) : (ve ? -ry : 0.0));
+    ox = vx ? sol : 0.0; oy = ve ? sol : 0.0;
+    const double gx = Gv(ox);
+    oz = vc ? idn * (gx - q) : 0.0;
+    os = vc ? (-rs - oz) * di : 0.0;                                        // :347,350
+  };
+  // get_step for (z, dz), (s, ds) (pdipm.py:182-186), NaN semantics as in the step kernel
+  auto step_pair = [&](double z, double dz, double s, double ds) -> double {
+    const double ninf = -inf_of<double>(), pinf = inf_of<double>();
+    const double az = -z / dz, as = -s / ds;
+    const uint32_t kmz = wave_umax(vc ? nan_key(az) : 0u), kms = wave_umax(vc ? nan_key(as) : 0u);
+    const double mz = wave_max(vc ? az : ninf), ms = wave_max(vc ? as : ninf);
+    const double fz = key_is_nan(kmz) ? 1.0 : __builtin_fmax(mz, 1.0), fs = key_is_nan(kms) ? 1.0 : __builtin_fmax(ms, 1.0);
+    const double pz = (dz > 0.0) ? fz : az, ps = (ds > 0.0) ? fs : as;
+    const uint32_t kl = wave_umax(vc ? umax(nan_key(pz), nan_key(ps)) : 0u);
+    const double l = wave_min(vc ? __builtin_fmin(pz, ps) : pinf);
+    return key_is_nan(kl) ? nan_of<double>() : l;
+  };
+
+  const int max_iter = SP.max_iter, lim = SP.lim;
+  const double eps = SP.eps;
+  const double mf = (double)ncs;
+  double x = 0, y = 0, s = 1, z = 1, dinv = 1, bx = 0;
+  double best_resid = inf_of<double>();
+  bool have_best = false, done = false;
+  int n_not = 0, iters = 0;
+  for (int it = -1; it < max_iter; ++it) {
+    double rx = 0, ry = 0, rs = 0, rz = 0, mu = 0, resid = 0;
+    if (it < 0) {                                                           // init: (p, 0, -h, -b), d = 1 (:57-63); p = 0
+      rx = 0.0; ry = -b_in; rz = -hn; dinv = 1.0;
+    } else {                                                                // residuals (:82-96), F = 0
+      rx = Gtw(vc ? z : 0.0) + qd * x;
+      if (e > 0) rx += Aty(y);
+      if (!vx) rx = 0.0;
+      rs = z;
+      const double gx = Gv(x);
+      rz = vc ? gx + s - hn : 0.0;
+      ry = (e > 0) ? Av(x) - b_in : 0.0;
+      const double n_rx = wave_sum(rx * rx), n_rz = wave_sum(rz * rz), n_ry = wave_sum(ry * ry);
+      const double sz = wave_sum(vc ? s * z : 0.0);
+      mu = sz / mf; mu = mu < 0 ? -mu : mu;
+      resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;
+      dinv = vc ? s / z : 1.0;
+    }
+    idn = 1.0 / dinv;
+    if (!vc) idn = 0.0;
+    factor();
+    if (it >= 0 && !done) {
+      ++iters;
+      if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }
+      else {
+        const bool improved = !have_best || (resid < best_resid);
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; }
+        else ++n_not;
+        if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;
+      }
+    }
+    if (it >= 0 && it == max_iter - 1) done = true;
+    if (done) break;
+    double ax = 0, ay = 0, as_ = 0, az = 0;
+    const int npass = (it < 0) ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
+      double ox, oy, os, oz;
+      solve_kkt(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+      if (it < 0) {
+        x = ox; s = os; z = oz; y = oy;
+        const uint32_t ks = wave_umax(vc ? nan_key(s) : 0u), kz = wave_umax(vc ? nan_key(z) : 0u);
+        double smin = wave_min(vc ? s : inf_of<double>()), zmin = wave_min(vc ? z : inf_of<double>());
+        if (key_is_nan(ks)) smin = nan_of<double>();
+        if (key_is_nan(kz)) zmin = nan_of<double>();
+        if (smin <= 0.0) s += 1.0 - smin;                                   // (:66-75)
+        if (zmin <= 0.0) z += 1.0 - zmin;
+        if (!vc) { s = 1.0; z = 1.0; }
+        if (ncs == 0) { bx = x; done = true; }                              // engines.py:92-103: the direct solve, no LCP
+      } else if (pass == 0) {
+        ax = ox; ay = oy; as_ = os; az = oz;
+        const double alpha = pmin(step_pair(z, az, s, as_), 1.0);
+        const double t3 = wave_sum(vc ? (s + alpha * as_) * (z + alpha * az) : 0.0);
+        const double t4 = wave_sum(vc ? s * z : 0.0);
+        const double r3 = t3 / t4, sig = r3 * r3 * r3;
+        rx = 0; ry = 0; rz = 0;
+        rs = vc ? (-mu * sig + as_ * az) / s : 0.0;                         // (:153)
+      } else {
+        const double cx = ox + ax, cy = oy + ay, cs = os + as_, cz = oz + az;
+        const double alpha = pmin(0.999 * step_pair(z, cz, s, cs), 1.0);
+        x += alpha * cx; y += alpha * cy;
+        if (vc) { s += alpha * cs; z += alpha * cz; }
+      }
+    }
+    if (done) break;
+  }
+  const double dp = -bx;                                                    // engines.py:115
+  if (__any(vx && (dp != dp))) status |= LCP_ST_NAN;
+  if (vx) {
+    ((float*)SP.v_new)[(size_t)scene * nz + lane] = (float)dp;
+    if (SP.p_out64) {                                                       // world.py:110-117: dp /= 2 ; body.move(dt)
+      const double dts = SP.dt_scene ? SP.dt_scene[scene] : SP.dt;
+      SP.p_out64[(size_t)scene * nz + lane] = SP.pos64[(size_t)scene * nz + lane] + (dp * 0.5) * dts;
+    }
+  }
+  if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+}
+
 }  // namespace primal
 
 // nz + neq rows on the lanes of one wave, a contact per lane
@@ -633,6 +894,15 @@ static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stre
 }
 int primal_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_dispatch<false>(SP, Gd, stream); }
 int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_dispatch<true>(SP, Gd, stream); }
+
+int primal_post_stab(const StepArgs& SP, void* stream) {
+  const int n = 3 * SP.nb + SP.e;
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24>), dim3(SP.B), dim3(64), 0, st, SP);
+  else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40>), dim3(SP.B), dim3(64), 0, st, SP);
+  else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56>), dim3(SP.B), dim3(64), 0, st, SP);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
 
 // dense boundary: the scenes lcp_classify_big marked 3 (launched next to the contact-space and generic kernels, which take 2 and 0)
 int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {

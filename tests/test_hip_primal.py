@@ -3,6 +3,7 @@ one wavefront per scene) against the contact-space kernels it replaces behind `l
 `lcp_step_backward_f32` (`lcp_big.hip`, forced with the debug path "big") and against the fp64 oracle.  The two formulations
 take the same Newton steps in exact arithmetic (pdipm.py:325-454 eliminates x first, the body-space kernel the inequality block),
 so new_v has to agree far below the fp32 outputs' resolution."""
+import numpy as np
 import pytest
 import torch
 
@@ -255,3 +256,47 @@ def test_quad_body_space_without_equality_rows():
         rs = O.lcp_forward(*lcp64)
         ex = float(parity.err_x(-va[k].reshape(1, -1), rs.x, lcp64[0], lcp64[1]).max())
         assert ex <= 1e-4, (k, n, ex)
+
+
+@pytest.mark.parametrize("nbox,pts", [(4, 4), (6, 4), (11, 2)])
+def test_post_stabilization_body_space_matches_the_generic_kernel_and_the_oracle(nbox, pts):
+    """`lcp_post_stabilization_f32` (engines.py:80-116 + the correction move of world.py:109-117) on the body-space kernel
+    against the generic workgroup-per-scene kernel (forced path) and the oracle: ragged contact counts (0 = the direct KKT solve),
+    perturbed velocities so that the contacts have something to correct."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics.batched_world import post_stabilization
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    from oracle import world_oracle as WO
+    B = 48
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=300 + nbox, dtype=torch.float32)
+    sc.v = sc.v + 0.3 * torch.randn(sc.v.shape, generator=torch.Generator().manual_seed(1))
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.randint(0, sc.nc + 1, (B,), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    count[:8] = sc.nc
+    p = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(DEV)
+    dts = (0.01 + 0.02 * torch.rand(B, generator=torch.Generator().manual_seed(4), dtype=torch.float64)).to(DEV)
+    pa, pb = torch.empty_like(p), torch.empty_like(p)
+    run = lambda po: post_stabilization(B, sc.nb, sc.nc, 3, count.to(DEV), scg.Mdiag, scg.v, scg.rest, cb, scg.Je, p=p, dt_scene=dts, p_out=po)
+    a = run(pa)
+    _lib.set_path("generic")
+    try:
+        b = run(pb)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_path("auto")
+    move = p + (a["dp"].double() * 0.5) * dts.reshape(B, 1, 1)           # world.py:110-117 (the kernel moves with its fp64 dp, `dp` is its fp32 copy)
+    assert float((pa - move).abs().max()) <= 1e-7 and float((pa - pb).abs().max()) <= 1e-5
+    da, db = a["dp"].double().cpu(), b["dp"].double().cpu()
+    scale = db.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    err = (da - db).abs().reshape(B, -1).max(dim=1)[0] / scale
+    print("post-stabilisation, body space vs generic: worst scaled |dp - dp'|", float(err.max()))
+    assert float(err.max()) <= 1e-5
+    assert int((a["status"] & 8).sum()) == 0
+    for k in range(0, B, 7):                                  # the oracle, scene by scene (engines.py:80-116 restated)
+        n = int(count[k])
+        contacts = [((sc.c_n[k, c].numpy(), sc.c_p1[k, c].numpy(), sc.c_p2[k, c].numpy(), 0.0), int(sc.c_i1[k, c]), int(sc.c_i2[k, c])) for c in range(n)]
+        ref = WO.post_stabilization(sc.Mdiag[k].numpy(), sc.v[k].numpy(), contacts, sc.rest[k].numpy(), sc.Je[k].numpy())
+        e = float(np.abs(da[k].numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        assert e <= 2e-3, (k, n, e)                           # (the bound of the trajectory test: this LCP is ill-conditioned at rest)
