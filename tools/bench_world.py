@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--maxc", type=int, default=16, help="contact capacity per scene")
     ap.add_argument("--box", type=float, default=40.0)
     ap.add_argument("--graph", action="store_true", help="time ContactWorld.run(steps, graph=True): HIP graph replay")
+    ap.add_argument("--post-stab", action="store_true", help="with post-stabilisation (world.py:109-121; off by default as in the reference)")
     args = ap.parse_args()
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics import batched_world as bw
@@ -31,7 +32,7 @@ def main():
     w = scenes.make_drop_world(args.batch, nbox=args.nbox, box=args.box)
     geom = ct.GeometryBatch.from_shapes(w["shapes"], args.batch).to(dev)
     g = lambda k: w[k].to(dev)
-    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc)
+    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc, post_stab=args.post_stab)
     for _ in range(args.settle):
         world.step()
     world.check_capacity()
