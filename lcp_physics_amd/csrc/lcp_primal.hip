@@ -25,7 +25,9 @@
 // registers.  LU without pivoting (x rows first: Q + G^T M^-1 G has a positive definite symmetric part; then the equality
 // rows, whose Schur complement -A S^-1 A^T is negative definite), pivot rows broadcast with v_readlane.
 // Kernels: forward of the fused step (engines.py:26-78) and its backward w.r.t. the physical inputs (lcp.py:37-64 contracted
-// through the assembly), behind lcp_solve_dynamics_f32 / lcp_step_backward_f32.
+// through the assembly), behind lcp_solve_dynamics_f32 / lcp_step_backward_f32; the same solve behind the dense LCPFunction
+// boundary (DENSE: lcp_pdipm_forward_f32 / _backward_f32 at 17..64 contacts); post-stabilisation (engines.py:80-116,
+// lcp_poststab_primal_kernel behind lcp_post_stabilization_f32).
 #include "lcp_wave_scene.h"
 
 namespace lcp {

@@ -20,6 +20,11 @@
 // over identity rows, a scene without contacts leaves after the initialisation solve (engines.py:36-50).
 // Kernels: lcp_fwd_quad (dense or fused forward), lcp_bwd_quad (lcp.py:37-64, dense gradients), lcp_bwd_step_quad
 // (gradients w.r.t. the physical inputs of the fused step).
+// lcp_fwd_quad comes in three factorisations (template parameter ALG): 0 = the reduced 2 nc x 2 nc contact-space system described
+// above (the dense boundary, nz > 16, fp32 arithmetic); 1 = the BODY-space system K = [[Q + G^T M^-1 G, A^T], [A, 0]] of nz + neq <= 20
+// rows (x-row and equality row per lane; lcp_primal.hip has the algebra); 2 = the same with the pinned leading coordinates of a
+// fixed floor (A = [I 0]) taken out - one row per lane, nz - neq pivots - alone in its kernel.  The contact-list entry points
+// launch 2 and, behind it, 1 for the waves 2 declined; the backward kernels stay in contact space (factor_bwd_q).
 // Same algorithm and the same reference lines as lcp_wave64.hip / lcp_generic.hip.
 #include "lcp_wave_common.h"
 
