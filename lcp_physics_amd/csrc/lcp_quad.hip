@@ -184,6 +184,40 @@ __host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, 
   return (size_t)(q - smem);
 }
 
+// ---------------------------------------------------------------- J v / J^T w products as v_fmac_f64_dpp blocks (fp64, nz <= 16)
+// acc += (lane K of the row's `src`) * mult in ONE instruction instead of v_mov_b64_dpp + v_fma_f64 (same FMA, same accumulators in the
+// same order: bitwise the builtin form).  Rules as for the LU blocks below: `s_nop 1` first, DPP sources read-only in the statement.
+#define LCP_DPP_FULL_EARLY "row_mask:0xf bank_mask:0xf"
+#define LCP_GV_ONE(ACC, M, K) "v_fmac_f64_dpp %[" #ACC "], %[v], %[" #M "] row_newbcast:%[" #K "] " LCP_DPP_FULL_EARLY "\n\t"
+// columns J0 .. J0+7 of (Jc v, Jt v): n0 / t0 take the even columns, n1 / t1 the odd ones
+template <int J0> __device__ __forceinline__ void gv8_dpp(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t"
+      LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1)
+      LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3)
+      LCP_GV_ONE(n0, c4, k4) LCP_GV_ONE(t0, t4_, k4) LCP_GV_ONE(n1, c5, k5) LCP_GV_ONE(t1, t5_, k5)
+      LCP_GV_ONE(n0, c6, k6) LCP_GV_ONE(t0, t6_, k6) LCP_GV_ONE(n1, c7, k7) LCP_GV_ONE(t1, t7_, k7)
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]),
+        [t0_] "v"(t[0]), [t1_] "v"(t[1]), [t2_] "v"(t[2]), [t3_] "v"(t[3]), [t4_] "v"(t[4]), [t5_] "v"(t[5]), [t6_] "v"(t[6]), [t7_] "v"(t[7]),
+        [k0] "n"(J0), [k1] "n"(J0 + 1), [k2] "n"(J0 + 2), [k3] "n"(J0 + 3), [k4] "n"(J0 + 4), [k5] "n"(J0 + 5), [k6] "n"(J0 + 6), [k7] "n"(J0 + 7));
+}
+// contacts C0 .. C0+7 of J^T w: a0 += wn_C g_C, a1 += wt_C t_C for the even contacts, a2 / a3 for the odd ones
+#define LCP_GTW_ONE(ACC, SRC, M, K) "v_fmac_f64_dpp %[" #ACC "], %[" #SRC "], %[" #M "] row_newbcast:%[" #K "] " LCP_DPP_FULL_EARLY "\n\t"
+template <int C0> __device__ __forceinline__ void gtw8_dpp(double& a0, double& a1, double& a2, double& a3, double wn, double wt, const double (&g)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t"
+      LCP_GTW_ONE(a0, wn, g0, k0) LCP_GTW_ONE(a1, wt, t0_, k0) LCP_GTW_ONE(a2, wn, g1, k1) LCP_GTW_ONE(a3, wt, t1_, k1)
+      LCP_GTW_ONE(a0, wn, g2, k2) LCP_GTW_ONE(a1, wt, t2_, k2) LCP_GTW_ONE(a2, wn, g3, k3) LCP_GTW_ONE(a3, wt, t3_, k3)
+      LCP_GTW_ONE(a0, wn, g4, k4) LCP_GTW_ONE(a1, wt, t4_, k4) LCP_GTW_ONE(a2, wn, g5, k5) LCP_GTW_ONE(a3, wt, t5_, k5)
+      LCP_GTW_ONE(a0, wn, g6, k6) LCP_GTW_ONE(a1, wt, t6_, k6) LCP_GTW_ONE(a2, wn, g7, k7) LCP_GTW_ONE(a3, wt, t7_, k7)
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3)
+      : [wn] "v"(wn), [wt] "v"(wt), [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]),
+        [t0_] "v"(t[0]), [t1_] "v"(t[1]), [t2_] "v"(t[2]), [t3_] "v"(t[3]), [t4_] "v"(t[4]), [t5_] "v"(t[5]), [t6_] "v"(t[6]), [t7_] "v"(t[7]),
+        [k0] "n"(C0), [k1] "n"(C0 + 1), [k2] "n"(C0 + 2), [k3] "n"(C0 + 3), [k4] "n"(C0 + 4), [k5] "n"(C0 + 5), [k6] "n"(C0 + 6), [k7] "n"(C0 + 7));
+}
+#ifndef LCP_Q_ASM_PRODUCTS
+#define LCP_Q_ASM_PRODUCTS 1
+#endif
+
 // ---------------------------------------------------------------- per-lane scene data and products
 // An x-space vector: entry 16 h + l16 of the scene's nz-vector for h < XH (XH = 1: nz <= 16, the tuned headline case;
 // XH = 2: nz <= 32, six to ten bodies).
@@ -204,8 +238,20 @@ struct SceneQ {
   // m-space <- x-space:  (Jc v)_c and (Jt v)_c
   // (the wave is alone on its SIMD: a single accumulator would serialise on the FMA latency, so every product below
   //  runs two to four independent partial sums)
+  // ASMP: the v_fmac_f64_dpp form (the body-space forward asks for it: -1.3 % there; the backward kernels got 3 % slower with it)
+  template <bool ASMP = false>
   __device__ __forceinline__ void Gv(const XV<TC, XH>& v, TC& gn, TC& gt) const {
     TC n0 = 0, n1 = 0, t0 = 0, t1 = 0;
+    if constexpr (ASMP && LCP_Q_ASM_PRODUCTS && std::is_same<TC, double>::value && XH == 1) {
+      static_for<2>([&](auto Hh) LCP_INL {
+        constexpr int J0 = 8 * Hh;
+        double c[8], t[8];
+        static_for<8>([&](auto I) LCP_INL { c[I] = (double)launder(jc[J0 + I]); t[I] = (double)launder(jt[J0 + I]); });
+        gv8_dpp<J0>(n0, n1, t0, t1, v.v[0], c, t);
+      });
+      gn = n0 + n1; gt = t0 + t1;
+      return;
+    }
     static_for<8 * XH>([&](auto H) LCP_INL {
       constexpr int J = 2 * H, hx = J >> 4;
       fmac_bc<J & 15>(n0, v.v[hx], (TC)launder(jc[J])); fmac_bc<J & 15>(t0, v.v[hx], (TC)launder(jt[J]));
@@ -214,6 +260,7 @@ struct SceneQ {
     gn = n0 + n1; gt = t0 + t1;
   }
   // x-space <- m-space:  (G^T w)_j = sum_c Jc[c][j] w_n,c + Jt[c][j] (w_f1,c - w_f2,c)
+  template <bool ASMP = false>
   __device__ __forceinline__ XV<TC, XH> Gtw(TC wn, TC wt) const {
     XV<TC, XH> out;
     const int oz = lds_opaque_zero();
@@ -228,6 +275,11 @@ struct SceneQ {
         TI gv[8], tv[8];
         static_for<8>([&](auto I) LCP_INL { gv[I] = gl[(C0 + I) * RS]; tv[I] = gtl[(C0 + I) * RS]; });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ASMP && LCP_Q_ASM_PRODUCTS && std::is_same<TC, double>::value) {
+          double gd[8], td[8];
+          static_for<8>([&](auto I) LCP_INL { gd[I] = (double)gv[I]; td[I] = (double)tv[I]; });
+          gtw8_dpp<C0>(a0, a1, a2, a3, wn, wt, gd, td);
+        } else
         static_for<4>([&](auto H) LCP_INL {
           constexpr int I = 2 * H, C = C0 + I;
           fmac_bc<C>(a0, wn, (TC)gv[I]);
@@ -789,7 +841,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
   M4<TC> q = m4<TC>(rs.n * di.n - rz.n, rs.f1 * di.f1 - rz.f1, rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);
   if (!valid) q = m4<TC>(0, 0, 0, 0);
   const M4<TC> u = minv_pq<TI, TC, PQ>(R, S, q);
-  const XV<TC, 1> gu = S.Gtw(valid ? u.n : (TC)0, valid ? u.f1 - u.f2 : (TC)0);
+  const XV<TC, 1> gu = S.template Gtw<true>(valid ? u.n : (TC)0, valid ? u.f1 - u.f2 : (TC)0);
   TC wx = (l16 < nz) ? gu.v[0] - rx.v[0] : (TC)0;
   TC we = (l16 < e) ? -ry : (TC)0;
   LCP_QTICK(pr, 3)                                                         // solve_kkt: products before
@@ -815,7 +867,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
     ox.v[0] = (l16 < e) ? we : ((l16 < nz) ? wx * R.udx : (TC)0);
     oy = (l16 < e) ? wx : (TC)0;
     TC gn, gt;
-    S.Gv(ox, gn, gt);
+    S.template Gv<true>(ox, gn, gt);
     oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
     if (!valid) oz = m4<TC>(0, 0, 0, 0);
     os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
@@ -851,7 +903,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
   ox.v[0] = (l16 < nz) ? wx * R.udx : (TC)0;
   oy = (l16 < e) ? we * R.ude : (TC)0;
   TC gn, gt;
-  S.Gv(ox, gn, gt);
+  S.template Gv<true>(ox, gn, gt);
   oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
   if (!valid) oz = m4<TC>(0, 0, 0, 0);
   os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
@@ -1141,7 +1193,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63)
       rx = p; ry = -b; rs = m4<TC>(0, 0, 0, 0); rz = m4<TC>(-hn, 0, 0, 0); dinv = m4<TC>(1, 1, 1, 1);
     } else {                                                               // residuals (:82-96)
-      rx = S.Gtw(z.n, z.f1 - z.f2);
+      rx = S.template Gtw<ALG != 0>(z.n, z.f1 - z.f2);
       static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = rx.v[HX] + S.qd[HX] * x.v[HX] + p.v[HX]; });
       if (e > 0) {
         if constexpr (ALG != 0) {
@@ -1151,7 +1203,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       }
       rs = z;
       TC gn, gt;
-      S.Gv(x, gn, gt);
+      S.template Gv<ALG != 0>(x, gn, gt);
       // F z is lane-local for the contact structure (engines.py:69-73)
       rz = m4<TC>(gn + s.n - hn, gt + s.f1 - z.g, -gt + s.f2 - z.g, s.g - (S.mu * z.n - (z.f1 + z.f2)));
       if (!vc) rz = m4<TC>(0, 0, 0, 0);
