@@ -149,7 +149,8 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  * the same stream with the same workspace and the same (unchanged) inputs.
  *   in : the inputs of the forward, dl_dv[B,nb,3] = d(loss)/d(v_new)
  *   out: dMdiag[B,nb,3] dv[B,nb,3] df[B,nb,3] drest[B,nb] dfric[B,nb] dc_n[B,nc,2] dc_p1[B,nc,2] dc_p2[B,nc,2]
- *        (any may be NULL; padded contact slots get 0).  The joint Jacobian Je is treated as a constant.
+ *        (any may be NULL; padded contact slots get 0).  The joint Jacobian Je is treated as a constant here: see
+ *        lcp_step_backward_je_f32 for its gradient.
  * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
  * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout - lcp_step_fused_f32
  * serves those sizes from the generic kernels, whose workspace this entry cannot read); else LCP_E_TOOLARGE. */
@@ -161,6 +162,18 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* dl_dv, int compute,
                           float* dMdiag, float* dv, float* df, float* drest, float* dfric,
                           float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream);
+
+/* The same with the gradient of the joint Jacobian as a ninth output: dJe[B,e,3 nb] = dnu (x) x + nu (x) dx (lcp.py:57, A = Je
+ * in engines.py:75) - what the reference back-propagates into Joint.J() / FixedJoint.J() (constraints.py:26-36, 64-73: the
+ * anchor arms follow the bodies' poses) when a world with joints is differentiated through its steps.  dJe may be NULL. */
+int lcp_step_backward_je_f32(int B, int nb, int nc, int e,
+                             const float* Mdiag, const float* v, const float* f,
+                             const float* rest, const float* fric,
+                             const float* c_n, const float* c_p1, const float* c_p2,
+                             const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                             const float* dl_dv, int compute,
+                             float* dMdiag, float* dv, float* df, float* drest, float* dfric,
+                             float* dc_n, float* dc_p1, float* dc_p2, float* dJe, void* ws, void* stream);
 
 /* Replaces PdipmEngine.solve_dynamics (physics/engines.py:26-78) for B scenes whose contact lists have
  * DIFFERENT lengths (what contact detection produces): scene k uses the first c_count[k] <= maxc records of

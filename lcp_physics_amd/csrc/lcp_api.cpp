@@ -236,6 +236,15 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
                           const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
                           const float* dl_dv, int compute, float* dMdiag, float* dv, float* df, float* drest,
                           float* dfric, float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream) {
+  return lcp_step_backward_je_f32(B, nb, nc, e, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt, dl_dv, compute, dMdiag,
+                                  dv, df, drest, dfric, dc_n, dc_p1, dc_p2, nullptr, ws, stream);
+}
+
+int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
+                             const float* rest, const float* fric, const float* c_n, const float* c_p1,
+                             const float* c_p2, const int32_t* c_i1, const int32_t* c_i2, const float* Je, float dt,
+                             const float* dl_dv, int compute, float* dMdiag, float* dv, float* df, float* drest,
+                             float* dfric, float* dc_n, float* dc_p1, float* dc_p2, float* dJe, void* ws, void* stream) {
   bool generic;
   compute = split_compute(compute, &generic);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
@@ -246,7 +255,7 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, cons
   P.ws = ws;
   lcp::StepBwdArgs G;
   G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
-  G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
+  G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2; G.dJe = (e > 0) ? dJe : nullptr;
   // the same family decision as the forward entry points (launch_step): the workspace layout is the family's
   switch (step_family(3 * nb, 4 * nc, e, compute, generic)) {
     case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream);

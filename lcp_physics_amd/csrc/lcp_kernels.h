@@ -77,6 +77,7 @@ struct StepArgs {
 struct StepBwdArgs {
   const void* dl_dv;                                   // [B, nb, 3]  d(loss)/d(v_new)
   void *dMdiag, *dv, *df, *drest, *dfric, *dcn, *dcp1, *dcp2;
+  void* dJe;                                           // [B, e, 3 nb]  d(loss)/d(Je) = dnu (x) x + nu (x) dx (lcp.py:57), or NULL
 };
 
 struct ContactArgs {

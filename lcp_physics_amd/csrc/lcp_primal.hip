@@ -464,6 +464,16 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       if (Gd.dv) ((float*)Gd.dv)[o] = (float)(dx * md + dv_h);
       if (Gd.df) ((float*)Gd.df)[o] = (float)(dx * (double)SP.dt);
     }
+    if (Gd.dJe && e > 0) {                                                    // dA = dnu (x) x + nu (x) dx (lcp.py:57; A = Je)
+      float* o = (float*)Gd.dJe + (size_t)scene * e * nz;
+#pragma unroll
+      for (int a = 0; a < EQB; ++a) {
+        if (a < e) {
+          const double dn = bcast_lane(dnu, nz + a), nu = Wit[64 + a];
+          if (vx) o[a * nz + lane] = (float)(dn * x + nu * dx);
+        }
+      }
+    }
     if (lane < nb) {                                                          // per-body sums over the contacts, fixed order
       double ar = 0, af = 0;
       for (int c = 0; c < ncs; ++c) {

@@ -1599,6 +1599,17 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
       if (Gd.df) ((TI*)Gd.df)[o] = (TI)(dxj * (TC)SP.dt);
     }
   });
+  if (Gd.dJe && e > 0) {                                                  // dA = dnu (x) x + nu (x) dx (lcp.py:57; A = Je)
+    const TC nu = (l16 < e) ? W.y[l16] : (TC)0;
+    TI* o = (TI*)Gd.dJe + (size_t)scene * e * nz;
+    static_for<EQ>([&](auto A_) LCP_INL {
+      constexpr int a = A_;
+      if (a < e) {
+        const TC dn = bc<a>(dnu), yr = bc<a>(nu);
+        static_for<XH>([&](auto HX) LCP_INL { const int j = 16 * HX + l16; if (j < nz) o[a * nz + j] = (TI)(dn * x.v[HX] + yr * dx.v[HX]); });
+      }
+    });
+  }
   if (l16 < nb) {                                                          // per-body sums over the contacts, fixed order
     TC ar = 0, af = 0;
     for (int c = 0; c < ncs; ++c) {

@@ -99,12 +99,13 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
 _PATH = {"auto": 0, "generic": _lib.PATH_GENERIC}     # `path="generic"`: force the workgroup-per-scene kernels (A/B aid)
 
 
-def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
+def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None, want_Je=False):
     """Backward of `fused_step` with respect to the physical inputs of the scenes: d(loss)/d(v_new) [B,nb,3] ->
     dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,nc,2]) - what the reference computes by
     autograd through `engines.py:31-32,50-77` and `world.py:144-234` after `LCPFunction.backward`.  One launch of
-    `lcp_step_backward_f32`; the dense LCP gradients are never materialised.  `out` is the dict `fused_step`
-    returned (its workspace is read); the scene must not have changed in between."""
+    `lcp_step_backward_je_f32`; the dense LCP gradients are never materialised.  `out` is the dict `fused_step`
+    returned (its workspace is read); the scene must not have changed in between.  `want_Je`: also "Je" [B,e,3nb], the
+    gradient of the joint Jacobian (`lcp.py:57`, dA = dnu x^T + nu dx^T)."""
     lib = _lib.load()
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
@@ -114,15 +115,18 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None):
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         grads = {"Mdiag": new(B, nb, 3), "v": new(B, nb, 3), "f": new(B, nb, 3), "rest": new(B, nb), "fric": new(B, nb),
                  "c_n": new(B, nc, 2), "c_p1": new(B, nc, 2), "c_p2": new(B, nc, 2)}
+    if want_Je and e and "Je" not in grads:
+        grads["Je"] = torch.empty(B, e, 3 * nb, dtype=torch.float32, device=dev)
     P = _lib.ptr
     with torch.cuda.device(dev):
-        rc = lib.lcp_step_backward_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n),
-                                       P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None,
-                                       float(sc.dt), P(dl_dv), _COMPUTE[compute] | _PATH[out.get("path", "auto")],
-                                       P(grads["Mdiag"]), P(grads["v"]),
-                                       P(grads["f"]), P(grads["rest"]), P(grads["fric"]), P(grads["c_n"]),
-                                       P(grads["c_p1"]), P(grads["c_p2"]), P(out["ws"]), _lib.stream_ptr(dev))
-    _lib.check(rc, "lcp_step_backward_f32")
+        rc = lib.lcp_step_backward_je_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n),
+                                          P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None,
+                                          float(sc.dt), P(dl_dv), _COMPUTE[compute] | _PATH[out.get("path", "auto")],
+                                          P(grads["Mdiag"]), P(grads["v"]),
+                                          P(grads["f"]), P(grads["rest"]), P(grads["fric"]), P(grads["c_n"]),
+                                          P(grads["c_p1"]), P(grads["c_p2"]), P(grads["Je"]) if (want_Je and e) else None,
+                                          P(out["ws"]), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_step_backward_je_f32")
     return grads
 
 
@@ -248,11 +252,13 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
     return out
 
 
-def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt, dl_dv, out, compute="f64", grads=None):
+def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt, dl_dv, out, compute="f64", grads=None,
+                            want_Je=False):
     """Backward of `solve_dynamics` with respect to its physical inputs (what the reference gets by autograd through
-    `engines.py:31-32,50-77`, `world.py:144-234` and `lcp.py:37-64`): one launch of `lcp_step_backward_f32` on the
-    workspace the forward left in `out`.  Padded contact slots get zero gradients; the joint Jacobian is a constant.
-    Returns dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,maxc,2])."""
+    `engines.py:31-32,50-77`, `world.py:144-234` and `lcp.py:37-64`): one launch of `lcp_step_backward_je_f32` on the
+    workspace the forward left in `out`.  Padded contact slots get zero gradients.
+    Returns dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,maxc,2]) and, with `want_Je`, Je [B,e,3nb] - the
+    gradient of the joint Jacobian (`lcp.py:57` with A = Je), which worlds with pose-dependent joints propagate on."""
     lib = _lib.load()
     dev = v.device
     dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
@@ -260,15 +266,17 @@ def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt,
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         grads = {"Mdiag": new(B, nb, 3), "v": new(B, nb, 3), "f": new(B, nb, 3), "rest": new(B, nb), "fric": new(B, nb),
                  "c_n": new(B, maxc, 2), "c_p1": new(B, maxc, 2), "c_p2": new(B, maxc, 2)}
+    if want_Je and e and "Je" not in grads:
+        grads["Je"] = torch.empty(B, e, 3 * nb, dtype=torch.float32, device=dev)
     P = _lib.ptr
     with torch.cuda.device(dev):
-        rc = lib.lcp_step_backward_f32(B, nb, maxc, e, P(Mdiag), P(v), P(f), P(rest), P(fric), P(cb.c_n), P(cb.c_p1),
-                                       P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(dt), P(dl_dv),
-                                       _COMPUTE[compute] | _PATH[out.get("path", "auto")],
-                                       P(grads["Mdiag"]), P(grads["v"]), P(grads["f"]), P(grads["rest"]), P(grads["fric"]),
-                                       P(grads["c_n"]), P(grads["c_p1"]), P(grads["c_p2"]), P(out["ws"]),
-                                       _lib.stream_ptr(dev))
-    _lib.check(rc, "lcp_step_backward_f32")
+        rc = lib.lcp_step_backward_je_f32(B, nb, maxc, e, P(Mdiag), P(v), P(f), P(rest), P(fric), P(cb.c_n), P(cb.c_p1),
+                                          P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(dt), P(dl_dv),
+                                          _COMPUTE[compute] | _PATH[out.get("path", "auto")],
+                                          P(grads["Mdiag"]), P(grads["v"]), P(grads["f"]), P(grads["rest"]), P(grads["fric"]),
+                                          P(grads["c_n"]), P(grads["c_p1"]), P(grads["c_p2"]),
+                                          P(grads["Je"]) if (want_Je and e) else None, P(out["ws"]), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_step_backward_je_f32")
     return grads
 
 
@@ -290,7 +298,8 @@ class SolveDynamicsFunction(torch.autograd.Function):
     backward = `lcp_step_backward_f32` (implicit differentiation, `lcp.py:37-64`, contracted through the assembly):
                gradients for Mdiag, v, f, rest, fric and the contact frame (c_n, c_p1, c_p2).
     All tensors float32, contiguous, on the GPU ([B,nb,3], [B,nb], [B,maxc,2], int32 [B,maxc] / [B]); `Je` [B,e,3nb] or
-    None (treated as a constant); `opts`: dict(max_iter, eps, not_improved_lim, compute) - it receives the forward's
+    None (its gradient - `lcp.py:57` with A = Je - is returned when the caller's Je requires one: worlds whose joints follow
+    the pose); `opts`: dict(max_iter, eps, not_improved_lim, compute) - it receives the forward's
     `out` dict under "last" (z, s, y, iters, status).  Every call owns its workspace, so the steps of a roll-out can be
     back-propagated in reverse order."""
 
@@ -317,10 +326,12 @@ class SolveDynamicsFunction(torch.autograd.Function):
     def backward(ctx, dl_dv):
         Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2 = ctx.saved_tensors
         B, nb, maxc, e = ctx.dims
+        want_Je = bool(e) and ctx.needs_input_grad[11]
         g = solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, _Frame(c_n, c_p1, c_p2, c_i1, c_i2), ctx.Je,
-                                    ctx.dt, dl_dv, ctx.out, compute=ctx.compute)
+                                    ctx.dt, dl_dv, ctx.out, compute=ctx.compute, want_Je=want_Je)
         keys = ("Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2")
-        return tuple(g[k] if need else None for k, need in zip(keys, ctx.needs_input_grad[:8])) + (None,) * 6
+        return (tuple(g[k] if need else None for k, need in zip(keys, ctx.needs_input_grad[:8])) + (None, None, None) +
+                (g["Je"] if want_Je else None,) + (None, None))
 
 
 def post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, cb, Je, p=None, dt_scene=None, dt=0.0, p_out=None,
@@ -475,8 +486,9 @@ class ContactWorld:
             p_new   = p + v_new dt_used                               (bodies.py:80-82; dt_used: the dt the step_dt loop accepted)
 
         `Mdiag, f, rest, fric, v, p` (and what `force_fn` closes over) may require grad.  State tensors are replaced, not
-        overwritten, and every step keeps its own workspace and contact snapshot for the backward.  The joint Jacobian is a
-        constant of the backward; post-stabilisation is not differentiated."""
+        overwritten, and every step keeps its own workspace and contact snapshot for the backward.  The joint Jacobian of
+        revolute / fixed joints is differentiated through the pose and the joint angle (dL/dJe: lcp_step_backward_je_f32);
+        post-stabilisation is not differentiated."""
         if self.post_stab:
             raise RuntimeError("step_autograd: post-stabilisation is not differentiable here")
         ct = self._contacts_mod
@@ -490,8 +502,17 @@ class ContactWorld:
         c_n, c_p1, c_p2 = ct.ContactFrameFunction.apply(p_geo, self.geom, frame, self.eps)
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
         opts = {"max_iter": self.max_iter, "eps": self.solver_eps, "not_improved_lim": self.lim, "compute": self.compute}
+        Je = self.Je
+        js = self.joints
+        if js is not None and js.pose_dependent:
+            # the joint Jacobian as a function of the pose and of the revolute joints' angles (constraints.py:26-50): the
+            # kernel's values, the gradient of the torch expression; lcp_step_backward_je_f32 returns dL/dJe
+            if getattr(self, "_jrot_src", None) is not self.p:
+                self._jrot_ad, self._jrot_src = js.jrot1.clone(), self.p
+            Jt = js.jacobian_torch(self.p, self._jrot_ad).to(torch.float32)
+            Je = self.Je + (Jt - Jt.detach())
         v_new = SolveDynamicsFunction.apply(self.Mdiag, self.v.contiguous(), f, self.rest, self.fric, c_n, c_p1, c_p2, frame.c_i1,
-                                            frame.c_i2, frame.count, self.Je, self.dt, opts)
+                                            frame.c_i2, frame.count, Je, self.dt, opts)
         out = opts["last"]
         torch.bitwise_or(self.sticky_status, out["status"], out=self.sticky_status)
         p_start = self.p
@@ -505,8 +526,13 @@ class ContactWorld:
         g_lin = p_geo + torch.cat([dp[..., :1] * turned + (dp[..., :1] * (1 - turned)).detach(), dp[..., 1:]], dim=-1)
         self._p_geom, self._p_geom_src = g_lin + (cb.p_out - g_lin).detach(), self.p
         self.v = v_new
-        if self.joints is not None:                                        # (the joint Jacobian is a constant of the backward)
-            self.Je = self.joints.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
+        if js is not None:                                                 # joint.move(dt): rot1 += body1.v[0] dt (constraints.py:39-43)
+            self.Je = js.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
+            if js.pose_dependent:
+                ar = torch.arange(v_new.shape[0], device=v_new.device).unsqueeze(1)
+                w1 = v_new[ar, js.jb1.long(), 0].to(torch.float64) * cb.dt_used.clone().reshape(-1, 1)
+                r_lin = self._jrot_ad + w1 * js.revolute_mask
+                self._jrot_ad, self._jrot_src = r_lin + (js.jrot1 - r_lin).detach(), self.p
         ret = dict(out)
         ret["v_new"] = v_new
         return ret

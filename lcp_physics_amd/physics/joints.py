@@ -30,7 +30,18 @@ class JointSet:
 
     @property
     def pose_dependent(self):
-        return bool(((self.jtype == JOINT) | (self.jtype == FIXED)).any())
+        c = self.__dict__.get("_pose_dep")
+        if c is None:                                                      # one device read, then cached (the types never change)
+            c = self.__dict__["_pose_dep"] = bool(((self.jtype == JOINT) | (self.jtype == FIXED)).any())
+        return c
+
+    @property
+    def revolute_mask(self):
+        """1.0 where the joint is a revolute `Joint` (the only type whose `move` turns an angle), [B,nj] float64."""
+        m = self.__dict__.get("_rev_mask")
+        if m is None or m.device != self.jtype.device:
+            m = self.__dict__["_rev_mask"] = (self.jtype == JOINT).to(torch.float64)
+        return m
 
     def to(self, device):
         mv = lambda t: t.to(device).contiguous()
@@ -95,3 +106,56 @@ class JointSet:
                                             _lib.stream_ptr(p.device))
         _lib.check(rc, "lcp_joint_jacobian_f64")
         return out
+
+    def jacobian_torch(self, p, jrot1=None):
+        """The same Jacobian as a differentiable torch expression of the pose `p` [B,nb,3] (float64) and of the revolute joints'
+        angles `jrot1` [B,nj] (default: the state) - `Joint.J()` / `FixedJoint.J()` with `update_pos` (constraints.py:26-50,
+        64-85): pos1 = r1 (cos rot1, sin rot1), pos2 = body1.pos + pos1 - body2.pos.  Used for the GRADIENT of a
+        differentiable step (the values come from `jacobian()`); float64 [B,e,3nb].  The joint types are those of scene 0
+        (one list replicated over the batch: `from_list` / `from_arrays`); the bodies may differ per scene."""
+        B, nb = p.shape[0], p.shape[1]
+        dev = p.device
+        jrot1 = self.jrot1 if jrot1 is None else jrot1
+        types = self.__dict__.get("_types")
+        if types is None:
+            types = self.__dict__["_types"] = [int(t) for t in self.jtype[0].tolist()]
+        ar = torch.arange(B, device=dev)
+        one = torch.ones(B, dtype=p.dtype, device=dev)
+        bi, ri, ci, vals = [], [], [], []
+
+        def put(row, col, val):
+            bi.append(ar); ri.append(torch.full((B,), row, dtype=torch.long, device=dev)); ci.append(col); vals.append(val)
+
+        row = 0
+        for k, t in enumerate(types):
+            b1 = self.jb1[:, k].long()
+            if t in (JOINT, FIXED):
+                b2 = self.jb2[:, k].long()
+                has2 = (b2 >= 0).to(p.dtype)
+                b2c = b2.clamp_min(0)
+                if t == JOINT:
+                    pos1 = torch.stack([self.jr1[:, k] * torch.cos(jrot1[:, k]), self.jr1[:, k] * torch.sin(jrot1[:, k])], dim=1)
+                else:
+                    pos1 = torch.zeros(B, 2, dtype=p.dtype, device=dev)
+                pos2 = p[ar, b1, 1:] + pos1 - p[ar, b2c, 1:]
+                put(row, 3 * b1, -pos1[:, 1]); put(row, 3 * b1 + 1, one)                    # J1 = [[-pos1_y, 1, 0], [pos1_x, 0, 1]]
+                put(row + 1, 3 * b1, pos1[:, 0]); put(row + 1, 3 * b1 + 2, one)
+                put(row, 3 * b2c, has2 * pos2[:, 1]); put(row, 3 * b2c + 1, -has2)           # J2 = [[pos2_y, -1, 0], [-pos2_x, 0, -1]]
+                put(row + 1, 3 * b2c, -has2 * pos2[:, 0]); put(row + 1, 3 * b2c + 2, -has2)
+                if t == FIXED:
+                    put(row + 2, 3 * b1, one); put(row + 2, 3 * b2c, -has2)
+            elif t == XCON:
+                put(row, 3 * b1 + 1, one)
+            elif t == YCON:
+                put(row, 3 * b1 + 2, one)
+            elif t == ROTCON:
+                put(row, 3 * b1, one)
+            elif t == TOTAL:
+                for q in range(3):
+                    put(row + q, 3 * b1 + q, one)
+            row += ROWS.get(t, 0)
+        Je = torch.zeros(B, self.e, 3 * nb, dtype=p.dtype, device=dev)
+        if vals:
+            Je = Je.index_put((torch.cat(bi), torch.cat(ri), torch.cat(ci)), torch.cat(vals), accumulate=True)
+        return Je
+

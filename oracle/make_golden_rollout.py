@@ -123,9 +123,101 @@ def run_hulls(fb, fx):
     return rec
 
 
+# ---- third and fourth scenes: joints whose Jacobian depends on the pose (Joint.J / FixedJoint.J, constraints.py:26-85) ------
+# "j": a double pendulum (bob hinged to the world, a link hinged to the bob: 4 equality rows) that swings into a free ball;
+# "k": a dumbbell (two discs welded by a FixedJoint: 3 rows) pushed, spinning, into a free ball.  Learnable forces push the
+# first body and the ball for the first 0.1 s; loss = |ball - second body| after the roll-out.  The reference differentiates
+# through pos1 = r1 (cos rot1, sin rot1) with rot1 += body1.v[0] dt and pos2 = body1.pos + pos1 - body2.pos - the path
+# lcp_step_backward_je_f32's dL/dJe feeds.  (Scenes with at most 4 equality rows: the fused backward's limit.)
+J_NSTEPS = 36
+J_FORCES = [([0.0, 40.0, 0.0], [0.0, 0.0, 0.0]), ([0.0, 55.0, 5.0], [0.0, -3.0, 1.0]), ([2.0, 35.0, -4.0], [0.5, 2.0, 0.0]),
+            ([0.0, 48.0, 10.0], [-0.5, -1.0, -2.0]), ([-1.0, 60.0, 0.0], [0.0, 1.0, 3.0]), ([0.0, 30.0, 6.0], [0.2, -2.0, 0.0])]
+K_FORCES = [([0.0, 30.0, 0.0], [0.0, 0.0, 0.0]), ([3.0, 36.0, 4.0], [0.0, -2.0, 1.0]), ([-2.0, 28.0, -3.0], [0.3, 1.0, 0.0]),
+            ([5.0, 33.0, 6.0], [-0.3, -1.0, -1.0]), ([1.0, 40.0, -5.0], [0.0, 0.5, 2.0]), ([-4.0, 26.0, 2.0], [0.1, -1.5, 0.0])]
+
+
+def make_world_pendulum(f_first, f_ball):
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.constraints import Joint
+    from lcp_physics.physics.forces import ExternalForce, Gravity
+    from lcp_physics.physics.world import World
+    bob = Circle([300, 300], 20, restitution=0.3, fric_coeff=0.4)
+    link = Circle([300, 372], 18, restitution=0.3, fric_coeff=0.4)
+    ball = Circle([390, 300], 22, restitution=0.5, fric_coeff=0.3)
+    bob.add_no_contact(link)
+    for b in (bob, link):
+        b.add_force(Gravity(g=100))
+    bob.add_force(ExternalForce(f_first, multiplier=MULT))
+    ball.add_force(ExternalForce(f_ball, multiplier=MULT))
+    world = World([bob, link, ball], [Joint(bob, None, [300, 220]), Joint(bob, link, [300, 330])], dt=1.0 / 30)
+    return world, [[0, 1]], [0, 1]
+
+
+def make_world_dumbbell(f_first, f_ball):
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.constraints import FixedJoint
+    from lcp_physics.physics.forces import ExternalForce
+    from lcp_physics.physics.world import World
+    a = Circle([300, 300], 20, restitution=0.4, fric_coeff=0.5)
+    b = Circle([352, 300], 16, restitution=0.4, fric_coeff=0.5)
+    ball = Circle([430, 318], 22, restitution=0.5, fric_coeff=0.3)
+    a.add_no_contact(b)
+    a.add_force(ExternalForce(f_first, multiplier=MULT))
+    ball.add_force(ExternalForce(f_ball, multiplier=MULT))
+    world = World([a, b, ball], [FixedJoint(a, b)], dt=1.0 / 30)
+    return world, [[0, 1]], []
+
+
+def run_joints(make, fb, fx):
+    from lcp_physics.physics import constraints as C_
+    from lcp_physics.physics.forces import ExternalForce
+    f1 = torch.tensor(fb, dtype=torch.float64, requires_grad=True)
+    f2 = torch.tensor(fx, dtype=torch.float64, requires_grad=True)
+    world, no_contact, heavy = make(lambda t: f1 if t < T_PUSH else ExternalForce.ZEROS,
+                                    lambda t: f2 if t < T_PUSH else ExternalForce.ZEROS)
+    second, ball = world.bodies[1], world.bodies[2]
+    nb = len(world.bodies)
+    jt = {C_.Joint: 1, C_.FixedJoint: 2, C_.XConstraint: 3, C_.YConstraint: 4, C_.RotConstraint: 5, C_.TotalConstraint: 6}
+    rec = dict(Mdiag=torch.diagonal(world.M()).reshape(nb, 3).detach().numpy().copy(),
+               rest=np.array([float(b.restitution) for b in world.bodies]),
+               fric=np.array([float(b.fric_coeff) for b in world.bodies]),
+               rad=np.array([float(b.rad) for b in world.bodies]),
+               gravity=np.stack([np.array([0.0, 0.0, 100.0 * float(b.mass)]) if i in heavy else np.zeros(3) for i, b in enumerate(world.bodies)]),
+               jtype=np.array([jt[type(j[0])] for j in world.joints]), jb1=np.array([j[1] for j in world.joints]),
+               jb2=np.array([-1 if j[2] is None else j[2] for j in world.joints]),
+               jr1=np.array([float(j[0].r1) if isinstance(j[0], C_.Joint) else 0.0 for j in world.joints]),
+               jrot1=np.array([float(j[0].rot1) if isinstance(j[0], C_.Joint) else 0.0 for j in world.joints]),
+               Je=world.Je().detach().numpy().copy(), no_contact=np.array(no_contact),
+               p0=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
+               v0=world.get_v().reshape(nb, 3).detach().numpy().copy())
+    ncs, ts = [], []
+    for _ in range(J_NSTEPS):
+        world.step()
+        ncs.append(len(world.contacts)); ts.append(float(world.t))
+    dist = (ball.pos - second.pos).norm()
+    dist.backward()
+    rec.update(p_final=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(), loss=np.float64(float(dist)),
+               grad_first=f1.grad.numpy().copy(), grad_ball=f2.grad.numpy().copy(), ncontacts=np.array(ncs), t=np.array(ts))
+    return rec
+
+
+def jointed(prefix, make, forces):
+    recs = [run_joints(make, a, b) for a, b in forces]
+    out = {prefix + k: np.stack([r[k] for r in recs]) for k in recs[0]}
+    out.update({prefix + "force_first": np.array([a for a, _ in forces]), prefix + "force_ball": np.array([b for _, b in forces]),
+                prefix + "nsteps": np.int64(J_NSTEPS)})
+    for i, r in enumerate(recs):
+        print(prefix, forces[i], "loss %.4f" % r["loss"], "grad first", np.array2string(r["grad_first"], precision=4), "grad ball",
+              np.array2string(r["grad_ball"], precision=4), "steps with contact", np.nonzero(r["ncontacts"])[0].tolist(), "halved",
+              int((np.diff(np.concatenate([[0.0], r["t"]])) < 0.99 / 30).sum()))
+    return out
+
+
 def main():
     ref_shim.load_reference()
     torch.set_default_dtype(torch.float64)
+    jout = jointed("j_", make_world_pendulum, J_FORCES)
+    jout.update(jointed("k_", make_world_dumbbell, K_FORCES))
     hrecs = [run_hulls(a, b) for a, b in H_FORCES]
     hout = {"h_" + k: np.stack([r[k] for r in hrecs]) for k in hrecs[0]}
     hout.update(h_force_ball=np.array([a for a, _ in H_FORCES]), h_force_box=np.array([b for _, b in H_FORCES]), h_nsteps=np.int64(H_NSTEPS))
@@ -136,6 +228,7 @@ def main():
     recs = [run(f) for f in FORCES]
     out = {k: np.stack([r[k] for r in recs]) for k in recs[0]}
     out.update(hout)
+    out.update(jout)
     out.update(force0=np.array(FORCES), nsteps=np.int64(NSTEPS), t_push=np.float64(T_PUSH), mult=np.float64(MULT),
                dt=np.float64(1.0 / 30), no_contact=np.array([[0, 1], [0, 2]]), pushed_body=np.int64(1), loss_bodies=np.array([0, 2]))
     for i, r in enumerate(recs):

@@ -794,3 +794,71 @@ def test_rollout_gradient_through_hull_contacts_matches_the_reference_autograd()
     if os.environ.get("LCP_TEST_VERBOSE"):
         print(np.array2string(got, precision=5)); print(np.array2string(ref, precision=5))
     assert err[same].max() <= 1e-5, err
+
+
+@pytest.mark.parametrize("scene,with_dJe", [("j_", True), ("k_", True), ("j_", False), ("k_", False)])
+def test_rollout_gradient_through_pose_dependent_joints_matches_the_reference_autograd(scene, with_dJe):
+    """Joints whose Jacobian follows the pose.  "j_": a double pendulum (two revolute `Joint`s, one to the world) swinging into
+    a free ball; "k_": a dumbbell (two discs welded by a `FixedJoint`) pushed, spinning, into a ball.  Learnable forces on the
+    first body and on the ball, 36 steps, loss = |ball - second body|.  The reference differentiates through `Joint.J()` /
+    `FixedJoint.J()` (pos1 = r1 (cos rot1, sin rot1), rot1 += body1.v[0] dt, pos2 = body1.pos + pos1 - body2.pos:
+    constraints.py:26-85); here dL/dJe comes from `lcp_step_backward_je_f32` and reaches the pose and the joint angle through
+    `JointSet.jacobian_torch`.  Against the unmodified reference's autograd on six scenes each; with the Jacobian held constant
+    in the backward (`with_dJe=False`) the same comparison must FAIL - the test sees the path."""
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    from lcp_physics_amd.physics.joints import JointSet
+    d0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    d = {k[len(scene):]: d0[k] for k in d0.files if k.startswith(scene)}
+    nv, rep = d["force_first"].shape[0], 32
+    B = nv * rep
+    rp = lambda a, dt_: torch.tensor(np.repeat(a, rep, axis=0), dtype=dt_, device=DEV)
+    nb = d["rad"].shape[1]
+    geom = GeometryBatch.from_shapes([("circle", float(r)) for r in d["rad"][0]], B)
+    nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
+    for i, j in d["no_contact"][0].tolist():
+        nocon[:, i, j] = nocon[:, j, i] = 1
+    geom.no_contact = nocon
+    geom = geom.to(DEV)
+    joints = JointSet.from_arrays(d["jtype"][0], d["jb1"][0], d["jb2"][0], d["jr1"][0], d["jrot1"][0], B).to(DEV)
+    f1 = rp(d["force_first"], torch.float32).requires_grad_(True)
+    f2 = rp(d["force_ball"], torch.float32).requires_grad_(True)
+    grav = rp(d["gravity"], torch.float32)
+    mult, t_push = float(d0["mult"]), float(d0["t_push"])
+
+    def force_fn(t):
+        on = (t < t_push).to(torch.float32).unsqueeze(1)
+        z = torch.zeros(B, 1, 3, dtype=torch.float32, device=DEV)
+        return grav + torch.cat([(f1 * mult * on).unsqueeze(1), z, (f2 * mult * on).unsqueeze(1)], dim=1)
+
+    world = ContactWorld(geom, rp(d["p0"], torch.float64), rp(d["v0"], torch.float32), rp(d["Mdiag"], torch.float32),
+                         torch.zeros(B, nb, 3, device=DEV), rp(d["rest"], torch.float32), rp(d["fric"], torch.float32),
+                         joints=joints, dt=float(d0["dt"]), maxc=8, force_fn=force_fn)
+    assert np.abs(world.Je.cpu().numpy()[::rep] - d["Je"]).max() <= 1e-5
+    if not with_dJe:
+        joints.__dict__["_pose_dep"] = False            # the round-1 behaviour: Je a constant of the backward
+    ncs = []
+    for _ in range(int(d["nsteps"])):
+        world.step(differentiable=True)
+        ncs.append(world.contacts.count.clone())
+    pos = world.p[:, :, 1:]
+    loss = (pos[:, 2] - pos[:, 1]).norm(dim=1)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    t_ok = np.abs(world.t.cpu().numpy()[::rep] - d["t"][:, -1]) < 1e-12
+    n_ok = (torch.stack(ncs, 1).cpu().numpy()[::rep] == d["ncontacts"]).all(axis=1)
+    same = t_ok & n_ok
+    print("scenes on the reference's trajectory:", same.tolist())
+    assert same.sum() >= nv - 1
+    pf = world.p.detach().cpu().numpy()[::rep]
+    assert np.abs(pf - d["p_final"])[same].max() <= 2e-3, np.abs(pf - d["p_final"])[same].max()
+    ref = np.concatenate([d["grad_first"], d["grad_ball"]], axis=1)
+    got = np.concatenate([f1.grad.cpu().numpy()[::rep], f2.grad.cpu().numpy()[::rep]], axis=1)
+    err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print("jointed roll-out gradient (%s, dJe %s): relative error per scene" % (scene, with_dJe), np.array2string(err, precision=2))
+    if os.environ.get("LCP_TEST_VERBOSE"):
+        print(np.array2string(got, precision=5)); print(np.array2string(ref, precision=5))
+    if with_dJe:
+        assert err[same].max() <= 1e-4, err
+    else:
+        assert err[same].max() > 1e-2, err

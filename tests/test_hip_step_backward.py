@@ -20,7 +20,7 @@ def _run(sc, cot_v):
     from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, fused_step_backward, solution_of_step
     scg = sc.to(device=DEV)
     out = fused_step(scg)
-    pg = fused_step_backward(scg, out, cot_v.to(DEV))
+    pg = fused_step_backward(scg, out, cot_v.to(DEV), want_Je=True)
     lcp = assemble_contacts(scg)
     sol = solution_of_step(scg, out, lcp[2], lcp[4])
     dense = lcp_backward(sol, (-cot_v).reshape(sc.B, -1).to(DEV))            # d(loss)/dx = -d(loss)/d(v_new)
@@ -45,6 +45,11 @@ def test_matches_autograd_contraction_of_the_dense_gradients(nbox, pts):
         bound = 2e-3 if k in ("c_n", "c_p1", "c_p2", "rest", "fric") else 1e-4
         big = scale > 1e-6 * scale.max()
         assert float(err[big].max()) < bound, (k, float(err[big].max()), int(err.argmax()))
+    # the joint Jacobian's gradient IS the dense dA (lcp.py:57) - no assembly in between
+    assert sc.Je is not None and "Je" in pg
+    scale = dense["A"].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+    err = (pg["Je"] - dense["A"]).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(err.max()) < 1e-4, (float(err.max()), int(err.argmax()))
 
 
 @pytest.mark.parametrize("nbox,pts", [(2, 2), (4, 4)])
@@ -117,7 +122,7 @@ def test_mid_size_backward_matches_generic_dense(nbox, pts):
     cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
     count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
     out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
-    pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
+    pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV), want_Je=True).items()}
     gen = fused_step(scg, path="generic")
     lcp = assemble_contacts(scg)
     dense = lcp_backward(solution_of_step(scg, gen, lcp[2], lcp[4]), (-cot).reshape(B, -1).to(DEV))
@@ -130,6 +135,9 @@ def test_mid_size_backward_matches_generic_dense(nbox, pts):
         err = (pg[k] - ref[k]).abs().reshape(B, -1).max(dim=1)[0] / scale
         big = scale > 1e-6 * scale.max()
         assert float(err[big].max()) < 2e-3, (k, float(err[big].max()), int(err.argmax()))
+    scale = dense["A"].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)                # dJe = the dense dA (lcp.py:57)
+    err = (pg["Je"] - dense["A"]).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(err.max()) < 2e-3, ("Je", float(err.max()), int(err.argmax()))
 
 
 def test_large_scene_backward_matches_generic_dense_and_oracle():

@@ -123,3 +123,44 @@ def test_jointset_host_encoding_matches_the_recorded_reference_joints():
     js2 = JointSet.from_list([("total", 0), ("fixed", 1, 2)], w["p"][0])
     assert js2.e == 6 and js2.jtype[0].tolist() == w["jtype"].tolist() and js2.jb2[0].tolist() == w["jb2"].tolist()
     assert js2.pose_dependent and not JointSet.from_list([("total", 0), ("rot", 1)], w["p"][0]).pose_dependent
+
+
+def test_jointset_torch_jacobian_matches_oracle_and_reference_and_is_differentiable():
+    """`JointSet.jacobian_torch` (the differentiable restatement of `Joint.J` / `FixedJoint.J`, constraints.py:26-85, that carries
+    the gradient of a differentiable step; no GPU): values against `world_oracle.joint_jacobian` on random poses and against the
+    reference's recorded `World.Je()` along the chain and welded trajectories; derivatives against finite differences."""
+    import torch
+    from lcp_physics_amd.physics.joints import JointSet
+    torch.manual_seed(3)
+    nb = 4
+    p0 = torch.randn(nb, 3, dtype=torch.float64) * 10
+    js = JointSet.from_list([("joint", 0, None, (1.0, 2.0)), ("joint", 0, 1, (3.0, -1.0)), ("fixed", 1, 2), ("x", 3), ("y", 2),
+                             ("rot", 2), ("total", 3)], p0, B=3)
+    p = p0.unsqueeze(0).repeat(3, 1, 1) + torch.randn(3, nb, 3, dtype=torch.float64)
+    rot = js.jrot1 + torch.randn(3, js.jrot1.shape[1], dtype=torch.float64)
+    Je = js.jacobian_torch(p, rot)
+    assert Je.shape == (3, js.e, 3 * nb)
+    for b in range(3):
+        jd = {"jtype": js.jtype[b].numpy(), "jb1": js.jb1[b].numpy(), "jb2": js.jb2[b].numpy(), "jr1": js.jr1[b].numpy(), "jrot1": rot[b].numpy()}
+        assert np.abs(Je[b].numpy() - W.joint_jacobian(jd, p[b].numpy())).max() == 0.0
+    for name in ("chain", "welded"):
+        rec = TRAJ[name]
+        jsr = JointSet.from_arrays(rec["jtype"], rec["jb1"], rec["jb2"], rec["jr1"], rec["jrot1"], 1)
+        got = jsr.jacobian_torch(torch.tensor(rec["p"][:1]))[0].numpy()
+        assert np.abs(got - rec["Je_t"][0]).max() < 1e-9, name
+    # derivatives: a random functional of Je, by autograd and by central differences in p and rot
+    w = torch.randn_like(Je)
+    fun = lambda p_, r_: (js.jacobian_torch(p_, r_) * w).sum()
+    pr, rr = p.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+    fun(pr, rr).backward()
+    h = 1e-6
+    for t, g in ((p, pr.grad), (rot, rr.grad)):
+        fd = torch.zeros_like(t)
+        flat, ff = t.reshape(-1), fd.reshape(-1)
+        for i in range(flat.numel()):
+            a = flat.clone(); a[i] += h
+            b_ = flat.clone(); b_[i] -= h
+            args_a = (a.reshape(t.shape), rot) if t is p else (p, a.reshape(t.shape))
+            args_b = (b_.reshape(t.shape), rot) if t is p else (p, b_.reshape(t.shape))
+            ff[i] = (fun(*args_a) - fun(*args_b)) / (2 * h)
+        assert (fd - g).abs().max() < 1e-6, (fd - g).abs().max()
