@@ -153,7 +153,8 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  *        lcp_step_backward_je_f32 for its gradient.
  * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
  * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout - lcp_step_fused_f32
- * serves those sizes from the generic kernels, whose workspace this entry cannot read); else LCP_E_TOOLARGE. */
+ * serves those sizes from the generic kernels, whose workspace this entry cannot read); 5 <= e <= 16 equality rows (chains
+ * of joints) with nc <= 64 and 3 nb + e <= 56 (fp64 arithmetic) after either forward; else LCP_E_TOOLARGE. */
 int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* Mdiag, const float* v, const float* f,
                           const float* rest, const float* fric,
@@ -183,10 +184,10 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e,
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
  * Served by the four-scenes-per-wave kernel when 3 nb <= 32, maxc <= 16, e <= 4: the workspace it leaves then feeds
  * lcp_step_backward_f32 (padded slots get zero gradients) and, for 3 nb <= 16, lcp_pdipm_backward_f32 (m = 4 maxc).
- * Larger scenes, up to
- * maxc <= 64, 3 nb <= 43, e <= 4 (fp64 arithmetic), run on the register-tiled workgroup-per-scene kernel (BASELINE
- * config 5) and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs forward only on
- * the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).
+ * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 16 (chains of joints: two rows per revolute joint), or 3 nb <= 43,
+ * e <= 4 - run (fp64 arithmetic) on the wave-per-scene body-space kernel (BASELINE config 5) or the workgroup-per-scene
+ * contact-space kernel, and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs forward
+ * only on the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).
  *   out: v_new[B,nb,3]  z[B,4 maxc]  s[B,4 maxc]  y[B,e]  iters[B]  status[B] */
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
                            const float* Mdiag, const float* v, const float* f,

@@ -60,6 +60,7 @@ inline size_t scene_bytes(int nz, int m, int e, int compute, int io_f64) {
   }
   if (!lcp::quad_step_supported(nz, m, e) && lcp::big_supported(nz, m, e) && lcp::big_ws_bytes(m) > per_scene)
     per_scene = lcp::big_ws_bytes(m);      // (the sizes the quad kernel takes never reach lcp_big.hip)
+  if (lcp::primal_supported(nz, m, e) && lcp::primal_ws_bytes() > per_scene) per_scene = lcp::primal_ws_bytes();
   return (per_scene + 15) & ~(size_t)15;
 }
 
@@ -113,7 +114,7 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
     // classes per scene: 3 = contact structure, at most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure
     // (lcp_big.hip); 0 = anything else (the generic kernels)
-    const int primal_ok = (g_path != 3 && (nz % 3) == 0 && lcp::primal_supported(nz, m, e)) ? 1 : 0;
+    const int primal_ok = (g_path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? 1 : 0;
     int rc = lcp::big_dense_forward(P, cls, per_scene, primal_ok, stream);
     if (rc) return rc;
     if (primal_ok) { rc = lcp::primal_dense_forward(P, cls, per_scene, stream); if (rc) return rc; }
@@ -163,7 +164,7 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
     int rc = lcp::big_dense_backward(P, cls, per_scene, stream);           // (the classes the forward left behind the scene blocks)
     if (rc) return rc;
-    if ((nz % 3) == 0 && lcp::primal_supported(nz, m, e)) { rc = lcp::primal_dense_backward(P, cls, per_scene, stream); if (rc) return rc; }
+    if ((nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) { rc = lcp::primal_dense_backward(P, cls, per_scene, stream); if (rc) return rc; }
     P.cls = cls; P.ws_stride = per_scene / cs;
   }
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
@@ -324,7 +325,7 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   P.v_new = dp; P.iters = iters; P.status = status;
   P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
   // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
-  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
+  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_dense_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!pl.ok) return LCP_E_TOOLARGE;

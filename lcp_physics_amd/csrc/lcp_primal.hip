@@ -39,8 +39,9 @@ using namespace wsc;
 constexpr int LX = 64;           // lanes = stride of the stored iterate
 constexpr int EQB = 4;           // padded neq
 // workspace per scene (doubles): a 64-entry header (contact count), then the best iterate the backward needs, in the layout
-// lcp_big.hip uses: x[64] y[8] z[4][64] s[4][64] mu[64] diag(Q)[64]
-struct WsLayout { static constexpr int IT = 64, TOTAL = IT + 64 + 8 + 10 * LX; };
+// lcp_big.hip uses, with room for 16 equality multipliers: x[64] y[16] z[4][64] s[4][64] mu[64] diag(Q)[64]
+struct WsLayout { static constexpr int IT = 64, YCAP = 16, ZO = 64 + YCAP, TOTAL = IT + ZO + 10 * LX; };
+constexpr int ZO = WsLayout::ZO;     // offset of z in the iterate block
 
 #ifdef LCP_PRIMAL_PROFILE
 #define PR_TICK(i) { const long long now_ = clock64(); pc[i] += now_ - tk; tk = now_; }
@@ -59,13 +60,13 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 //        a contact list - scenes lcp_classify_big marked 3: the mixed contact LCP of engines.py:50-74 with a diagonal Q whose
 //        Jacobian rows touch at most two bodies -, the outputs are x, y, z, s (forward) or the seven dense gradients of
 //        lcp.py:52-61 (backward).
-template <int NCOL, bool BWD, bool DENSE>
+template <int NCOL, bool BWD, bool DENSE, int EQC>
 __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(StepArgs SP, StepBwdArgs Gd, DenseIO DN) {
   constexpr int LDK = NCOL + 1;
   constexpr int KSZ = (NCOL * LDK > 11 * LX) ? NCOL * LDK : 11 * LX;    // (the dense backward stages 144 + 8 nc <= 656 doubles here)
   __shared__ __attribute__((aligned(16))) double Kl[KSZ];          // image of the system matrix (formation); backward: staging
   __shared__ double xv[LX];                                        // x-space exchange / accumulation
-  __shared__ float At[EQB * LX];                                   // A rows
+  __shared__ float At[EQC * LX];                                   // A rows
   __shared__ int B12[2 * LX];
   __shared__ double stash[8 * LX];                                 // the affine direction, parked during the corrector solve
   const int scene = blockIdx.x, lane = threadIdx.x;
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   int c0 = 0, c1 = 0;                                                      // first columns of the contact's two bodies
   double mu_c = 0, hn = 0;
   double qd = 0, p = 0, b_in = 0;
-  for (int i = lane; i < EQB * LX; i += 64) At[i] = 0.0f;
+  for (int i = lane; i < EQC * LX; i += 64) At[i] = 0.0f;
   wsync();
   if constexpr (DENSE) {
     // dense boundary: G = [Jc; Jf; 0] with Jf rows (+jt, -jt) (engines.py:67-68, world.py:191-192), F[3nc + c][c] = mu_c
@@ -113,17 +114,17 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
 #pragma unroll
         for (int q = 0; q < 3; ++q) { jn[3 + q] = gc[c1 + q]; jf[3 + q] = gt[c1 + q]; }
       }
-      if (BWD) mu_c = Wit[72 + 8 * LX + lane];                              // (lcp_pdipm_backward_f32 gets G, A and the cotangent only)
+      if (BWD) mu_c = Wit[ZO + 8 * LX + lane];                              // (lcp_pdipm_backward_f32 gets G, A and the cotangent only)
       else {
         mu_c = (double)DN.F[(size_t)scene * m * m + (size_t)(3 * ncap + lane) * m + lane];
         hn = (double)DN.h[(size_t)scene * m + lane];
       }
     }
-    if (BWD) { if (vx) qd = Wit[72 + 9 * LX + lane]; }
+    if (BWD) { if (vx) qd = Wit[ZO + 9 * LX + lane]; }
     else {
       if (vx) { qd = (double)DN.Q[(size_t)scene * nz * nz + (size_t)lane * nz + lane]; p = (double)DN.p[(size_t)scene * nz + lane]; }
       if (ve) b_in = (double)DN.b[(size_t)scene * e + (lane - nz)];
-      Wit[72 + 8 * LX + lane] = mu_c; Wit[72 + 9 * LX + lane] = qd;
+      Wit[ZO + 8 * LX + lane] = mu_c; Wit[ZO + 9 * LX + lane] = qd;
     }
     for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = DN.A[(size_t)scene * e * nz + i]; }
   } else {
@@ -173,14 +174,24 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   };
   auto Av = [&](double v) -> double {                                     // equality lanes <- x lanes
     double out = 0;
+    if constexpr (EQC <= 4) {
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+      for (int a = 0; a < EQC; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+    } else {                                                              // many rows (chains of joints): every equality lane sums its own row
+      xv[lane] = vx ? v : 0.0; wsync();
+      if (ve) { const float* ar = At + (lane - nz) * LX; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
+      wsync();
+    }
     return out;
   };
   auto Aty = [&](double y) -> double {                                    // x lanes <- equality lanes
     double acc = 0;
+    if constexpr (EQC <= 4) {
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
+      for (int a = 0; a < EQC; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
+    } else {
+      for (int a = 0; a < e; ++a) acc = fma(acol(a), bcast_lane(y, nz + a), acc);
+    }
     return acc;
   };
 
@@ -218,8 +229,12 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
     wsync();
     if (lane < NCOL) Kl[lane * LDK + lane] = vx ? qd : (ve ? 0.0 : 1.0);   // rows beyond the system: identity
     if (vx) {
+      if constexpr (EQC <= 4) {
 #pragma unroll
-      for (int a = 0; a < EQB; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
+        for (int a = 0; a < EQC; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
+      } else {
+        for (int a = 0; a < e; ++a) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; }
+      }
     }
     wsync();
     if (vc) {
@@ -339,8 +354,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
     double x = vx ? Wit[lane] : 0.0, dx = 0, dnu = 0;
     M4<double> z = m4<double>(1, 1, 1, 1), s = z, dinv = z, ds, dl;
     if (vc) {
-      z = m4<double>(Wit[72 + lane], Wit[72 + LX + lane], Wit[72 + 2 * LX + lane], Wit[72 + 3 * LX + lane]);
-      s = m4<double>(Wit[72 + 4 * LX + lane], Wit[72 + 5 * LX + lane], Wit[72 + 6 * LX + lane], Wit[72 + 7 * LX + lane]);
+      z = m4<double>(Wit[ZO + lane], Wit[ZO + LX + lane], Wit[ZO + 2 * LX + lane], Wit[ZO + 3 * LX + lane]);
+      s = m4<double>(Wit[ZO + 4 * LX + lane], Wit[ZO + 5 * LX + lane], Wit[ZO + 6 * LX + lane], Wit[ZO + 7 * LX + lane]);
       dinv = m4<double>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                 // 1 / d, d = z / s (lcp.py:44)
     }
     // At a converged iterate the ratios D = s / z of the active rows underflow against Q (1e-12 and below), and Q + G^T M^-1 G
@@ -466,12 +481,9 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
     }
     if (Gd.dJe && e > 0) {                                                    // dA = dnu (x) x + nu (x) dx (lcp.py:57; A = Je)
       float* o = (float*)Gd.dJe + (size_t)scene * e * nz;
-#pragma unroll
-      for (int a = 0; a < EQB; ++a) {
-        if (a < e) {
-          const double dn = bcast_lane(dnu, nz + a), nu = Wit[64 + a];
-          if (vx) o[a * nz + lane] = (float)(dn * x + nu * dx);
-        }
+      for (int a = 0; a < e; ++a) {
+        const double dn = bcast_lane(dnu, nz + a), nu = Wit[64 + a];
+        if (vx) o[a * nz + lane] = (float)(dn * x + nu * dx);
       }
     }
     if (lane < nb) {                                                          // per-body sums over the contacts, fixed order
@@ -497,8 +509,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   auto keep_best = [&](double x_, double y_, const M4<double>& z_, const M4<double>& s_) {
     if (vx) Wit[lane] = x_;
     if (ve) Wit[64 + (lane - nz)] = y_;
-    Wit[72 + lane] = z_.n; Wit[72 + LX + lane] = z_.f1; Wit[72 + 2 * LX + lane] = z_.f2; Wit[72 + 3 * LX + lane] = z_.g;
-    Wit[72 + 4 * LX + lane] = s_.n; Wit[72 + 5 * LX + lane] = s_.f1; Wit[72 + 6 * LX + lane] = s_.f2; Wit[72 + 7 * LX + lane] = s_.g;
+    Wit[ZO + lane] = z_.n; Wit[ZO + LX + lane] = z_.f1; Wit[ZO + 2 * LX + lane] = z_.f2; Wit[ZO + 3 * LX + lane] = z_.g;
+    Wit[ZO + 4 * LX + lane] = s_.n; Wit[ZO + 5 * LX + lane] = s_.f1; Wit[ZO + 6 * LX + lane] = s_.f2; Wit[ZO + 7 * LX + lane] = s_.g;
   };
   double best_resid = inf_of<double>();
   bool have_best = false, done = false;
@@ -598,8 +610,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   // ---- outputs (row layout of a capacity-sized LCP, padded slots 0) ---------------------------------------------------------
   if (!have_best && ncs > 0) keep_best(x, y, z, s);                         // (max_iter = 0: the initial point)
   const double bx = vx ? Wit[lane] : 0.0, by = ve ? Wit[64 + (lane - nz)] : 0.0;
-  const M4<double> bz = m4<double>(Wit[72 + lane], Wit[72 + LX + lane], Wit[72 + 2 * LX + lane], Wit[72 + 3 * LX + lane]);
-  const M4<double> bs = m4<double>(Wit[72 + 4 * LX + lane], Wit[72 + 5 * LX + lane], Wit[72 + 6 * LX + lane], Wit[72 + 7 * LX + lane]);
+  const M4<double> bz = m4<double>(Wit[ZO + lane], Wit[ZO + LX + lane], Wit[ZO + 2 * LX + lane], Wit[ZO + 3 * LX + lane]);
+  const M4<double> bs = m4<double>(Wit[ZO + 4 * LX + lane], Wit[ZO + 5 * LX + lane], Wit[ZO + 6 * LX + lane], Wit[ZO + 7 * LX + lane]);
   bool bad = vx && (bx != bx);
   if (vc) bad = bad || (bz.n != bz.n) || (bs.n != bs.n) || (bz.f1 != bz.f1) || (bz.f2 != bz.f2) || (bz.g != bz.g) ||
                 (bs.f1 != bs.f1) || (bs.f2 != bs.f2) || (bs.g != bs.g);
@@ -888,13 +900,21 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
 
 // nz + neq rows on the lanes of one wave, a contact per lane
 bool primal_supported(int nz, int m, int e) {
-  return (m % 4) == 0 && m / 4 <= 64 && e <= primal::EQB && (nz % 3) == 0 && nz + e <= 56;
+  return (m % 4) == 0 && m / 4 <= 64 && e <= primal::WsLayout::YCAP && (nz % 3) == 0 && nz + e <= 56;
 }
+// the dense boundary and post-stabilisation keep the four-row instantiations
+bool primal_dense_supported(int nz, int m, int e) { return e <= primal::EQB && primal_supported(nz, m, e); }
 size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOTAL; }
 
 template <int NCOL, bool BWD, bool DENSE = false>
 static int primal_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, const DenseIO& DN = DenseIO{}) {
-  hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD, DENSE>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd, DN);
+  if constexpr (!DENSE) {
+    if (SP.e > primal::EQB) {                                             // 5 .. 16 equality rows: chains of joints
+      hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD, false, primal::WsLayout::YCAP>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd, DN);
+      return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD, DENSE, primal::EQB>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd, DN);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 template <bool BWD, bool DENSE = false>

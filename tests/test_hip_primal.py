@@ -300,3 +300,71 @@ def test_post_stabilization_body_space_matches_the_generic_kernel_and_the_oracle
         ref = WO.post_stabilization(sc.Mdiag[k].numpy(), sc.v[k].numpy(), contacts, sc.rest[k].numpy(), sc.Je[k].numpy())
         e = float(np.abs(da[k].numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
         assert e <= 2e-3, (k, n, e)                           # (the bound of the trajectory test: this LCP is ill-conditioned at rest)
+
+
+def _with_joint_rows(sc, e_target):
+    """Stack scenes with more joints: next to the TotalConstraint on the floor (3 rows) the top box is welded to the world (3),
+    then X / Rot / Y constraints on the boxes in between, until `e_target` rows (constraints.py:95-217: rows of the identity) -
+    and, so that the Jacobian is not only unit rows, the last row is a revolute-style row coupling two bodies."""
+    B, nb = sc.B, sc.nb
+    nz = 3 * nb
+    rows = []
+    unit = lambda c: torch.zeros(nz).index_fill_(0, torch.tensor([c]), 1.0)
+    for q in range(3):
+        rows.append(unit(3 * (nb - 1) + q))
+    for b in range(1, nb - 1):
+        for q in (1, 0, 2):
+            rows.append(unit(3 * b + q))
+    rows = rows[: e_target - 3]
+    r = rows[-1].clone()                                       # couple the last constrained coordinate to the floor's (pinned) rotation
+    r[0] = -12.5
+    rows[-1] = r
+    extra = torch.stack(rows).to(sc.Je.dtype).unsqueeze(0).repeat(B, 1, 1)
+    sc.Je = torch.cat([sc.Je, extra], dim=1).contiguous()
+    assert sc.Je.shape[1] == e_target
+    return sc
+
+
+@pytest.mark.parametrize("nbox,pts,e", [(4, 2, 7), (4, 4, 12), (8, 2, 12), (8, 2, 16), (12, 2, 16)])
+def test_chains_of_joints_up_to_16_equality_rows(nbox, pts, e):
+    """5 .. 16 equality rows (a chain of revolute joints has two per link: the reference's chain demo and `testChain`) run on the
+    body-space kernel's 16-row instantiation, forward and backward: new_v, y against the generic kernel and the oracle; the
+    gradients of `lcp_step_backward_je_f32` (Mdiag, v, f and dJe) against the generic kernels' dense backward (lcp.py:52-61)
+    contracted through the assembly."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, fused_step_backward, solution_of_step
+    B = 32
+    sc = _with_joint_rows(scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=900 + nbox + e, dtype=torch.float32), e)
+    count = torch.full((B,), sc.nc, dtype=torch.int32)
+    scg, out = _solve(sc, count)
+    gen = fused_step(scg, path="generic")
+    torch.cuda.synchronize()
+    va, vb = out["v_new"].double().cpu(), gen["v_new"].double().cpu()
+    scale = vb.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    err = (va - vb).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(err.max()) <= 2e-6, err.tolist()
+    assert int((out["status"] & 8).sum()) == 0
+    lcp = [None if t is None else t.double().cpu() for t in assemble_contacts(scg)]
+    ref = O.lcp_forward(*lcp)
+    ex = parity.err_x(-va.reshape(B, -1), ref.x, lcp[0], lcp[1])
+    assert float(ex.max()) <= 1e-4, float(ex.max())
+    ey = (out["y"].double().cpu() - ref.y).abs().max(dim=1)[0] / ref.y.abs().max(dim=1)[0].clamp_min(1.0)
+    assert float(ey.max()) <= 1e-4, ey.tolist()
+    # backward
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(21), dtype=torch.float32)
+    pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV), want_Je=True).items()}
+    lcpd = assemble_contacts(scg)
+    dense = lcp_backward(solution_of_step(scg, gen, lcpd[2], lcpd[4]), (-cot).reshape(B, -1).to(DEV))
+    torch.cuda.synchronize()
+    dense = {k: (None if t is None else t.double().cpu()) for k, t in zip("QpGhAbF", dense)}
+    ph = {k: v.double() if v.is_floating_point() else v for k, v in sc.phys_dict().items()}
+    refg = parity.physical_grads(ph, sc.dt, dense, O)
+    for k in ("Mdiag", "v", "f"):
+        scale = refg[k].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+        eg = (pg[k] - refg[k]).abs().reshape(B, -1).max(dim=1)[0] / scale
+        big = scale > 1e-6 * scale.max()
+        assert float(eg[big].max()) < 2e-3, (k, float(eg[big].max()), int(eg.argmax()))
+    scale = dense["A"].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30)
+    eg = (pg["Je"] - dense["A"]).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(eg.max()) < 2e-3, ("Je", float(eg.max()), int(eg.argmax()))

@@ -43,8 +43,8 @@ def main():
         "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0>"),
         "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0>"),
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
-        "lcp_primal_kernel_40_fwd": pick("lcp_primal_kernel<40, false, false>"),
-        "lcp_primal_kernel_40_bwd": pick("lcp_primal_kernel<40, true, false>"),
+        "lcp_primal_kernel_40_fwd": pick("lcp_primal_kernel<40, false, false, 4>"),
+        "lcp_primal_kernel_40_bwd": pick("lcp_primal_kernel<40, true, false, 4>"),
         "all_kernels": nice,
         "source": "hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py)",
     }
