@@ -207,8 +207,9 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
  * contacts those found after the move (world.py:87-94).  When p / p_out are given, p_out = p + (dp / 2) dt_k with
  * dt_k = dt_scene[k] (the dt the scene's step ended up using; NULL: the scalar `dt`) - world.py:110-117; the caller
  * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL); p_out may be p itself.
- * Runs on the workgroup-per-scene kernels (any size their plan takes: LCP_E_TOOLARGE beyond); workspace of
- * lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
+ * Runs on the wave-per-scene body-space kernel (fp64 arithmetic, maxc <= 64, e <= 16, 3 nb + e <= 56; it leaves its best
+ * iterate in the workspace for lcp_post_stabilization_backward_f32) or on the workgroup-per-scene generic kernels (any size
+ * their plan takes: LCP_E_TOOLARGE beyond); workspace of lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
  *   out: dp[B,nb,3]  p_out[B,nb,3] (optional)  iters[B]  status[B] */
 int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
                                const float* Mdiag, const float* v, const float* rest,
@@ -217,6 +218,23 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
                                double eps, int max_iter, int not_improved_lim, int compute,
                                const double* p, const double* dt_scene, double dt, double* p_out,
                                float* dp, int32_t* iters, int32_t* status, void* ws, void* stream);
+
+/* Backward of lcp_post_stabilization_f32 with respect to its physical inputs - what the reference obtains by autograd
+ * through PdipmEngine.post_stabilization (engines.py:80-116: ge = Je v, gc = Jc v + Jc v * -restitutions, the LCPFunction
+ * call and its backward lcp.py:37-64, dp = -x) when a World with post_stab=True is differentiated (experiments/inference.py).
+ * Must follow the forward on the same stream with the same workspace and unchanged inputs; the forward must have run on the
+ * body-space kernel (fp64 arithmetic, maxc <= 64, e <= 16, 3 nb + e <= 56: otherwise LCP_E_TOOLARGE).
+ *   in : the forward's inputs, dl_ddp[B,nb,3] = d(loss)/d(dp)
+ *   out: dMdiag[B,nb,3] dv[B,nb,3] drest[B,nb] dc_n[B,maxc,2] dc_p1[B,maxc,2] dc_p2[B,maxc,2] dJe[B,e,3nb]
+ *        (any may be NULL; padded contact slots get 0) */
+int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e,
+                                        const float* Mdiag, const float* v, const float* rest,
+                                        const float* c_n, const float* c_p1, const float* c_p2,
+                                        const int32_t* c_i1, const int32_t* c_i2, const float* Je,
+                                        const float* dl_ddp, int compute,
+                                        float* dMdiag, float* dv, float* drest,
+                                        float* dc_n, float* dc_p1, float* dc_p2, float* dJe,
+                                        void* ws, void* stream);
 
 /* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the
  * contact generation it calls, for B independent scenes in one launch:

@@ -325,12 +325,34 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   P.v_new = dp; P.iters = iters; P.status = status;
   P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
   // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
-  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_dense_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
+  P.ws = ws;                                                                // (lcp_primal.hip leaves the best iterate there for the backward)
+  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!pl.ok) return LCP_E_TOOLARGE;
-  P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
   return lcp::generic_post_stab(P, compute, pl.lds_bytes, stream);
+}
+
+int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const float* Mdiag, const float* v,
+                                        const float* rest, const float* c_n, const float* c_p1, const float* c_p2,
+                                        const int32_t* c_i1, const int32_t* c_i2, const float* Je, const float* dl_ddp,
+                                        int compute, float* dMdiag, float* dv, float* drest, float* dc_n, float* dc_p1,
+                                        float* dc_p2, float* dJe, void* ws, void* stream) {
+  bool generic;
+  compute = split_compute(compute, &generic);
+  if (compute != LCP_COMPUTE_F64) return (compute == LCP_COMPUTE_F32) ? LCP_E_TOOLARGE : LCP_E_BADARG;
+  lcp::StepArgs P;
+  int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, /*f*/ v, rest, /*fric*/ rest, c_n, c_p1, c_p2, c_i1, c_i2, Je, 0.0f);
+  if (rc) return rc;
+  if (!dl_ddp || !ws) return LCP_E_BADARG;
+  // only the body-space kernel keeps the iterate this backward reads (the same routing test as the forward)
+  if (generic || g_path != 0 || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
+  P.ws = ws;
+  lcp::StepBwdArgs G = {};
+  G.dl_dv = dl_ddp; G.dMdiag = dMdiag; G.dv = dv; G.drest = drest; G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
+  G.dJe = (e > 0) ? dJe : nullptr;
+  return lcp::primal_post_stab_backward(P, G, stream);
 }
 
 int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,

@@ -642,16 +642,21 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
 // D = s / z), then dp = -x and, when poses are given, the correction move p_out = p + (dp / 2) dt_scene.  No contact: the direct
 // KKT solve of :92-103, which is what the initialisation solve computes.  One wave per scene; replaces the generic
 // workgroup-per-scene kernel on this path (4.2 ms for 4096 x 16 contacts).
-template <int NCOL>
-__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_kernel(StepArgs SP) {
+template <int NCOL, bool BWD, int EQC>
+__global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
   constexpr int LDK = NCOL + 1;
   __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];
   __shared__ double xv[LX];
-  __shared__ float At[EQB * LX];
+  __shared__ float At[EQC * LX];
+  __shared__ int B12[2 * LX];
   const int scene = blockIdx.x, lane = threadIdx.x;
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
+  // workspace per scene (when given): the count and the best iterate, for the backward: [ncs .. | x[64] y[16] z[64] s[64]]
+  double* Wg = SP.ws ? (double*)SP.ws + (size_t)scene * (size_t)WsLayout::TOTAL : nullptr;
+  double* Wit = Wg ? Wg + WsLayout::IT : nullptr;
   int ncs = ncap;
-  if (SP.c_count) ncs = SP.c_count[scene];
+  if (BWD) ncs = (int)Wg[0];
+  else if (SP.c_count) ncs = SP.c_count[scene];
   const int truncated = (ncs > ncap) ? LCP_ST_TRUNCATED : 0;
   ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
   const bool vc = lane < ncs, vx = lane < nz, ve = lane >= nz && lane < n;
@@ -672,7 +677,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   }
   auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
   const double qd = vx ? (double)Md[lane] : 0.0;
-  for (int i = lane; i < EQB * LX; i += 64) At[i] = 0.0f;
+  for (int i = lane; i < EQC * LX; i += 64) At[i] = 0.0f;
   wsync();
   for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   wsync();
@@ -702,14 +707,24 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   };
   auto Av = [&](double v) -> double {
     double out = 0;
+    if constexpr (EQC <= 4) {
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+      for (int a = 0; a < EQC; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
+    } else {
+      xv[lane] = vx ? v : 0.0; wsync();
+      if (ve) { const float* ar = At + (lane - nz) * LX; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
+      wsync();
+    }
     return out;
   };
   auto Aty = [&](double y) -> double {
     double acc = 0;
+    if constexpr (EQC <= 4) {
 #pragma unroll
-    for (int a = 0; a < EQB; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
+      for (int a = 0; a < EQC; ++a) { if (a < e) acc = fma(acol(a), bcast_lane(y, nz + a), acc); }
+    } else {
+      for (int a = 0; a < e; ++a) acc = fma(acol(a), bcast_lane(y, nz + a), acc);
+    }
     return acc;
   };
   const double b_in = (e > 0) ? Av(vx ? (double)vv[lane] : 0.0) : 0.0;    // ge = Je v (engines.py:86), on the equality lanes
@@ -723,8 +738,12 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
     wsync();
     if (lane < NCOL) Kl[lane * LDK + lane] = vx ? qd : (ve ? 0.0 : 1.0);
     if (vx) {
+      if constexpr (EQC <= 4) {
 #pragma unroll
-      for (int a = 0; a < EQB; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
+        for (int a = 0; a < EQC; ++a) { if (a < e) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; } }
+      } else {
+        for (int a = 0; a < e; ++a) { const double av = acol(a); Kl[lane * LDK + nz + a] = av; Kl[(nz + a) * LDK + lane] = av; }
+      }
     }
     wsync();
     if (vc) {
@@ -812,10 +831,112 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
     return key_is_nan(kl) ? nan_of<double>() : l;
   };
 
+  if constexpr (BWD) {
+    // ---- backward: d(loss)/d(dp) -> d(loss)/d(Mdiag, v, rest, contact normal / arms, Je): lcp.py:37-64 on the frictionless LCP,
+    // contracted through h = gc = (Jc v)(1 - rbar), b = ge = Je v, G = Jc (engines.py:84-112) ---------------------------------
+    const double x = vx ? Wit[lane] : 0.0, nu_l = ve ? Wit[64 + (lane - nz)] : 0.0;
+    double z = 1, s = 1, dinv = 1;
+    if (vc) { z = Wit[ZO + lane]; s = Wit[ZO + LX + lane]; dinv = s / z; }
+    constexpr double BWD_FLOOR = 1e-9;                                       // (as in lcp_primal_kernel: floored D + one refinement step)
+    double dfl = dinv;
+    {
+      xv[lane] = vx ? 1.0 / qd : 0.0; wsync();
+      double wn = 0;
+      if (vc) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wn = fma((double)jn[q] * (double)jn[q], xv[colq(q)], wn);
+        dfl = __builtin_fmax(dinv, BWD_FLOOR * wn);
+      }
+      wsync();
+    }
+    idn = vc ? 1.0 / dfl : 0.0;
+    factor();
+    const double g = vx ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;     // dp = -x (engines.py:115)
+    double dx, ds, dl, dnu;
+    solve_kkt(dfl, g, 0.0, 0.0, 0.0, dx, ds, dl, dnu);
+    if (ncs > 0) {                                                           // refinement on the unreduced equations, true D
+      double r1 = -g - (qd * dx + Gtw(vc ? dl : 0.0));
+      if (e > 0) r1 -= Aty(dnu);
+      if (!vx) r1 = 0.0;
+      const double gx = Gv(dx);
+      const double r3 = vc ? -(gx - dinv * dl) : 0.0;
+      const double r2 = (e > 0) ? -Av(dx) : 0.0;
+      double cx, cs, cl, cnu;
+      solve_kkt(dfl, -r1, 0.0, -r3, -r2, cx, cs, cl, cnu);
+      dx += cx; dnu += cnu; dl += cl;
+    }
+    double* X = Kl; double* DX = Kl + LX; double* CR = Kl + 2 * LX;
+    wsync();
+    X[lane] = x; DX[lane] = vx ? dx : 0.0; wsync();
+    double djv = 0;
+    {
+      double cr = 0, dnx = 0, dny = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
+      int b1 = 0, b2 = 0;
+      if (vc) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        const double nx = ((const float*)SP.c_n)[cb * 2], ny = ((const float*)SP.c_n)[cb * 2 + 1];
+        const double p1x = ((const float*)SP.c_p1)[cb * 2], p1y = ((const float*)SP.c_p1)[cb * 2 + 1];
+        const double p2x = ((const float*)SP.c_p2)[cb * 2], p2y = ((const float*)SP.c_p2)[cb * 2 + 1];
+        b1 = SP.c_i1[cb]; b2 = SP.c_i2[cb];
+        const double rbar = 0.5 * ((double)((const float*)SP.rest)[(size_t)scene * nb + b1] + (double)((const float*)SP.rest)[(size_t)scene * nb + b2]);
+        const double jnd[6] = {p1x * ny - p1y * nx, nx, ny, -(p2x * ny - p2y * nx), -nx, -ny};     // world.py:177-183
+        const double gh = -dl;                                                // dh = -dlam (lcp.py:56)
+        djv = gh * (1.0 - rbar);                                              // h = (Jc v) + (Jc v) * -rbar (engines.py:89)
+        double gjn[6], jnv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
+          const double xq = X[col], dxq = DX[col], vq = (double)vv[col];
+          jnv = fma(jnd[q], vq, jnv);
+          gjn[q] = dl * xq + z * dxq + djv * vq;                              // dG row (lcp.py:53) + h through Jc
+        }
+        cr = 0.5 * (-gh * jnv);                                               // rbar = (rest_b1 + rest_b2) / 2 (world.py:144-151)
+        dnx = -gjn[0] * p1y + gjn[1] + gjn[3] * p2y - gjn[4];
+        dny = gjn[0] * p1x + gjn[2] - gjn[3] * p2x - gjn[5];
+        d1x = gjn[0] * ny; d1y = -gjn[0] * nx;
+        d2x = -gjn[3] * ny; d2y = gjn[3] * nx;
+      }
+      wsync();
+      CR[lane] = cr; B12[lane] = b1; B12[LX + lane] = b2;
+      if (lane < ncap) {
+        const size_t cb = (size_t)scene * ncap + lane;
+        if (Gd.dcn) { ((float*)Gd.dcn)[cb * 2] = (float)dnx; ((float*)Gd.dcn)[cb * 2 + 1] = (float)dny; }
+        if (Gd.dcp1) { ((float*)Gd.dcp1)[cb * 2] = (float)d1x; ((float*)Gd.dcp1)[cb * 2 + 1] = (float)d1y; }
+        if (Gd.dcp2) { ((float*)Gd.dcp2)[cb * 2] = (float)d2x; ((float*)Gd.dcp2)[cb * 2 + 1] = (float)d2y; }
+      }
+      wsync();
+    }
+    // v enters through gc = (1 - rbar) Jc v and ge = Je v: dv = Jc^T djv + Je^T db, db = -dnu (lcp.py:58)
+    double dv = Gtw(vc ? djv : 0.0);
+    if (e > 0) dv += Aty(ve ? -dnu : 0.0);
+    if (vx) {
+      const size_t o = (size_t)scene * nz + lane;
+      if (Gd.dMdiag) ((float*)Gd.dMdiag)[o] = (float)(dx * x);               // Q = diag(M): dQ_jj = dx_j x_j (lcp.py:59-60); p = 0
+      if (Gd.dv) ((float*)Gd.dv)[o] = (float)dv;
+    }
+    if (Gd.dJe && e > 0) {                                                    // dA = dnu (x) x + nu (x) dx (lcp.py:57) + db (x) v
+      float* o = (float*)Gd.dJe + (size_t)scene * e * nz;
+      const double vl = vx ? (double)vv[lane] : 0.0;
+      for (int a = 0; a < e; ++a) {
+        const double dn = bcast_lane(dnu, nz + a), nu = bcast_lane(nu_l, nz + a);
+        if (vx) o[a * nz + lane] = (float)(dn * x + nu * dx - dn * vl);
+      }
+    }
+    if (lane < nb && Gd.drest) {
+      double ar = 0;
+      for (int c = 0; c < ncs; ++c) {
+        const double w = ((B12[c] == lane) ? 1.0 : 0.0) + ((B12[LX + c] == lane) ? 1.0 : 0.0);
+        if (w != 0.0) ar += w * CR[c];
+      }
+      ((float*)Gd.drest)[(size_t)scene * nb + lane] = (float)ar;
+    }
+    return;
+  }
+
   const int max_iter = SP.max_iter, lim = SP.lim;
   const double eps = SP.eps;
   const double mf = (double)ncs;
-  double x = 0, y = 0, s = 1, z = 1, dinv = 1, bx = 0;
+  double x = 0, y = 0, s = 1, z = 1, dinv = 1, bx = 0, by = 0, bz = 1, bs = 1;
   double best_resid = inf_of<double>();
   bool have_best = false, done = false;
   int n_not = 0, iters = 0;
@@ -845,7 +966,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }
       else {
         const bool improved = !have_best || (resid < best_resid);
-        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; }
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; by = y; bz = z; bs = s; }
         else ++n_not;
         if (n_not == lim || best_resid < eps || mu > mu_limit<double>()) done = true;
       }
@@ -866,7 +987,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
         if (smin <= 0.0) s += 1.0 - smin;                                   // (:66-75)
         if (zmin <= 0.0) z += 1.0 - zmin;
         if (!vc) { s = 1.0; z = 1.0; }
-        if (ncs == 0) { bx = x; done = true; }                              // engines.py:92-103: the direct solve, no LCP
+        if (ncs == 0) { bx = x; by = y; done = true; }                              // engines.py:92-103: the direct solve, no LCP
       } else if (pass == 0) {
         ax = ox; ay = oy; as_ = os; az = oz;
         const double alpha = pmin(step_pair(z, az, s, as_), 1.0);
@@ -892,6 +1013,12 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
       const double dts = SP.dt_scene ? SP.dt_scene[scene] : SP.dt;
       SP.p_out64[(size_t)scene * nz + lane] = SP.pos64[(size_t)scene * nz + lane] + (dp * 0.5) * dts;
     }
+  }
+  if (Wg) {                                                                 // the best iterate, for lcp_post_stabilization_backward_f32
+    if (lane == 0) Wg[0] = (double)ncs;
+    if (vx) Wit[lane] = bx;
+    if (ve) Wit[64 + (lane - nz)] = by;
+    Wit[ZO + lane] = vc ? bz : 1.0; Wit[ZO + LX + lane] = vc ? bs : 1.0;
   }
   if (lane == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
 }
@@ -927,14 +1054,24 @@ static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stre
 int primal_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_dispatch<false>(SP, Gd, stream); }
 int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_dispatch<true>(SP, Gd, stream); }
 
-int primal_post_stab(const StepArgs& SP, void* stream) {
+template <bool BWD>
+static int primal_post_stab_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   const int n = 3 * SP.nb + SP.e;
   hipStream_t st = (hipStream_t)stream;
-  if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24>), dim3(SP.B), dim3(64), 0, st, SP);
-  else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40>), dim3(SP.B), dim3(64), 0, st, SP);
-  else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56>), dim3(SP.B), dim3(64), 0, st, SP);
+  constexpr int E16 = primal::WsLayout::YCAP;
+  if (SP.e > primal::EQB) {                                                  // chains of joints
+    if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24, BWD, E16>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40, BWD, E16>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56, BWD, E16>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+  } else {
+    if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+  }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
+int primal_post_stab(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_post_stab_launch<false>(SP, Gd, stream); }
+int primal_post_stab_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_post_stab_launch<true>(SP, Gd, stream); }
 
 // dense boundary: the scenes lcp_classify_big marked 3 (launched next to the contact-space and generic kernels, which take 2 and 0)
 int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {

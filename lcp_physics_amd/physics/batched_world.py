@@ -364,6 +364,60 @@ def post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, cb, Je, p=None, dt
     return out
 
 
+def post_stabilization_backward(B, nb, maxc, e, Mdiag, v, rest, cb, Je, dl_ddp, out, compute="f64", want_Je=False):
+    """Backward of `post_stabilization` with respect to its physical inputs (the reference's autograd through
+    `engines.py:80-116` and `lcp.py:37-64`): one launch of `lcp_post_stabilization_backward_f32` on the workspace the forward
+    left in `out`.  Returns dict(Mdiag, v [B,nb,3], rest [B,nb], c_n, c_p1, c_p2 [B,maxc,2]) and, with `want_Je`, Je [B,e,3nb]."""
+    lib = _lib.load()
+    dev = v.device
+    dl_ddp = _lib.require_gpu_tensor(dl_ddp.to(torch.float32).contiguous(), "dl_ddp", torch.float32)
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    grads = {"Mdiag": new(B, nb, 3), "v": new(B, nb, 3), "rest": new(B, nb), "c_n": new(B, maxc, 2), "c_p1": new(B, maxc, 2),
+             "c_p2": new(B, maxc, 2)}
+    if want_Je and e:
+        grads["Je"] = new(B, e, 3 * nb)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        rc = lib.lcp_post_stabilization_backward_f32(B, nb, maxc, e, P(Mdiag), P(v), P(rest), P(cb.c_n), P(cb.c_p1), P(cb.c_p2),
+                                                     P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, P(dl_ddp), _COMPUTE[compute],
+                                                     P(grads["Mdiag"]), P(grads["v"]), P(grads["rest"]), P(grads["c_n"]),
+                                                     P(grads["c_p1"]), P(grads["c_p2"]), P(grads["Je"]) if (want_Je and e) else None,
+                                                     P(out["ws"]), _lib.stream_ptr(dev))
+    _lib.check(rc, "lcp_post_stabilization_backward_f32")
+    return grads
+
+
+class PostStabilizationFunction(torch.autograd.Function):
+    """dp = PostStabilizationFunction.apply(Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts) - the engine's
+    `post_stabilization` (`engines.py:80-116`) as an autograd node: forward `lcp_post_stabilization_f32` (no pose update),
+    backward `lcp_post_stabilization_backward_f32`.  All tensors float32 on the GPU; every call owns its workspace."""
+
+    @staticmethod
+    def forward(ctx, Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts):
+        B, nb = v.shape[0], v.shape[1]
+        maxc = c_n.shape[1]
+        e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+        for name, t in (("Mdiag", Mdiag), ("v", v), ("rest", rest), ("c_n", c_n), ("c_p1", c_p1), ("c_p2", c_p2)):
+            _lib.require_gpu_tensor(t, name, torch.float32)
+        frame = _Frame(c_n, c_p1, c_p2, c_i1, c_i2)
+        out = post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, frame, Je if e else None, compute=opts.get("compute", "f64"))
+        ctx.save_for_backward(Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2)
+        ctx.Je, ctx.out, ctx.dims, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), opts.get("compute", "f64")
+        opts["last_post_stab"] = out
+        return out["dp"]
+
+    @staticmethod
+    def backward(ctx, dl_ddp):
+        Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2 = ctx.saved_tensors
+        B, nb, maxc, e = ctx.dims
+        want_Je = bool(e) and ctx.needs_input_grad[9]
+        g = post_stabilization_backward(B, nb, maxc, e, Mdiag, v, rest, _Frame(c_n, c_p1, c_p2, c_i1, c_i2), ctx.Je, dl_ddp,
+                                        ctx.out, compute=ctx.compute, want_Je=want_Je)
+        keys = ("Mdiag", "v", "rest", "c_n", "c_p1", "c_p2")
+        return (tuple(g[k] if need else None for k, need in zip(keys, ctx.needs_input_grad[:6])) + (None, None, None) +
+                (g["Je"] if want_Je else None,) + (None,))
+
+
 class ContactWorld:
     """B independent scenes WITH contact detection, advanced together on one GPU: the batched counterpart of
     the reference's `World` (`physics/world.py:17-122`) with its default `DiffContactHandler` and `PdipmEngine`.
@@ -490,9 +544,7 @@ class ContactWorld:
         `Mdiag, f, rest, fric, v, p` (and what `force_fn` closes over) may require grad.  State tensors are replaced, not
         overwritten, and every step keeps its own workspace and contact snapshot for the backward.  The joint Jacobian of
         revolute / fixed joints is differentiated through the pose and the joint angle (dL/dJe: lcp_step_backward_je_f32);
-        post-stabilisation is not differentiated."""
-        if self.post_stab:
-            raise RuntimeError("step_autograd: post-stabilisation is not differentiable here")
+        with `post_stab` the correction move is one more node (`PostStabilizationFunction`, world.py:109-121)."""
         ct = self._contacts_mod
         cb = self.contacts
         frame = ct.snapshot_frame(cb)
@@ -535,6 +587,36 @@ class ContactWorld:
                 w1 = v_new[ar, js.jb1.long(), 0].to(torch.float64) * cb.dt_used.clone().reshape(-1, 1)
                 r_lin = self._jrot_ad + w1 * js.revolute_mask
                 self._jrot_ad, self._jrot_src = r_lin + (js.jrot1 - r_lin).detach(), self.p
+        if self.post_stab:
+            # world.py:109-121: dp = engine.post_stabilization(world) at the moved pose with the contacts found there and the
+            # NEW velocities; dp /= 2; the bodies (and the joints) move by dp dt; contacts are detected again
+            frame2 = ct.snapshot_frame(cb)
+            dt_used = cb.dt_used.clone()
+            g_n, g_p1, g_p2 = ct.ContactFrameFunction.apply(self._p_geom, self.geom, frame2, self.eps)
+            Je2 = self.Je
+            if js is not None and js.pose_dependent:
+                Jt = js.jacobian_torch(self.p, self._jrot_ad).to(torch.float32)
+                Je2 = self.Je + (Jt - Jt.detach())
+            dp_s = PostStabilizationFunction.apply(self.Mdiag, v_new.contiguous(), self.rest, g_n, g_p1, g_p2, frame2.c_i1, frame2.c_i2,
+                                                   frame2.count, Je2, opts)
+            ps = opts["last_post_stab"]
+            torch.bitwise_or(self.sticky_status, ps["status"], out=self.sticky_status)
+            mv = (dp_s.to(torch.float64) * 0.5) * dt_used.reshape(-1, 1, 1)
+            p_mid, g_mid = self.p, self._p_geom
+            self.p = p_mid + mv
+            turned = (mv[..., :1] != 0).to(mv.dtype)                          # (bodies.py:199-202, as above)
+            self._p_geom = g_mid + torch.cat([mv[..., :1] * turned + (mv[..., :1] * (1 - turned)).detach(), mv[..., 1:]], dim=-1)
+            self._p_geom_src = self.p
+            if js is not None:
+                self.Je = js.jacobian(self.p.detach().contiguous(), v=dp_s.detach().contiguous(), dt_scene=dt_used, vscale=0.5)
+                if js.pose_dependent:
+                    ar = torch.arange(self.B, device=dp_s.device).unsqueeze(1)
+                    w1 = 0.5 * dp_s[ar, js.jb1.long(), 0].to(torch.float64) * dt_used.reshape(-1, 1)
+                    r_lin = self._jrot_ad + w1 * js.revolute_mask
+                    self._jrot_ad, self._jrot_src = r_lin + (js.jrot1 - r_lin).detach(), self.p
+            ct.find_contacts(self.geom, self.p.detach().contiguous(), maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
+            out = dict(out)
+            out["post_stab"] = ps
         ret = dict(out)
         ret["v_new"] = v_new
         return ret

@@ -201,6 +201,83 @@ def run_joints(make, fb, fx):
     return rec
 
 
+# ---- fifth scene: experiments/inference.py:26-89 in small - a chain of four links (revolute joints, 8 equality rows) hit by a
+# projectile, World(post_stab=True); the learnable parameters are the links' mass (it enters the inertia, the mass and gravity,
+# inference.py:104-113) and the projectile's push; loss = mean squared distance of the final poses from fixed targets.  The
+# reference differentiates through solve_dynamics, the joints, the contacts AND post_stabilization (engines.py:80-116).
+C_NSTEPS = 30
+C_LINKS = 4
+C_PARAMS = [(0.7, [0.0, 1.0, 0.0]), (1.2, [0.0, 1.2, 0.1]), (0.45, [0.0, 0.9, -0.1]), (2.0, [0.1, 1.1, 0.0]), (0.9, [0.0, 1.4, 0.05]),
+            (1.5, [-0.1, 0.8, 0.0])]
+
+
+def make_world_chain(mass, f_proj):
+    from lcp_physics.physics.bodies import Circle, Rect
+    from lcp_physics.physics.constraints import Joint
+    from lcp_physics.physics.forces import ExternalForce, Gravity
+    from lcp_physics.physics.world import World
+    bodies, joints = [], []
+    r = Rect([300, 50], [20, 60], mass=mass)
+    bodies.append(r)
+    joints.append(Joint(r, None, [300, 30]))
+    for i in range(1, C_LINKS):
+        r = Rect([300, 50 + 50 * i], [20, 60], mass=mass)
+        r.add_force(Gravity(g=100))
+        bodies.append(r)
+        joints.append(Joint(bodies[-1], bodies[-2], [300, 25 + 50 * i]))
+        bodies[-1].add_no_contact(bodies[-2])
+    c = Circle([231.7, float(bodies[-1].pos[1]) + 3.3], 20, restitution=1.0)   # (off the grid: x = 230 + 150 t touches the link EXACTLY at a step)
+    bodies.append(c)
+    c.add_force(ExternalForce(f_proj, multiplier=1500))
+    return World(bodies, joints, dt=1.0 / 30, post_stab=True)
+
+
+def run_chain(mass0, force0):
+    from lcp_physics.physics import constraints as C_
+    from lcp_physics.physics.bodies import Circle
+    from lcp_physics.physics.forces import ExternalForce
+    mass = torch.tensor(mass0, dtype=torch.float64, requires_grad=True)
+    f0 = torch.tensor(force0, dtype=torch.float64, requires_grad=True)
+    world = make_world_chain(mass, lambda t: f0 if t < T_PUSH else ExternalForce.ZEROS)
+    nb = len(world.bodies)
+    jt = {C_.Joint: 1, C_.FixedJoint: 2, C_.XConstraint: 3, C_.YConstraint: 4, C_.RotConstraint: 5, C_.TotalConstraint: 6}
+    Md = torch.diagonal(world.M()).reshape(nb, 3).detach().numpy().copy()
+    rec = dict(Mdiag=Md, Mdiag_per_mass=np.concatenate([Md[:C_LINKS] / mass0, np.zeros((1, 3))]),
+               gravity_per_mass=np.array([[0.0, 0.0, 0.0]] + [[0.0, 0.0, 100.0]] * (C_LINKS - 1) + [[0.0, 0.0, 0.0]]),
+               rest=np.array([float(b.restitution) for b in world.bodies]), fric=np.array([float(b.fric_coeff) for b in world.bodies]),
+               kind=np.array([0 if isinstance(b, Circle) else 1 for b in world.bodies]),
+               size=np.array([[float(b.rad), 0.0] if isinstance(b, Circle) else b.dims.numpy().tolist() for b in world.bodies]),
+               jtype=np.array([jt[type(j[0])] for j in world.joints]), jb1=np.array([j[1] for j in world.joints]),
+               jb2=np.array([-1 if j[2] is None else j[2] for j in world.joints]),
+               jr1=np.array([float(j[0].r1) for j in world.joints]), jrot1=np.array([float(j[0].rot1) for j in world.joints]),
+               no_contact=np.array([[i, i - 1] for i in range(1, C_LINKS)]),
+               p0=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
+               v0=world.get_v().reshape(nb, 3).detach().numpy().copy())
+    ncs, ts = [], []
+    for _ in range(C_NSTEPS):
+        world.step()
+        ncs.append(len(world.contacts)); ts.append(float(world.t))
+    pf = torch.stack([b.p for b in world.bodies])
+    target = torch.tensor(rec["p0"]) + torch.tensor([0.3, 25.0, -10.0])
+    loss = ((pf - target) ** 2).mean()
+    loss.backward()
+    rec.update(p_final=pf.detach().numpy().copy(), loss=np.float64(float(loss)), grad_mass=mass.grad.numpy().copy(),
+               grad_force=f0.grad.numpy().copy(), ncontacts=np.array(ncs), t=np.array(ts), target=target.numpy().copy())
+    return rec
+
+
+def chain():
+    recs = [run_chain(m, f) for m, f in C_PARAMS]
+    out = {"c_" + k: np.stack([r[k] for r in recs]) for k in recs[0]}
+    out.update(c_mass=np.array([m for m, _ in C_PARAMS]), c_force=np.array([f for _, f in C_PARAMS]), c_nsteps=np.int64(C_NSTEPS),
+               c_mult=np.float64(1500.0))
+    for i, r in enumerate(recs):
+        print("c_", C_PARAMS[i], "loss %.4f" % r["loss"], "grad mass", np.array2string(r["grad_mass"], precision=5), "grad force",
+              np.array2string(r["grad_force"], precision=4), "steps with contact", np.nonzero(r["ncontacts"])[0].tolist(), "halved",
+              int((np.diff(np.concatenate([[0.0], r["t"]])) < 0.99 / 30).sum()))
+    return out
+
+
 def jointed(prefix, make, forces):
     recs = [run_joints(make, a, b) for a, b in forces]
     out = {prefix + k: np.stack([r[k] for r in recs]) for k in recs[0]}
@@ -218,6 +295,7 @@ def main():
     torch.set_default_dtype(torch.float64)
     jout = jointed("j_", make_world_pendulum, J_FORCES)
     jout.update(jointed("k_", make_world_dumbbell, K_FORCES))
+    jout.update(chain())
     hrecs = [run_hulls(a, b) for a, b in H_FORCES]
     hout = {"h_" + k: np.stack([r[k] for r in hrecs]) for k in hrecs[0]}
     hout.update(h_force_ball=np.array([a for a, _ in H_FORCES]), h_force_box=np.array([b for _, b in H_FORCES]), h_nsteps=np.int64(H_NSTEPS))

@@ -862,3 +862,135 @@ def test_rollout_gradient_through_pose_dependent_joints_matches_the_reference_au
         assert err[same].max() <= 1e-4, err
     else:
         assert err[same].max() > 1e-2, err
+
+
+@pytest.mark.parametrize("nbox,pts,extra_rows", [(2, 2, 0), (4, 2, 0), (6, 2, 0), (4, 2, 4), (8, 2, 5)])
+def test_post_stabilization_backward_matches_oracle(nbox, pts, extra_rows):
+    """`lcp_post_stabilization_backward_f32` against the fp64 oracle end to end: per scene, the oracle solves the frictionless LCP
+    of engines.py:80-116, `lcp.py:37-64` gives the dense gradients, and autograd carries them through the assembly (ge = Je v,
+    gc = Jc v (1 - restitutions), G = Jc, Q = M) to Mdiag, v, rest, the contact frame and Je.  Ragged contact counts (0 = the
+    direct KKT solve); with `extra_rows` the scene has 3 + extra_rows equality rows (the 16-row instantiation).  Two contact
+    points per interface and joints that leave no body pinned twice: the multipliers are unique, so the gradients with respect
+    to the contact frame and Je are (four collinear points per interface leave z, hence dG, undetermined - SURVEY §8d)."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import post_stabilization, post_stabilization_backward
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    from oracle import pdipm_oracle as O
+    B = 12
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=170 + nbox, dtype=torch.float32)
+    if extra_rows:
+        from tests.test_hip_primal import _with_joint_rows
+        sc = _with_joint_rows(sc, 3 + extra_rows)
+    e = sc.Je.shape[1]
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    counts = [sc.nc, sc.nc, sc.nc - 1, sc.nc // 2, 1, 0, sc.nc, 3, 2, sc.nc, 0, sc.nc]
+    count = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    out = post_stabilization(B, sc.nb, sc.nc, e, count, scg.Mdiag, scg.v, scg.rest, cb, scg.Je)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(4), dtype=torch.float32)
+    g = post_stabilization_backward(B, sc.nb, sc.nc, e, scg.Mdiag, scg.v, scg.rest, cb, scg.Je, cot.to(DEV), out, want_Je=True)
+    torch.cuda.synchronize()
+    g = {k: t.double().cpu() for k, t in g.items()}
+    worst = {}
+    for k, n in enumerate(counts):
+        leaf = lambda t: t[k:k + 1].double().clone().requires_grad_(True)
+        Md, v, rest, Je = leaf(sc.Mdiag), leaf(sc.v), leaf(sc.rest), leaf(sc.Je)
+        cn, cp1, cp2 = leaf(sc.c_n[:, :n]), leaf(sc.c_p1[:, :n]), leaf(sc.c_p2[:, :n])
+        cx = -cot[k:k + 1].double().reshape(1, -1)                                  # dp = -x
+        if n == 0:                                                                  # engines.py:92-103: x = P^-1 [0; ge]
+            nz = 3 * sc.nb
+            Pm = torch.cat([torch.cat([torch.diag(Md.reshape(-1)), -Je[0].t()], dim=1),
+                            torch.cat([Je[0], torch.zeros(e, e, dtype=torch.float64)], dim=1)])
+            x = torch.linalg.solve(Pm, torch.cat([torch.zeros(nz, dtype=torch.float64), Je[0] @ v.reshape(-1)]))[:nz]
+            (x * cx[0]).sum().backward()
+        else:
+            lcp = O.assemble_post_stabilization(Md, v, cn, cp1, cp2, sc.c_i1[k:k + 1, :n], sc.c_i2[k:k + 1, :n], rest, Je)
+            det = [None if t is None else t.detach() for t in lcp]
+            sol = O.lcp_forward(*det)
+            gr = O.lcp_backward(sol, *det, cx)
+            outs, cots = [], []
+            for t, key in zip(lcp, ("dQ", "dp", "dG", "dh", "dA", "db", "dF")):
+                if t is not None and t.requires_grad and gr[key] is not None:
+                    outs.append(t); cots.append(gr[key])
+            torch.autograd.backward(outs, cots)
+        ref = {"Mdiag": Md.grad, "v": v.grad, "rest": rest.grad, "Je": Je.grad}
+        if n:
+            ref.update({"c_n": cn.grad, "c_p1": cp1.grad, "c_p2": cp2.grad})
+        for key, r in ref.items():
+            r = torch.zeros_like(leaf(getattr(sc, key))) if r is None else r
+            got = g[key][k:k + 1]
+            if key in ("c_n", "c_p1", "c_p2"):
+                assert float(got[:, n:].abs().max()) == 0.0 if n < sc.nc else True          # padded slots
+                got = got[:, :n]
+            scale = max(float(r.abs().max()), 1e-6 * max(float(ref["v"].abs().max()), 1e-30))
+            err = float((got - r).abs().max()) / scale
+            worst[key] = max(worst.get(key, 0.0), err)
+            # (the contact-frame gradients are differences of products that nearly cancel, as in test_hip_step_backward.py)
+            assert err <= (2e-3 if key in ("c_n", "c_p1", "c_p2") else 1e-4), (nbox, k, n, key, err)
+    print("post-stabilisation backward", nbox, pts, e, {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_rollout_gradient_through_a_chain_with_post_stabilization_matches_the_reference_autograd():
+    """`experiments/inference.py:26-89` in small: a chain of four links on revolute joints (8 equality rows) hit by a projectile,
+    `World(post_stab=True)`, 30 steps; the parameters are the links' mass (inertia, mass and gravity follow it) and the
+    projectile's push.  d(loss)/d(mass) and d(loss)/d(push) through `SolveDynamicsFunction`, `PostStabilizationFunction`, the
+    joints' Jacobians and the contact frames, against the unmodified reference's autograd on six scenes."""
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    from lcp_physics_amd.physics.joints import JointSet
+    d0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    d = {k[2:]: d0[k] for k in d0.files if k.startswith("c_")}
+    nv, rep = d["mass"].shape[0], 16
+    B = nv * rep
+    rp = lambda a, dt_: torch.tensor(np.repeat(a, rep, axis=0), dtype=dt_, device=DEV)
+    shapes = [("circle", float(s[0])) if int(k) == 0 else ("rect", (float(s[0]), float(s[1]))) for k, s in zip(d["kind"][0], d["size"][0])]
+    nb = len(shapes)
+    geom = GeometryBatch.from_shapes(shapes, B)
+    nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
+    for i, j in d["no_contact"][0].tolist():
+        nocon[:, i, j] = nocon[:, j, i] = 1
+    geom.no_contact = nocon
+    geom = geom.to(DEV)
+    joints = JointSet.from_arrays(d["jtype"][0], d["jb1"][0], d["jb2"][0], d["jr1"][0], d["jrot1"][0], B).to(DEV)
+    mass = rp(d["mass"], torch.float32).requires_grad_(True)
+    push = rp(d["force"], torch.float32).requires_grad_(True)
+    per_mass, grav = rp(d["Mdiag_per_mass"], torch.float32), rp(d["gravity_per_mass"], torch.float32)
+    fixed = rp(d["Mdiag"], torch.float32) * (per_mass == 0).to(torch.float32)          # the projectile's own mass matrix
+    Mdiag = per_mass * mass.reshape(B, 1, 1) + fixed                                    # bodies.py:44-47,269-270 with mass = the parameter
+    mult, t_push = float(d["mult"]), float(d0["t_push"])
+
+    def force_fn(t):
+        on = (t < t_push).to(torch.float32).reshape(B, 1, 1)
+        sel = torch.zeros(1, nb, 1, dtype=torch.float32, device=DEV)
+        sel[0, nb - 1, 0] = 1.0
+        return grav * mass.reshape(B, 1, 1) + sel * (push * mult).unsqueeze(1) * on     # forces.py:51-67 Gravity, :29-48 ExternalForce
+
+    world = ContactWorld(geom, rp(d["p0"], torch.float64), rp(d["v0"], torch.float32), Mdiag, torch.zeros(B, nb, 3, device=DEV),
+                         rp(d["rest"], torch.float32), rp(d["fric"], torch.float32), joints=joints, dt=float(d0["dt"]), maxc=8,
+                         force_fn=force_fn, post_stab=True)
+    world.Mdiag = Mdiag                                                                 # (keep the graph: the constructor detaches nothing but copies)
+    ncs = []
+    for _ in range(int(d["nsteps"])):
+        world.step(differentiable=True)
+        ncs.append(world.contacts.count.clone())
+    target = rp(d["target"], torch.float64)
+    loss = ((world.p - target) ** 2).mean(dim=(1, 2))
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    t_ok = np.abs(world.t.cpu().numpy()[::rep] - d["t"][:, -1]) < 1e-12
+    n_ok = (torch.stack(ncs, 1).cpu().numpy()[::rep] == d["ncontacts"]).all(axis=1)
+    same = t_ok & n_ok
+    print("scenes on the reference's trajectory:", same.tolist())
+    assert same.sum() >= nv - 1
+    pf = world.p.detach().cpu().numpy()[::rep]
+    assert np.abs(pf - d["p_final"])[same].max() <= 2e-3, np.abs(pf - d["p_final"])[same].max()
+    ls = loss.detach().cpu().numpy()[::rep]
+    assert (np.abs(ls - d["loss"]) / np.abs(d["loss"]))[same].max() <= 1e-5
+    ref = np.concatenate([d["grad_mass"].reshape(nv, 1), d["grad_force"]], axis=1)
+    got = np.concatenate([mass.grad.cpu().numpy()[::rep].reshape(nv, 1), push.grad.cpu().numpy()[::rep]], axis=1)
+    err = np.abs(got - ref) / np.abs(ref).max(axis=1, keepdims=True)
+    print("chain + post-stabilisation roll-out gradient: relative error per scene", np.array2string(err.max(axis=1), precision=2))
+    if os.environ.get("LCP_TEST_VERBOSE"):
+        print(np.array2string(got, precision=5)); print(np.array2string(ref, precision=5))
+    assert err[same].max() <= 1e-4, err
