@@ -153,7 +153,7 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  *        lcp_step_backward_je_f32 for its gradient.
  * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
  * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout - lcp_step_fused_f32
- * serves those sizes from the generic kernels, whose workspace this entry cannot read); 5 <= e <= 16 equality rows (chains
+ * serves those sizes from the generic kernels, whose workspace this entry cannot read); 5 <= e <= 24 equality rows (chains
  * of joints) with nc <= 64 and 3 nb + e <= 56 (fp64 arithmetic) after either forward; else LCP_E_TOOLARGE. */
 int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* Mdiag, const float* v, const float* f,
@@ -184,7 +184,7 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e,
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
  * Served by the four-scenes-per-wave kernel when 3 nb <= 32, maxc <= 16, e <= 4: the workspace it leaves then feeds
  * lcp_step_backward_f32 (padded slots get zero gradients) and, for 3 nb <= 16, lcp_pdipm_backward_f32 (m = 4 maxc).
- * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 16 (chains of joints: two rows per revolute joint), or 3 nb <= 43,
+ * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 24 (chains of joints: two rows per revolute joint), or 3 nb <= 43,
  * e <= 4 - run (fp64 arithmetic) on the wave-per-scene body-space kernel (BASELINE config 5) or the workgroup-per-scene
  * contact-space kernel, and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs forward
  * only on the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).
@@ -207,7 +207,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
  * contacts those found after the move (world.py:87-94).  When p / p_out are given, p_out = p + (dp / 2) dt_k with
  * dt_k = dt_scene[k] (the dt the scene's step ended up using; NULL: the scalar `dt`) - world.py:110-117; the caller
  * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL); p_out may be p itself.
- * Runs on the wave-per-scene body-space kernel (fp64 arithmetic, maxc <= 64, e <= 16, 3 nb + e <= 56; it leaves its best
+ * Runs on the wave-per-scene body-space kernel (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56; it leaves its best
  * iterate in the workspace for lcp_post_stabilization_backward_f32) or on the workgroup-per-scene generic kernels (any size
  * their plan takes: LCP_E_TOOLARGE beyond); workspace of lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
  *   out: dp[B,nb,3]  p_out[B,nb,3] (optional)  iters[B]  status[B] */
@@ -223,7 +223,7 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
  * through PdipmEngine.post_stabilization (engines.py:80-116: ge = Je v, gc = Jc v + Jc v * -restitutions, the LCPFunction
  * call and its backward lcp.py:37-64, dp = -x) when a World with post_stab=True is differentiated (experiments/inference.py).
  * Must follow the forward on the same stream with the same workspace and unchanged inputs; the forward must have run on the
- * body-space kernel (fp64 arithmetic, maxc <= 64, e <= 16, 3 nb + e <= 56: otherwise LCP_E_TOOLARGE).
+ * body-space kernel (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56: otherwise LCP_E_TOOLARGE).
  *   in : the forward's inputs, dl_ddp[B,nb,3] = d(loss)/d(dp)
  *   out: dMdiag[B,nb,3] dv[B,nb,3] drest[B,nb] dc_n[B,maxc,2] dc_p1[B,maxc,2] dc_p2[B,maxc,2] dJe[B,e,3nb]
  *        (any may be NULL; padded contact slots get 0) */

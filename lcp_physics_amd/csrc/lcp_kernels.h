@@ -114,7 +114,7 @@ int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, 
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
 // body-space (primal) contact-structured path: one wave per scene, <= 64 contacts, nz + neq <= 56 - lcp_primal.hip
-bool primal_supported(int nz, int m, int e);          // contact-list entry points: up to 16 equality rows
+bool primal_supported(int nz, int m, int e);          // contact-list entry points: up to 24 equality rows
 bool primal_dense_supported(int nz, int m, int e);    // dense boundary, post-stabilisation: up to 4
 size_t primal_ws_bytes();
 int primal_step(const StepArgs& P, void* stream);

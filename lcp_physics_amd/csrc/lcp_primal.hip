@@ -39,8 +39,8 @@ using namespace wsc;
 constexpr int LX = 64;           // lanes = stride of the stored iterate
 constexpr int EQB = 4;           // padded neq
 // workspace per scene (doubles): a 64-entry header (contact count), then the best iterate the backward needs, in the layout
-// lcp_big.hip uses, with room for 16 equality multipliers: x[64] y[16] z[4][64] s[4][64] mu[64] diag(Q)[64]
-struct WsLayout { static constexpr int IT = 64, YCAP = 16, ZO = 64 + YCAP, TOTAL = IT + ZO + 10 * LX; };
+// lcp_big.hip uses, with room for 24 equality multipliers: x[64] y[24] z[4][64] s[4][64] mu[64] diag(Q)[64]
+struct WsLayout { static constexpr int IT = 64, YCAP = 24, ZO = 64 + YCAP, TOTAL = IT + ZO + 10 * LX; };
 constexpr int ZO = WsLayout::ZO;     // offset of z in the iterate block
 
 #ifdef LCP_PRIMAL_PROFILE
@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   constexpr int KSZ = (NCOL * LDK > 11 * LX) ? NCOL * LDK : 11 * LX;    // (the dense backward stages 144 + 8 nc <= 656 doubles here)
   __shared__ __attribute__((aligned(16))) double Kl[KSZ];          // image of the system matrix (formation); backward: staging
   __shared__ double xv[LX];                                        // x-space exchange / accumulation
-  __shared__ float At[EQC * LX];                                   // A rows
+  constexpr int AST = (EQC <= 4) ? LX : NCOL;                        // row stride of the A image (many rows: packed to the system's width)
+  __shared__ float At[EQC * AST];                                  // A rows
   __shared__ int B12[2 * LX];
   __shared__ double stash[8 * LX];                                 // the affine direction, parked during the corrector solve
   const int scene = blockIdx.x, lane = threadIdx.x;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
   int c0 = 0, c1 = 0;                                                      // first columns of the contact's two bodies
   double mu_c = 0, hn = 0;
   double qd = 0, p = 0, b_in = 0;
-  for (int i = lane; i < EQC * LX; i += 64) At[i] = 0.0f;
+  for (int i = lane; i < EQC * AST; i += 64) At[i] = 0.0f;
   wsync();
   if constexpr (DENSE) {
     // dense boundary: G = [Jc; Jf; 0] with Jf rows (+jt, -jt) (engines.py:67-68, world.py:191-192), F[3nc + c][c] = mu_c
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       if (ve) b_in = (double)DN.b[(size_t)scene * e + (lane - nz)];
       Wit[ZO + 8 * LX + lane] = mu_c; Wit[ZO + 9 * LX + lane] = qd;
     }
-    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = DN.A[(size_t)scene * e * nz + i]; }
+    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * AST + k] = DN.A[(size_t)scene * e * nz + i]; }
   } else {
     if (vc) {
       const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
@@ -142,14 +143,14 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       qd = (double)Md[lane];
       p = (double)momentum_entry<float>(Md[lane], vv[lane], (float)SP.dt, ff[lane]);          // engines.py:32
     }
-    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+    for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * AST + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   }
   auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
   wsync();
   int status = truncated;
   if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
   // the lane's column / row of A: x lanes hold A[:, lane], the equality lane nz + a holds nothing extra (its row is read from At)
-  auto acol = [&](int a) -> double { return (double)At[a * LX + lane]; };    // (zero beyond nz: At is cleared)
+  auto acol = [&](int a) -> double { return (EQC <= 4 || lane < NCOL) ? (double)At[a * AST + lane] : 0.0; };    // (zero beyond nz: At is cleared)
 
   // ---- products ------------------------------------------------------------------------------------------------------
   auto Gv = [&](double v, double& gn, double& gt) {                       // m-space <- x-space (v on the x lanes)
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_primal_kernel(St
       for (int a = 0; a < EQC; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
     } else {                                                              // many rows (chains of joints): every equality lane sums its own row
       xv[lane] = vx ? v : 0.0; wsync();
-      if (ve) { const float* ar = At + (lane - nz) * LX; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
+      if (ve) { const float* ar = At + (lane - nz) * AST; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
       wsync();
     }
     return out;
@@ -647,7 +648,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   constexpr int LDK = NCOL + 1;
   __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];
   __shared__ double xv[LX];
-  __shared__ float At[EQC * LX];
+  constexpr int AST = (EQC <= 4) ? LX : NCOL;
+  __shared__ float At[EQC * AST];
   __shared__ int B12[2 * LX];
   const int scene = blockIdx.x, lane = threadIdx.x;
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
@@ -677,13 +679,13 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   }
   auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
   const double qd = vx ? (double)Md[lane] : 0.0;
-  for (int i = lane; i < EQC * LX; i += 64) At[i] = 0.0f;
+  for (int i = lane; i < EQC * AST; i += 64) At[i] = 0.0f;
   wsync();
-  for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * LX + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
+  for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * AST + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   wsync();
   int status = truncated;
   if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
-  auto acol = [&](int a) -> double { return (double)At[a * LX + lane]; };
+  auto acol = [&](int a) -> double { return (EQC <= 4 || lane < NCOL) ? (double)At[a * AST + lane] : 0.0; };
   auto Gv = [&](double v) -> double {                                     // (Jc v)_c
     xv[lane] = vx ? v : 0.0; wsync();
     double gn = 0;
@@ -712,7 +714,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
       for (int a = 0; a < EQC; ++a) { if (a < e) { const double sm = wave_sum(acol(a) * (vx ? v : 0.0)); if (lane == nz + a) out = sm; } }
     } else {
       xv[lane] = vx ? v : 0.0; wsync();
-      if (ve) { const float* ar = At + (lane - nz) * LX; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
+      if (ve) { const float* ar = At + (lane - nz) * AST; for (int k = 0; k < nz; ++k) out = fma((double)ar[k], xv[k], out); }
       wsync();
     }
     return out;
@@ -1036,7 +1038,7 @@ size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOT
 template <int NCOL, bool BWD, bool DENSE = false>
 static int primal_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, const DenseIO& DN = DenseIO{}) {
   if constexpr (!DENSE) {
-    if (SP.e > primal::EQB) {                                             // 5 .. 16 equality rows: chains of joints
+    if (SP.e > primal::EQB) {                                             // 5 .. 24 equality rows: chains of joints
       hipLaunchKernelGGL((primal::lcp_primal_kernel<NCOL, BWD, false, primal::WsLayout::YCAP>), dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, Gd, DN);
       return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
     }
@@ -1058,7 +1060,7 @@ template <bool BWD>
 static int primal_post_stab_launch(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) {
   const int n = 3 * SP.nb + SP.e;
   hipStream_t st = (hipStream_t)stream;
-  constexpr int E16 = primal::WsLayout::YCAP;
+  constexpr int E16 = primal::WsLayout::YCAP;                               // (24 rows)
   if (SP.e > primal::EQB) {                                                  // chains of joints
     if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24, BWD, E16>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
     else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40, BWD, E16>), dim3(SP.B), dim3(64), 0, st, SP, Gd);

@@ -433,7 +433,7 @@ class ContactWorld:
     step in torch's autograd graph (roll-out gradients, `demos/grad_demo.py`).  Joints: a constant Jacobian `Je`
     (Total/X/Y/Rot constraints) or a `JointSet` (revolute / fixed joints, Jacobian rebuilt every step and differentiated);
     at most 16 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the four-scenes-per-wave solver, up to
-    64 contacts and 16 equality rows (3 nb + e <= 56) on the wave-per-scene body-space solver (both with a fused backward),
+    64 contacts and 24 equality rows (3 nb + e <= 56) on the wave-per-scene body-space solver (both with a fused backward),
     anything else on the generic kernels (slower, forward only).
     `post_stab=True` (off by default, as in the reference: utils.py:30) adds the two launches of world.py:109-121 to a
     step: `lcp_post_stabilization_f32` (frictionless LCP + correction move) and a contact re-detection.

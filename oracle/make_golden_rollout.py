@@ -211,7 +211,7 @@ C_PARAMS = [(0.7, [0.0, 1.0, 0.0]), (1.2, [0.0, 1.2, 0.1]), (0.45, [0.0, 0.9, -0
             (1.5, [-0.1, 0.8, 0.0])]
 
 
-def make_world_chain(mass, f_proj):
+def make_world_chain(mass, f_proj, links=C_LINKS):
     from lcp_physics.physics.bodies import Circle, Rect
     from lcp_physics.physics.constraints import Joint
     from lcp_physics.physics.forces import ExternalForce, Gravity
@@ -220,7 +220,7 @@ def make_world_chain(mass, f_proj):
     r = Rect([300, 50], [20, 60], mass=mass)
     bodies.append(r)
     joints.append(Joint(r, None, [300, 30]))
-    for i in range(1, C_LINKS):
+    for i in range(1, links):
         r = Rect([300, 50 + 50 * i], [20, 60], mass=mass)
         r.add_force(Gravity(g=100))
         bodies.append(r)
@@ -232,29 +232,29 @@ def make_world_chain(mass, f_proj):
     return World(bodies, joints, dt=1.0 / 30, post_stab=True)
 
 
-def run_chain(mass0, force0):
+def run_chain(mass0, force0, links=C_LINKS, nsteps=C_NSTEPS):
     from lcp_physics.physics import constraints as C_
     from lcp_physics.physics.bodies import Circle
     from lcp_physics.physics.forces import ExternalForce
     mass = torch.tensor(mass0, dtype=torch.float64, requires_grad=True)
     f0 = torch.tensor(force0, dtype=torch.float64, requires_grad=True)
-    world = make_world_chain(mass, lambda t: f0 if t < T_PUSH else ExternalForce.ZEROS)
+    world = make_world_chain(mass, lambda t: f0 if t < T_PUSH else ExternalForce.ZEROS, links)
     nb = len(world.bodies)
     jt = {C_.Joint: 1, C_.FixedJoint: 2, C_.XConstraint: 3, C_.YConstraint: 4, C_.RotConstraint: 5, C_.TotalConstraint: 6}
     Md = torch.diagonal(world.M()).reshape(nb, 3).detach().numpy().copy()
-    rec = dict(Mdiag=Md, Mdiag_per_mass=np.concatenate([Md[:C_LINKS] / mass0, np.zeros((1, 3))]),
-               gravity_per_mass=np.array([[0.0, 0.0, 0.0]] + [[0.0, 0.0, 100.0]] * (C_LINKS - 1) + [[0.0, 0.0, 0.0]]),
+    rec = dict(Mdiag=Md, Mdiag_per_mass=np.concatenate([Md[:links] / mass0, np.zeros((1, 3))]),
+               gravity_per_mass=np.array([[0.0, 0.0, 0.0]] + [[0.0, 0.0, 100.0]] * (links - 1) + [[0.0, 0.0, 0.0]]),
                rest=np.array([float(b.restitution) for b in world.bodies]), fric=np.array([float(b.fric_coeff) for b in world.bodies]),
                kind=np.array([0 if isinstance(b, Circle) else 1 for b in world.bodies]),
                size=np.array([[float(b.rad), 0.0] if isinstance(b, Circle) else b.dims.numpy().tolist() for b in world.bodies]),
                jtype=np.array([jt[type(j[0])] for j in world.joints]), jb1=np.array([j[1] for j in world.joints]),
                jb2=np.array([-1 if j[2] is None else j[2] for j in world.joints]),
                jr1=np.array([float(j[0].r1) for j in world.joints]), jrot1=np.array([float(j[0].rot1) for j in world.joints]),
-               no_contact=np.array([[i, i - 1] for i in range(1, C_LINKS)]),
+               no_contact=np.array([[i, i - 1] for i in range(1, links)]),
                p0=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(),
                v0=world.get_v().reshape(nb, 3).detach().numpy().copy())
     ncs, ts = [], []
-    for _ in range(C_NSTEPS):
+    for _ in range(nsteps):
         world.step()
         ncs.append(len(world.contacts)); ts.append(float(world.t))
     pf = torch.stack([b.p for b in world.bodies])
@@ -266,13 +266,18 @@ def run_chain(mass0, force0):
     return rec
 
 
-def chain():
-    recs = [run_chain(m, f) for m, f in C_PARAMS]
-    out = {"c_" + k: np.stack([r[k] for r in recs]) for k in recs[0]}
-    out.update(c_mass=np.array([m for m, _ in C_PARAMS]), c_force=np.array([f for _, f in C_PARAMS]), c_nsteps=np.int64(C_NSTEPS),
-               c_mult=np.float64(1500.0))
+# the full size of experiments/inference.py: ten links, 20 equality rows, 11 bodies (three scenes)
+D_LINKS, D_NSTEPS = 10, 36
+D_PARAMS = [(0.7, [0.0, 1.0, 0.0]), (1.3, [0.0, 1.3, 0.1]), (0.5, [0.05, 0.9, -0.1])]
+
+
+def chain(prefix="c_", params=C_PARAMS, links=C_LINKS, nsteps=C_NSTEPS):
+    recs = [run_chain(m, f, links, nsteps) for m, f in params]
+    out = {prefix + k: np.stack([r[k] for r in recs]) for k in recs[0]}
+    out.update({prefix + "mass": np.array([m for m, _ in params]), prefix + "force": np.array([f for _, f in params]),
+                prefix + "nsteps": np.int64(nsteps), prefix + "mult": np.float64(1500.0)})
     for i, r in enumerate(recs):
-        print("c_", C_PARAMS[i], "loss %.4f" % r["loss"], "grad mass", np.array2string(r["grad_mass"], precision=5), "grad force",
+        print(prefix, params[i], "loss %.4f" % r["loss"], "grad mass", np.array2string(r["grad_mass"], precision=5), "grad force",
               np.array2string(r["grad_force"], precision=4), "steps with contact", np.nonzero(r["ncontacts"])[0].tolist(), "halved",
               int((np.diff(np.concatenate([[0.0], r["t"]])) < 0.99 / 30).sum()))
     return out
@@ -296,6 +301,7 @@ def main():
     jout = jointed("j_", make_world_pendulum, J_FORCES)
     jout.update(jointed("k_", make_world_dumbbell, K_FORCES))
     jout.update(chain())
+    jout.update(chain("d_", D_PARAMS, D_LINKS, D_NSTEPS))
     hrecs = [run_hulls(a, b) for a, b in H_FORCES]
     hout = {"h_" + k: np.stack([r[k] for r in hrecs]) for k in hrecs[0]}
     hout.update(h_force_ball=np.array([a for a, _ in H_FORCES]), h_force_box=np.array([b for _, b in H_FORCES]), h_nsteps=np.int64(H_NSTEPS))
