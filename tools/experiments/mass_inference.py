@@ -1,0 +1,63 @@
+"""The reference's `experiments/inference.py:26-89` on a batch: recover the mass of a chain's links from an observed trajectory by
+gradient descent through the simulator.  B scenes start from different guesses; every iteration rolls all of them out
+(`ContactWorld.step(differentiable=True)`: solve_dynamics, joints, contacts and post-stabilisation in the graph) and
+back-propagates the mean squared distance to the observed poses (RMSprop, lr 0.5, as in the reference, on log-mass).
+
+    python tools/experiments/mass_inference.py [--batch 64] [--links 10] [--steps 36] [--iters 40]
+
+Prints one JSON line: the recovered masses, the wall time per iteration (forward + backward of B roll-outs)."""
+import json, os, sys, time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from lcp_physics_amd import scenes
+    a = sys.argv[1:]
+    opt = lambda k, d: type(d)(a[a.index(k) + 1]) if k in a else d
+    B, links, steps, iters, true_mass = opt("--batch", 64), opt("--links", 10), opt("--steps", 36), opt("--iters", 40), opt("--mass", 0.7)
+    dev = "cuda"
+
+    def rollout(mass):
+        world = scenes.make_chain_world(mass.shape[0], links=links, mass=mass, device=dev)
+        poses = []
+        for _ in range(steps):
+            world.step(differentiable=True)
+            poses.append(world.p)
+        return torch.stack(poses, 1), world
+
+    with torch.no_grad():
+        observed, _ = rollout(torch.full((1,), true_mass, device=dev))
+    g = torch.Generator().manual_seed(0)
+    log_m = torch.log(0.3 + 1.7 * torch.rand(B, generator=g)).to(dev).requires_grad_(True)
+    start = log_m.detach().exp().cpu()
+    optim = torch.optim.RMSprop([log_m], lr=0.05)
+    times, hist = [], []
+    for it in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        optim.zero_grad()
+        poses, world = rollout(log_m.exp())
+        loss = ((poses - observed) ** 2).mean(dim=(1, 2, 3))
+        loss.sum().backward()
+        optim.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        hist.append(float(loss.detach().mean()))
+        if os.environ.get("LCP_VERBOSE"):
+            print(it, hist[-1], log_m.detach().exp()[:4].cpu().tolist(), log_m.grad[:4].cpu().tolist())
+    m = log_m.detach().exp().cpu()
+    times = sorted(times[2:])
+    print(json.dumps({"experiment": "mass inference through the simulator (experiments/inference.py), batched", "batch": B, "links": links,
+                      "equality_rows": 2 * links, "steps_per_rollout": steps, "iterations": iters, "true_mass": true_mass,
+                      "start_mass_min_max": [float(start.min()), float(start.max())],
+                      "recovered_mass_median": float(m.median()), "recovered_within_2pct": float(((m - true_mass).abs() < 0.02 * true_mass).float().mean()),
+                      "loss_first_last": [hist[0], hist[-1]], "s_per_iteration_median": times[len(times) // 2],
+                      "sim_steps_fwd_bwd_per_s": B * steps / times[len(times) // 2], "status_flags": int(world.sticky_status.max())}))
+
+
+if __name__ == "__main__":
+    main()
