@@ -583,8 +583,7 @@ class ContactWorld:
         if js is not None:                                                 # joint.move(dt): rot1 += body1.v[0] dt (constraints.py:39-43)
             self.Je = js.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
             if js.pose_dependent:
-                ar = torch.arange(v_new.shape[0], device=v_new.device).unsqueeze(1)
-                w1 = v_new[ar, js.jb1.long(), 0].to(torch.float64) * cb.dt_used.clone().reshape(-1, 1)
+                w1 = v_new[:, :, 0].gather(1, js.jb1.long()).to(torch.float64) * cb.dt_used.clone().reshape(-1, 1)
                 r_lin = self._jrot_ad + w1 * js.revolute_mask
                 self._jrot_ad, self._jrot_src = r_lin + (js.jrot1 - r_lin).detach(), self.p
         if self.post_stab:
@@ -610,8 +609,7 @@ class ContactWorld:
             if js is not None:
                 self.Je = js.jacobian(self.p.detach().contiguous(), v=dp_s.detach().contiguous(), dt_scene=dt_used, vscale=0.5)
                 if js.pose_dependent:
-                    ar = torch.arange(self.B, device=dp_s.device).unsqueeze(1)
-                    w1 = 0.5 * dp_s[ar, js.jb1.long(), 0].to(torch.float64) * dt_used.reshape(-1, 1)
+                    w1 = 0.5 * dp_s[:, :, 0].gather(1, js.jb1.long()).to(torch.float64) * dt_used.reshape(-1, 1)
                     r_lin = self._jrot_ad + w1 * js.revolute_mask
                     self._jrot_ad, self._jrot_src = r_lin + (js.jrot1 - r_lin).detach(), self.p
             ct.find_contacts(self.geom, self.p.detach().contiguous(), maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121

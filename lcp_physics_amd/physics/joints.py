@@ -107,55 +107,77 @@ class JointSet:
         _lib.check(rc, "lcp_joint_jacobian_f64")
         return out
 
-    def jacobian_torch(self, p, jrot1=None):
-        """The same Jacobian as a differentiable torch expression of the pose `p` [B,nb,3] (float64) and of the revolute joints'
-        angles `jrot1` [B,nj] (default: the state) - `Joint.J()` / `FixedJoint.J()` with `update_pos` (constraints.py:26-50,
-        64-85): pos1 = r1 (cos rot1, sin rot1), pos2 = body1.pos + pos1 - body2.pos.  Used for the GRADIENT of a
-        differentiable step (the values come from `jacobian()`); float64 [B,e,3nb].  The joint types are those of scene 0
-        (one list replicated over the batch: `from_list` / `from_arrays`); the bodies may differ per scene."""
-        B, nb = p.shape[0], p.shape[1]
-        dev = p.device
-        jrot1 = self.jrot1 if jrot1 is None else jrot1
-        types = self.__dict__.get("_types")
-        if types is None:
-            types = self.__dict__["_types"] = [int(t) for t in self.jtype[0].tolist()]
+    def _torch_plan(self, B, nb, dtype, dev):
+        """What `jacobian_torch` needs that does not change with the pose: the constant entries of Je ([B,e,3nb]) and, for the
+        revolute / fixed joints, the (batch, row, column) indices of their four pose-dependent entries - built once."""
+        key = (B, nb, dtype, str(dev))
+        plan = self.__dict__.get("_plan")
+        if plan is not None and plan["key"] == key:
+            return plan
+        types = [int(t) for t in self.jtype[0].tolist()]                  # (one list replicated over the batch)
         ar = torch.arange(B, device=dev)
-        one = torch.ones(B, dtype=p.dtype, device=dev)
-        bi, ri, ci, vals = [], [], [], []
-
-        def put(row, col, val):
-            bi.append(ar); ri.append(torch.full((B,), row, dtype=torch.long, device=dev)); ci.append(col); vals.append(val)
-
+        const = torch.zeros(B, self.e, 3 * nb, dtype=dtype, device=dev)
+        one = torch.ones(B, dtype=dtype, device=dev)
+        rows, ks = [], []
         row = 0
         for k, t in enumerate(types):
             b1 = self.jb1[:, k].long()
             if t in (JOINT, FIXED):
                 b2 = self.jb2[:, k].long()
-                has2 = (b2 >= 0).to(p.dtype)
+                has2 = (b2 >= 0).to(dtype)
                 b2c = b2.clamp_min(0)
-                if t == JOINT:
-                    pos1 = torch.stack([self.jr1[:, k] * torch.cos(jrot1[:, k]), self.jr1[:, k] * torch.sin(jrot1[:, k])], dim=1)
-                else:
-                    pos1 = torch.zeros(B, 2, dtype=p.dtype, device=dev)
-                pos2 = p[ar, b1, 1:] + pos1 - p[ar, b2c, 1:]
-                put(row, 3 * b1, -pos1[:, 1]); put(row, 3 * b1 + 1, one)                    # J1 = [[-pos1_y, 1, 0], [pos1_x, 0, 1]]
-                put(row + 1, 3 * b1, pos1[:, 0]); put(row + 1, 3 * b1 + 2, one)
-                put(row, 3 * b2c, has2 * pos2[:, 1]); put(row, 3 * b2c + 1, -has2)           # J2 = [[pos2_y, -1, 0], [-pos2_x, 0, -1]]
-                put(row + 1, 3 * b2c, -has2 * pos2[:, 0]); put(row + 1, 3 * b2c + 2, -has2)
+                const[ar, row, 3 * b1 + 1] += one; const[ar, row + 1, 3 * b1 + 2] += one          # J1 = [[-pos1_y, 1, 0], [pos1_x, 0, 1]]
+                const[ar, row, 3 * b2c + 1] -= has2; const[ar, row + 1, 3 * b2c + 2] -= has2      # J2 = [[pos2_y, -1, 0], [-pos2_x, 0, -1]]
                 if t == FIXED:
-                    put(row + 2, 3 * b1, one); put(row + 2, 3 * b2c, -has2)
+                    const[ar, row + 2, 3 * b1] += one; const[ar, row + 2, 3 * b2c] -= has2
+                rows.append(row); ks.append(k)
             elif t == XCON:
-                put(row, 3 * b1 + 1, one)
+                const[ar, row, 3 * b1 + 1] += one
             elif t == YCON:
-                put(row, 3 * b1 + 2, one)
+                const[ar, row, 3 * b1 + 2] += one
             elif t == ROTCON:
-                put(row, 3 * b1, one)
+                const[ar, row, 3 * b1] += one
             elif t == TOTAL:
                 for q in range(3):
-                    put(row + q, 3 * b1 + q, one)
+                    const[ar, row + q, 3 * b1 + q] += one
             row += ROWS.get(t, 0)
-        Je = torch.zeros(B, self.e, 3 * nb, dtype=p.dtype, device=dev)
-        if vals:
-            Je = Je.index_put((torch.cat(bi), torch.cat(ri), torch.cat(ci)), torch.cat(vals), accumulate=True)
-        return Je
+        plan = {"key": key, "const": const, "ks": ks}
+        if ks:
+            nz = 3 * nb
+            kk = torch.tensor(ks, dtype=torch.long, device=dev)
+            r0 = torch.tensor(rows, dtype=torch.long, device=dev).unsqueeze(0).expand(B, -1)     # [B,njf]
+            b1 = self.jb1[:, kk].long()
+            b2 = self.jb2[:, kk].long()
+            b2c = b2.clamp_min(0)
+            c2 = torch.where(b2 >= 0, 3 * b2c, torch.full_like(b2c, nz))                          # no second body: a spare column
+            ri = torch.stack([r0, r0 + 1, r0, r0 + 1], dim=2)
+            ci = torch.stack([3 * b1, 3 * b1, c2, c2], dim=2)
+            ext = torch.zeros(B, self.e, nz + 1, dtype=dtype, device=dev)
+            ext[:, :, :nz] = const
+            gi = lambda b: b.unsqueeze(-1).expand(-1, -1, 2).contiguous()
+            plan.update(kk=kk, g1=gi(b1), g2=gi(b2c), has2=(b2 >= 0).to(dtype), rev=(self.jtype[:, kk] == JOINT).to(dtype),
+                        ext=ext.reshape(B, -1), flat=(ri * (nz + 1) + ci).reshape(B, -1), nz=nz)
+        self.__dict__["_plan"] = plan
+        return plan
 
+    def jacobian_torch(self, p, jrot1=None):
+        """The same Jacobian as a differentiable torch expression of the pose `p` [B,nb,3] (float64) and of the revolute joints'
+        angles `jrot1` [B,nj] (default: the state) - `Joint.J()` / `FixedJoint.J()` with `update_pos` (constraints.py:26-50,
+        64-85): pos1 = r1 (cos rot1, sin rot1), pos2 = body1.pos + pos1 - body2.pos.  Used for the GRADIENT of a
+        differentiable step (the values come from `jacobian()`); float64 [B,e,3nb].  The joint types are those of scene 0
+        (one list replicated over the batch: `from_list` / `from_arrays`); the bodies may differ per scene.  A dozen tensor
+        operations whatever the number of joints (the index plan is built once)."""
+        B, nb = p.shape[0], p.shape[1]
+        plan = self._torch_plan(B, nb, p.dtype, p.device)
+        if not plan["ks"]:
+            return plan["const"]
+        jrot1 = self.jrot1 if jrot1 is None else jrot1
+        kk, has2, rev, nz = plan["kk"], plan["has2"], plan["rev"], plan["nz"]
+        r1, th = self.jr1[:, kk] * rev, jrot1[:, kk]                      # (a FixedJoint's anchor is body 1 itself: pos1 = 0)
+        pos1 = torch.stack([r1 * torch.cos(th), r1 * torch.sin(th)], dim=2)                       # [B,njf,2]
+        pxy = p[:, :, 1:]
+        pos2 = pxy.gather(1, plan["g1"]) + pos1 - pxy.gather(1, plan["g2"])
+        vals = torch.stack([-pos1[..., 1], pos1[..., 0], has2 * pos2[..., 1], -has2 * pos2[..., 0]], dim=2)
+        # the four pose-dependent entries of every such joint land on distinct zeros of the constant part: one scatter
+        Je = plan["ext"].scatter(1, plan["flat"], vals.reshape(B, -1))
+        return Je.reshape(B, self.e, nz + 1)[:, :, :nz].contiguous()
