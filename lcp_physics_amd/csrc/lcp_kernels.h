@@ -119,6 +119,7 @@ bool primal_dense_supported(int nz, int m, int e);    // dense boundary, post-st
 size_t primal_ws_bytes();
 int primal_step(const StepArgs& P, void* stream);
 int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
+int primal_chain_launch(const StepArgs& P, const StepBwdArgs& G, int backward, void* stream);   // lcp_primal_chain.hip: 5 .. 24 equality rows
 int primal_post_stab_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);   // lcp.py:37-64 on that LCP, contracted through engines.py:84-112
 int primal_post_stab(const StepArgs& P, void* stream);                                         // engines.py:80-116 in body space
 int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);      // scenes of class 3

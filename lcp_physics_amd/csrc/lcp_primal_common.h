@@ -1,0 +1,33 @@
+// lcp_primal_common.h - what the three translation units of the body-space kernels share (lcp_primal.hip: the step and the
+// dense boundary at up to 4 equality rows; lcp_primal_chain.hip: the step with 5 .. 24 equality rows; lcp_primal_poststab.hip:
+// post-stabilisation): constants, the workspace layout, small device helpers.
+#pragma once
+#include "lcp_wave_scene.h"
+
+namespace lcp {
+namespace primal {
+
+using namespace w64;
+using namespace wsc;
+
+constexpr int LX = 64;           // lanes = stride of the stored iterate
+constexpr int EQB = 4;           // padded neq
+// workspace per scene (doubles): a 64-entry header (contact count), then the best iterate the backward needs, in the layout
+// lcp_big.hip uses, with room for 24 equality multipliers: x[64] y[24] z[4][64] s[4][64] mu[64] diag(Q)[64]
+struct WsLayout { static constexpr int IT = 64, YCAP = 24, ZO = 64 + YCAP, TOTAL = IT + ZO + 10 * LX; };
+constexpr int ZO = WsLayout::ZO;     // offset of z in the iterate block
+
+#ifdef LCP_PRIMAL_PROFILE
+#define PR_TICK(i) { const long long now_ = clock64(); pc[i] += now_ - tk; tk = now_; }
+#else
+#define PR_TICK(i)
+#endif
+
+// keeps a wave-uniform value in scalar registers at this point (the batches of pivot-row broadcasts stay batches)
+__device__ __forceinline__ void sgpr_pin(double& v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ds_add_f64 (no return)
+}
+
+}  // namespace primal
+}  // namespace lcp
