@@ -1,6 +1,6 @@
 // lcp_primal_chain.hip - the body-space step kernel (lcp_primal.hip, lcp_primal_step.inc) instantiated for 5 .. 24 equality rows:
 // chains of joints (two rows per revolute `Joint`, constraints.py:13-50 - the reference's chain demo, `testChain`, the ten links
-// of experiments/inference.py).  The rows of A live packed in LDS (stride NCOL), every equality lane sums its own row for A v.
+// of experiments/inference.py).  The rows of A live packed in LDS (e x nz floats), every equality lane sums its own row for A v.
 // A translation unit of its own so that the build compiles the instantiations in parallel.
 #include "lcp_primal_common.h"
 

@@ -14,6 +14,12 @@ constexpr int LX = 64;           // lanes = stride of the stored iterate
 constexpr int EQB = 4;           // padded neq
 // workspace per scene (doubles): a 64-entry header (contact count), then the best iterate the backward needs, in the layout
 // lcp_big.hip uses, with room for 24 equality multipliers: x[64] y[24] z[4][64] s[4][64] mu[64] diag(Q)[64]
+// floats the packed A image needs: e rows of nz <= NCOL - e entries, e <= eqc
+constexpr int at_cap(int ncol, int eqc) {
+  int m = 0;
+  for (int e = 1; e <= eqc; ++e) { const int v = e * (ncol - e); if (v > m) m = v; }
+  return m;
+}
 struct WsLayout { static constexpr int IT = 64, YCAP = 24, ZO = 64 + YCAP, TOTAL = IT + ZO + 10 * LX; };
 constexpr int ZO = WsLayout::ZO;     // offset of z in the iterate block
 

@@ -16,11 +16,12 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   constexpr int LDK = NCOL + 1;
   __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];
   __shared__ double xv[LX];
-  constexpr int AST = (EQC <= 4) ? LX : NCOL;
-  __shared__ float At[EQC * AST];
+  constexpr int ASZ = (EQC <= 4) ? EQC * LX : at_cap(NCOL, EQC);    // the A image: rows of 64 (few rows) or packed e x nz (many rows)
+  __shared__ float At[ASZ];
   __shared__ int B12[2 * LX];
   const int scene = blockIdx.x, lane = threadIdx.x;
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
+  const int AST = (EQC <= 4) ? LX : nz;                                      // row stride of the A image
   // workspace per scene (when given): the count and the best iterate, for the backward: [ncs .. | x[64] y[16] z[64] s[64]]
   double* Wg = SP.ws ? (double*)SP.ws + (size_t)scene * (size_t)WsLayout::TOTAL : nullptr;
   double* Wit = Wg ? Wg + WsLayout::IT : nullptr;
@@ -47,13 +48,13 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   }
   auto colq = [&](int q) { return q < 3 ? c0 + q : c1 + (q - 3); };
   const double qd = vx ? (double)Md[lane] : 0.0;
-  for (int i = lane; i < EQC * AST; i += 64) At[i] = 0.0f;
+  for (int i = lane; i < ASZ; i += 64) At[i] = 0.0f;
   wsync();
   for (int i = lane; i < e * nz; i += 64) { const int a = i / nz, k = i - a * nz; At[a * AST + k] = ((const float*)SP.Je)[(size_t)scene * e * nz + i]; }
   wsync();
   int status = truncated;
   if (__any(vx && !(qd != 0.0))) status |= LCP_ST_SINGULAR_Q;
-  auto acol = [&](int a) -> double { return (EQC <= 4 || lane < NCOL) ? (double)At[a * AST + lane] : 0.0; };
+  auto acol = [&](int a) -> double { return (EQC <= 4 || lane < nz) ? (double)At[a * AST + lane] : 0.0; };
   auto Gv = [&](double v) -> double {                                     // (Jc v)_c
     xv[lane] = vx ? v : 0.0; wsync();
     double gn = 0;
