@@ -996,6 +996,20 @@ def test_rollout_gradient_through_a_chain_with_post_stabilization_matches_the_re
     if os.environ.get("LCP_TEST_VERBOSE"):
         print(np.array2string(got, precision=5)); print(np.array2string(ref, precision=5))
     assert err[same].max() <= 1e-4, err
+    # the same roll-out with the plain `step()` (joints + post-stabilisation, no autograd): every accepted dt and every contact
+    # count of the reference's run, step by step, and its final poses
+    with torch.no_grad():
+        joints2 = JointSet.from_arrays(d["jtype"][0], d["jb1"][0], d["jb2"][0], d["jr1"][0], d["jrot1"][0], B).to(DEV)
+        plain = ContactWorld(geom, rp(d["p0"], torch.float64), rp(d["v0"], torch.float32), Mdiag.detach(), torch.zeros(B, nb, 3, device=DEV),
+                             rp(d["rest"], torch.float32), rp(d["fric"], torch.float32), joints=joints2, dt=float(d0["dt"]), maxc=8,
+                             force_fn=force_fn, post_stab=True)
+        on_track = np.ones(nv, dtype=bool)
+        for k in range(int(d["nsteps"])):
+            plain.step()
+            on_track &= (np.abs(plain.t.cpu().numpy()[::rep] - d["t"][:, k]) < 1e-12) & (plain.contacts.count.cpu().numpy()[::rep] == d["ncontacts"][:, k])
+        assert on_track.sum() >= nv - 1 and on_track.sum() >= 2, on_track.tolist()
+        pf2 = plain.p.cpu().numpy()[::rep]
+        assert np.abs(pf2 - d["p_final"])[on_track].max() <= 2e-3, np.abs(pf2 - d["p_final"])[on_track].max()
 
 
 def test_mass_inference_through_differentiable_rollouts_recovers_the_mass():

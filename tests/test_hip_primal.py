@@ -325,7 +325,7 @@ def _with_joint_rows(sc, e_target):
     return sc
 
 
-@pytest.mark.parametrize("nbox,pts,e", [(4, 2, 7), (4, 4, 12), (8, 2, 12), (8, 2, 16), (12, 2, 16), (8, 2, 24), (10, 2, 20)])
+@pytest.mark.parametrize("nbox,pts,e", [(4, 2, 7), (4, 4, 12), (8, 2, 12), (8, 2, 16), (12, 2, 16), (8, 2, 24), (10, 2, 20), (11, 2, 20)])
 def test_chains_of_joints_up_to_24_equality_rows(nbox, pts, e):
     """5 .. 24 equality rows (a chain of revolute joints has two per link: the reference's chain demo, `testChain`, the ten links
     of experiments/inference.py) run on the body-space kernel's 24-row instantiation, forward and backward: new_v, y against the generic kernel and the oracle; the
