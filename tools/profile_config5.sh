@@ -20,7 +20,7 @@ f=$(find $OUT/prof_${TAG}_c5_trace -name "*.db" | head -1)
 python tools/rocprof_summary.py $f > $OUT/prof_${TAG}_config5_kernel_stats.txt
 python tools/pmc_summary.py $OUT/prof_${TAG}_c5_pmc_* > $OUT/prof_${TAG}_config5_pmc.txt
 rm -rf $OUT/prof_${TAG}_c5_*/
-if [ -f tools/liblcp_primalprof.so ]; then      # lcp_primal.hip built with -DLCP_PRIMAL_PROFILE: cycles per phase
+if [ -f tools/liblcp_primalprof.so ]; then      # `make -C lcp_physics_amd/csrc primalprof`: lcp_primal.hip with -DLCP_PRIMAL_PROFILE, cycles per phase
   LCP_HIP_LIB=$ROOT/tools/liblcp_primalprof.so timeout 200 python tools/bench_config5.py ${BATCH:-4096} > $OUT/prof_${TAG}_config5_phases.txt 2>&1
 fi
 timeout 200 python tools/bench_config5.py ${BATCH:-4096} big > $OUT/prof_${TAG}_config5_contact_space.txt 2>&1
