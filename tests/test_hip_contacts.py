@@ -1041,3 +1041,22 @@ def test_mass_inference_through_differentiable_rollouts_recovers_the_mass():
     m = log_m.detach().exp().cpu()
     assert bool((loss.detach() < 1e-3 * first).all()), (first.tolist(), loss.tolist())
     assert float((m - true_mass).abs().max()) < 0.01 * true_mass, m.tolist()
+
+
+@pytest.mark.parametrize("post_stab", [False, True])
+def test_chain_world_graph_replay_is_bitwise_the_eager_run(post_stab):
+    """The jointed world under HIP-graph replay: `ContactWorld.run(n, graph=True)` on chains of four links (joint Jacobian rebuilt
+    on the device every step, a time-dependent push, with and without post-stabilisation) against the eager run, bit for bit."""
+    from lcp_physics_amd import scenes
+    B, n = 6, 25
+    mass = torch.linspace(0.5, 1.5, B)
+    a = scenes.make_chain_world(B, links=4, mass=mass, device=DEV, post_stab=post_stab)
+    b = scenes.make_chain_world(B, links=4, mass=mass, device=DEV, post_stab=post_stab)
+    for _ in range(n):
+        a.step()
+    b.run(n, graph=True)
+    torch.cuda.synchronize()
+    assert len(b._graphs) >= 1
+    assert torch.equal(a.p, b.p) and torch.equal(a.v, b.v) and torch.equal(a.t, b.t) and torch.equal(a.Je, b.Je)
+    assert torch.equal(a.contacts.count, b.contacts.count) and torch.equal(a.joints.jrot1, b.joints.jrot1)
+    assert float(a.t.min()) > 0.4 and float((a.p[:, :4, 0].abs().max())) > 0.05          # the chain was hit and swings
