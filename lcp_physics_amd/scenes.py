@@ -257,51 +257,82 @@ def make_drop_world(B, nbox=4, box=40.0, seed=2024, gap=(0.3, 2.0), xjit=6.0):
                 Je=f32(Je))
 
 
-def make_chain_world(B, links=10, mass=1.0, push=(0.0, 1.0, 0.0), projectile_x=231.7, device="cuda", post_stab=True, maxc=8, dt=1.0 / 30,
-                     push_time=0.1, push_multiplier=1500.0):
+class ChainWorlds:
     """The scene of the reference's `experiments/inference.py:92-125`, B times: a chain of `links` rectangles 20 x 60 hinged by
     revolute joints (the first one to the world, 2 equality rows each), gravity on all links but the first, and a projectile
-    (disc of radius 20, restitution 1) pushed towards the last link for `push_time` seconds.  `mass` ([B] tensor or float: the
-    mass of every link - inertia, mass and gravity follow it, bodies.py:44-47,269-270, forces.py:51-67) and `push` ([B,3] or 3
-    floats, times `push_multiplier`: forces.py:29-48) may require grad.  Returns a `ContactWorld` (differentiable with
-    `step(differentiable=True)`)."""
-    from .physics.batched_world import ContactWorld
-    from .physics.contacts import GeometryBatch
-    from .physics.joints import JointSet
-    nb = links + 1
-    f32 = lambda t: torch.as_tensor(t, dtype=torch.float32, device=device)
-    mass = f32(mass).expand(B) if f32(mass).dim() == 0 else f32(mass)
-    push = f32(push).expand(B, 3) if f32(push).dim() == 1 else f32(push)
-    shapes = [("rect", (20.0, 60.0))] * links + [("circle", 20.0)]
-    geom = GeometryBatch.from_shapes(shapes, B)
-    nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
-    for i in range(1, links):                                                   # bodies[-1].add_no_contact(bodies[-2])
-        nocon[:, i, i - 1] = nocon[:, i - 1, i] = 1
-    geom.no_contact = nocon
-    geom = geom.to(device)
-    p0 = torch.zeros(nb, 3, dtype=torch.float64)
-    for i in range(links):
-        p0[i, 1], p0[i, 2] = 300.0, 50.0 + 50.0 * i
-    p0[links, 1], p0[links, 2] = projectile_x, float(p0[links - 1, 2]) + 3.3
-    joints = [("joint", 0, None, (300.0, 30.0))] + [("joint", i, i - 1, (300.0, 25.0 + 50.0 * i)) for i in range(1, links)]
-    js = JointSet.from_list(joints, p0, B=B).to(device)
-    per_mass = torch.zeros(nb, 3, dtype=torch.float32, device=device)
-    per_mass[:links] = f32([(20.0 ** 2 + 60.0 ** 2) / 12.0, 1.0, 1.0])         # Rect: inertia = mass (w^2 + h^2) / 12
-    fixed = torch.zeros(nb, 3, dtype=torch.float32, device=device)
-    fixed[links] = f32([0.5 * 20.0 ** 2, 1.0, 1.0])                             # Circle of mass 1: inertia = mass r^2 / 2
-    Mdiag = per_mass.unsqueeze(0) * mass.reshape(B, 1, 1) + fixed.unsqueeze(0)
-    grav = torch.zeros(nb, 3, dtype=torch.float32, device=device)
-    grav[1:links, 2] = 100.0                                                    # Gravity(g=100) on every link but the first
-    sel = torch.zeros(1, nb, 1, dtype=torch.float32, device=device)
-    sel[0, links, 0] = 1.0
+    (disc of radius 20, restitution 1) pushed towards the last link for `push_time` seconds.
 
-    def force_fn(t):
-        on = (t < push_time).to(torch.float32).reshape(B, 1, 1)
-        return grav.unsqueeze(0) * mass.reshape(B, 1, 1) + sel * (push * push_multiplier).unsqueeze(1) * on
+        chains = ChainWorlds(B, links=10)
+        world = chains.world(mass, push)          # a fresh `ContactWorld` at the initial pose
 
-    rest = torch.full((B, nb), 0.5, dtype=torch.float32, device=device)
-    rest[:, links] = 1.0
-    fric = torch.full((B, nb), 0.9, dtype=torch.float32, device=device)
-    p = p0.unsqueeze(0).repeat(B, 1, 1).to(device)
-    return ContactWorld(geom, p, torch.zeros(B, nb, 3, device=device), Mdiag, torch.zeros(B, nb, 3, device=device), rest, fric, joints=js,
-                        dt=dt, maxc=maxc, force_fn=force_fn, post_stab=post_stab)
+    `mass` ([B] tensor or float: the mass of every link - inertia, mass and gravity follow it, bodies.py:44-47,269-270,
+    forces.py:51-67) and `push` ([B,3] or 3 floats, times `push_multiplier`: forces.py:29-48) may require grad; the world is
+    differentiable with `step(differentiable=True)`.  Everything that needs the host (shapes, joint anchors, index plans) is
+    prepared once in the constructor: `world()` issues device work only, so a whole roll-out - forward and backward - can be
+    captured into a HIP graph (tools/experiments/mass_inference.py --graph)."""
+
+    def __init__(self, B, links=10, projectile_x=231.7, device="cuda", post_stab=True, maxc=8, dt=1.0 / 30, push_time=0.1,
+                 push_multiplier=1500.0):
+        from .physics.contacts import GeometryBatch
+        from .physics.joints import JointSet
+        self.B, self.links, self.nb, self.device = B, links, links + 1, device
+        self.post_stab, self.maxc, self.dt, self.push_time, self.push_multiplier = post_stab, maxc, dt, push_time, push_multiplier
+        nb = self.nb
+        f32 = lambda t: torch.as_tensor(t, dtype=torch.float32, device=device)
+        shapes = [("rect", (20.0, 60.0))] * links + [("circle", 20.0)]
+        geom = GeometryBatch.from_shapes(shapes, B)
+        nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
+        for i in range(1, links):                                                   # bodies[-1].add_no_contact(bodies[-2])
+            nocon[:, i, i - 1] = nocon[:, i - 1, i] = 1
+        geom.no_contact = nocon
+        self.geom = geom.to(device)
+        p0 = torch.zeros(nb, 3, dtype=torch.float64)
+        for i in range(links):
+            p0[i, 1], p0[i, 2] = 300.0, 50.0 + 50.0 * i
+        p0[links, 1], p0[links, 2] = projectile_x, float(p0[links - 1, 2]) + 3.3
+        joints = [("joint", 0, None, (300.0, 30.0))] + [("joint", i, i - 1, (300.0, 25.0 + 50.0 * i)) for i in range(1, links)]
+        self.joints = JointSet.from_list(joints, p0, B=B).to(device)
+        self.p0 = p0.unsqueeze(0).repeat(B, 1, 1).to(device)
+        self.per_mass = torch.zeros(nb, 3, dtype=torch.float32, device=device)
+        self.per_mass[:links] = f32([(20.0 ** 2 + 60.0 ** 2) / 12.0, 1.0, 1.0])     # Rect: inertia = mass (w^2 + h^2) / 12
+        self.fixed = torch.zeros(nb, 3, dtype=torch.float32, device=device)
+        self.fixed[links] = f32([0.5 * 20.0 ** 2, 1.0, 1.0])                         # Circle of mass 1: inertia = mass r^2 / 2
+        self.grav = torch.zeros(nb, 3, dtype=torch.float32, device=device)
+        self.grav[1:links, 2] = 100.0                                                # Gravity(g=100) on every link but the first
+        self.sel = torch.zeros(1, nb, 1, dtype=torch.float32, device=device)
+        self.sel[0, links, 0] = 1.0
+        self.rest = torch.full((B, nb), 0.5, dtype=torch.float32, device=device)
+        self.rest[:, links] = 1.0
+        self.fric = torch.full((B, nb), 0.9, dtype=torch.float32, device=device)
+        self.zeros = torch.zeros(B, nb, 3, dtype=torch.float32, device=device)
+        self.unit_push = f32([0.0, 1.0, 0.0]).expand(B, 3)                            # ExternalForce.RIGHT
+        if str(device).startswith("cuda"):                                          # the joints' host-side plans (one device read each)
+            self.joints.pose_dependent; self.joints.revolute_mask; self.joints._torch_plan(B, nb, torch.float64, self.p0.device)
+
+    def world(self, mass=1.0, push=None):
+        """`mass`, `push`: floats / sequences (copied to the device: not inside a graph capture) or device tensors."""
+        from .physics.batched_world import ContactWorld
+        from .physics.joints import JointSet
+        B, nb, dev = self.B, self.nb, self.device
+        f32 = lambda t: t.to(torch.float32) if torch.is_tensor(t) and t.device.type == torch.device(dev).type else torch.as_tensor(t, dtype=torch.float32, device=dev)
+        mass = f32(mass)
+        mass = mass.expand(B) if mass.dim() == 0 else mass
+        push = self.unit_push if push is None else f32(push)
+        push = push.expand(B, 3) if push.dim() == 1 else push
+        j0 = self.joints
+        js = JointSet(j0.jtype, j0.jb1, j0.jb2, j0.jr1, j0.jrot1.clone(), j0.e)      # fresh joint state, shared plans
+        js.__dict__.update({k: v for k, v in j0.__dict__.items() if k.startswith("_")})
+        Mdiag = self.per_mass.unsqueeze(0) * mass.reshape(B, 1, 1) + self.fixed.unsqueeze(0)
+        grav, sel, t_push, mult = self.grav, self.sel, self.push_time, self.push_multiplier
+
+        def force_fn(t):
+            on = (t < t_push).to(torch.float32).reshape(B, 1, 1)
+            return grav.unsqueeze(0) * mass.reshape(B, 1, 1) + sel * (push * mult).unsqueeze(1) * on
+
+        return ContactWorld(self.geom, self.p0.clone(), self.zeros.clone(), Mdiag, self.zeros, self.rest, self.fric, joints=js, dt=self.dt,
+                            maxc=self.maxc, force_fn=force_fn, post_stab=self.post_stab, check=False)
+
+
+def make_chain_world(B, links=10, mass=1.0, push=None, device="cuda", **kw):
+    """One world of `ChainWorlds` (see there)."""
+    return ChainWorlds(B, links=links, device=device, **kw).world(mass, push)

@@ -1060,3 +1060,48 @@ def test_chain_world_graph_replay_is_bitwise_the_eager_run(post_stab):
     assert torch.equal(a.p, b.p) and torch.equal(a.v, b.v) and torch.equal(a.t, b.t) and torch.equal(a.Je, b.Je)
     assert torch.equal(a.contacts.count, b.contacts.count) and torch.equal(a.joints.jrot1, b.joints.jrot1)
     assert float(a.t.min()) > 0.4 and float((a.p[:, :4, 0].abs().max())) > 0.05          # the chain was hit and swings
+
+
+def test_differentiable_rollout_captured_in_a_hip_graph_equals_the_eager_run():
+    """A whole differentiable roll-out - `scenes.ChainWorlds.world()`, 12 `step(differentiable=True)` with joints and
+    post-stabilisation, the loss and its backward - captured into one HIP graph (`torch.cuda.graph`): every launch of the C ABI
+    goes to the capturing stream, nothing touches the host.  Replayed with new parameter values it must return the loss and the
+    gradient of the eager run, bit for bit."""
+    from lcp_physics_amd import scenes
+    B, links, steps = 8, 4, 12
+    chains = scenes.ChainWorlds(B, links=links, device=DEV)
+    target = chains.p0 + torch.tensor([0.2, 20.0, -5.0], dtype=torch.float64, device=DEV)
+
+    def loss_of(mass, push):
+        world = chains.world(mass, push)
+        for _ in range(steps):
+            world.step(differentiable=True)
+        return ((world.p - target) ** 2).mean(dim=(1, 2))
+
+    mass = torch.linspace(0.5, 1.6, B, device=DEV).requires_grad_(True)
+    push = (torch.tensor([0.0, 1.0, 0.05], device=DEV) * torch.linspace(0.8, 1.3, B, device=DEV).unsqueeze(1)).requires_grad_(True)
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            mass.grad = push.grad = None
+            loss_of(mass, push).sum().backward()
+    torch.cuda.current_stream().wait_stream(side)
+    mass.grad = push.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_g = loss_of(mass, push)
+        loss_g.sum().backward()
+    with torch.no_grad():                                        # new parameter values in the captured tensors
+        mass.mul_(1.1); push.mul_(0.95)
+    g.replay()
+    torch.cuda.synchronize()
+    got = (loss_g.clone(), mass.grad.clone(), push.grad.clone())
+    m2, p2 = mass.detach().clone().requires_grad_(True), push.detach().clone().requires_grad_(True)
+    loss_e = loss_of(m2, p2)
+    loss_e.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], loss_e.detach()) and torch.equal(got[1], m2.grad) and torch.equal(got[2], p2.grad)
+    assert float(m2.grad.abs().min()) > 0.0
