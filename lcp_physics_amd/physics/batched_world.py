@@ -468,6 +468,7 @@ class ContactWorld:
                 raise ValueError("give either a constant Je or a JointSet")
             self.e = joints.e
             self.Je = joints.jacobian(self.p)
+            self._jrot0 = joints.jrot1.clone()                              # (for `restart`)
         else:
             self.e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
             self.Je = f32(Je) if self.e else None
@@ -486,6 +487,24 @@ class ContactWorld:
             self.check_capacity()
             if self.strict and bool((self.contacts.max_pen > self.tol).any()):
                 raise AssertionError("Interpenetration at start (world.py:68-70)")
+
+    def restart(self, p, v=None, jrot1=None, t=0.0):
+        """Put the world back at pose `p` [B,nb,3] with velocities `v` (default: at rest), joint angles `jrot1` (default: those
+        the `JointSet` had when the world was built) and clock `t`: contacts re-detected, joint Jacobian rebuilt - device work
+        only (no host check), so that a roll-out which starts with `restart` can be captured into a HIP graph.  `p` / `v` may
+        require grad (differentiable steps); `Mdiag`, `f`, `rest`, `fric`, `force_fn` are plain attributes and can be reassigned."""
+        own = lambda x, dt_: x.to(dt_).contiguous() if x.requires_grad else x.detach().to(dt_).clone().contiguous()
+        self.p = own(p, torch.float64)
+        self.v = torch.zeros(self.B, self.nb, 3, dtype=torch.float32, device=self.p.device) if v is None else own(v, torch.float32)
+        self.t.fill_(float(t))
+        self._p_geom_src = self._jrot_src = None
+        self._graphs, self._phase = {}, 0
+        pd = self.p.detach()
+        if self.joints is not None:
+            self.joints.jrot1.copy_(self._jrot0 if jrot1 is None else jrot1)
+            self.Je = self.joints.jacobian(pd)
+        self.contacts = self._contacts_mod.find_contacts(self.geom, pd, maxc=self.maxc, eps=self.eps)
+        return self
 
     def check_capacity(self):
         """Host check (synchronises): no scene produced more than `maxc` contacts."""

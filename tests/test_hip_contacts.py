@@ -1105,3 +1105,44 @@ def test_differentiable_rollout_captured_in_a_hip_graph_equals_the_eager_run():
     torch.cuda.synchronize()
     assert torch.equal(got[0], loss_e.detach()) and torch.equal(got[1], m2.grad) and torch.equal(got[2], p2.grad)
     assert float(m2.grad.abs().min()) > 0.0
+
+
+def test_grad_demo_rollout_from_one_hip_graph_equals_the_eager_run_and_the_reference():
+    """`ContactWorld.restart` + 36 differentiable steps + loss + backward of the batched `grad_demo` captured into ONE HIP graph:
+    replayed, it returns the gradients of the eager run bit for bit - hence the reference's (rollout_grad.npz) to 1e-4."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    rep = 16
+    world, force0 = _rollout_world(d, rep)
+    p0, v0 = world.p.clone(), world.v.clone()
+    a, b = [int(i) for i in d["loss_bodies"]]
+
+    def loss_of():
+        world.restart(p0, v0)
+        for _ in range(int(d["nsteps"])):
+            world.step(differentiable=True)
+        pos = world.p[:, :, 1:]
+        return (pos[:, a] - pos[:, b]).norm(dim=1)
+
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            force0.grad = None
+            loss_of().sum().backward()
+    torch.cuda.current_stream().wait_stream(side)
+    eager = force0.grad.clone()
+    force0.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_g = loss_of()
+        loss_g.sum().backward()
+    force0.grad.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(force0.grad, eager)
+    gr = force0.grad.cpu().numpy()[::rep]
+    err = np.abs(gr - d["grad"]).max(axis=1) / np.abs(d["grad"]).max(axis=1)
+    assert err.max() <= 1e-4, err
+    assert np.abs(loss_g.detach().cpu().numpy()[::rep] - d["loss"]).max() <= 1e-5 * np.abs(d["loss"]).max()
