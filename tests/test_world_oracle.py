@@ -164,3 +164,40 @@ def test_jointset_torch_jacobian_matches_oracle_and_reference_and_is_differentia
             args_b = (b_.reshape(t.shape), rot) if t is p else (p, b_.reshape(t.shape))
             ff[i] = (fun(*args_a) - fun(*args_b)) / (2 * h)
         assert (fd - g).abs().max() < 1e-6, (fd - g).abs().max()
+
+
+@pytest.mark.parametrize("scene", ["j_", "k_", "c_", "d_"])
+def test_world_oracle_follows_the_reference_rollouts_with_joints_and_post_stabilization(scene):
+    """The oracle's `step_dt` against the roll-outs the unmodified reference recorded for the gradient fixtures
+    (oracle/make_golden_rollout.py): "j_" a double pendulum and "k_" a welded dumbbell hitting a ball (joints whose Jacobian
+    follows the pose), "c_" / "d_" chains of four / ten links with `post_stab=True` (joints AND post-stabilisation in one
+    world - no other fixture has both).  Every accepted dt, every contact count, the final poses to 1e-9."""
+    import os
+    d0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    d = {k[2:]: d0[k] for k in d0.files if k.startswith(scene)}
+    chain = scene in ("c_", "d_")
+    for s in range(d["p0"].shape[0]):
+        if chain:
+            shapes = [("circle", float(a[0])) if int(k) == 0 else ("rect", (float(a[0]), float(a[1]))) for k, a in zip(d["kind"][s], d["size"][s])]
+            grav = d["gravity_per_mass"][s] * d["mass"][s]
+            pushes = {len(shapes) - 1: d["force"][s] * float(d["mult"])}
+        else:
+            shapes = [("circle", float(r)) for r in d["rad"][s]]
+            grav = d["gravity"][s]
+            pushes = {0: d["force_first"][s] * float(d0["mult"]), 2: d["force_ball"][s] * float(d0["mult"])}
+        p, v = d["p0"][s].copy(), d["v0"][s].copy()
+        joints = {"jtype": d["jtype"][s], "jb1": d["jb1"][s], "jb2": d["jb2"][s], "jr1": d["jr1"][s], "jrot1": d["jrot1"][s].copy()}
+        assert np.abs(W.joint_jacobian(joints, p) - d["Je"][s]).max() < 1e-12 if "Je" in d else True
+        nocon = [tuple(x) for x in d["no_contact"][s].tolist()]
+        cs = C.find_contacts(W.bodies_at(shapes, p), eps=0.1, no_contact=nocon)
+        t = 0.0
+        for k in range(int(d["nsteps"])):
+            f = grav.copy()
+            if t < float(d0["t_push"]):
+                for b, fb in pushes.items():
+                    f[b] += fb
+            p, v, cs, dt_used, _, joints = W.step_dt(shapes, p, v, cs, d["Mdiag"][s], f, d["rest"][s], d["fric"][s], None, float(d0["dt"]),
+                                                     no_contact=nocon, post_stab=chain, joints=joints)
+            t += dt_used
+            assert abs(t - d["t"][s][k]) < 1e-12 and len(cs) == d["ncontacts"][s][k], (scene, s, k, t, d["t"][s][k], len(cs))
+        assert np.abs(p - d["p_final"][s]).max() < 1e-9, (scene, s, np.abs(p - d["p_final"][s]).max())
