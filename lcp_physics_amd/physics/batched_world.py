@@ -476,6 +476,7 @@ class ContactWorld:
         self.maxc, self.max_iter, self.compute = int(maxc), int(max_iter), compute
         self.solver_eps, self.lim, self.max_trials = solver_eps, not_improved_lim, max_trials
         self.t = torch.zeros(self.B, dtype=torch.float64, device=dev)
+        self._xy_mask = (torch.arange(3, device=dev) > 0).reshape(1, 1, 3)    # (rot, x, y): the translation columns (device op: capturable)
         self._ws = self._out = None
         self.check = bool(check)
         # OR of every step's per-scene status bits (device side, no synchronisation): LCP_ST_TRUNCATED in here means a
@@ -595,8 +596,7 @@ class ContactWorld:
         dp = v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
         p_lin = p_start + dp
         self.p = p_lin + (cb.p_out - p_lin).detach()
-        turned = (dp[..., :1] != 0).to(dp.dtype)
-        g_lin = p_geo + torch.cat([dp[..., :1] * turned + (dp[..., :1] * (1 - turned)).detach(), dp[..., 1:]], dim=-1)
+        g_lin = p_geo + torch.where((dp != 0) | self._xy_mask, dp, dp.detach())       # (a zero rotation increment carries no gradient)
         self._p_geom, self._p_geom_src = g_lin + (cb.p_out - g_lin).detach(), self.p
         self.v = v_new
         if js is not None:                                                 # joint.move(dt): rot1 += body1.v[0] dt (constraints.py:39-43)
@@ -622,8 +622,7 @@ class ContactWorld:
             mv = (dp_s.to(torch.float64) * 0.5) * dt_used.reshape(-1, 1, 1)
             p_mid, g_mid = self.p, self._p_geom
             self.p = p_mid + mv
-            turned = (mv[..., :1] != 0).to(mv.dtype)                          # (bodies.py:199-202, as above)
-            self._p_geom = g_mid + torch.cat([mv[..., :1] * turned + (mv[..., :1] * (1 - turned)).detach(), mv[..., 1:]], dim=-1)
+            self._p_geom = g_mid + torch.where((mv != 0) | self._xy_mask, mv, mv.detach())         # (bodies.py:199-202, as above)
             self._p_geom_src = self.p
             if js is not None:
                 self.Je = js.jacobian(self.p.detach().contiguous(), v=dp_s.detach().contiguous(), dt_scene=dt_used, vscale=0.5)

@@ -314,7 +314,7 @@ class ChainWorlds:
         from .physics.batched_world import ContactWorld
         from .physics.joints import JointSet
         B, nb, dev = self.B, self.nb, self.device
-        f32 = lambda t: t.to(torch.float32) if torch.is_tensor(t) and t.device.type == torch.device(dev).type else torch.as_tensor(t, dtype=torch.float32, device=dev)
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32) if torch.is_tensor(t) else torch.tensor(t, dtype=torch.float32, device=dev)
         mass = f32(mass)
         mass = mass.expand(B) if mass.dim() == 0 else mass
         push = self.unit_push if push is None else f32(push)
