@@ -11,18 +11,20 @@ is lifted to the GPU as a batch of ONE scene and handed to the contact-list entr
 * `HipPdipmEngine` - differentiable.  `solve_dynamics` is one `SolveDynamicsFunction` node (forward
   `lcp_solve_dynamics_f32`: assembly + PDIPM solve, both branches of `engines.py:26-78`; backward
   `lcp_step_backward_f32`: the implicit differentiation of `lcp.py:37-64` contracted through the assembly on chip), so
-  `loss.backward()` reaches masses, forces, velocities, restitution / friction coefficients and the contact frame
-  exactly where the reference's autograd does.  The joint Jacobian is treated as a constant.
+  `loss.backward()` reaches masses, forces, velocities, restitution / friction coefficients, the contact frame and
+  the joint Jacobian `world.Je()` (hence the joints' anchors: `constraints.py:26-50` stays the reference's torch code)
+  exactly where the reference's autograd does.  `post_stabilization` (`engines.py:80-116`) is a
+  `PostStabilizationFunction` node (forward `lcp_post_stabilization_f32`, backward
+  `lcp_post_stabilization_backward_f32`): a `World(post_stab=True)` differentiates as in `experiments/inference.py`.
 * `HipFusedEngine` - the same launches without recording a graph (inference).
 
-`post_stabilization` (`engines.py:80-116`) runs `lcp_post_stabilization_f32` in both; its result only corrects poses
-and carries no gradient here.  Sizes: what the contact-list kernels take (64 contacts, 14 bodies, 4 joint rows for the
-differentiable backward); beyond that the call raises - there is no CPU or dense fallback.
+Sizes: what the contact-list kernels take (64 contacts; for the backward 3 nb + e <= 56 with up to 24 joint rows, or the
+four-scenes-per-wave sizes); beyond that the call raises - there is no CPU or dense fallback.
 """
 import torch
 
 from . import batched_world
-from .batched_world import SolveDynamicsFunction
+from .batched_world import PostStabilizationFunction, SolveDynamicsFunction
 
 
 class Engine:
@@ -56,7 +58,7 @@ class _Lifted:
         self.f = up(world.apply_forces(world.t), nb, 3) if forces else None
         Je = world.Je()
         self.e = Je.size(0) if (Je.ndimension() > 1 and Je.numel() > 0) else 0
-        self.Je = up(Je.detach(), self.e, 3 * nb) if self.e else None
+        self.Je = up(Je, self.e, 3 * nb) if self.e else None                 # (its gradient flows on to the joints' anchors)
         contacts = world.contacts or []
         self.nc = len(contacts)
         cap = max(1, self.nc)
@@ -99,12 +101,11 @@ class HipPdipmEngine(Engine):
 
     def post_stabilization(self, world):
         base = world.get_v()
-        with torch.no_grad():
+        opts = self._options()
+        with torch.set_grad_enabled(self.differentiable and torch.is_grad_enabled()):
             s = _Lifted(world, forces=False)
-            frame = batched_world._Frame(s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2)
-            out = batched_world.post_stabilization(1, s.nb, s.cap, s.e, s.count, s.Mdiag, s.v, s.rest, frame, s.Je,
-                                                   compute=self.compute)
-            return out["dp"].reshape(-1).to(device=base.device, dtype=base.dtype)
+            dp = PostStabilizationFunction.apply(s.Mdiag, s.v, s.rest, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2, s.count, s.Je, opts)
+            return dp.reshape(-1).to(device=base.device, dtype=base.dtype)
 
 
 class HipFusedEngine(HipPdipmEngine):

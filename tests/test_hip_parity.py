@@ -537,6 +537,59 @@ def test_engine_plugin_is_differentiable_like_the_reference(name, st, kernel_pat
     pg = {k: lv[k].grad.unsqueeze(0) for k in parity.PHYS_KEYS}
     ep = parity.err_physical(pg, ref, ph, floor)
     assert float(ep.max()) < TOL_G32, (name, float(ep.max()))
+    # the joint Jacobian: d(loss)/d(world.Je()) IS the reference's recorded dA (lcp.py:57)
+    # (dA = dnu x^T + nu dx^T: on a resting stack x and dx vanish on the pinned body and dA is 1e-12 in fp64 - the fp32 solve
+    #  leaves |nu| x its own dx error there, hence the absolute term)
+    dA = dense["A"].reshape(world._Je.shape).double()
+    eA = float((world._Je.grad - dA).abs().max())
+    assert world._Je.grad is not None and eA <= 2e-4 * float(dA.abs().max()) + 1e-6 * float(st["nus"].abs().max()) * float(floor.max()), (name, eA)
+
+
+@pytest.mark.parametrize("name,st", STEPS[::5], ids=IDS[::5])
+def test_engine_plugin_post_stabilization_is_differentiable_like_the_reference(name, st):
+    """`HipPdipmEngine.post_stabilization(world)` as a node of the autograd graph (what a reference `World(post_stab=True)` with the
+    engine swapped differentiates, experiments/inference.py): gradients at the world's leaves against the fp64 oracle's solve of
+    engines.py:80-116, `lcp.py:37-64` and autograd through the assembly."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics import HipPdipmEngine
+    from tests.world_io import RecordedWorld
+    _lib.set_path("auto")                   # (the backward reads the iterate the body-space kernel keeps: the default routing)
+    world = RecordedWorld(st, leaf=True)
+    dp = HipPdipmEngine().post_stabilization(world)
+    cot = torch.randn(dp.shape, generator=torch.Generator().manual_seed(11), dtype=dp.dtype)
+    (dp * cot).sum().backward()
+    nb = st["v"].shape[0]
+    leaf = lambda t: t.detach().double().clone().unsqueeze(0).requires_grad_(True)
+    Md, v, rest, Je = leaf(world._Md), leaf(world._v), leaf(world._rest), leaf(world._Je)
+    cn, cp1, cp2 = leaf(world._cn), leaf(world._cp1), leaf(world._cp2)
+    lcp = O.assemble_post_stabilization(Md, v, cn, cp1, cp2, st["c_i1"].unsqueeze(0), st["c_i2"].unsqueeze(0), rest, Je)
+    det = [None if t is None else t.detach() for t in lcp]
+    sol = O.lcp_forward(*det)
+    gr = O.lcp_backward(sol, *det, -cot.reshape(1, -1).double())               # dp = -x
+    outs, cots = [], []
+    for t, key in zip(lcp, ("dQ", "dp", "dG", "dh", "dA", "db", "dF")):
+        if t is not None and t.requires_grad and gr[key] is not None:
+            outs.append(t); cots.append(gr[key])
+    torch.autograd.backward(outs, cots)
+    # ten iterations do not always converge on this LCP (a resting contact has rhs ~ 0, tests/test_world_oracle.py): the gradients
+    # are compared where the oracle's iterate is a solution with strictly complementary rows
+    zs, ss = sol.z.max(dim=1, keepdim=True)[0], sol.s.max(dim=1, keepdim=True)[0]
+    converged = float((sol.s * sol.z).abs().max()) <= 1e-9 * max(1.0, float((zs * ss).max()))
+    strict = float(torch.maximum(sol.z / zs, sol.s / ss).min()) > 1e-6
+    for t in (world._Md, world._v, world._rest, world._Je, world._cn, world._cp1, world._cp2):
+        assert t.grad is not None and bool(torch.isfinite(t.grad).all())
+    if not (converged and strict):
+        pytest.skip("the oracle's ten iterations did not reach a strictly complementary solution of this step")
+    assert float((dp.detach().double() + sol.x[0]).abs().max()) <= 1e-4 * max(1.0, float(sol.x.abs().max()))
+    vscale = max(float(v.grad.abs().max()), 1e-30)
+    for key, got, ref in (("Mdiag", world._Md.grad, Md.grad), ("v", world._v.grad, v.grad), ("rest", world._rest.grad, rest.grad),
+                          ("Je", world._Je.grad, Je.grad), ("c_n", world._cn.grad, cn.grad), ("c_p1", world._cp1.grad, cp1.grad),
+                          ("c_p2", world._cp2.grad, cp2.grad)):
+        assert got is not None, key
+        r = ref[0] if ref is not None else torch.zeros_like(got)
+        scale = max(float(r.abs().max()), 1e-6 * vscale)
+        bound = 2e-3 if key in ("c_n", "c_p1", "c_p2") else 2e-4
+        assert float((got.double().reshape(r.shape) - r).abs().max()) <= bound * scale, (name, key, float((got.double().reshape(r.shape) - r).abs().max()), scale)
 
 
 @pytest.mark.parametrize("name,st", STEPS[::5], ids=IDS[::5])

@@ -41,7 +41,7 @@ class RecordedWorld:
         self.t, self.dt = float(st["t"]) if "t" in st else 0.0, st["dt"]
         self._v, self._f, self._Md = mk(st["v"]), mk(st["f"]), mk(st["Mdiag"])
         self._rest, self._fric = mk(st["rest"]), mk(st["fric"])
-        self._Je = st["Je"].double()
+        self._Je = mk(st["Je"])                          # (a leaf too: the engine's backward returns d(loss)/dJe, lcp.py:57)
         nb = st["v"].shape[0]
         self.bodies = [_RecordedBody(self._rest[i], self._fric[i]) for i in range(nb)]
         self._cn, self._cp1, self._cp2 = mk(st["c_n"]), mk(st["c_p1"]), mk(st["c_p2"])
