@@ -36,13 +36,20 @@ extern "C" {
 
 #define LCP_COMPUTE_F32 0
 #define LCP_COMPUTE_F64 1
-/* May be OR-ed into the `compute` argument of lcp_pdipm_backward_f32: the caller asserts that EVERY scene of the batch
- * was solved as a contact-structured LCP with diagonal Q by the four-scenes-per-wave kernel (true by construction after
- * lcp_step_fused_f32 / lcp_solve_dynamics_f32).  The backward then skips the launches that serve the other classes. */
+/* May be OR-ed into the `compute` argument of lcp_pdipm_backward_f32: the workspace was left by a CONTACT-LIST forward
+ * (lcp_step_fused_f32 / lcp_solve_dynamics_f32, sizes of the four-scenes-per-wave kernels: nz <= 16, <= 16 contacts, neq <= 4)
+ * called with this same `compute` word - the dense backward (lcp.py:37-64) of a fused step.  One launch; it factors in body
+ * space when that forward did (the workspace then holds no contact-space matrix at all). */
 #define LCP_HINT_ALL_CONTACT 0x100
 /* May be OR-ed into any `compute` argument: serve this call from the generic workgroup-per-scene kernels whatever the
  * sizes (A/B and debugging aid; a backward must carry the same flag as its forward - they share the workspace layout). */
 #define LCP_PATH_GENERIC 0x200
+/* Likewise (A/B aids): the contact-space kernels where the default is a body-space one; one wave per scene (lcp_primal) at every
+ * size.  The kernel family of a call is a function of its sizes and its `compute` WORD: pass the word of the forward to the
+ * backward and both plan the same workspace layout on any host threads.  The forward also leaves a layout tag in the workspace;
+ * a backward planned for another layout returns NaN gradients instead of misreading it. */
+#define LCP_PATH_CONTACT_SPACE 0x2000
+#define LCP_PATH_PRIMAL 0x4000
 /* OR-ed into the `compute` argument of lcp_workspace_bytes by callers of the fp64-I/O entry points (lcp_pdipm_forward_f64 /
  * lcp_pdipm_backward_f64): their workspace also keeps an fp64 copy of F. */
 #define LCP_IO_F64 0x400
@@ -163,6 +170,13 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* dl_dv, int compute,
                           float* dMdiag, float* dv, float* df, float* drest, float* dfric,
                           float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream);
+
+/* Host-only: 1 when lcp_step_backward_f32 / _je_f32 can follow a contact-list forward (lcp_step_fused_f32,
+ * lcp_solve_dynamics_f32) called with these sizes and this `compute` word - the kernel families that keep the iterate in the
+ * workspace (<= 64 contacts, 3 nb + e <= 56, fp64 arithmetic; the four-scenes-per-wave sizes in either arithmetic) -, else 0:
+ * the generic kernels step such scenes forward only, and the backward entry points return LCP_E_TOOLARGE for them.  The
+ * reference differentiates any size through LCPFunction.backward (lcp/lcp.py:37-64): use the dense boundary there. */
+int lcp_step_has_backward(int nb, int maxc, int e, int compute);
 
 /* The same with the gradient of the joint Jacobian as a ninth output: dJe[B,e,3 nb] = dnu (x) x + nu (x) dx (lcp.py:57, A = Je
  * in engines.py:75) - what the reference back-propagates into Joint.J() / FixedJoint.J() (constraints.py:26-36, 64-73: the

@@ -5,6 +5,7 @@ caller gets an exception.  PyTorch is only used for device memory and streams.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -16,6 +17,8 @@ COMPUTE_F64 = 1
 HINT_ALL_CONTACT = 0x100
 PATH_GENERIC = 0x200
 IO_F64 = 0x400
+PATH_CONTACT_SPACE = 0x2000
+PATH_PRIMAL = 0x4000
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2
@@ -42,6 +45,7 @@ SIGNATURES = {
                            + [_P, _P, _P, _P]),
     "lcp_step_backward_f32": (_I, [_I] * 4 + [_P] * 11 + [_c.c_float, _P, _I] + [_P] * 8 + [_P, _P]),
     "lcp_step_backward_je_f32": (_I, [_I] * 4 + [_P] * 11 + [_c.c_float, _P, _I] + [_P] * 9 + [_P, _P]),
+    "lcp_step_has_backward": (_I, [_I, _I, _I, _I]),
     "lcp_post_stabilization_backward_f32": (_I, [_I] * 4 + [_P] * 10 + [_I] + [_P] * 7 + [_P, _P]),
     "lcp_solve_dynamics_f32": (_I, [_I] * 4 + [_P] * 12 + [_c.c_float, _c.c_double, _I, _I, _I] + [_P] * 4
                                + [_P, _P, _P, _P]),
@@ -102,9 +106,41 @@ def require_gpu_tensor(t, name, dtype=None):
     return t
 
 
+_PATH_BITS = {"auto": 0, "wave64": 0, "generic": PATH_GENERIC, "big": PATH_CONTACT_SPACE, "primal": PATH_PRIMAL}
+_tls = threading.local()          # the default is per host thread, like the library's own debugging aids
+
+
 def set_path(path):
-    """A/B aid: 'auto' | 'generic' | 'wave64' kernel family."""
-    load().lcp_debug_set_path({"auto": 0, "generic": 1, "wave64": 2, "big": 3, "primal": 4}[path])
+    """A/B aid: 'auto' | 'generic' | 'big' (contact-space kernels where the default is a body-space one) | 'primal' (one wave per
+    scene at every size) - the calling thread's default.  Every forward wrapper ORs `path_bits()` into the `compute` word of its
+    call and RECORDS the word in the handle it returns (`LCPSolution.compute`, `out["compute"]`); the backward wrappers pass the
+    recorded word on, so a backward picks its forward's kernel family on whatever thread autograd runs it (PyTorch runs the
+    backward of a CUDA op on a device worker thread, where no default was ever set)."""
+    if path not in _PATH_BITS:
+        raise ValueError("unknown kernel path %r" % (path,))
+    _tls.path = path
+
+
+class thread_path:
+    """The fp64-I/O entry points carry no `compute` word: for the duration of ONE call the calling thread's library default
+    (lcp_debug_set_path) is set from the path bits recorded with the op, and reset afterwards."""
+    _CODE = {0: 0, PATH_GENERIC: 1, PATH_CONTACT_SPACE: 3, PATH_PRIMAL: 4}
+
+    def __init__(self, word):
+        self.code = self._CODE[word & (PATH_GENERIC | PATH_CONTACT_SPACE | PATH_PRIMAL)]
+
+    def __enter__(self):
+        if self.code:
+            load().lcp_debug_set_path(self.code)
+
+    def __exit__(self, *a):
+        if self.code:
+            load().lcp_debug_set_path(0)
+
+
+def path_bits(path="auto"):
+    """LCP_PATH_* bits of a per-call `path` argument ('auto' = the module default set by `set_path`)."""
+    return _PATH_BITS[getattr(_tls, "path", "auto") if path == "auto" else path]
 
 
 def workspace_bytes(B, nz, m, e, compute):

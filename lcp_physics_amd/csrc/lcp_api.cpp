@@ -12,15 +12,35 @@ namespace {
 // debugging aids below are per calling thread (thread_local), and the kernel family can also be forced per call with
 // LCP_PATH_GENERIC in the `compute` word.
 thread_local double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
-thread_local int g_path = 0;              // 0 = automatic, 1 = force the generic kernels, 2 = force the wave64 kernels,
-                                          // 3 = contact-space lcp_big.hip instead of the body-space lcp_primal.hip (A/B aid)
+thread_local int g_path = 0;              // this thread's DEFAULT kernel path for calls whose `compute` word names none:
+                                          // 0 = automatic, 1 = generic kernels, 3 = contact-space kernels instead of the body-space ones,
+                                          // 4 = one wave per scene (lcp_primal.hip) at every size (A/B aids)
 
-// `compute` word of an entry point -> arithmetic type; *generic = the caller (or this thread's debug setting) forces the
-// workgroup-per-scene kernels
-inline int split_compute(int compute, bool* generic) {
-  *generic = (compute & LCP_PATH_GENERIC) != 0 || g_path == 1;
-  return compute & ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64);
+constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL;
+
+// `compute` word of an entry point -> arithmetic type and kernel path.  The path is a function of the WORD whenever the word
+// names one (LCP_PATH_*): a forward and its backward that carry the same word pick the same kernel family on any two host
+// threads.  Only a word without path bits falls back on the calling thread's lcp_debug_set_path default.
+// *path: 0 automatic, 1 generic, 3 contact space, 4 primal;  *generic = (path == 1)
+inline int split_compute(int compute, bool* generic, int* path = nullptr) {
+  int p = g_path;
+  if (compute & LCP_PATH_GENERIC) p = 1;
+  else if (compute & LCP_PATH_CONTACT_SPACE) p = 3;
+  else if (compute & LCP_PATH_PRIMAL) p = 4;
+  if (path) *path = p;
+  *generic = p == 1;
+  return compute & ~FLAG_BITS;
 }
+
+// Workspace trailer (one 256-byte block behind the scene blocks and the class words): tag[0] = which forward laid the workspace
+// out.  Every forward kernel writes it, every backward kernel compares it with what ITS launch plan expects and returns NaN
+// gradients on a mismatch (a backward planned for another kernel family would otherwise misread the layout silently).
+enum WsTag {
+  TAG_DENSE_WAVE = 1, TAG_DENSE_BIG = 2, TAG_DENSE_GENERIC = 3,                       // lcp_pdipm_forward_*
+  TAG_STEP_QUAD_BODY = 4, TAG_STEP_QUAD_CS = 5, TAG_STEP_PRIMAL = 6, TAG_STEP_BIG = 7, TAG_STEP_WAVE64 = 8, TAG_STEP_GENERIC = 9,
+  TAG_POSTSTAB_PRIMAL = 10, TAG_POSTSTAB_GENERIC = 11
+};
+constexpr size_t TRAILER_BYTES = 256;
 
 // Which kernel family serves a problem.  Deterministic in (sizes, io type) so that forward and
 // backward of one op agree on the workspace layout.
@@ -32,11 +52,11 @@ inline bool use_wave64(int io_f64, int nz, int m, int e, bool generic) {
 // Kernel family of the contact-list entry points (lcp_step_fused_f32, lcp_solve_dynamics_f32, lcp_step_backward_f32):
 // ONE function of (sizes, arithmetic, forced path), so that a backward always reads the workspace layout its forward wrote.
 enum StepFamily { FAM_QUAD, FAM_PRIMAL, FAM_BIG, FAM_WAVE64, FAM_GENERIC };
-inline StepFamily step_family(int nz, int m, int e, int compute, bool generic) {
-  if (generic) return FAM_GENERIC;
-  if (g_path == 4 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // (A/B: one wave per scene at every size)
+inline StepFamily step_family(int nz, int m, int e, int compute, int path) {
+  if (path == 1) return FAM_GENERIC;
+  if (path == 4 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // (A/B: one wave per scene at every size)
   if (lcp::quad_step_supported(nz, m, e)) return FAM_QUAD;                     // <= 16 contacts, <= 10 bodies, e <= 4
-  if (compute == LCP_COMPUTE_F64 && g_path != 3 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // <= 64 contacts, body-space systems
+  if (compute == LCP_COMPUTE_F64 && path != 3 && lcp::primal_supported(nz, m, e)) return FAM_PRIMAL;   // <= 64 contacts, body-space systems
   if (compute == LCP_COMPUTE_F64 && lcp::big_supported(nz, m, e)) return FAM_BIG;   // <= 64 contacts (fp64 arithmetic)
   if (lcp::wave64_supported(nz, m, e)) return FAM_WAVE64;                      // nz <= 16, e 5..8
   return FAM_GENERIC;
@@ -50,6 +70,17 @@ inline int csize_of(int io_f64, int compute) { return (io_f64 || compute == LCP_
 inline bool use_big_dense(int io_f64, int nz, int m, int e, int compute, bool generic) {
   return !io_f64 && !generic && compute == LCP_COMPUTE_F64 && !lcp::wave64_supported(nz, m, e) && lcp::big_dense_supported(nz, m, e);
 }
+// workspace tag a contact-list forward of this family leaves (the quad family has two layouts: with and without W)
+inline int step_tag(StepFamily fam, int nz, int compute, int path) {
+  switch (fam) {
+    case FAM_QUAD: return lcp::quad_step_is_body_space(nz, compute, path != 3) ? TAG_STEP_QUAD_BODY : TAG_STEP_QUAD_CS;
+    case FAM_PRIMAL: return TAG_STEP_PRIMAL;
+    case FAM_BIG: return TAG_STEP_BIG;
+    case FAM_WAVE64: return TAG_STEP_WAVE64;
+    default: return TAG_STEP_GENERIC;
+  }
+}
+
 inline size_t scene_bytes(int nz, int m, int e, int compute, int io_f64) {
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
@@ -63,6 +94,8 @@ inline size_t scene_bytes(int nz, int m, int e, int compute, int io_f64) {
   if (lcp::primal_supported(nz, m, e) && lcp::primal_ws_bytes() > per_scene) per_scene = lcp::primal_ws_bytes();
   return (per_scene + 15) & ~(size_t)15;
 }
+inline size_t cls_bytes_of(int B) { return (((size_t)B * sizeof(int32_t)) + 255) & ~(size_t)255; }
+inline int32_t* trailer_of(void* ws, int B, size_t per_scene) { return (int32_t*)((unsigned char*)ws + (size_t)B * per_scene + cls_bytes_of(B)); }
 
 }  // namespace
 
@@ -73,14 +106,16 @@ const char* lcp_version(void) { return "lcp_hip 0.2.0 gfx950"; }
 size_t lcp_workspace_bytes(int B, int nz, int m, int e, int compute) {
   if (B <= 0 || nz <= 0 || m <= 0 || e < 0) return 0;
   const int io_f64 = (compute & LCP_IO_F64) ? 1 : 0;
-  compute &= ~(LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64);
+  compute &= ~FLAG_BITS;
   if (io_f64) compute = LCP_COMPUTE_F64;
   const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
-  const size_t cls_bytes = (((size_t)B * sizeof(int32_t)) + 255) & ~(size_t)255;     // per-scene classes of the dense lcp_big path
-  return (size_t)B * per_scene + cls_bytes;
+  // scene blocks | per-scene classes of the dense lcp_big path | trailer (the layout tag)
+  return (size_t)B * per_scene + cls_bytes_of(B) + TRAILER_BYTES;
 }
 
-// Debugging / A-B aid: 0 = automatic kernel selection, 1 = generic kernels only, 2 = wave64 when legal.
+// Debugging / A-B aid: the calling thread's default path for calls whose `compute` word carries no LCP_PATH_* bit
+// (0 automatic, 1 generic kernels, 3 contact-space kernels, 4 one wave per scene).  Prefer the per-call bits: they travel with
+// the word from a forward to its backward, whatever threads the two run on.
 void lcp_debug_set_path(int path) { g_path = path; }
 
 // Debugging aid (not part of the drop-in surface): when set, the dense forward writes
@@ -95,26 +130,31 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   if (!Q || !p || !G || !h || !F || !x || !z || !s || !ws) return LCP_E_BADARG;
   if (e > 0 && (!A || !b)) return LCP_E_BADARG;
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
   const bool w64 = use_wave64(io_f64, nz, m, e, generic);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
+  const size_t per_scene_all = scene_bytes(nz, m, e, io_f64 ? LCP_COMPUTE_F64 : compute, io_f64);
+  const bool bigd = use_big_dense(io_f64, nz, m, e, compute, generic);
   lcp::FwdArgs P;
   memset(&P, 0, sizeof(P));
+  P.tag = trailer_of(ws, B, per_scene_all);
+  P.tag_value = w64 ? TAG_DENSE_WAVE : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
   P.B = B; P.nz = nz; P.m = m; P.e = e;
   P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b; P.F = F;
   P.x = x; P.y = y; P.z = z; P.s = s; P.iters = iters; P.status = status;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.eps = eps; P.max_iter = max_iter; P.lim = lim;
   P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds; P.trace = g_trace;
   if (w64) return lcp::wave64_forward(P, compute, stream, io_f64);
-  if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
-    const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
+  if (bigd) {
+    const size_t per_scene = per_scene_all;
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
     // classes per scene: 3 = contact structure, at most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure
     // (lcp_big.hip); 0 = anything else (the generic kernels)
-    const int primal_ok = (g_path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? 1 : 0;
+    const int primal_ok = (path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? 1 : 0;
     int rc = lcp::big_dense_forward(P, cls, per_scene, primal_ok, stream);
     if (rc) return rc;
     if (primal_ok) { rc = lcp::primal_dense_forward(P, cls, per_scene, stream); if (rc) return rc; }
@@ -147,20 +187,33 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (e > 0 && !A) return LCP_E_BADARG;
   const int hint = compute & LCP_HINT_ALL_CONTACT;
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   const int cs = csize_of(io_f64, compute);
   const bool w64 = use_wave64(io_f64, nz, m, e, generic);
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!w64 && !pl.ok) return LCP_E_TOOLARGE;
+  const size_t per_scene_all = scene_bytes(nz, m, e, io_f64 ? LCP_COMPUTE_F64 : compute, io_f64);
+  const bool bigd = use_big_dense(io_f64, nz, m, e, compute, generic);
   lcp::BwdArgs P;
   memset(&P, 0, sizeof(P));
+  P.tag = trailer_of(ws, B, per_scene_all);
+  P.tag_value = w64 ? TAG_DENSE_WAVE : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  if (w64) return lcp::wave64_backward(P, compute, hint != 0, stream, io_f64);
-  if (use_big_dense(io_f64, nz, m, e, compute, generic)) {
-    const size_t per_scene = scene_bytes(nz, m, e, compute, io_f64);
+  if (w64 && hint) {
+    // LCP_HINT_ALL_CONTACT: the workspace was left by a contact-list forward (lcp_step_fused_f32 / lcp_solve_dynamics_f32) called with
+    // this `compute` word.  Only the four-scenes-per-wave family keeps a workspace this dense backward can read: in body space (no
+    // W in it: lcp_bwd_quad<..., BODY>) or in contact space, exactly as that forward decided.
+    if (io_f64 || step_family(nz, m, e, compute, path) != FAM_QUAD || !lcp::quad_supported(nz, m, e)) return LCP_E_BADARG;
+    P.tag_value = step_tag(FAM_QUAD, nz, compute, path);
+    return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY);
+  }
+  if (w64) return lcp::wave64_backward(P, compute, false, stream, io_f64);
+  if (bigd) {
+    const size_t per_scene = per_scene_all;
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
     int rc = lcp::big_dense_backward(P, cls, per_scene, stream);           // (the classes the forward left behind the scene blocks)
     if (rc) return rc;
@@ -183,7 +236,7 @@ int lcp_pdipm_backward_f64(int B, int nz, int m, int e, const double* G, const d
                          stream);
 }
 
-static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream);
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream);
 
 static int fill_step(lcp::StepArgs& P, int B, int nb, int nc, int e, const float* pos, const float* Mdiag,
                      const float* v, const float* f, const float* rest, const float* fric, const float* c_n,
@@ -219,7 +272,8 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
                        float* v_new, float* p_new, float* z, float* s, float* y, int32_t* iters,
                        int32_t* status, void* ws, void* stream) {
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, nc, e, pos, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -229,7 +283,7 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = p_new; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  return launch_step(P, nz, m, e, compute, generic, stream);
+  return launch_step(P, nz, m, e, compute, path, stream);
 }
 
 int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
@@ -247,7 +301,8 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
                              const float* dl_dv, int compute, float* dMdiag, float* dv, float* df, float* drest,
                              float* dfric, float* dc_n, float* dc_p1, float* dc_p2, float* dJe, void* ws, void* stream) {
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, nc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -257,22 +312,40 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
   lcp::StepBwdArgs G;
   G.dl_dv = dl_dv; G.dMdiag = dMdiag; G.dv = dv; G.df = df; G.drest = drest; G.dfric = dfric;
   G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2; G.dJe = (e > 0) ? dJe : nullptr;
-  // the same family decision as the forward entry points (launch_step): the workspace layout is the family's
-  switch (step_family(3 * nb, 4 * nc, e, compute, generic)) {
-    case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream);
+  // the same family decision as the forward entry points (launch_step): a function of the sizes and the `compute` word; the
+  // kernels check the tag that forward left in the workspace trailer
+  const StepFamily fam = step_family(3 * nb, 4 * nc, e, compute, path);
+  P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * nc, e, compute, 0));
+  P.tag_value = step_tag(fam, 3 * nb, compute, path);
+  switch (fam) {
+    case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream, path != 3);
     case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream);
     case FAM_BIG: return lcp::big_step_backward(P, G, stream);
     default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read
   }
 }
 
+int lcp_step_has_backward(int nb, int maxc, int e, int compute) {
+  if (nb <= 0 || maxc <= 0 || e < 0) return 0;
+  bool generic;
+  int path;
+  compute = split_compute(compute, &generic, &path);
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return 0;
+  const StepFamily fam = step_family(3 * nb, 4 * maxc, e, compute, path);
+  return (fam == FAM_QUAD || fam == FAM_PRIMAL || fam == FAM_BIG) ? 1 : 0;
+}
+
 // forward of the contact-list entry points, by family
-static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, bool generic, void* stream) {
-  switch (step_family(nz, m, e, compute, generic)) {
-    case FAM_QUAD: return lcp::quad_step(P, compute, stream, g_path != 3);
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream) {
+  StepFamily fam = step_family(nz, m, e, compute, path);
+  if (fam == FAM_WAVE64 && P.c_count) fam = FAM_GENERIC;                    // (its kernel takes full lists only)
+  P.tag = trailer_of(P.ws, P.B, scene_bytes(nz, m, e, compute, 0));
+  P.tag_value = step_tag(fam, nz, compute, path);
+  switch (fam) {
+    case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3);
     case FAM_PRIMAL: return lcp::primal_step(P, stream);
     case FAM_BIG: return lcp::big_step(P, stream);
-    case FAM_WAVE64: if (!P.c_count) return lcp::wave64_step(P, compute, stream);   // (its kernel takes full lists only)
+    case FAM_WAVE64: return lcp::wave64_step(P, compute, stream);
     default: break;
   }
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
@@ -289,7 +362,8 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
                            int not_improved_lim, int compute, float* v_new, float* z, float* s, float* y,
                            int32_t* iters, int32_t* status, void* ws, void* stream) {
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -299,7 +373,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  return launch_step(P, 3 * nb, 4 * maxc, e, compute, generic, stream);
+  return launch_step(P, 3 * nb, 4 * maxc, e, compute, path, stream);
 }
 
 int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,
@@ -308,8 +382,9 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
                                double eps, int max_iter, int not_improved_lim, int compute, const double* p,
                                const double* dt_scene, double dt, double* p_out, float* dp, int32_t* iters,
                                int32_t* status, void* ws, void* stream) {
-  bool generic_unused;
-  compute = split_compute(compute, &generic_unused);
+  bool generic;
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   // (forces and friction do not enter this LCP: engines.py:80-116 reads M, v, Je, Jc and the restitutions only)
@@ -326,7 +401,10 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
   // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
   P.ws = ws;                                                                // (lcp_primal.hip leaves the best iterate there for the backward)
-  if (!generic_unused && g_path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e)) return lcp::primal_post_stab(P, stream);
+  const bool body = path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e);
+  P.tag = trailer_of(ws, B, scene_bytes(nz, m, e, compute, 0));
+  P.tag_value = body ? TAG_POSTSTAB_PRIMAL : TAG_POSTSTAB_GENERIC;
+  if (body) return lcp::primal_post_stab(P, stream);
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
   if (!pl.ok) return LCP_E_TOOLARGE;
@@ -340,15 +418,18 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const fl
                                         int compute, float* dMdiag, float* dv, float* drest, float* dc_n, float* dc_p1,
                                         float* dc_p2, float* dJe, void* ws, void* stream) {
   bool generic;
-  compute = split_compute(compute, &generic);
+  int path;
+  compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F64) return (compute == LCP_COMPUTE_F32) ? LCP_E_TOOLARGE : LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, /*f*/ v, rest, /*fric*/ rest, c_n, c_p1, c_p2, c_i1, c_i2, Je, 0.0f);
   if (rc) return rc;
   if (!dl_ddp || !ws) return LCP_E_BADARG;
   // only the body-space kernel keeps the iterate this backward reads (the same routing test as the forward)
-  if (generic || g_path != 0 || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
+  if (path != 0 || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
   P.ws = ws;
+  P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * maxc, e, compute, 0));
+  P.tag_value = TAG_POSTSTAB_PRIMAL;
   lcp::StepBwdArgs G = {};
   G.dl_dv = dl_ddp; G.dMdiag = dMdiag; G.dv = dv; G.drest = drest; G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
   G.dJe = (e > 0) ? dJe : nullptr;

@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
   // SIMD while the other three idle.  Blocks 256 apart are the ones that tend to share a CU.
   const bool w0 = wave == ((NCB == 64 || NT == 64) ? 0 : (int)((blockIdx.x >> 8) & 3));
   const int ti = tid >> GSH, tj = tid & (G - 1);                          // tile coordinates of the matrix role
+  if (!BWD && blockIdx.x == 0 && threadIdx.x == 0 && SP.tag) *SP.tag = SP.tag_value;   // workspace trailer: which kernel family laid it out
+  const bool tag_ok = !BWD || !SP.tag || *SP.tag == SP.tag_value;          // (a backward on another family's workspace returns NaN gradients)
   if (DENSE && DN.cls[blockIdx.x] != 2) return;                            // (a general scene: the generic kernels serve it)
   const int nb = SP.nb, nz = DENSE ? DN.nz : 3 * nb, ncap = SP.nc, e = SP.e;
   Lds L;
@@ -839,7 +841,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
       const int m = 4 * ncap;
       if (w0) {
         ua = L.dU[lc]; uu = L.dU[NCB + lc];
-        const double g = (lane < nz) ? (double)DN.dl_dx[(size_t)scene * nz + lane] : 0.0;
+        const double g = !tag_ok ? nan_of<double>() : (lane < nz) ? (double)DN.dl_dx[(size_t)scene * nz + lane] : 0.0;
         const M4<double> zero = m4<double>(0, 0, 0, 0);
         solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu, false);         // lcp.py:47-50
         const double nu = (lane < 8) ? Wit[64 + lane] : 0.0;
@@ -868,7 +870,7 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     if (!w0) return;
     ua = L.dU[lc]; uu = L.dU[NCB + lc];
     // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
-    const double g = (lane < nz) ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
+    const double g = !tag_ok ? nan_of<double>() : (lane < nz) ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;
     const M4<double> zero = m4<double>(0, 0, 0, 0);
     solve_kkt(dinv, g, zero, zero, 0.0, dx, ds, dl, dnu, false);                   // lcp.py:47-50
     // x-space vectors to LDS so that a contact lane can read the entries of its two bodies
@@ -1187,6 +1189,7 @@ int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int prima
   SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
   SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;
   SP.v_new = P.x; SP.z = P.z; SP.s = P.s; SP.y = P.y; SP.iters = P.iters; SP.status = P.status;
+  SP.tag = P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
   return big_class(SP.nc) == 32 ? big_launch<32, false, true>(SP, Gd, stream, DN) : big_launch<64, false, true>(SP, Gd, stream, DN);
 }
@@ -1198,6 +1201,7 @@ int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* st
   DN.dQ = (float*)P.dQ; DN.dp = (float*)P.dp; DN.dG = (float*)P.dG; DN.dh = (float*)P.dh; DN.dA = (float*)P.dA; DN.db = (float*)P.db; DN.dF = (float*)P.dF;
   StepArgs SP = {};
   SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  SP.tag = (int32_t*)P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
   return big_class(SP.nc) == 32 ? big_launch<32, true, true>(SP, Gd, stream, DN) : big_launch<64, true, true>(SP, Gd, stream, DN);
 }

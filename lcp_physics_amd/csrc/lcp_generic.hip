@@ -619,6 +619,7 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_fwd_kernel(FwdArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.tag) *P.tag = P.tag_value;   // workspace trailer: which kernel family laid it out
   if (P.cls && P.cls[scene] >= 2) return;              // served by lcp_big.hip / lcp_primal.hip (contact-structured, diagonal Q)
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
@@ -648,6 +649,7 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.tag) *P.tag = P.tag_value;
   const int ncap = P.nc;
   int ncs = ncap;
   int truncated = 0;                                                       // the detection kernel found more contacts than the list holds
@@ -686,6 +688,7 @@ template <typename TI, typename TC, bool PIVOT>
 __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.tag) *P.tag = P.tag_value;
   const int ncap = P.nc, mcap = 4 * ncap;                                 // capacity: array strides, workspace layout
   int ncs = ncap;                                                         // contacts of this scene (engines.py:36,51)
   int truncated = 0;                                                       // the detection kernel found more contacts than the list holds
@@ -779,7 +782,8 @@ __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
     for (int a = tid; a < e; a += NT) S.y[a] = W.y[a];
   }
   const TI* g = (const TI*)P.dl_dx + (size_t)scene * nz;
-  for (int j = tid; j < nz; j += NT) { S.x[j] = W.x[j]; S.rx[j] = (TC)g[j]; }
+  const bool tag_ok = !P.tag || *P.tag == P.tag_value;           // (another family's workspace: NaN gradients instead of a misread)
+  for (int j = tid; j < nz; j += NT) { S.x[j] = W.x[j]; S.rx[j] = tag_ok ? (TC)g[j] : nan_of<TC>(); }
   for (int i = tid; i < m; i += NT) {
     const TC zz = W.z[i], ss = W.s[i];
     S.z[i] = zz; S.s[i] = ss;

@@ -29,6 +29,8 @@ struct FwdArgs {
   int ldT, t_in_lds;
   double* trace;     // optional [B, max_iter, 4] (resid, mu, sigma, alpha) - debugging aid
   const int32_t* cls;  // optional per-scene class (lcp_classify_big): the generic kernels leave scenes of class 2 alone
+  int32_t* tag;        // workspace trailer word: every forward kernel writes `tag_value` (kernel family + layout) there
+  int tag_value;
 };
 
 struct BwdArgs {
@@ -39,11 +41,15 @@ struct BwdArgs {
   size_t ws_stride;
   int ldT, t_in_lds;
   const int32_t* cls;  // as FwdArgs::cls
+  const int32_t* tag;  // workspace trailer word the forward left; a backward that finds another value than `tag_value` (a workspace
+  int tag_value;       // laid out by another kernel family) returns NaN gradients instead of reading it
 };
 
 // dense (Q, p, G, h, A, b, F) boundary of lcp_big.hip: LCPFunction sizes beyond the wave-per-scene kernels (nineq <= 256)
 struct DenseIO {
   int nz, m;
+  int32_t* tag;                                     // workspace trailer word (see FwdArgs::tag)
+  int tag_value;
   const float *Q, *p, *G, *h, *A, *b, *F;           // forward inputs
   float *x, *y, *z, *s;                             // forward outputs
   int32_t *iters, *status;
@@ -72,6 +78,8 @@ struct StepArgs {
   const double* pos64;
   const double* dt_scene;
   double* p_out64;
+  int32_t* tag;             // workspace trailer word (see FwdArgs::tag): written by the forward kernels, compared by the backward ones
+  int tag_value;
 };
 
 struct StepBwdArgs {
@@ -131,9 +139,10 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body = 0);   // body: workspace of a body-space forward
 int quad_step(const StepArgs& P, int compute, void* stream, int body_space = 1);
-int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream);
+int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream, int body_space = 1);
+bool quad_step_is_body_space(int nz, int compute, int body_space);   // does quad_step run the body-space kernels for these arguments ?
 
 // workgroup-per-scene contact-structured forward for up to 64 contacts (fused step, forward only) - lcp_big.hip
 bool big_supported(int nz, int m, int e);

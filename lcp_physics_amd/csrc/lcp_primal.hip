@@ -73,6 +73,7 @@ int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* 
   SP.B = P.B; SP.nb = P.nz / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
   SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;
   SP.v_new = P.x; SP.z = P.z; SP.s = P.s; SP.y = P.y; SP.iters = P.iters; SP.status = P.status;
+  SP.tag = P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
   return primal_dispatch<false, true>(SP, Gd, stream, DN);
 }
@@ -83,6 +84,7 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
   DN.dQ = (float*)P.dQ; DN.dp = (float*)P.dp; DN.dG = (float*)P.dG; DN.dh = (float*)P.dh; DN.dA = (float*)P.dA; DN.db = (float*)P.db; DN.dF = (float*)P.dF;
   StepArgs SP = {};
   SP.B = P.B; SP.nb = P.nz / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
+  SP.tag = (int32_t*)P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
   return primal_dispatch<true, true>(SP, Gd, stream, DN);
 }

@@ -20,6 +20,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   __shared__ float At[ASZ];
   __shared__ int B12[2 * LX];
   const int scene = blockIdx.x, lane = threadIdx.x;
+  if (!BWD && blockIdx.x == 0 && lane == 0 && SP.tag) *SP.tag = SP.tag_value;   // workspace trailer: which kernel family laid it out
   const int nb = SP.nb, nz = 3 * nb, ncap = SP.nc, e = SP.e, n = nz + e;
   const int AST = (EQC <= 4) ? LX : nz;                                      // row stride of the A image
   // workspace per scene (when given): the count and the best iterate, for the backward: [ncs .. | x[64] y[16] z[64] s[64]]
@@ -222,7 +223,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
     }
     idn = vc ? 1.0 / dfl : 0.0;
     factor();
-    const double g = vx ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;     // dp = -x (engines.py:115)
+    double g = vx ? -(double)((const float*)Gd.dl_dv)[(size_t)scene * nz + lane] : 0.0;     // dp = -x (engines.py:115)
+    if (SP.tag && *SP.tag != SP.tag_value) g = nan_of<double>();          // (another family's workspace: NaN gradients instead of a misread)
     double dx, ds, dl, dnu;
     solve_kkt(dfl, g, 0.0, 0.0, 0.0, dx, ds, dl, dnu);
     if (ncs > 0) {                                                           // refinement on the unreduced equations, true D

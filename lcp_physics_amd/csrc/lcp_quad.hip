@@ -1163,7 +1163,15 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       if (!R.pin_rt) return;                                             // the general kernel behind this one takes the wave
     }
   }
-  int status = prefactor_q<TI, TC, XH>(S, W, live) | truncated;
+  if (blockIdx.x == 0 && lane == 0) { int32_t* tg = FUSED ? SP.tag : P.tag; if (tg) *tg = FUSED ? SP.tag_value : P.tag_value; }
+  int status = truncated;
+  if constexpr (ALG == 0) status |= prefactor_q<TI, TC, XH>(S, W, live);
+  else {
+    // body space: nothing of the contact-space pre-factorisation (W = J P J^T, G Q^-1 A^T, (A Q^-1 A^T)^-1) is formed - the
+    // backward kernels of this path factor in body space too (bwd_solve_body) and read Q's diagonal, mu and the best iterate only
+    if (row_any(l16 < nz && !(S.qd[0] != (TC)0))) status |= LCP_ST_SINGULAR_Q;
+    if (live) { W.Qit[l16] = S.qid[0]; W.Qit[128 + l16] = S.qd[0]; }
+  }
   TC* const wsx = ws_x<XH>(W);
 
   TC ta[ALG == 0 ? 32 : 20], tu[ALG == 0 ? 32 : 20];                    // ALG 1, 2: x-rows and equality rows of the body-space system
@@ -1225,6 +1233,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     if constexpr (ALG == 0) sing_ = factor_q<TI, TC, LCP_Q_LDSW != 0, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);            // (:99-100)
     else sing_ = factor_pq<TI, TC, decltype(R)>(ta, tu, R, S, dinv, vc LCP_QPROF_PASS);
     const bool singular = row_any(sing_);
+    if (ALG != 0 && it < 0 && singular && e > 0) status |= LCP_ST_SINGULAR_S11;   // (d = 1: the x block is positive definite, a zero pivot is A's)
     if (it >= 0 && !done) {
       ++iters;
       if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
@@ -1363,8 +1372,64 @@ __device__ __forceinline__ void factor_bwd_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC
   factor_q<TI, TC, false, XH>(ta, tu, R, S, W2q, dinv, vc LCP_QPROF_PASS);
 }
 
-// ---------------------------------------------------------------- backward kernel (lcp.py:37-64)
+// ---------------------------------------------------------------- backward solve in body space (lcp.py:44-50)
+// The backward of a forward that ran in body space (ALG = 1, 2): the same K = [[Q + G^T M^-1 G, A^T], [A, 0]] factorisation at the
+// best iterate, nothing read from the workspace but Q's diagonal, mu and the iterate (no W: the forward does not form it).
+// At a converged iterate the ratios D = s / z of the active rows underflow against Q (1e-12 and below) and Q + G^T M^-1 G would
+// lose Q: as in lcp_primal_step.inc the factorisation uses D floored at 1e-9 x the row's effective inverse mass j Q^-1 j^T, and
+// ONE step of iterative refinement on the UNREDUCED equations (residuals formed with M = F_c + diag(D), the true D, not with
+// M^-1) takes the perturbation out again - 1e-8 of the natural scale |g| / min Q against the contact-space solve.
+// g: entry l16 of d(loss)/dx.  Returns dx (x lanes), dlam per contact, dnu (equality lanes).
 template <typename TI, typename TC>
+__device__ __forceinline__ void bwd_solve_body(const SceneQ<TI, TC, 1>& S, bool vc, const M4<TC>& z, const M4<TC>& s, TC g,
+                                               TC& dx, M4<TC>& dl, TC& dnu LCP_QPROF_ARG) {
+  const int l16 = S.l16, nz = S.nz, e = S.e;
+  const M4<TC> dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (lcp.py:44)
+  M4<TC> dfl = dinv;
+  {
+    TC wn = 0, wt = 0;
+    static_for<16>([&](auto J) LCP_INL { const TC qi = bc<J>(S.qid[0]); wn = fma((TC)S.jc[J] * (TC)S.jc[J], qi, wn); wt = fma((TC)S.jt[J] * (TC)S.jt[J], qi, wt); });
+    constexpr TC BWD_FLOOR = (TC)1e-9;
+    if (vc) { dfl.n = fmax_(dinv.n, BWD_FLOOR * wn); dfl.f1 = fmax_(dinv.f1, BWD_FLOOR * wt); dfl.f2 = fmax_(dinv.f2, BWD_FLOOR * wt); }
+  }
+  PrimQ<TC, false> R;
+  {                                                     // A = [I 0] in all four scenes of the wave ?  (the pinned floor of the demo worlds)
+    bool okl = true;
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; if (a < e) okl = okl && ((TC)S.L.AtL[a * 16 + l16] == ((l16 == a) ? (TC)1 : (TC)0)); });
+    R.pin_rt = __all(okl) != 0;
+  }
+  TC xr[20], er[20];
+  factor_pq<TI, TC, PrimQ<TC, false>>(xr, er, R, S, dfl, vc LCP_QPROF_PASS);                               // lcp.py:46
+  const M4<TC> zero = m4<TC>(0, 0, 0, 0);
+  XV<TC, 1> rx, ox;
+  M4<TC> ds;
+  rx.v[0] = g;
+  solve_kkt_pq<TI, TC, PrimQ<TC, false>>(S, xr, er, R, dfl, vc, rx, zero, zero, (TC)0, ox, ds, dl, dnu LCP_QPROF_PASS);   // lcp.py:47-50
+  dx = ox.v[0];
+  // residuals of  Q dx + G^T dl + A^T dnu = -g ,  G dx - M dl = 0 ,  A dx = 0  with the TRUE D, then one correction solve
+  const XV<TC, 1> gl = S.template Gtw<false>(vc ? dl.n : (TC)0, vc ? dl.f1 - dl.f2 : (TC)0);
+  TC r1 = -g - (S.qd[0] * dx + gl.v[0]);
+  if (e > 0) { const XV<TC, 1> ay = S.Aty(dnu); r1 -= ay.v[0]; }
+  if (!(l16 < nz)) r1 = 0;
+  TC gn, gt;
+  S.template Gv<false>(ox, gn, gt);
+  M4<TC> r3 = m4<TC>(-(gn - dinv.n * dl.n), -(gt - (dinv.f1 * dl.f1 + dl.g)), -(-gt - (dinv.f2 * dl.f2 + dl.g)),
+                     (S.mu * dl.n - (dl.f1 + dl.f2)) + dinv.g * dl.g);
+  if (!vc) r3 = zero;
+  const TC r2 = (e > 0) ? -S.Av(ox) : (TC)0;
+  XV<TC, 1> cx;
+  M4<TC> cs, cl;
+  TC cnu;
+  rx.v[0] = -r1;
+  solve_kkt_pq<TI, TC, PrimQ<TC, false>>(S, xr, er, R, dfl, vc, rx, zero, m4<TC>(-r3.n, -r3.f1, -r3.f2, -r3.g), -r2, cx, cs, cl, cnu LCP_QPROF_PASS);
+  dx += cx.v[0]; dnu += cnu;
+  dl = m4<TC>(dl.n + cl.n, dl.f1 + cl.f1, dl.f2 + cl.f2, dl.g + cl.g);
+}
+
+// ---------------------------------------------------------------- backward kernel (lcp.py:37-64)
+// BODY: the workspace was left by a body-space forward (lcp_fwd_quad ALG = 1, 2 behind the contact-list entry points): no W in it,
+// the solve runs in body space (bwd_solve_body); otherwise the contact-space W is re-factored (factor_bwd_q).
+template <typename TI, typename TC, bool BODY = false>
 __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene, int accept) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
@@ -1395,11 +1460,11 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
     static_for<16>([&](auto K) LCP_INL {
       if (l16 < EQ) S.L.AtL[l16 * 16 + K] = (l16 < e && K < nz) ? A[l16 * nz + K] : (TI)0;
     });
-    static_for<EQ>([&](auto A_) LCP_INL {
+    if constexpr (!BODY) static_for<EQ>([&](auto A_) LCP_INL {
       S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
       S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
     });
-    S.qid[0] = W.Qit[l16]; S.qd[0] = 0;
+    S.qid[0] = W.Qit[l16]; S.qd[0] = BODY ? W.Qit[128 + l16] : (TC)0;
     S.mu = vc ? W.meta[1 + l16] : (TC)0;
   }
   __syncthreads();
@@ -1408,19 +1473,25 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   XV<TC, 1> g;
   g.v[0] = (l16 < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + l16] : (TC)0;
-  M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                  // 1 / d, d = z / s (lcp.py:44)
-  TC ta[32], tu[32];
-  RedQ<TC> R;
+  if (P.tag && *P.tag != P.tag_value) g.v[0] = nan_of<TC>();      // a workspace another kernel family laid out: NaN gradients, not a misread
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_bwd_q<TI, TC, 1>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
-  XV<TC, 1> dxv;
-  TC dnu;
-  M4<TC> ds, dl;
-  const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC, 1>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dxv, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
-  const TC dx = dxv.v[0];
+  TC dx, dnu;
+  M4<TC> dl;
+  if constexpr (BODY) {
+    bwd_solve_body<TI, TC>(S, vc, z, s, g.v[0], dx, dl, dnu LCP_QPROF_PASS);
+  } else {
+    M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);                  // 1 / d, d = z / s (lcp.py:44)
+    TC ta[32], tu[32];
+    RedQ<TC> R;
+    factor_bwd_q<TI, TC, 1>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);                // lcp.py:46
+    XV<TC, 1> dxv;
+    M4<TC> ds;
+    const M4<TC> zero = m4<TC>(0, 0, 0, 0);
+    solve_kkt_q<TI, TC, 1>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dxv, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
+    dx = dxv.v[0];
+  }
   if (!live) return;
   // outer products (lcp.py:52-61), one output row per instruction, lanes over the columns
   if (P.dp && l16 < nz) ((TI*)P.dp)[(size_t)scene * nz + l16] = (TI)dx;
@@ -1491,8 +1562,9 @@ __global__ void __launch_bounds__(64) lcp_bwd_quad(BwdArgs P, int lds_per_scene,
 // (lcp.py:37-64) has materialised dQ, dp, dG, dh, dF.  Here the rank-1 LCP gradients are contracted in registers:
 //   dp = dx, dQ_jj = dx_j x_j, dG_row = dlam_row x + lam_row dx, dh = -dlam, dF[gamma_c, n_c] = -dlam_gamma lam_n
 // and only ~0.6 KB per scene leaves the chip instead of the 21.6 KB of dense gradients.
-template <typename TI, typename TC, int XH>
+template <typename TI, typename TC, int XH, bool BODY = false>
 __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs Gd, int lds_per_scene) {
+  static_assert(!BODY || XH == 1, "the body-space forward serves nz <= 16");
   using XVt = XV<TC, XH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int lane = threadIdx.x, l16 = lane & 15, row = lane >> 4;
@@ -1513,7 +1585,7 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   XVt p_;
   TC hn_, b_;
   assemble_q<TI, TC, XH>(S, SP, scene, p_, hn_, b_);                      // the same rows the forward solved with
-  static_for<EQ>([&](auto A_) LCP_INL {
+  if constexpr (!BODY) static_for<EQ>([&](auto A_) LCP_INL {
     S.gan[A_] = W.GAc[(l16 * 2 + 0) * EQ + A_]; S.gat[A_] = W.GAc[(l16 * 2 + 1) * EQ + A_];
     S.s11row[A_] = (l16 < EQ) ? W.S11i[l16 * EQ + A_] : (TC)0;
   });
@@ -1527,18 +1599,24 @@ __global__ void __launch_bounds__(64) lcp_bwd_step_quad(StepArgs SP, StepBwdArgs
   });
   const M4<TC> z = vc ? m4<TC>(W.z[l16], W.z[nc + 2 * l16], W.z[nc + 2 * l16 + 1], W.z[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
   const M4<TC> s = vc ? m4<TC>(W.s[l16], W.s[nc + 2 * l16], W.s[nc + 2 * l16 + 1], W.s[3 * nc + l16]) : m4<TC>(1, 1, 1, 1);
-  M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
-  TC ta[32], tu[32];
-  RedQ<TC> R;
+  if (SP.tag && *SP.tag != SP.tag_value) static_for<XH>([&](auto HX) LCP_INL { g.v[HX] = nan_of<TC>(); });   // (foreign workspace: NaN gradients)
 #ifdef LCP_Q_PROFILE
   Prof pr; pr.last = 0;
 #endif
-  factor_bwd_q<TI, TC, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);               // lcp.py:46
   XVt dx;
   TC dnu;
-  M4<TC> ds, dl;
-  const M4<TC> zero = m4<TC>(0, 0, 0, 0);
-  solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
+  M4<TC> dl;
+  if constexpr (BODY) {
+    bwd_solve_body<TI, TC>(S, vc, z, s, g.v[0], dx.v[0], dl, dnu LCP_QPROF_PASS);
+  } else {
+    M4<TC> dinv = m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g);
+    TC ta[32], tu[32];
+    RedQ<TC> R;
+    factor_bwd_q<TI, TC, XH>(ta, tu, R, S, W.R2, dinv, vc LCP_QPROF_PASS);               // lcp.py:46
+    M4<TC> ds;
+    const M4<TC> zero = m4<TC>(0, 0, 0, 0);
+    solve_kkt_q<TI, TC, XH>(S, ta, tu, R, dinv, vc, g, zero, zero, (TC)0, dx, ds, dl, dnu, false LCP_QPROF_PASS);  // lcp.py:47-50
+  }
   // x-space vectors to LDS so that a contact lane can read the entries of its two bodies (GAL is free in this kernel:
   // 128 TC = X[32] DX[32] CR[16] CF[16] B12[32 ints])
   TC* X = S.L.GAL; TC* DX = X + 32; TC* CR = X + 64; TC* CF = X + 80;
@@ -1667,6 +1745,9 @@ int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
+// does quad_step / quad_step_backward run the body-space kernels for these arguments ?  (fp64 arithmetic, nz <= 16, not forced off)
+bool quad_step_is_body_space(int nz, int compute, int body_space) { return body_space && compute == LCP_COMPUTE_F64 && nz <= 16; }
+
 // `body_space`: factor / solve the (nz + neq)-row body-space system instead of the 32-row contact-space one (fp64 arithmetic, nz <= 16)
 int quad_step(const StepArgs& SP, int compute, void* stream, int body_space) {
   FwdArgs P = {};
@@ -1689,10 +1770,14 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64) {
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64, int body) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
-  if (io_f64) {
+  if (body) {                                    // workspace of a body-space forward (fp32 I/O, fp64 arithmetic)
+    if (io_f64 || compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
+    const int ls = (int)q16_lds<double>(false);
+    hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, ls, accept);
+  } else if (io_f64) {
     const int ls = (int)q16_lds<double, double>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<double, double>), grid, blk, 4 * ls, st, P, ls, accept);
   } else if (compute == LCP_COMPUTE_F64) {
@@ -1705,13 +1790,14 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int i
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream) {
+int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream, int body_space) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
   const bool wide = 3 * SP.nb > 16;
   if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(false, wide ? 2 : 1);
     if (wide) hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 2>), grid, blk, 4 * ls, st, SP, Gd, ls);
+    else if (body_space) hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 1, true>), grid, blk, 4 * ls, st, SP, Gd, ls);
     else hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 1>), grid, blk, 4 * ls, st, SP, Gd, ls);
   } else {
     const int ls = (int)q16_lds<float>(false, wide ? 2 : 1);

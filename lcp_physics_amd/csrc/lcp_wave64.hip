@@ -897,6 +897,7 @@ __device__ __forceinline__ bool factor(TC (&t)[MP], const Ops<TI, TC>& O, const 
 template <typename TI, typename TC>
 __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
   const int scene = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && P.tag) *P.tag = P.tag_value;   // workspace trailer: which kernel family laid it out
   if (scene >= P.B) return;
   const int nz = P.nz, m = P.m;
   Ws<TI, TC> W(P.ws, scene);
@@ -955,6 +956,7 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int scene = blockIdx.x * WPB + wave;
+  if (FUSED && blockIdx.x == 0 && threadIdx.x == 0 && SP.tag) *SP.tag = SP.tag_value;   // (dense inputs: lcp_classify_wave wrote it)
   if (scene >= (FUSED ? SP.B : P.B)) return;            // whole wave leaves; s_barrier ignores terminated waves
   unsigned char* smem = smem_all + (size_t)wave * lds_per_wave;
   const int nz = FUSED ? 3 * SP.nb : P.nz, m = FUSED ? 4 * SP.nc : P.m, e = FUSED ? SP.e : P.e;
@@ -1150,7 +1152,8 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   const TC x = (jx < nz) ? W.x[jx] : (TC)0;
   const TC z = vm ? W.z[lane] : (TC)1, s = vm ? W.s[lane] : (TC)1;
   const TC y = (ae < e) ? W.y[ae] : (TC)0;
-  const TC g = (jx < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + jx] : (TC)0;
+  TC g = (jx < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + jx] : (TC)0;
+  if (P.tag && *P.tag != P.tag_value) g = nan_of<TC>();            // (another family's workspace: NaN gradients instead of a misread)
   const TC d = vm ? z / s : (TC)1;                                           // lcp.py:44
   TC t[MP];
   int mystep, porder;

@@ -64,7 +64,7 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
         _lib.require_gpu_tensor(A, "A", dtype)
         _lib.require_gpu_tensor(b, "b", dtype)
     assert Q.shape == (B, nz, nz) and p.shape == (B, nz) and h.shape == (B, m) and F.shape == (B, m, m)
-    comp = _lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]
+    comp = (_lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]) | _lib.path_bits()
     need = _lib.workspace_bytes(B, nz, m, e, comp | (_lib.IO_F64 if dtype == torch.float64 else 0))
     if need == 0:
         raise RuntimeError("invalid LCP sizes B=%d nz=%d nineq=%d neq=%d" % (B, nz, m, e))
@@ -83,10 +83,11 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
     st = _lib.stream_ptr(dev)
     with torch.cuda.device(dev):
         if dtype == torch.float64:
-            rc = lib.lcp_pdipm_forward_f64(B, nz, m, e, P(Q), P(p), P(G), P(h), P(A), P(b), P(F),
-                                           float(eps), int(max_iter), int(not_improved_lim),
-                                           P(sol.x), P(sol.y), P(sol.z), P(sol.s), P(sol.iters),
-                                           P(sol.status), P(ws), st)
+            with _lib.thread_path(comp):
+                rc = lib.lcp_pdipm_forward_f64(B, nz, m, e, P(Q), P(p), P(G), P(h), P(A), P(b), P(F),
+                                               float(eps), int(max_iter), int(not_improved_lim),
+                                               P(sol.x), P(sol.y), P(sol.z), P(sol.s), P(sol.iters),
+                                               P(sol.status), P(ws), st)
         else:
             rc = lib.lcp_pdipm_forward_f32(B, nz, m, e, P(Q), P(p), P(G), P(h), P(A), P(b), P(F),
                                            float(eps), int(max_iter), int(not_improved_lim), comp,
@@ -111,8 +112,9 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
     st = _lib.stream_ptr(dev)
     with torch.cuda.device(dev):
         if dtype == torch.float64:
-            rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
-                                            *[P(o) for o in out], P(sol.ws), st)
+            with _lib.thread_path(sol.compute):
+                rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
+                                                *[P(o) for o in out], P(sol.ws), st)
         else:
             hint = _lib.HINT_ALL_CONTACT if getattr(sol, "all_contact", False) else 0
             rc = lib.lcp_pdipm_backward_f32(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint,

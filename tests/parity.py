@@ -166,3 +166,52 @@ def err_physical(pg, pg_ref, phys, floor, keys=None):
         num = num + (w * _n(pg[k] - pg_ref[k])) ** 2
         den = den + (w * _n(pg_ref[k])) ** 2
     return num.sqrt() / torch.maximum(den.sqrt(), floor).clamp_min(1e-300)
+
+
+# ----------------------------------------------------------------------------
+# one report for "the kernel the metric times against the oracle" (tests/test_hip_headline_parity.py and
+# bench.py's `parity` object print the same fields)
+# ----------------------------------------------------------------------------
+def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4)):
+    """`lcp64`: the LCP the kernel solved (fp64 copies of the fp32 data the HIP assembly produced: identical inputs),
+    `x, z, s, iters`: what the kernel returned for those scenes, `dp` (optional): its dl/dp for the cotangent `cot`.
+    Returns (report dict, oracle solution).  Fields:
+      fwd_err_x_*                      SURVEY 8d err_x per scene
+      index_set_mismatches_unmasked    rows where (z_i > s_i) differs from the oracle's, NO mask
+      index_set_mismatches             the same on the decisive rows (`decisive_rows`, floor = floors[0])
+      index_set_masked_frac            share of rows that mask drops (ties of two numbers that both converged to zero)
+      index_set_mismatches_floor_1e-4 / masked_frac_floor_1e-4   with the looser floor the body-space kernels are gated on
+      iters_delta_hist                 histogram of iters - iters_oracle (pdipm.py:80-136 loop iterations per scene)
+      iters_differ_frac                share of scenes with a non-zero delta
+      bwd_*                            dl/dp against lcp.py:52 on the scenes whose backward system is well posed"""
+    Q, p, G, h, A, b, F = lcp64
+    ref = oracle.lcp_forward(*lcp64)
+    n = Q.shape[0]
+    ex = err_x(x.double(), ref.x, Q, p)
+    out = {"scenes": int(n), "tolerance": 1e-4, "fwd_err_x_max": float(ex.max()), "fwd_err_x_median": float(ex.median())}
+    z, s = z.double(), s.double()
+    diff = (z > s) != (ref.z > ref.s)
+    out["index_set_rows_total"] = int(diff.numel())
+    out["index_set_mismatches_unmasked"] = int(diff.sum())
+    for i, fl in enumerate(floors):
+        dec = decisive_rows(ref.z, ref.s, floor=fl)
+        sfx = "" if i == 0 else "_floor_%g" % fl
+        out["index_set_mismatches" + sfx] = int((diff & dec).sum())
+        out["index_set_masked_frac" + sfx] = 1.0 - float(dec.sum()) / dec.numel()
+        if i == 0:
+            out["index_set_rows_compared"] = int(dec.sum())
+    d = (iters.to(torch.int64).cpu() - ref.iters.to(torch.int64))
+    out["iters_delta_hist"] = {str(int(k)): int((d == k).sum()) for k in torch.unique(d)}
+    out["iters_differ_frac"] = float((d != 0).sum()) / n
+    out["iters_max_abs_delta"] = int(d.abs().max())
+    if dp is not None:
+        c64 = cot.double()
+        gref = oracle.lcp_backward(ref, *lcp64, c64)
+        ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
+        fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
+        eg = err_grads({"p": dp.double()}, {"p": gref["dp"]}, fl)["p"]
+        if bool(ok.any()):
+            out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})
+        out["bwd_well_posed_scenes"] = int(ok.sum())
+        out["bwd_well_posed_frac"] = float(ok.sum()) / n
+    return out, ref

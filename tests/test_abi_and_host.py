@@ -34,7 +34,7 @@ def test_workspace_bytes_and_argument_checks_host_only():
     w64 = lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F64)
     w32 = lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F32)
     assert w64 > w32 and w64 >= 4096 * 8 * (64 * 64 + 15 * 15 + 64 * 3 + 9 + 15 + 128 + 3)
-    tail = (4096 * 4 + 255) & ~255                              # per-scene classes of the dense lcp_big path, behind the scene blocks
+    tail = ((4096 * 4 + 255) & ~255) + 256                      # behind the scene blocks: per-scene classes of the dense lcp_big path + the layout-tag trailer
     assert (w64 - tail) % 4096 == 0 and ((w64 - tail) // 4096) % 256 == 0        # per-scene stride keeps 256 B alignment
     # fp64 I/O keeps an fp64 copy of F in the workspace: the caller says so with LCP_IO_F64
     assert lib.lcp_workspace_bytes(4096, 15, 64, 3, _lib.COMPUTE_F64 | _lib.IO_F64) > w64
@@ -49,6 +49,13 @@ def test_workspace_bytes_and_argument_checks_host_only():
     assert rc == -1
     rc = lib.lcp_pdipm_backward_f32(4, 15, 64, 3, N, N, N, 1, N, N, N, N, N, N, N, N, N)
     assert rc == -1
+    # which contact-list sizes have a fused backward (host-only planning query; the family is a function of sizes + compute word)
+    assert lib.lcp_step_has_backward(5, 16, 3, _lib.COMPUTE_F64) == 1            # four scenes per wave
+    assert lib.lcp_step_has_backward(11, 64, 3, _lib.COMPUTE_F64) == 1           # body space, one wave per scene
+    assert lib.lcp_step_has_backward(11, 40, 20, _lib.COMPUTE_F64) == 1          # chains of joints
+    assert lib.lcp_step_has_backward(5, 16, 3, _lib.COMPUTE_F64 | _lib.PATH_GENERIC) == 0
+    assert lib.lcp_step_has_backward(20, 64, 3, _lib.COMPUTE_F64) == 0           # 3 nb + e > 56: generic kernels, forward only
+    assert lib.lcp_step_has_backward(11, 64, 3, _lib.COMPUTE_F32) == 0
 
 
 def test_no_cpu_fallback():

@@ -158,7 +158,7 @@ def test_dense_boundary_routes_every_scene_to_its_kernel():
         return sol, grads
 
     sol, grads = run("auto")
-    per_scene = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255)) // B
+    per_scene = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255) - 256) // B
     cls = sol.ws[B * per_scene: B * per_scene + 4 * B].view(torch.int32).cpu().tolist()
     want = [3] * B
     want[2] = want[7] = 2

@@ -120,3 +120,97 @@ def test_contact_world_reports_overflow_instead_of_clamping_silently():
     with pytest.raises(RuntimeError, match="exceeded maxc"):
         small.run(60, graph=False)
     assert small.truncated_scenes().numel() > 0
+
+
+# ------------------------------------------------------------------ kernel family of a backward = its forward's, on any thread
+def _fwd_bwd_on_threads(path, bwd_in_thread):
+    """Fused step under `path` on this thread; the two backwards (dense gradients, physical gradients) either here or on a
+    fresh thread whose path default was never set (what torch's autograd worker thread is)."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step
+    sc = _scenes(21, B=256)
+    lcp = assemble_contacts(sc)
+    cot = torch.randn(sc.B, 3 * sc.nb, generator=torch.Generator().manual_seed(5)).to(DEV)
+    _lib.set_path(path)
+    try:
+        out = fused_step(sc)
+    finally:
+        _lib.set_path("auto")
+    res = {}
+
+    def bwd():
+        with torch.cuda.device(0):
+            res["dense"] = lcp_backward(solution_of_step(sc, out, lcp[2], lcp[4]), cot)
+            res["phys"] = fused_step_backward(sc, out, (-cot).reshape(sc.B, sc.nb, 3).contiguous())
+            torch.cuda.synchronize()
+    if bwd_in_thread:
+        t = threading.Thread(target=bwd); t.start(); t.join()
+    else:
+        bwd()
+    return out, res
+
+
+@pytest.mark.parametrize("path", ["auto", "big"])
+def test_backward_on_another_thread_picks_the_forwards_kernel_family(path):
+    """the kernel family (and with it the workspace layout) used to be re-derived from thread-local state at backward
+    time.  Now it is a function of the `compute` word recorded at forward time: the backward run on another host thread is
+    bitwise the one run on the forward's thread - for the body-space layout (no W in the workspace) and the contact-space one."""
+    out_a, a = _fwd_bwd_on_threads(path, False)
+    out_b, b = _fwd_bwd_on_threads(path, True)
+    assert torch.equal(out_a["v_new"], out_b["v_new"])
+    for ga, gb in zip(a["dense"], b["dense"]):
+        assert torch.equal(ga, gb) and bool(torch.isfinite(ga).all())
+    for k in a["phys"]:
+        assert torch.equal(a["phys"][k], b["phys"][k]) and bool(torch.isfinite(a["phys"][k]).all()), k
+
+
+def test_backward_planned_for_another_layout_returns_nan_not_garbage():
+    """The forward leaves a layout tag in the workspace trailer; a backward whose `compute` word plans another kernel family /
+    layout finds the mismatch on the device and returns NaN gradients (the launch itself cannot fail: nothing synchronises)."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics import assemble_contacts, fused_step
+    from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step
+    sc = _scenes(22, B=64)
+    lcp = assemble_contacts(sc)
+    cot = torch.ones(sc.B, 3 * sc.nb, device=DEV)
+    out = fused_step(sc)                                        # body-space forward: no W in the workspace
+    good = fused_step_backward(sc, out, cot.reshape(sc.B, sc.nb, 3))
+    wrong = dict(out)
+    wrong["compute"] = out["compute"] | _lib.PATH_CONTACT_SPACE  # a backward that would re-factor a W that is not there
+    bad = fused_step_backward(sc, wrong, cot.reshape(sc.B, sc.nb, 3))
+    bad_dense = lcp_backward(solution_of_step(sc, wrong, lcp[2], lcp[4]), cot)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(good["v"]).all())
+    assert bool(torch.isnan(bad["v"]).all()) and bool(torch.isnan(bad_dense[1]).all())
+    # and the dense forward's workspace is not a contact-list forward's: LCP_HINT_ALL_CONTACT on it is refused on the device too
+    from lcp_physics_amd.lcp import lcp_solve
+    sol = lcp_solve(*lcp)
+    sol.all_contact = True
+    nanp = lcp_backward(sol, cot)[1]
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(nanp).all())
+
+
+def test_differentiable_step_without_a_fused_backward_fails_at_forward_time():
+    """sizes the generic kernels step forward (no iterate kept for a fused backward) must not fail with LCP_E_TOOLARGE
+    in the middle of loss.backward(): SolveDynamicsFunction says so when the step is recorded."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction
+    sc = _scenes(23, B=8)
+    Md = sc.Mdiag.clone().requires_grad_(True)
+    count = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=DEV)
+    args = (Md, sc.v, sc.f, sc.rest, sc.fric, sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2, count, sc.Je, sc.dt)
+    v_new = SolveDynamicsFunction.apply(*args, {})
+    v_new.sum().backward()                                       # the default path has one
+    assert Md.grad is not None and bool(torch.isfinite(Md.grad).all())
+    _lib.set_path("generic")
+    try:
+        with pytest.raises(RuntimeError, match="no fused backward"):
+            SolveDynamicsFunction.apply(*args, {})
+        with torch.no_grad():
+            SolveDynamicsFunction.apply(*args, {})               # forward only: fine
+    finally:
+        _lib.set_path("auto")
