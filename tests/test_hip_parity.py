@@ -364,7 +364,7 @@ def test_mixed_batch_every_scene_served_by_the_right_kernel(kernel_path):
         from lcp_physics_amd import _lib
         import ctypes
         # classification flags live in the workspace: meta[0] of each scene (see lcp_wave_common.h `Ws`)
-        XX
+        stride = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255) - 256) // B     # (the tail holds lcp_big's classes and the layout tag)
         flags = sol.ws[:B * stride].view(torch.float64).reshape(B, stride // 8)[:, 5080].cpu()
         assert flags.tolist() == [2.0] * 4 + [1.0] * 4 + [0.0] * 5
     cot = torch.randn(B, nz, generator=g, dtype=torch.float32)
