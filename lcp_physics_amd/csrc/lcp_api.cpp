@@ -203,13 +203,21 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
-  if (w64 && hint) {
+  if (hint) {
     // LCP_HINT_ALL_CONTACT: the workspace was left by a contact-list forward (lcp_step_fused_f32 / lcp_solve_dynamics_f32) called with
-    // this `compute` word.  Only the four-scenes-per-wave family keeps a workspace this dense backward can read: in body space (no
-    // W in it: lcp_bwd_quad<..., BODY>) or in contact space, exactly as that forward decided.
-    if (io_f64 || step_family(nz, m, e, compute, path) != FAM_QUAD || !lcp::quad_supported(nz, m, e)) return LCP_E_BADARG;
-    P.tag_value = step_tag(FAM_QUAD, nz, compute, path);
-    return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY);
+    // this `compute` word.  Three of its kernel families keep a workspace a dense backward can read - the four-scenes-per-wave one
+    // (in body space, no W in it: lcp_bwd_quad<..., BODY>, or in contact space, exactly as that forward decided), the wave64 step
+    // kernel and the generic one (their dense layouts) -, the tag says which one it was.
+    if (io_f64) return LCP_E_BADARG;
+    const StepFamily fam = step_family(nz, m, e, compute, path);
+    P.tag_value = step_tag(fam, nz, compute, path);
+    if (fam == FAM_QUAD) {
+      if (!lcp::quad_supported(nz, m, e)) return LCP_E_TOOLARGE;             // (nz 17..32: the physical backward only)
+      return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY);
+    }
+    if (fam == FAM_WAVE64) return lcp::wave64_backward(P, compute, false, stream, 0);
+    if (fam != FAM_GENERIC) return LCP_E_TOOLARGE;                            // (lcp_primal / lcp_big: lcp_step_backward_f32 is their backward)
+    return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
   }
   if (w64) return lcp::wave64_backward(P, compute, false, stream, io_f64);
   if (bigd) {

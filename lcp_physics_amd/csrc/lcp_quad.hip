@@ -1307,6 +1307,9 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   }
 #ifdef LCP_Q_PROFILE
   if (!FUSED && P.trace && lane == 0) { double* tr = P.trace + (size_t)scene * 4 * max_iter; for (int i = 0; i < 8; ++i) tr[i] = (double)pr.t[i]; tr[8] = (double)iters; }
+  long long prof_keep[9];                               // (contact-list entry: the record replaces the tail of the wave's first `s` row, below)
+  for (int i = 0; i < 8; ++i) prof_keep[i] = pr.t[i];
+  prof_keep[8] = iters;
 #endif
 
   // outputs (natural m-space order: n rows, friction pairs, gamma rows).  The best iterate also goes to the workspace,
@@ -1348,6 +1351,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       }
     });
     if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+#ifdef LCP_Q_PROFILE
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0 && so && m >= 16) { TI* o = so + (size_t)scene * m + (m - 9); for (int i = 0; i < 9; ++i) o[i] = (TI)prof_keep[i]; }
+#endif
   } else {
     if (l16 < nz) ((TI*)P.x)[(size_t)scene * nz + l16] = (TI)bx.v[0];
     if (l16 == 0) { if (P.iters) P.iters[scene] = iters; if (P.status) P.status[scene] = status; }
@@ -1372,13 +1379,17 @@ __device__ __forceinline__ void factor_bwd_q(TC (&ta)[32], TC (&tu)[32], RedQ<TC
   factor_q<TI, TC, false, XH>(ta, tu, R, S, W2q, dinv, vc LCP_QPROF_PASS);
 }
 
+#ifndef LCP_Q_BWD_REFINE
+#define LCP_Q_BWD_REFINE 2      // refinement steps of the body-space backward solve
+#endif
 // ---------------------------------------------------------------- backward solve in body space (lcp.py:44-50)
 // The backward of a forward that ran in body space (ALG = 1, 2): the same K = [[Q + G^T M^-1 G, A^T], [A, 0]] factorisation at the
 // best iterate, nothing read from the workspace but Q's diagonal, mu and the iterate (no W: the forward does not form it).
 // At a converged iterate the ratios D = s / z of the active rows underflow against Q (1e-12 and below) and Q + G^T M^-1 G would
 // lose Q: as in lcp_primal_step.inc the factorisation uses D floored at 1e-9 x the row's effective inverse mass j Q^-1 j^T, and
 // ONE step of iterative refinement on the UNREDUCED equations (residuals formed with M = F_c + diag(D), the true D, not with
-// M^-1) takes the perturbation out again - 1e-8 of the natural scale |g| / min Q against the contact-space solve.
+// M^-1) takes the perturbation out again - 1e-8 of the natural scale |g| / min Q against the contact-space solve (LCP_Q_BWD_REFINE
+// steps; they cost a KKT solve each and the kernels around them are bound by their stores).
 // g: entry l16 of d(loss)/dx.  Returns dx (x lanes), dlam per contact, dnu (equality lanes).
 template <typename TI, typename TC>
 __device__ __forceinline__ void bwd_solve_body(const SceneQ<TI, TC, 1>& S, bool vc, const M4<TC>& z, const M4<TC>& s, TC g,
@@ -1406,24 +1417,29 @@ __device__ __forceinline__ void bwd_solve_body(const SceneQ<TI, TC, 1>& S, bool 
   rx.v[0] = g;
   solve_kkt_pq<TI, TC, PrimQ<TC, false>>(S, xr, er, R, dfl, vc, rx, zero, zero, (TC)0, ox, ds, dl, dnu LCP_QPROF_PASS);   // lcp.py:47-50
   dx = ox.v[0];
-  // residuals of  Q dx + G^T dl + A^T dnu = -g ,  G dx - M dl = 0 ,  A dx = 0  with the TRUE D, then one correction solve
-  const XV<TC, 1> gl = S.template Gtw<false>(vc ? dl.n : (TC)0, vc ? dl.f1 - dl.f2 : (TC)0);
-  TC r1 = -g - (S.qd[0] * dx + gl.v[0]);
-  if (e > 0) { const XV<TC, 1> ay = S.Aty(dnu); r1 -= ay.v[0]; }
-  if (!(l16 < nz)) r1 = 0;
-  TC gn, gt;
-  S.template Gv<false>(ox, gn, gt);
-  M4<TC> r3 = m4<TC>(-(gn - dinv.n * dl.n), -(gt - (dinv.f1 * dl.f1 + dl.g)), -(-gt - (dinv.f2 * dl.f2 + dl.g)),
-                     (S.mu * dl.n - (dl.f1 + dl.f2)) + dinv.g * dl.g);
-  if (!vc) r3 = zero;
-  const TC r2 = (e > 0) ? -S.Av(ox) : (TC)0;
-  XV<TC, 1> cx;
-  M4<TC> cs, cl;
-  TC cnu;
-  rx.v[0] = -r1;
-  solve_kkt_pq<TI, TC, PrimQ<TC, false>>(S, xr, er, R, dfl, vc, rx, zero, m4<TC>(-r3.n, -r3.f1, -r3.f2, -r3.g), -r2, cx, cs, cl, cnu LCP_QPROF_PASS);
-  dx += cx.v[0]; dnu += cnu;
-  dl = m4<TC>(dl.n + cl.n, dl.f1 + cl.f1, dl.f2 + cl.f2, dl.g + cl.g);
+  // residuals of  Q dx + G^T dl + A^T dnu = -g ,  G dx - M dl = 0 ,  A dx = 0  with the TRUE D, then a correction solve; twice
+  // (the first pass leaves ~1e-7 of the natural scale on the worst-conditioned scenes of the stack configs, the second 1e-9)
+#pragma unroll 1
+  for (int ref = 0; ref < LCP_Q_BWD_REFINE; ++ref) {
+    const XV<TC, 1> gl = S.template Gtw<false>(vc ? dl.n : (TC)0, vc ? dl.f1 - dl.f2 : (TC)0);
+    TC r1 = -g - (S.qd[0] * dx + gl.v[0]);
+    if (e > 0) { const XV<TC, 1> ay = S.Aty(dnu); r1 -= ay.v[0]; }
+    if (!(l16 < nz)) r1 = 0;
+    TC gn, gt;
+    ox.v[0] = dx;
+    S.template Gv<false>(ox, gn, gt);
+    M4<TC> r3 = m4<TC>(-(gn - dinv.n * dl.n), -(gt - (dinv.f1 * dl.f1 + dl.g)), -(-gt - (dinv.f2 * dl.f2 + dl.g)),
+                       (S.mu * dl.n - (dl.f1 + dl.f2)) + dinv.g * dl.g);
+    if (!vc) r3 = zero;
+    const TC r2 = (e > 0) ? -S.Av(ox) : (TC)0;
+    XV<TC, 1> cx;
+    M4<TC> cs, cl;
+    TC cnu;
+    rx.v[0] = -r1;
+    solve_kkt_pq<TI, TC, PrimQ<TC, false>>(S, xr, er, R, dfl, vc, rx, zero, m4<TC>(-r3.n, -r3.f1, -r3.f2, -r3.g), -r2, cx, cs, cl, cnu LCP_QPROF_PASS);
+    dx += cx.v[0]; dnu += cnu;
+    dl = m4<TC>(dl.n + cl.n, dl.f1 + cl.f1, dl.f2 + cl.f2, dl.g + cl.g);
+  }
 }
 
 // ---------------------------------------------------------------- backward kernel (lcp.py:37-64)

@@ -319,6 +319,22 @@ class SolveDynamicsFunction(torch.autograd.Function):
     `out` dict under "last" (z, s, y, iters, status).  Every call owns its workspace, so the steps of a roll-out can be
     back-propagated in reverse order."""
 
+    @classmethod
+    def apply(cls, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts):
+        # The generic kernels step any size forward but keep no iterate a fused backward could read: say so when the step is
+        # RECORDED, not with LCP_E_TOOLARGE in the middle of loss.backward().  (Checked here: inside forward() grad mode is off.)
+        args = (Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts)
+        if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+            nb, maxc = v.shape[1], c_n.shape[1]
+            e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+            if not _lib.load().lcp_step_has_backward(nb, maxc, e, _COMPUTE[opts.get("compute", "f64")] | _lib.path_bits()):
+                raise RuntimeError(
+                    "SolveDynamicsFunction: a differentiable step of %d bodies / %d contacts / %d joint rows (compute=%s) has no fused "
+                    "backward (limits: 64 contacts, 3 nb + e <= 56, fp64 arithmetic beyond 16 contacts); differentiate this size "
+                    "through the dense boundary - assemble_contacts() + lcp_physics_amd.lcp.LCPFunction (lcp/lcp.py:37-64) - or "
+                    "call under torch.no_grad()" % (nb, maxc, e, opts.get("compute", "f64")))
+        return super(SolveDynamicsFunction, cls).apply(*args)
+
     @staticmethod
     def forward(ctx, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts):
         B, nb = v.shape[0], v.shape[1]
@@ -330,15 +346,6 @@ class SolveDynamicsFunction(torch.autograd.Function):
         for name, t in (("c_i1", c_i1), ("c_i2", c_i2), ("count", count)):
             _lib.require_gpu_tensor(t, name, torch.int32)
         frame = _Frame(c_n, c_p1, c_p2, c_i1, c_i2)
-        if any(ctx.needs_input_grad) and not _lib.load().lcp_step_has_backward(
-                nb, maxc, e, _COMPUTE[opts.get("compute", "f64")] | _lib.path_bits()):
-            # (the generic kernels step any size forward but keep no iterate a fused backward could read: say so HERE, not with
-            #  LCP_E_TOOLARGE in the middle of loss.backward())
-            raise RuntimeError(
-                "SolveDynamicsFunction: a differentiable step of %d bodies / %d contacts / %d joint rows (compute=%s) has no fused "
-                "backward (limits: 64 contacts, 3 nb + e <= 56, fp64 arithmetic beyond 16 contacts); differentiate this size "
-                "through the dense boundary - assemble_contacts() + lcp_physics_amd.lcp.LCPFunction (lcp/lcp.py:37-64) - or call "
-                "under torch.no_grad()" % (nb, maxc, e, opts.get("compute", "f64")))
         out = solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, frame, Je if e else None, float(dt),
                              eps=opts.get("eps", 1e-12), not_improved_lim=opts.get("not_improved_lim", 3),
                              max_iter=opts.get("max_iter", 10), compute=opts.get("compute", "f64"))
