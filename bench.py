@@ -16,13 +16,18 @@ N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling,
          the output is the number of ranks that reported, on distinct devices.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline      - dominant kernel (the forward PDIPM kernel): `frac` = ALGORITHMIC FLOPs (SURVEY.md §8d dense
-                  formulation, lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by
-                  its average launch duration measured with HIP events on the launch stream inside the timed
-                  region, over the FP64 vector rate (the kernel issues no MFMA: `bound` says "valu_fp64");
-                  `frac_executed` = the FLOPs the structure-exploiting kernel really executes (body-space system / reduced 2nc
-                  system) over the same peak; counters / registers quoted from the committed rocprof and
-                  compiler reports under profiles/.
+  roofline      - dominant kernel (the forward PDIPM kernel).  `achieved` / `frac` = the FLOPs the kernel really EXECUTES
+                  (lcp_physics_amd/flops.py: body-space system of the pinned variant - formation + LU of nz - neq rows per
+                  iteration, two KKT solves, residuals - with the iteration counts the kernel reports) divided by its average
+                  launch duration, measured with HIP events on the launch stream inside the timed region, over the FP64 VECTOR
+                  rate (the kernel issues no MFMA: `bound` says "valu_fp64").  `frac_algorithmic` = SURVEY.md §8d's count of
+                  the REFERENCE's dense formulation over the same time and peak: it exceeds 1 because the kernel factors
+                  nz - neq = 12 rows where the reference factors nineq = 64 - a different algorithm with the same answers,
+                  not an efficiency.  `insts_per_useful_fma` cross-checks the executed model against the SQ_INSTS_VALU counter;
+                  `traffic` = HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE counters; counters and registers are
+                  quoted from the committed rocprofv3 / compiler reports under profiles/ (bench.py cannot run --pmc itself).
+                  `roofline.bwd` = the backward kernel against the HBM roofline (it is bound by the 21.6 KB of dense
+                  gradients it writes per scene): `achieved` = measured traffic (else algorithmic bytes) / its event time.
   cpu_baseline  - the oracle (a port, torch CPU fp64) timed on this host's cores on the same workload (rank 0,
                   N=1 only);  cpu_reference - the UNMODIFIED reference timed in the build container
                   (profiles/r01_reference_cpu_timing.json; /root/reference does not exist on the GPU box).
@@ -82,9 +87,10 @@ def timed_steps(work, steps, warmup, sync, reduce_dev):
     for k in range(steps):
         work.step(events[k])
     sync()
+    own = time.perf_counter() - t0                   # this rank's K steps, device work included, before it waits for the others
     shard.barrier()
     wall = time.perf_counter() - t0
-    return shard.max_over_ranks(wall, device=reduce_dev), events
+    return shard.max_over_ranks(wall, device=reduce_dev), events, own
 
 
 def run_rank(args, make_work, device=None):
@@ -102,7 +108,7 @@ def run_rank(args, make_work, device=None):
     rdev = shard.reduce_device(dev)
     sync = torch.cuda.synchronize if is_gpu else (lambda: None)
     work = make_work(args, rank, dev)
-    wall, events = timed_steps(work, args.steps, args.warmup, sync, rdev)
+    wall, events, own_wall = timed_steps(work, args.steps, args.warmup, sync, rdev)
     # how many ranks really ran, and on how many distinct devices
     reported = int(round(shard.sum_over_ranks(1.0, device=rdev)))
     dev_index = torch.device(dev).index or 0
@@ -142,7 +148,16 @@ def run_rank(args, make_work, device=None):
         "dtype": args.compute,
         "data": "synthetic",
     }
-    out.update(work.report(events, world))
+    rep_ = work.report(events, world)                 # (every rank: its own kernel timings go into `per_rank`)
+    out.update(rep_)
+    # per-rank record, so that an N > 1 line can be audited rank by rank: this rank's own wall clock over the timed region (the
+    # metric uses the MAX) and its event-timed kernel durations
+    roof = rep_.get("roofline") or {}
+    mine = torch.tensor([[float(rank), float(dev_index), own_wall / args.steps * 1e3, float(roof.get("fwd_ms") or 0.0),
+                          float(roof.get("bwd_ms") or 0.0)]], dtype=torch.float64, device=rdev)
+    allr = shard.gather_scenes(mine, world, device=rdev) if world > 1 else mine
+    out["per_rank"] = [{"rank": int(r[0]), "device": int(r[1]), "ms_per_step": float(r[2]), "fwd_ms": float(r[3]), "bwd_ms": float(r[4])}
+                       for r in allr.cpu().tolist()]
     out["config"]["global_batch"] = work.units_per_step * world
     out["config"]["parallelism"] = "scenes sharded x%d, no collectives" % world
     if is_gpu and devices_used != reported:
@@ -202,45 +217,29 @@ def cpu_reference_quote():
             "measured_in_this_run": False, "source": "profiles/r01_reference_cpu_timing.json (" + j["source"] + ")"}
 
 
-def parity_vs_oracle(sc_cpu, cot, x_gpu, z_gpu, s_gpu, dp_gpu, n=256):
-    """The metric's second half ("fwd+bwd rel-err vs ref"): the step just timed against the fp64 oracle on the first
-    `n` scenes (identical fp32 inputs).  err_x = |x - x_ref| / max(|x_ref|, |Q^-1 p|) per scene; the
-    backward error is taken on dp = dx (lcp.py:52), scaled by |Q^-1 dl_dx|, over the scenes where the oracle's own
-    backward system is well posed (same mask as tests/test_hip_parity.py::test_stack_scenes_backward_parity)."""
+def parity_vs_oracle(lcp_gpu, cot, x_gpu, z_gpu, s_gpu, iters_gpu, dp_gpu, n=512):
+    """The metric's second half ("fwd+bwd rel-err vs ref"): the step just timed against the fp64 oracle on `n` scenes sampled
+    over the batch, on IDENTICAL inputs - the fp32 LCP data the HIP assembly produced for the kernel (all assembling kernels
+    share one contraction-free builder; tests/test_hip_parity.py::test_assembly_kernel_matches_oracle), solved by the oracle in
+    fp64.  Fields: tests/parity.py::headline_report - err_x (SURVEY 8d), contact index sets UNMASKED and on the decisive rows,
+    the histogram of iteration-count differences, dl/dp on the scenes whose backward system is well posed; the same report
+    tests/test_hip_headline_parity.py gates at configs[1] / [2] / [3]."""
     from oracle import pdipm_oracle as O
     from tests import parity
-    n = min(n, sc_cpu.B)
-    # identical LCP inputs: assembled in fp32 exactly as the step kernel assembles them (engines.py:50-74 in the
-    # data's dtype; tests/test_hip_parity.py::test_assembly_kernel_matches_oracle), then solved in fp64
-    lcp = [None if t is None else t.double() for t in O.assemble_lcp(*sc_cpu.slice(0, n).assembly_args())]
-    Q, p, G, h, A, b, F = lcp
-    ref = O.lcp_forward(*lcp)
-    ex = parity.err_x(x_gpu[:n].double().cpu(), ref.x, Q, p)
-    out = {"scenes": n, "tolerance": 1e-4, "fwd_err_x_max": float(ex.max()), "fwd_err_x_median": float(ex.median())}
-    # contact index sets {i : z_i > s_i} (SURVEY 8d): bit-exact wherever the oracle's own decision is not a tie between
-    # two numbers that both converged to zero (parity.decisive_rows); the masked-out share is reported and gated
-    z, sl = z_gpu[:n].double().cpu(), s_gpu[:n].double().cpu()
-    dec = parity.decisive_rows(ref.z, ref.s)
-    out["index_set_mismatches"] = int((((z > sl) != (ref.z > ref.s)) & dec).sum())
-    out["index_set_rows_compared"] = int(dec.sum())
-    out["index_set_rows_total"] = int(dec.numel())
-    out["index_set_masked_frac"] = 1.0 - float(dec.sum()) / dec.numel()
-    if dp_gpu is not None:
-        c64 = cot[:n].double()
-        gref = O.lcp_backward(ref, *lcp, c64)
-        ok = parity.backward_well_posed(Q, G, A, F, ref, c64, gref)
-        fl = parity.grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
-        eg = parity.err_grads({"p": dp_gpu[:n].double().cpu()}, {"p": gref["dp"]}, fl)["p"]
-        if bool(ok.any()):
-            out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})
-        out["bwd_well_posed_scenes"] = int(ok.sum())
-        out["bwd_well_posed_frac"] = float(ok.sum()) / n
-    return out
+    B = x_gpu.shape[0]
+    n = min(n, B)
+    idx = torch.arange(0, B, max(1, B // n))[:n]
+    di = idx.to(x_gpu.device)
+    lcp64 = [None if t is None else t[di].double().cpu() for t in lcp_gpu]
+    rep, _ = parity.headline_report(O, lcp64, x_gpu[di].cpu(), z_gpu[di].cpu(), s_gpu[di].cpu(), iters_gpu[di].cpu(),
+                                    dp=None if dp_gpu is None else dp_gpu[di].cpu(), cot=cot[idx])
+    rep["sample"] = "every %d-th scene of the batch" % max(1, B // n)
+    return rep
 
 
 def _quoted(name, key):
     """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             j = json.load(open(path)).get(key)
@@ -324,20 +323,17 @@ class HipStackWorkload:
         iters = (self.sol.iters if a.mode == "dense" else self.step_out["iters"]).double()
         status = (self.sol.status if a.mode == "dense" else self.step_out["status"])
         it_list = iters.cpu().tolist()
-        fl_fwd = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
-        # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic), the dense
-        # boundary the contact-space one
+        fl_alg = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
+        # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic; the stack scenes pin
+        # their floor: ALG = 2), the dense boundary the contact-space one
         body_space = a.mode == "fused" and a.compute == "f64" and nz <= 16
         fl_exec = float(sum((flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)(nz, nc, e, it)
                             for it in it_list))
-        fl_bwd = flops.flops_backward(nz, m, e) * B
-        achieved = fl_fwd / (fwd_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.compute]
         alg_bytes = (flops.bytes_fused_step(nb, nc) if a.mode == "fused" else flops.bytes_forward(nz, m, e)) * B
         key = "%s_B%d_nc%d_%s" % (a.mode, B, nc, a.compute)
-        # HBM traffic and issue counters of the forward kernel: measured separately with rocprofv3 --pmc (FETCH_SIZE,
-        # WRITE_SIZE in their own passes; FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/;
-        # bench.py cannot run the counters itself, so it quotes the committed file when it matches this configuration.
+        # HBM traffic and issue counters: measured separately with rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in their own passes;
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/; bench.py quotes the file that matches.
         tj = _quoted("traffic", key)
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
@@ -347,28 +343,57 @@ class HipStackWorkload:
             (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
         what = "forward only" if a.fwd_only else "forward + backward (implicit diff)"
         st = status.cpu()
+        tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
                 "kernel": "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
                     "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
                     ", fused assembly + integrate; the event-timed forward also contains the (empty) second pass lcp_fwd_quad<...,1,1> for "
                     "scenes whose equality rows do not pin the leading coordinates" if a.mode == "fused"
                     else "; the event-timed forward call also contains the classify launch"),
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "achieved": tf(fl_exec, fwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(fl_exec, fwd_ms) / peak,
+                "flops": "executed",
                 "executed_flops_per_launch": fl_exec,
-                "achieved_executed": fl_exec / (fwd_ms * 1e-3) / 1e12,
-                "frac_executed": fl_exec / (fwd_ms * 1e-3) / 1e12 / peak,
-                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
-                "bwd_achieved": fl_bwd / (bwd_ms * 1e-3) / 1e12,
-                "algorithmic_flops_per_launch": fl_fwd,
+                "executed_model": ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True): per iteration formation of "
+                                   "Q + G^T M^-1 G (4 nc nz^2) + LU of nz - neq rows + 2 KKT solves + residuals" if body_space
+                                   else "flops.flops_forward_executed: the reduced 2 nc contact-space system"),
+                "kernel_ms": fwd_ms,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "hbm_frac_algorithmic": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "frac = SURVEY 8d dense-formulation FLOPs / time / FP64 vector peak (no MFMA is issued by this kernel); "
-                        "frac_executed counts what the kernel really executes: " +
-                        ("the body-space system of nz + neq rows (formation + LU per iteration)" if body_space else "the reduced 2nc contact-space system")}
+                "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                "hbm_frac": (traffic / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "frac_algorithmic": tf(fl_alg, fwd_ms) / peak,
+                "algorithmic_flops_per_launch": fl_alg,
+                "note_algorithmic": "SURVEY 8d counts the reference's dense formulation (LU of nineq = %d rows per iteration); the kernel "
+                                    "factors %d rows: a fraction above 1 is the algorithmic saving, not an efficiency" % (m, (nz - e) if body_space else 2 * nc),
+                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms}
         if cj:
-            roof.update({"valu_active": cj.get("valu_active"), "wait_frac": cj.get("wait_frac"), "counters_source": cj["source"]})
+            waves = (B + 3) // 4
+            useful = fl_exec / 2.0 / waves / 64.0                               # wave-wide FMA instructions' worth of executed FLOPs
+            roof.update({"valu_active": cj.get("valu_active"), "wait_frac": cj.get("wait_frac"),
+                         "valu_insts_per_wave": cj.get("valu_insts_per_wave"),
+                         "insts_per_useful_fma": (cj["valu_insts_per_wave"] / useful) if cj.get("valu_insts_per_wave") else None,
+                         "counters_source": cj["source"]})
+        if tj:
+            roof["traffic_source"] = tj["source"]
         if rj:
             roof["regs"] = rj
+        if not a.fwd_only:
+            dense_bwd = a.bwd == "dense"
+            bkey = key + ("_bwd" if dense_bwd else "_bwd_physical")
+            btj = _quoted("traffic", bkey)
+            btraffic = (2 * btj["fetch_kb"] + btj["write_kb"]) * 1024.0 if btj else None
+            balg = (flops.bytes_backward(nz, m, e) if dense_bwd else 4 * (14 * nb + 7 * nc + 3 * nb) + 4 * (11 * nb + 6 * nc)) * B
+            used = btraffic if btraffic else balg
+            roof["bwd"] = {"bound": "hbm",
+                           "kernel": ("lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
+                                      % ("true" if body_space else "false")) if dense_bwd else "lcp_bwd_step_quad (gradients w.r.t. the physical inputs)",
+                           "achieved": used / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": used / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "bytes": "measured traffic" if btraffic else "algorithmic",
+                           "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
+                           "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if body_space else None}
+            if btj:
+                roof["bwd"]["traffic_source"] = btj["source"]
         return {
             "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
                                    "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s"
@@ -388,7 +413,8 @@ class HipStackWorkload:
         src = self.sol if a.mode == "dense" else None
         z_gpu = src.z if src is not None else self.step_out["z"]
         s_gpu = src.s if src is not None else self.step_out["s"]
-        out["parity"] = parity_vs_oracle(self.sc_cpu, self.cot_cpu, x_gpu, z_gpu, s_gpu, dp_gpu)
+        it_gpu = src.iters if src is not None else self.step_out["iters"]
+        out["parity"] = parity_vs_oracle(self.lcp, self.cot_cpu, x_gpu, z_gpu, s_gpu, it_gpu, dp_gpu)
         return out
 
 

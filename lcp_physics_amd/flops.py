@@ -33,19 +33,33 @@ def flops_forward_executed(nz, nc, e, it):
     return P + Fk + S_full + it * I
 
 
-def flops_forward_executed_body_space(nz, nc, e, it):
-    """FLOPs the body-space variant executes per scene (lcp_quad.hip ALG = 1, lcp_primal.hip): per factorisation the formation of
-    Q + G^T M^-1 G (dense over the nz columns in the quad kernel: 2 rank-1 updates of an nz x nz block per contact) and the LU
-    of the (nz + e)-square system; per KKT solve one J^T w, one J v, the two triangular sweeps and the closed-form 4 x 4 block
-    inverses; W = J P J^T is still formed once (the backward kernels read it)."""
-    n = nz + e
-    P = 2 * (2 * nc) ** 2 * nz                          # prefactor of the contact-space W, kept for the backward
-    Fk = 4 * nc * nz * nz + 6 * nc * nz + (2.0 / 3) * n ** 3 + 30 * nc
+def flops_forward_executed_body_space(nz, nc, e, it, pinned=True):
+    """FLOPs the body-space variant executes per scene (lcp_quad.hip ALG = 1 / 2, lcp_primal.hip).  Per factorisation: the
+    formation of Q + G^T M^-1 G (dense over the nz columns in the quad kernel: per contact the two rows P = B [jc; jt] - 4 nz flops -
+    and two rank-1 updates of an nz x nz block - 4 nz^2 -, plus the closed-form 2 x 2 block B of the contact, ~30) and the LU:
+    `pinned` (ALG = 2: the equality rows are A = [I 0], the TotalConstraint on the floor) factors the nz - e free rows only,
+    otherwise the (nz + e)-square system.  Per KKT solve: one J^T w and one J v (4 nc nz each, dense rows), the two triangular
+    sweeps, the pinned-column correction and the closed-form 4 x 4 block inverses (~60 per contact).  Nothing of the contact-space
+    pre-factorisation is formed (round 3: the backward kernels of this path factor in body space too)."""
+    n = (nz - e) if pinned else (nz + e)
+    Fk = 4 * nc * nz * nz + 4 * nc * nz + (2.0 / 3) * n ** 3 + 30 * nc
     prod = 4 * nc * nz                                  # one J v or J^T w product (dense rows)
-    S = 2 * prod + 2 * n * n + 60 * nc + 2 * nz
-    Rk = 2 * prod + (4 * e * nz if e > 0 else 0) + 2 * nz + 30 * nc
+    S = 2 * prod + 2 * n * n + (2 * e * nz if pinned else 0) + 60 * nc + 2 * nz
+    Rk = 2 * prod + (0 if pinned else 4 * e * nz) + 2 * nz + 30 * nc
     I = Fk + 2 * S + Rk + 60 * nc
-    return P + Fk + S + it * I
+    return Fk + S + it * I
+
+
+def flops_backward_executed_body_space(nz, nc, e, refine=2, pinned=True):
+    """The body-space backward solve (lcp_quad.hip bwd_solve_body): one formation + LU, 1 + `refine` KKT solves and the residual
+    products of the refinement steps; the outer products of lcp.py:52-61 are counted with the dense gradient sizes."""
+    n = (nz - e) if pinned else (nz + e)
+    m = 4 * nc
+    Fk = 4 * nc * nz * nz + 4 * nc * nz + (2.0 / 3) * n ** 3 + 30 * nc
+    prod = 4 * nc * nz
+    S = 2 * prod + 2 * n * n + 60 * nc + 2 * nz
+    outer = 2 * nz * nz + 3 * m * nz + m * m + 3 * e * nz
+    return Fk + (1 + refine) * S + refine * (2 * prod + 4 * e * nz + 20 * nc) + outer
 
 
 def flops_backward(nz, m, e):

@@ -128,6 +128,10 @@ def test_bench_rank_protocol_two_gloo_ranks():
     assert out["ms_per_step"] >= 4.0                        # MAX over ranks: the slow rank's 4 ms per step
     assert abs(out["value"] - 8192 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
     assert out["cpu_baseline"] is None                      # reported at N = 1 only
+    # every rank's own clock is in the line (the metric takes the MAX): rank 1 sleeps twice as long per step as rank 0
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and pr[1]["ms_per_step"] >= 4.0 > pr[0]["ms_per_step"] >= 2.0
+    assert abs(max(r["ms_per_step"] for r in pr) - out["ms_per_step"]) < 0.5
 
 
 def _run_bench(argv, env_extra=None, timeout=300):

@@ -1,11 +1,16 @@
 """Turn a tools/pmc_summary.py table into the two small JSON files bench.py quotes in its `roofline` object:
-    python tools/make_profile_json.py profiles/r02_pmc.txt r02
+    python tools/make_profile_json.py profiles/r03_pmc.txt r03
 writes profiles/r02_traffic.json (FETCH_SIZE / WRITE_SIZE, KB per launch of the forward kernel) and profiles/r02_counters.json
 (VALU-active and wait fractions of the wave cycles), keyed like bench.py keys its configurations."""
 import json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E", "dense_B4096_nc16_f64": "lcp_fwd_quadIfdLb0ELi1E"}
+# bench.py's configuration key -> (a substring of) the mangled kernel name in the rocprofv3 tables
+KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E",                 # the headline forward (body space, pinned floor)
+           "fused_B4096_nc16_f64_bwd": "lcp_bwd_quadIfdLb1E",                      # the dense backward behind it (body space)
+           "fused_B4096_nc16_f64_bwd_physical": "lcp_bwd_step_quadIfdLi1ELb1E",    # --bwd physical
+           "dense_B4096_nc16_f64": "lcp_fwd_quadIfdLb0ELi1E",
+           "dense_B4096_nc16_f64_bwd": "lcp_bwd_quadIfdLb0E"}
 
 
 def main(path, tag):
