@@ -50,6 +50,11 @@ extern "C" {
  * a backward planned for another layout returns NaN gradients instead of misreading it. */
 #define LCP_PATH_CONTACT_SPACE 0x2000
 #define LCP_PATH_PRIMAL 0x4000
+/* Contact-list forwards of the four-scenes-per-wave sizes choose by batch size between four scenes per wavefront (lcp_quad.hip) and
+ * one scene per wavefront (lcp_solo.hip, small batches); these force one of the two (A/B aids; same workspace layout, any backward
+ * follows either). */
+#define LCP_PATH_QUAD 0x8000
+#define LCP_PATH_SOLO 0x10000
 /* OR-ed into the `compute` argument of lcp_workspace_bytes by callers of the fp64-I/O entry points (lcp_pdipm_forward_f64 /
  * lcp_pdipm_backward_f64): their workspace also keeps an fp64 copy of F. */
 #define LCP_IO_F64 0x400

@@ -19,6 +19,8 @@ PATH_GENERIC = 0x200
 IO_F64 = 0x400
 PATH_CONTACT_SPACE = 0x2000
 PATH_PRIMAL = 0x4000
+PATH_QUAD = 0x8000
+PATH_SOLO = 0x10000
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2
@@ -106,7 +108,8 @@ def require_gpu_tensor(t, name, dtype=None):
     return t
 
 
-_PATH_BITS = {"auto": 0, "wave64": 0, "generic": PATH_GENERIC, "big": PATH_CONTACT_SPACE, "primal": PATH_PRIMAL}
+_PATH_BITS = {"auto": 0, "wave64": 0, "generic": PATH_GENERIC, "big": PATH_CONTACT_SPACE, "primal": PATH_PRIMAL,
+              "quad": PATH_QUAD, "solo": PATH_SOLO}     # quad / solo: four scenes / one scene per wavefront at every batch size
 _tls = threading.local()          # the default is per host thread, like the library's own debugging aids
 
 
@@ -124,7 +127,7 @@ def set_path(path):
 class thread_path:
     """The fp64-I/O entry points carry no `compute` word: for the duration of ONE call the calling thread's library default
     (lcp_debug_set_path) is set from the path bits recorded with the op, and reset afterwards."""
-    _CODE = {0: 0, PATH_GENERIC: 1, PATH_CONTACT_SPACE: 3, PATH_PRIMAL: 4}
+    _CODE = {0: 0, PATH_GENERIC: 1, PATH_CONTACT_SPACE: 3, PATH_PRIMAL: 4}          # (quad / solo do not apply to the dense fp64 entries)
 
     def __init__(self, word):
         self.code = self._CODE[word & (PATH_GENERIC | PATH_CONTACT_SPACE | PATH_PRIMAL)]

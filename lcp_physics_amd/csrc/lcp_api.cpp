@@ -16,13 +16,14 @@ thread_local int g_path = 0;              // this thread's DEFAULT kernel path f
                                           // 0 = automatic, 1 = generic kernels, 3 = contact-space kernels instead of the body-space ones,
                                           // 4 = one wave per scene (lcp_primal.hip) at every size (A/B aids)
 
-constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL;
+constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL | LCP_PATH_QUAD | LCP_PATH_SOLO;
 
 // `compute` word of an entry point -> arithmetic type and kernel path.  The path is a function of the WORD whenever the word
 // names one (LCP_PATH_*): a forward and its backward that carry the same word pick the same kernel family on any two host
 // threads.  Only a word without path bits falls back on the calling thread's lcp_debug_set_path default.
 // *path: 0 automatic, 1 generic, 3 contact space, 4 primal;  *generic = (path == 1)
-inline int split_compute(int compute, bool* generic, int* path = nullptr) {
+inline int split_compute(int compute, bool* generic, int* path = nullptr, int* solo = nullptr) {
+  if (solo) *solo = (compute & LCP_PATH_SOLO) ? 1 : ((compute & LCP_PATH_QUAD) ? 0 : -1);   // (same workspace layout either way: forward only)
   int p = g_path;
   if (compute & LCP_PATH_GENERIC) p = 1;
   else if (compute & LCP_PATH_CONTACT_SPACE) p = 3;
@@ -244,7 +245,7 @@ int lcp_pdipm_backward_f64(int B, int nz, int m, int e, const double* G, const d
                          stream);
 }
 
-static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream);
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream, int solo = -1);
 
 static int fill_step(lcp::StepArgs& P, int B, int nb, int nc, int e, const float* pos, const float* Mdiag,
                      const float* v, const float* f, const float* rest, const float* fric, const float* c_n,
@@ -280,8 +281,8 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
                        float* v_new, float* p_new, float* z, float* s, float* y, int32_t* iters,
                        int32_t* status, void* ws, void* stream) {
   bool generic;
-  int path;
-  compute = split_compute(compute, &generic, &path);
+  int path, solo;
+  compute = split_compute(compute, &generic, &path, &solo);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, nc, e, pos, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -291,7 +292,7 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e, const float* pos, const flo
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = p_new; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  return launch_step(P, nz, m, e, compute, path, stream);
+  return launch_step(P, nz, m, e, compute, path, stream, solo);
 }
 
 int lcp_step_backward_f32(int B, int nb, int nc, int e, const float* Mdiag, const float* v, const float* f,
@@ -344,13 +345,13 @@ int lcp_step_has_backward(int nb, int maxc, int e, int compute) {
 }
 
 // forward of the contact-list entry points, by family
-static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream) {
+static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int path, void* stream, int solo) {
   StepFamily fam = step_family(nz, m, e, compute, path);
   if (fam == FAM_WAVE64 && P.c_count) fam = FAM_GENERIC;                    // (its kernel takes full lists only)
   P.tag = trailer_of(P.ws, P.B, scene_bytes(nz, m, e, compute, 0));
   P.tag_value = step_tag(fam, nz, compute, path);
   switch (fam) {
-    case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3);
+    case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3, solo);
     case FAM_PRIMAL: return lcp::primal_step(P, stream);
     case FAM_BIG: return lcp::big_step(P, stream);
     case FAM_WAVE64: return lcp::wave64_step(P, compute, stream);
@@ -370,8 +371,8 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
                            int not_improved_lim, int compute, float* v_new, float* z, float* s, float* y,
                            int32_t* iters, int32_t* status, void* ws, void* stream) {
   bool generic;
-  int path;
-  compute = split_compute(compute, &generic, &path);
+  int path, solo;
+  compute = split_compute(compute, &generic, &path, &solo);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, Je, dt);
@@ -381,7 +382,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
   P.eps = eps; P.max_iter = max_iter; P.lim = not_improved_lim;
   P.v_new = v_new; P.p_new = nullptr; P.z = z; P.s = s; P.y = y; P.iters = iters; P.status = status;
   P.ws = ws;
-  return launch_step(P, 3 * nb, 4 * maxc, e, compute, path, stream);
+  return launch_step(P, 3 * nb, 4 * maxc, e, compute, path, stream, solo);
 }
 
 int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_count, const float* Mdiag,

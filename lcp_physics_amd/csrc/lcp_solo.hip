@@ -1,0 +1,484 @@
+// lcp_solo.hip - the contact-list step of SMALL batches: ONE scene per wavefront, the body-space PDIPM of lcp_quad.hip (ALG = 2)
+// spread over the four 16-lane DPP rows of the wave.
+//
+// Why: lcp_fwd_quad puts four scenes on a wavefront, and a scene's solve is a dependent chain of ~0.095 ms whatever the batch - at
+// BASELINE configs[1] (1024 scenes) that is 256 wavefronts on a chip with 1024 SIMDs, three quarters of it idle.  Here the batch
+// is 1024 wavefronts, and the 64 lanes of each work on one scene:
+//   * m-space (the 4 nc inequality rows): lane (r, c) = COMPONENT r (normal, friction +, friction -, cone) of CONTACT c - DPP row r,
+//     lane c of the row.  Every element-wise statement of pdipm.py (residuals, s / z, step lengths, updates) is one instruction
+//     instead of four; the per-contact coupling (F z, the closed-form 4 x 4 block inverse M^-1) first gathers the contact's four
+//     components into every row (gather4: v_permlane16_swap + v_permlane32_swap, gfx950) and then runs redundantly in the rows.
+//   * x-space (nz <= 16) and the matrix Q + G^T M^-1 G: replicated in the four rows, lane j of a row = entry / matrix row j, exactly
+//     the layout of lcp_quad.hip - the pivot-free LU and the triangular sweeps are its code (`row_newbcast` broadcasts,
+//     v_fmac_f64_dpp blocks), executed identically by the four rows.
+//   * formation: DPP row r accumulates COLUMNS 4 r .. 4 r + 3 of the matrix (a quarter of the FMAs), the four quarters are
+//     exchanged with gather4; J v is ONE product for all four components (the lane holds its component's row of G); J^T w is
+//     one product per row (its component's weights) followed by a sum over the rows.
+//   * reductions over m-space: DPP row reduction, then two swap stages over the rows.
+// Same equations, same exits (pdipm.py:49-186 per scene, best iterate, three strikes), same workspace fields as lcp_fwd_quad with
+// ALG = 2: the backward kernels of lcp_quad.hip follow either forward.  Like ALG = 2 it serves scenes whose equality rows pin the
+// leading coordinates (A = [I 0], b = 0: the TotalConstraint on the floor of the demo worlds) or that have none; another scene is
+// marked (meta[21]) and left to lcp_fwd_quad<..., ALG = 1>, launched behind.
+// Contact-list inputs, fp32 I/O, fp64 arithmetic, nz <= 16, <= 16 contacts, neq <= 4.
+#include "lcp_quad_prims.h"
+
+namespace lcp {
+namespace solo {
+
+using namespace w64;
+using namespace q16;
+
+// ---------------------------------------------------------------- moves between the four DPP rows (same lane of the row)
+struct U2 { uint32_t a, b; };
+__device__ __forceinline__ U2 swap16(uint32_t x, uint32_t y) {     // odd rows of x <-> even rows of y
+  auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  return U2{r[0], r[1]};
+}
+__device__ __forceinline__ U2 swap32(uint32_t x, uint32_t y) {     // rows 2, 3 of x <-> rows 0, 1 of y
+  auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  return U2{r[0], r[1]};
+}
+__device__ __forceinline__ void swap16(double v, double& even, double& odd) {   // even = [v0 v0 v2 v2], odd = [v1 v1 v3 v3] (by row)
+  const U2 lo = swap16((uint32_t)__double2loint(v), (uint32_t)__double2loint(v));
+  const U2 hi = swap16((uint32_t)__double2hiint(v), (uint32_t)__double2hiint(v));
+  even = __hiloint2double((int)hi.a, (int)lo.a); odd = __hiloint2double((int)hi.b, (int)lo.b);
+}
+__device__ __forceinline__ void swap32(double v, double& low, double& high) {   // low = [v0 v1 v0 v1], high = [v2 v3 v2 v3]
+  const U2 lo = swap32((uint32_t)__double2loint(v), (uint32_t)__double2loint(v));
+  const U2 hi = swap32((uint32_t)__double2hiint(v), (uint32_t)__double2hiint(v));
+  low = __hiloint2double((int)hi.a, (int)lo.a); high = __hiloint2double((int)hi.b, (int)lo.b);
+}
+// the values the four rows hold at this lane of the row, in every row: (row 0, row 1, row 2, row 3) = (n, f1, f2, g)
+__device__ __forceinline__ M4<double> gather4(double v) {
+  double ev, od, r0, r2, r1, r3;
+  swap16(v, ev, od);
+  swap32(ev, r0, r2);
+  swap32(od, r1, r3);
+  return m4<double>(r0, r1, r2, r3);
+}
+__device__ __forceinline__ double rows_sum(double v) {
+  double a, b; swap32(v, a, b); v = a + b;
+  swap16(v, a, b); return a + b;
+}
+__device__ __forceinline__ double rows_fmax(double v) {
+  double a, b; swap32(v, a, b); v = fmax_(a, b);
+  swap16(v, a, b); return fmax_(a, b);
+}
+__device__ __forceinline__ double rows_fmin(double v) {
+  double a, b; swap32(v, a, b); v = fmin_(a, b);
+  swap16(v, a, b); return fmin_(a, b);
+}
+__device__ __forceinline__ uint32_t rows_or(uint32_t k) {
+  U2 t = swap32(k, k); k = t.a | t.b;
+  t = swap16(k, k); return t.a | t.b;
+}
+__device__ __forceinline__ uint32_t row_or(uint32_t k) {
+  k |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xf, 0xf, true);
+  k |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xf, 0xf, true);
+  k |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xf, 0xf, true);
+  k |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xf, 0xf, true);
+  return k;
+}
+// Four sums over all 64 lanes at once, results everywhere: the rows are folded FIRST (two swap stages without copies leave DPP row
+// 0 / 1 / 2 / 3 with the row-folded values of v1 / v3 / v2 / v4), ONE DPP row reduction then serves all four, gather4 hands the
+// totals round.  33 instructions instead of 4 x 22.
+__device__ __forceinline__ void swap32_pair(double& a, double& b) {     // a = [a0 a1 b0 b1], b = [a2 a3 b2 b3] (by row)
+  const U2 lo = swap32((uint32_t)__double2loint(a), (uint32_t)__double2loint(b));
+  const U2 hi = swap32((uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b));
+  a = __hiloint2double((int)hi.a, (int)lo.a); b = __hiloint2double((int)hi.b, (int)lo.b);
+}
+__device__ __forceinline__ void swap16_pair(double& a, double& b) {     // a = [a0 b0 a2 b2], b = [a1 b1 a3 b3]
+  const U2 lo = swap16((uint32_t)__double2loint(a), (uint32_t)__double2loint(b));
+  const U2 hi = swap16((uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b));
+  a = __hiloint2double((int)hi.a, (int)lo.a); b = __hiloint2double((int)hi.b, (int)lo.b);
+}
+__device__ __forceinline__ void wave_sum4(double& v1, double& v2, double& v3, double& v4) {
+  swap32_pair(v1, v2); swap32_pair(v3, v4);
+  double t12 = v1 + v2, t34 = v3 + v4;          // rows: [v1(0+2) v1(1+3) v2(0+2) v2(1+3)], [v3 .. v4 ..]
+  swap16_pair(t12, t34);
+  const double u = row_sum(t12 + t34);          // rows: [V1 V3 V2 V4]
+  const M4<double> g = gather4(u);
+  v1 = g.n; v3 = g.f1; v2 = g.f2; v4 = g.g;
+}
+// two maxima over all 64 lanes at once (NaN-skipping v_max), results everywhere
+__device__ __forceinline__ void wave_fmax2(double& a, double& b) {
+  swap32_pair(a, b);
+  double t = fmax_(a, b), ev, od;               // rows: [a(0,2) a(1,3) b(0,2) b(1,3)]
+  swap16(t, ev, od);
+  t = row_fmax(fmax_(ev, od));                  // rows: [A A B B]
+  swap32(t, a, b);
+}
+// over all 64 lanes, result everywhere
+__device__ __forceinline__ double wave_sum(double v) { return rows_sum(row_sum(v)); }
+__device__ __forceinline__ double wave_fmax(double v) { return rows_fmax(row_fmax(v)); }
+__device__ __forceinline__ double wave_fmin(double v) { return rows_fmin(row_fmin(v)); }
+__device__ __forceinline__ uint32_t wave_or(uint32_t k) { return rows_or(row_or(k)); }
+
+// acc0 / acc1 += sum over the 16 lanes k of the row of (lane k's `src`) * coef[k]  (even k -> acc0, odd k -> acc1): J v with the lane's
+// row of G as coefficients, J^T w with its column.  Same rules as the blocks of lcp_quad_prims.h: `s_nop 1` first, DPP source read-only.
+#define LCP_SOLO_DOT(ACC, K) "v_fmac_f64_dpp %[" #ACC "], %[v], %[c" #K "] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void dot16_dpp(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t"
+      LCP_SOLO_DOT(a0, 0) LCP_SOLO_DOT(a1, 1) LCP_SOLO_DOT(a0, 2) LCP_SOLO_DOT(a1, 3) LCP_SOLO_DOT(a0, 4) LCP_SOLO_DOT(a1, 5)
+      LCP_SOLO_DOT(a0, 6) LCP_SOLO_DOT(a1, 7) LCP_SOLO_DOT(a0, 8) LCP_SOLO_DOT(a1, 9) LCP_SOLO_DOT(a0, 10) LCP_SOLO_DOT(a1, 11)
+      LCP_SOLO_DOT(a0, 12) LCP_SOLO_DOT(a1, 13) LCP_SOLO_DOT(a0, 14) LCP_SOLO_DOT(a1, 15)
+      : [a0] "+v"(a0), [a1] "+v"(a1)
+      : [v] "v"(v), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]),
+        [c7] "v"(c[7]), [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]),
+        [c14] "v"(c[14]), [c15] "v"(c[15]));
+}
+// formation, one contact K: the lane's four matrix columns += a * (lane K's p0) + b * (lane K's p1)
+#define LCP_SOLO_FORM(X, P, M, K) "v_fmac_f64_dpp %[" #X "], %[" #P "], %[" #M "] row_newbcast:%[" #K "] row_mask:0xf bank_mask:0xf\n\t"
+template <int K> __device__ __forceinline__ void form4(double (&x)[4], const double (&p0)[4], const double (&p1)[4], double a, double b) {
+  asm("s_nop 1\n\t"
+      LCP_SOLO_FORM(x0, p0, a, k) LCP_SOLO_FORM(x1, p1, a, k) LCP_SOLO_FORM(x2, p2, a, k) LCP_SOLO_FORM(x3, p3, a, k)
+      LCP_SOLO_FORM(x0, q0, b, k) LCP_SOLO_FORM(x1, q1, b, k) LCP_SOLO_FORM(x2, q2, b, k) LCP_SOLO_FORM(x3, q3, b, k)
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3])
+      : [p0] "v"(p0[0]), [p1] "v"(p0[1]), [p2] "v"(p0[2]), [p3] "v"(p0[3]), [q0] "v"(p1[0]), [q1] "v"(p1[1]), [q2] "v"(p1[2]), [q3] "v"(p1[3]),
+        [a] "v"(a), [b] "v"(b), [k] "n"(K));
+}
+
+// four contacts K0 .. K0 + 3 in one statement (one s_nop for 32 instructions)
+#define LCP_SOLO_FORM1(A, B, KK) \
+  LCP_SOLO_FORM(x0, p0, A, KK) LCP_SOLO_FORM(x1, p1, A, KK) LCP_SOLO_FORM(x2, p2, A, KK) LCP_SOLO_FORM(x3, p3, A, KK) \
+  LCP_SOLO_FORM(x0, q0, B, KK) LCP_SOLO_FORM(x1, q1, B, KK) LCP_SOLO_FORM(x2, q2, B, KK) LCP_SOLO_FORM(x3, q3, B, KK)
+template <int K0> __device__ __forceinline__ void form4x4(double (&x)[4], const double (&p0)[4], const double (&p1)[4], const double (&a)[4],
+                                                         const double (&b)[4]) {
+  asm("s_nop 1\n\t"
+      LCP_SOLO_FORM1(a0, b0, k0) LCP_SOLO_FORM1(a1, b1, k1) LCP_SOLO_FORM1(a2, b2, k2) LCP_SOLO_FORM1(a3, b3, k3)
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3])
+      : [p0] "v"(p0[0]), [p1] "v"(p0[1]), [p2] "v"(p0[2]), [p3] "v"(p0[3]), [q0] "v"(p1[0]), [q1] "v"(p1[1]), [q2] "v"(p1[2]), [q3] "v"(p1[3]),
+        [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]),
+        [k0] "n"(K0), [k1] "n"(K0 + 1), [k2] "n"(K0 + 2), [k3] "n"(K0 + 3));
+}
+
+// ---------------------------------------------------------------- the kernel
+#ifndef LCP_SOLO_OCC
+#define LCP_SOLO_OCC 1      // wavefronts per SIMD the register allocation allows (2: at most 256 unified registers, fp32 tables)
+#endif
+__global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP) {
+  using TI = float;
+  using TC = double;
+  __shared__ TI GL[NCQ * 16], GTL[NCQ * 16], AtL[EQ * 16];
+  const int lane = threadIdx.x, l16 = lane & 15, comp = lane >> 4;
+  const int scene = blockIdx.x;
+  const int nb = SP.nb, nz = 3 * nb, nc = SP.nc, e = SP.e, m = 4 * nc;
+  const int max_iter = SP.max_iter, lim = SP.lim;
+  const TC eps = SP.eps;
+  Ws<TI, TC> W(SP.ws, scene);
+  if (blockIdx.x == 0 && lane == 0 && SP.tag) *SP.tag = SP.tag_value;
+  int ncs = nc, truncated = 0;
+  if (SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; truncated = c > nc ? LCP_ST_TRUNCATED : 0; }
+  const bool vc = l16 < ncs;                                       // this lane's contact is live
+  const bool c0 = comp == 0, c1 = comp == 1, c2 = comp == 2, c3 = comp == 3;
+  auto pick = [&](const M4<TC>& a) -> TC { return c0 ? a.n : (c1 ? a.f1 : (c2 ? a.f2 : a.g)); };
+
+  // ---- contact list -> rows (physics/engines.py:31-32,50-74; physics/world.py:144-234), as assemble_q of lcp_quad.hip
+  const TI* Md = (const TI*)SP.Mdiag + (size_t)scene * nz;
+  const TI* vv = (const TI*)SP.v + (size_t)scene * nz;
+  const TI* ff = (const TI*)SP.f + (size_t)scene * nz;
+  TI hrow = 0, mu_f = 0;
+  if (c0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { GL[l16 * 16 + j] = 0; GTL[l16 * 16 + j] = 0; }
+    if (vc) {
+      const ContactRows<TI> r = make_contact<TI>((const TI*)SP.c_n + (size_t)scene * nc * 2, (const TI*)SP.c_p1 + (size_t)scene * nc * 2,
+                                                 (const TI*)SP.c_p2 + (size_t)scene * nc * 2, SP.c_i1 + (size_t)scene * nc,
+                                                 SP.c_i2 + (size_t)scene * nc, (const TI*)SP.rest + (size_t)scene * nb,
+                                                 (const TI*)SP.fric + (size_t)scene * nb, vv, l16);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int col = (q < 3) ? 3 * r.b1 + q : 3 * r.b2 + (q - 3);
+        GL[l16 * 16 + col] = r.jn[q];
+        GTL[l16 * 16 + col] = r.jf[q];
+      }
+      hrow = r.h; mu_f = r.mu;
+    }
+    if (l16 < EQ) {
+      const TI* Je = (const TI*)SP.Je + (size_t)scene * e * nz;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) AtL[l16 * 16 + k] = (l16 < e && k < nz) ? Je[l16 * nz + k] : (TI)0;
+    }
+  }
+  // h and mu of contact l16 to the other rows (row 0 computed them)
+  {
+    const M4<TC> hh = gather4((TC)hrow), mm = gather4((TC)mu_f);
+    hrow = (TI)hh.n; mu_f = (TI)mm.n;
+  }
+  __syncthreads();
+  const TC mu_c = (TC)mu_f;
+  // G row of (component, contact): jc | +jt | -jt | 0, and the same matrix by columns (column l16 over the contacts) for J^T w
+  const TC sgn = c2 ? (TC)-1 : (c3 ? (TC)0 : (TC)1);
+  const TI* gsrc = c0 ? GL : GTL;
+  // (LCP_SOLO_OCC = 2 keeps them as fp32 - they are exact - and widens them at every use: 249 registers, two wavefronts per SIMD;
+  //  the default keeps fp64 copies: this kernel serves batches of at most one wavefront per SIMD, where its time is the length of
+  //  one wave's dependent chains and the conversions are on them)
+  using TT = std::conditional_t<(LCP_SOLO_OCC >= 2), TI, TC>;
+  TT Grow[16], GTc[16];
+  static_for<16>([&](auto J) LCP_INL { Grow[J] = (TT)(sgn * (TC)gsrc[l16 * 16 + J]); GTc[J] = (TT)(sgn * (TC)gsrc[J * 16 + l16]); });
+  // formation operands: the lane's contact at the row's four columns 4 comp + jj; the weights jc_c[l16], jt_c[l16] of matrix row l16
+  // over the contacts c are read from LDS per group of four contacts
+  TI jcq[4], jtq[4];
+  static_for<4>([&](auto JJ) LCP_INL { jcq[JJ] = GL[l16 * 16 + 4 * comp + JJ]; jtq[JJ] = GTL[l16 * 16 + 4 * comp + JJ]; });
+  const TC qd = (l16 < nz) ? (TC)Md[l16] : (TC)0;
+  const TC qid = (l16 < nz) ? (TC)1 / (TC)Md[l16] : (TC)0;
+  const TC p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16 < nz ? l16 : 0], vv[l16 < nz ? l16 : 0], (TI)SP.dt, ff[l16 < nz ? l16 : 0]) : (TC)0;   // engines.py:32
+  // F z of the contact structure (engines.py:69-73) with the contact's gathered multipliers: (F z)_comp = fn z_n + f1 (z_f1 + z_f2) + fg z_g
+  const TC fzn = c3 ? mu_c : (TC)0, fz12 = c3 ? (TC)-1 : (TC)0, fzg = (c1 || c2) ? (TC)1 : (TC)0;
+  const TC hn = c0 ? (TC)hrow : (TC)0;                              // h = [Jc v rbar; 0; 0; 0]
+
+  // ---- equality rows: pinned leading coordinates (A = [I 0]) or none; anything else goes to the general kernel behind
+  bool okl = true;
+  static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; if (a < e) okl = okl && ((TC)AtL[a * 16 + l16] == ((l16 == a) ? (TC)1 : (TC)0)); });
+  const bool pin = __all(okl) != 0;
+  if (lane == 0) {
+    W.meta[21] = pin ? (TC)0 : (TC)1;
+    W.meta[0] = (TC)2; W.meta[18] = (TC)1; W.meta[19] = (TC)ncs;
+  }
+  if (!pin) return;
+  if (c0 && vc) W.meta[1 + l16] = mu_c;
+  int status = truncated;
+  if (row_any(l16 < nz && !(qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
+  if (c0) { W.Qit[l16] = qid; W.Qit[128 + l16] = qd; }
+
+  // ---- state: x-space entry l16 (replicated in the rows), m-space scalar of (comp, contact)
+  TC x = 0, y = 0, s = 1, z = 1, dinv = 1;
+  TC best_resid = inf_of<TC>(), bx = 0, by = 0, bz = 1, bs = 1;
+  bool have_best = false, done = false;
+  int n_not = 0, iters = 0;
+  const TC mf = (TC)(4 * ncs);
+  TC xr[20];                                                       // matrix row l16 of Q + G^T M^-1 G, then its LU (columns 0 .. 15)
+  TC udx = 1, sp[EQ];
+  TC idn = 1, i1 = 1, i2 = 1, kap = 1;
+
+  // J v for the lane's (component, contact)
+  auto Gv = [&](TC v) -> TC {
+    TC a0 = 0, a1 = 0, cf[16];
+    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(Grow[J]); else cf[J] = Grow[J]; });
+    dot16_dpp(a0, a1, v, cf);
+    return a0 + a1;
+  };
+  // J^T w: every row sums its component over the contacts, then the rows are added (result replicated)
+  auto Gtw = [&](TC w) -> TC {
+    TC a0 = 0, a1 = 0, cf[16];
+    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(GTc[J]); else cf[J] = GTc[J]; });
+    dot16_dpp(a0, a1, w, cf);
+    return rows_sum(a0 + a1);
+  };
+  // M^-1 t for the contact's gathered components (lcp_quad.hip minv_pq)
+  auto minv = [&](const M4<TC>& t) -> M4<TC> {
+    M4<TC> o;
+    o.n = idn * t.n;
+    o.g = kap * ((t.g - mu_c * o.n) + fma(i1, t.f1, i2 * t.f2));
+    o.f1 = i1 * (t.f1 - o.g);
+    o.f2 = i2 * (t.f2 - o.g);
+    return o;
+  };
+
+  // factor: formation of Q + G^T M^-1 G (this row's four columns, then exchanged) and the pivot-free LU over the free coordinates
+  auto factor = [&](TC di) -> bool {
+    const int ll = launder(l16), nzs = __builtin_amdgcn_readfirstlane(nz), es = __builtin_amdgcn_readfirstlane(e);
+    const int ncw = __builtin_amdgcn_readfirstlane(ncs);
+    const M4<TC> D = gather4(di);
+    idn = fast_rcp(D.n); i1 = fast_rcp(D.f1); i2 = fast_rcp(D.f2);
+    kap = fast_rcp(D.g + (i1 + i2));
+    const TC b00 = vc ? idn : (TC)0;
+    const TC b10 = vc ? kap * (i1 - i2) * (mu_c * idn) : (TC)0;
+    const TC b11 = vc ? kap * fma(i1 + i2, D.g, (TC)4 * (i1 * i2)) : (TC)0;
+    TC p0[4], p1[4], x4[4];
+    static_for<4>([&](auto JJ) LCP_INL {
+      const TC jc_ = (TC)launder(jcq[JJ]), jt_ = (TC)launder(jtq[JJ]);
+      p0[JJ] = b00 * jc_; p1[JJ] = fma(b10, jc_, b11 * jt_);
+      x4[JJ] = (ll == 4 * comp + JJ) ? ((ll < nzs) ? qd : (TC)1) : (TC)0;
+    });
+    {
+      const int oz = lds_opaque_zero();
+      const TI* gl = GL + ll + oz;
+      const TI* gtl = GTL + ll + oz;
+      static_for<4>([&](auto Gq) LCP_INL {
+        if (4 * Gq < ncw) {
+          TI av[4], bv[4];
+          static_for<4>([&](auto Kq) LCP_INL { av[Kq] = gl[(4 * Gq + Kq) * 16]; bv[Kq] = gtl[(4 * Gq + Kq) * 16]; });
+          TC ad[4], bd[4];
+          static_for<4>([&](auto Kq) LCP_INL { ad[Kq] = (TC)av[Kq]; bd[Kq] = (TC)bv[Kq]; });
+          form4x4<4 * Gq>(x4, p0, p1, ad, bd);
+        }
+      });
+    }
+    static_for<4>([&](auto JJ) LCP_INL {
+      const M4<TC> g = gather4(x4[JJ]);
+      xr[JJ] = g.n; xr[4 + JJ] = g.f1; xr[8 + JJ] = g.f2; xr[12 + JJ] = g.g;
+    });
+    bool singular = false;
+    udx = 1;
+    TC pivv = bc<0>(xr[0]), inv = (TC)1;
+    bool primed = false;
+    static_for<16>([&](auto K) LCP_INL {
+      constexpr int k = K;
+      if (k >= es && k < nzs) {
+        if (!primed) { pivv = bc<k>(xr[k]); inv = fast_rcp(pivv); primed = true; }
+        singular = singular || (pivv == (TC)0);
+        const TC lx = keep_if(xr[k] * inv, ll > k);
+        xr[k] = (ll > k) ? lx : xr[k];
+        udx = (ll == k) ? inv : udx;
+        if constexpr (k + 1 < 16) {
+          fnmac_bc<k>(xr[k + 1], xr[k + 1], lx);
+          pivv = bc<(k + 1) & 15>(xr[k + 1]); inv = fast_rcp(pivv);
+          lu_cols_x<k, k + 2, 14 - k>(xr, lx);
+        }
+      }
+    });
+    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; sp[a] = xr[a]; xr[a] = (a < es) ? (TC)0 : xr[a]; });
+    return row_any(singular);
+  };
+
+  // solve_kkt (pdipm.py:325-354) in body space with pinned coordinates (lcp_quad.hip solve_kkt_pq): rs, rz, os, oz per (component, contact)
+  auto solve = [&](TC di, TC rx, TC rs, TC rz, TC ry, TC& ox, TC& os, TC& oz, TC& oy) {
+    const int nzs = __builtin_amdgcn_readfirstlane(nz), es = __builtin_amdgcn_readfirstlane(e);
+    const TC q = vc ? rs * di - rz : (TC)0;
+    const M4<TC> u4 = minv(gather4(q));
+    const TC gu = Gtw(vc ? pick(u4) : (TC)0);
+    TC wx = (l16 < nzs) ? gu - rx : (TC)0;
+    const TC we = (l16 < es) ? -ry : (TC)0;
+    if (es > 0) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; fnmac_bc<a>(wx, we, keep_if(sp[a], a < es)); });
+    static_for<4>([&](auto Gq) LCP_INL {                                   // L y = rhs (the steps of the pinned columns meet zeros)
+      if (4 * Gq < nzs) static_for<4>([&](auto Kq) LCP_INL { constexpr int k = 4 * Gq + Kq; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k)); });
+    });
+    static_for<4>([&](auto GR) LCP_INL {                                   // U x = y
+      constexpr int Gq = 3 - GR;
+      if (4 * Gq < nzs) static_for<4>([&](auto KR) LCP_INL {
+        constexpr int k = 4 * Gq + 3 - KR;
+        const TC xs = wx * udx;
+        fnmac_bc<k>(wx, xs, keep_if(xr[k], l16 < k));
+      });
+    });
+    ox = (l16 < es) ? we : ((l16 < nzs) ? wx * udx : (TC)0);
+    oy = (l16 < es) ? wx : (TC)0;
+    const TC t = Gv(ox) - q;                                               // (cone row: G is zero there)
+    const M4<TC> o4 = minv(gather4(t));
+    oz = vc ? pick(o4) : (TC)0;
+    os = vc ? (-rs - oz) * di : (TC)0;                                     // :347,350
+  };
+
+  // get_step for (z, dz), (s, ds) of the scene (pdipm.py:182-186): min(step(z, dz), step(s, ds)), NaN semantics as step_pair_q
+  auto step_pair = [&](TC zv, TC dz, TC sv, TC ds) -> TC {
+    const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
+    const TC az = -zv / dz, as = -sv / ds;
+    const uint32_t nz_ = key_is_nan<TC>(nan_key(az)) ? 1u : 0u, ns_ = key_is_nan<TC>(nan_key(as)) ? 2u : 0u;
+    const uint32_t kf = wave_or(vc ? (nz_ | ns_) : 0u);                    // a.max(): NaN if any entry is NaN ...
+    TC mz = vc ? az : ninf, ms = vc ? as : ninf;
+    wave_fmax2(mz, ms);
+    const TC fz = (kf & 1u) ? (TC)1 : fmax_(mz, (TC)1), fs = (kf & 2u) ? (TC)1 : fmax_(ms, (TC)1);   // ... and max(1.0, .) maps NaN to 1.0
+    const TC pz = (dz > (TC)0) ? fz : az, ps = (ds > (TC)0) ? fs : as;     // a[dv > 0] = fill
+    const uint32_t kl = wave_or(vc ? ((key_is_nan<TC>(nan_key(pz)) || key_is_nan<TC>(nan_key(ps))) ? 1u : 0u) : 0u);
+    const TC l = wave_fmin(vc ? fmin_(pz, ps) : pinf);                     // a.min(): NaN if any remaining entry is NaN
+    return kl ? nan_of<TC>() : l;
+  };
+
+#pragma unroll 1
+  for (int it = -1; it < max_iter; ++it) {
+    TC rx, ry, rs, rz, mu = 0, resid = 0, szsum = 0;
+    if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63); b = 0 from a contact list
+      rx = p; ry = 0; rs = 0; rz = -hn; dinv = 1;
+    } else {                                                               // residuals (:82-96)
+      rx = Gtw(vc ? z : (TC)0) + qd * x + p;
+      if (e > 0) rx += (l16 < e) ? y : (TC)0;                              // A = [I 0]: A^T y is y on the pinned lanes
+      rs = z;
+      const M4<TC> z4 = gather4(z);
+      const TC fzv = fma(fzn, z4.n, fma(fz12, z4.f1 + z4.f2, fzg * z4.g));
+      const TC gxv = Gv(x);                                                // (a cross-lane product: never inside a per-lane conditional)
+      rz = vc ? (gxv + s) - (hn + fzv) : (TC)0;
+      ry = (e > 0 && l16 < e) ? x : (TC)0;                                 // A x = x_p, b = 0
+      TC n_rz = rz * rz, sz = vc ? s * z : (TC)0;
+      TC n_rx = (c0 && l16 < nz) ? rx * rx : (TC)0, n_ry = c0 ? ry * ry : (TC)0;    // (x-space is replicated in the rows: row 0 counts)
+      wave_sum4(n_rz, sz, n_rx, n_ry);
+      szsum = sz;
+      mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
+      resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
+      dinv = vc ? s / z : (TC)1;                                           // 1 / d, d = z / s (:98)
+    }
+    const bool singular = factor(dinv);                                    // (:99-100)
+    if (it < 0 && singular && e > 0) status |= LCP_ST_SINGULAR_S11;
+    if (it >= 0 && !done) {
+      ++iters;
+      if (singular && it > 0) { status |= LCP_ST_SINGULAR_T; done = true; }   // except: return best (:99-102)
+      else {
+        const bool improved = !have_best || (resid < best_resid);             // (:107-132)
+        if (improved) { best_resid = resid; n_not = 0; have_best = true; bx = x; by = y; bz = z; bs = s; }
+        else ++n_not;
+        if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
+      }
+    }
+    if (done) break;
+    if (it >= 0 && it == max_iter - 1) break;                             // (the iterate the last pass would produce is never evaluated)
+    TC ax = 0, ay = 0, as_ = 0, az = 0;
+    const int npass = (it < 0) ? 1 : 2;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      TC ox, oy, os, oz;
+      solve(dinv, rx, rs, rz, ry, ox, os, oz, oy);
+      if (it < 0) {
+        x = ox; s = os; z = oz; y = oy;                                       // (:60-63)
+        const uint32_t kn = wave_or(vc ? ((s != s ? 1u : 0u) | (z != z ? 2u : 0u)) : 0u);
+        TC smin = wave_fmin(vc ? s : inf_of<TC>()), zmin = wave_fmin(vc ? z : inf_of<TC>());
+        if (kn & 1u) smin = nan_of<TC>();
+        if (kn & 2u) zmin = nan_of<TC>();
+        if (smin <= (TC)0) s += (TC)1 - smin;                                 // (:66-75)
+        if (zmin <= (TC)0) z += (TC)1 - zmin;
+        if (!vc) { s = 1; z = 1; }
+        if (ncs == 0) { bx = x; by = y; done = true; }                        // engines.py:36-50: x = P^-1 u, no LCP
+      } else if (pass == 0) {
+        ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
+        const TC alpha = pmin(step_pair(z, az, s, as_), (TC)1);              // (:142-144)
+        const TC t3 = wave_sum(vc ? (s + alpha * as_) * (z + alpha * az) : (TC)0);
+        const TC r3 = t3 / szsum, sig = r3 * r3 * r3;                         // (:146-150)
+        const TC ms = -mu * sig;
+        rx = 0; ry = 0; rz = 0;
+        rs = vc ? (ms + as_ * az) / s : (TC)0;                                // (:153)
+      } else {
+        const TC cx = ox + ax, cy = oy + ay, cs = os + as_, cz = oz + az;     // (:160-163)
+        const TC alpha = pmin((TC)0.999 * step_pair(z, cz, s, cs), (TC)1);   // (:164-166)
+        x += alpha * cx; y += alpha * cy;                                     // (:171-174)
+        if (vc) { s += alpha * cs; z += alpha * cz; }
+      }
+    }
+    if (done) break;
+  }
+
+  // ---- outputs: natural m-space order [normal | friction pairs | cone]; the best iterate also goes to the workspace in fp64
+  const int oi = c0 ? l16 : (c3 ? 3 * nc + l16 : nc + 2 * l16 + (comp - 1));
+  if (c0) {
+    if (l16 < nz) W.x[l16] = bx; else bx = 0;
+    if (l16 < e) W.y[l16] = by; else by = 0;
+  }
+  if (vc) { W.z[oi] = bz; W.s[oi] = bs; } else { bz = 1; bs = 1; }
+  bool bad = (bx != bx);
+  if (vc) bad = bad || (bz != bz) || (bs != bs);
+  if (__any(bad)) status |= LCP_ST_NAN;
+  TI* zo = (TI*)SP.z; TI* so = (TI*)SP.s; TI* yo = (TI*)SP.y;
+  if (l16 < nc) {
+    const TI k = vc ? (TI)1 : (TI)0;                                      // padded slots report 0
+    if (zo) zo[(size_t)scene * m + oi] = k * (TI)bz;
+    if (so) so[(size_t)scene * m + oi] = k * (TI)bs;
+  }
+  if (c0) {
+    if (l16 < e && yo) yo[(size_t)scene * e + l16] = (TI)by;
+    if (l16 < nz) {
+      const TC nv = -bx;                                                  // engines.py:76-77
+      ((TI*)SP.v_new)[(size_t)scene * nz + l16] = (TI)nv;
+      if (SP.p_new) ((TI*)SP.p_new)[(size_t)scene * nz + l16] = (TI)((TC)((const TI*)SP.pos)[(size_t)scene * nz + l16] + nv * (TC)SP.dt);   // bodies.py:81
+    }
+    if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
+  }
+}
+
+}  // namespace solo
+
+// sizes lcp_fwd_solo takes (the body-space four-scenes-per-wave sizes with nz <= 16)
+bool solo_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
+int solo_step(const StepArgs& SP, void* stream) {
+  hipLaunchKernelGGL(solo::lcp_fwd_solo, dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+}  // namespace lcp
