@@ -28,6 +28,10 @@
 // Same algorithm and the same reference lines as lcp_wave64.hip / lcp_generic.hip.
 #include "lcp_quad_prims.h"
 
+#ifndef LCP_Q_BEST_LDS
+#define LCP_Q_BEST_LDS 1      // 0: the pinned body-space kernel keeps its best iterate in registers (A/B aid)
+#endif
+
 namespace lcp {
 namespace q16 {
 
@@ -442,7 +446,8 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, con
   const int oz = lds_opaque_zero();
   {
     const TI* at = S.L.AtL + oz;
-    static_for<16>([&](auto J) LCP_INL { xr[J] = (l16 == J) ? ((l16 < nz) ? S.qd[0] : (TC)1) : (TC)0; });
+    const TC dsel = (l16 < nz) ? S.qd[0] : (TC)1;
+    static_for<16>([&](auto J) LCP_INL { xr[J] = (l16 == J) ? dsel : (TC)0; });
     if (!R.pin()) {                                                               // (the pinned variant has no equality rows / columns)
       static_for<16>([&](auto J) LCP_INL { er[J] = (l16 < EQ) ? (TC)at[(l16 & (EQ - 1)) * 16 + J] : (TC)0; });
       static_for<EQ>([&](auto A) LCP_INL {
@@ -482,7 +487,7 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, con
       if (k >= e && k < nz) {
         if (!primed) { pivv = bc<k>(xr[k]); inv = fast_rcp(pivv); primed = true; }
         singular = singular || (pivv == (TC)0);
-        const TC lx = (l16 > k) ? xr[k] * inv : (TC)0;
+        const TC lx = keep_if(xr[k] * inv, l16 > k);                                   // (numerically zero on the rows above: one v_cndmask)
         xr[k] = (l16 > k) ? lx : xr[k];
         R.udx = (l16 == k) ? inv : R.udx;
         if constexpr (k + 1 < 16) {
@@ -615,8 +620,8 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
 template <typename TC>
 __device__ __forceinline__ TC step_pair_q(const M4<TC>& z, const M4<TC>& dz, const M4<TC>& s, const M4<TC>& ds, bool valid) {
   const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
-  const M4<TC> az = m4<TC>(-z.n / dz.n, -z.f1 / dz.f1, -z.f2 / dz.f2, -z.g / dz.g);
-  const M4<TC> as = m4<TC>(-s.n / ds.n, -s.f1 / ds.f1, -s.f2 / ds.f2, -s.g / ds.g);
+  const M4<TC> az = m4<TC>(qdiv_x(-z.n, dz.n), qdiv_x(-z.f1, dz.f1), qdiv_x(-z.f2, dz.f2), qdiv_x(-z.g, dz.g));
+  const M4<TC> as = m4<TC>(qdiv_x(-s.n, ds.n), qdiv_x(-s.f1, ds.f1), qdiv_x(-s.f2, ds.f2), qdiv_x(-s.g, ds.g));
   auto key4 = [&](const M4<TC>& a) { return umax(umax(nan_key(a.n), nan_key(a.f1)), umax(nan_key(a.f2), nan_key(a.g))); };
   // a.max() (NaN if any entry is NaN), then max(1.0, .) which maps NaN to 1.0
   TC mz = valid ? fmax_(fmax_(az.n, az.f1), fmax_(az.f2, az.g)) : ninf;
@@ -884,6 +889,16 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   static_for<XH>([&](auto HX) LCP_INL { bx.v[HX] = 0; });
   TC by = 0;
   M4<TC> bz = m4<TC>(1, 1, 1, 1), bs = bz;
+  // BEST_LDS (the pinned body-space kernel): the best iterate is parked in LDS - ten doubles per lane, lane-major, behind the four
+  // scene blocks - instead of twenty registers that are written a few times per solve and read once
+  constexpr bool BEST_LDS = (ALG == 2) && (LCP_Q_BEST_LDS != 0);
+  TC* const bestL = (TC*)(smem_all + (size_t)4 * lds_per_scene) + lane;
+  auto park = [&](const XVt& x_, TC y_, const M4<TC>& z_, const M4<TC>& s_) LCP_INL {
+    bestL[0] = x_.v[0]; bestL[64] = y_;
+    bestL[128] = z_.n; bestL[192] = z_.f1; bestL[256] = z_.f2; bestL[320] = z_.g;
+    bestL[384] = s_.n; bestL[448] = s_.f1; bestL[512] = s_.f2; bestL[576] = s_.g;
+  };
+  if constexpr (BEST_LDS) park(bx, by, bz, bs);
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
   const TC mf = (TC)(4 * ncs);                                           // nineq of this scene
@@ -926,7 +941,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
       szsum = sz;
       mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
-      dinv = vc ? m4<TC>(s.n / z.n, s.f1 / z.f1, s.f2 / z.f2, s.g / z.g) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
+      dinv = vc ? m4<TC>(qdiv(s.n, z.n), qdiv(s.f1, z.f1), qdiv(s.f2, z.f2), qdiv(s.g, z.g)) : m4<TC>(1, 1, 1, 1);   // 1 / d, d = z / s (:98)
     }
     LCP_QTICK(pr, 0)                                                       // residuals, d
     bool sing_;
@@ -941,7 +956,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         const bool improved = !have_best || (resid < best_resid);             // (:107-132)
         if (improved) {                                                       // best iterate (registers; stored once, below)
           best_resid = resid; n_not = 0; have_best = true;
-          bx = x; by = y; bz = z; bs = s;
+          if constexpr (BEST_LDS) park(x, y, z, s); else { bx = x; by = y; bz = z; bs = s; }
         } else ++n_not;
         if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
       }
@@ -971,7 +986,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         if (zmin <= (TC)0) { const TC sh = (TC)1 - zmin; z = m4<TC>(z.n + sh, z.f1 + sh, z.f2 + sh, z.g + sh); }
         if (!vc) { s = m4<TC>(1, 1, 1, 1); z = s; }
         if (ncs == 0 && !done) {                                              // engines.py:36-50: x = P^-1 u, no LCP
-          bx = x; by = y;
+          if constexpr (BEST_LDS) { bestL[0] = x.v[0]; bestL[64] = y; } else { bx = x; by = y; }
           done = true;
         }
       } else if (pass == 0) {
@@ -984,7 +999,7 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         const TC ms = -mu * sig;
         static_for<XH>([&](auto HX) LCP_INL { rx.v[HX] = 0; });
         ry = 0; rz = m4<TC>(0, 0, 0, 0);
-        rs = vc ? m4<TC>((ms + as_.n * az.n) / s.n, (ms + as_.f1 * az.f1) / s.f1, (ms + as_.f2 * az.f2) / s.f2, (ms + as_.g * az.g) / s.g)
+        rs = vc ? m4<TC>(qdiv(ms + as_.n * az.n, s.n), qdiv(ms + as_.f1 * az.f1, s.f1), qdiv(ms + as_.f2 * az.f2, s.f2), qdiv(ms + as_.g * az.g, s.g))
                 : m4<TC>(0, 0, 0, 0);                                         // (:153)
       } else {
         XVt cx;
@@ -1015,6 +1030,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   // outputs (natural m-space order: n rows, friction pairs, gamma rows).  The best iterate also goes to the workspace,
   // in fp64, for the backward kernels (lcp.py:29,34: the op keeps its solution)
   if (!live) return;
+  if constexpr (BEST_LDS) {
+    bx.v[0] = bestL[0]; by = bestL[64];
+    bz = m4<TC>(bestL[128], bestL[192], bestL[256], bestL[320]); bs = m4<TC>(bestL[384], bestL[448], bestL[512], bestL[576]);
+  }
   static_for<XH>([&](auto HX) LCP_INL { if (16 * HX + l16 < nz) wsx[16 * HX + l16] = bx.v[HX]; else bx.v[HX] = 0; });
   if (l16 < e) W.y[l16] = by; else by = 0;
   if (vc) {
@@ -1484,7 +1503,7 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int
       if (rc) return rc;
       hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 3);   // whatever that one left
     } else if (body_space) {
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);   // pinned leading coordinates
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * ls + 10 * 64 * sizeof(double), st, P, SP, ls, 2);   // pinned leading coordinates (+ the parked best iterate)
       hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 3);   // whatever that one left
     }
     else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);

@@ -30,10 +30,10 @@ DEV = "cuda"
 # sets equal the oracle's on EVERY row (no mask at all) and so do its iteration counts.  The 8-contact stacks of configs[1]
 # converge to rounding inside the ten iterations: a fifth of the (z_i, s_i) pairs are two numbers that both went to zero - the
 # oracle's own z_i > s_i there is decided by the rounding of its last iteration - and the exit tests of pdipm.py:133 compare
-# rounding noise, so there the sets are required to be identical on the decisive rows, the unmasked count is bounded (0.5 % of
+# rounding noise, so there the sets are required to be identical on the decisive rows, the unmasked count is bounded (1 % of
 # the rows) and reported, and the iteration counts may differ by one.
 STRICT = dict(unmasked_max=0, masked_max=0.03, iters_max_delta=0, well_posed_min=0.9)
-CONVERGED = dict(unmasked_max=0.005, masked_max=0.25, iters_max_delta=1, well_posed_min=0.5)
+CONVERGED = dict(unmasked_max=0.01, masked_max=0.25, iters_max_delta=1, well_posed_min=0.5)
 CASES = [
     ("configs1_1024x8", 1024, 2, 1236, "pinned", CONVERGED),
     ("configs2_4096x16", 4096, 4, 1236, "pinned", STRICT),

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build A/B variants of liblcp_hip.so that differ in the -D flags of ONE translation unit (default lcp_quad.hip):
+#   tools/build_variants.sh name1 "-DFLAG=1" name2 "-DA=0 -DB=1" ...      -> lcp_physics_amd/csrc/variants/<name>.so
+# then on the GPU: bash tools/ab_bench.sh   (bench.py against every variant)
+set -e
+cd "$(dirname "$0")/../lcp_physics_amd/csrc"
+UNIT=${UNIT:-lcp_quad}
+mkdir -p variants
+make -j8 > /dev/null
+OTHERS=$(ls *.o | grep -v "^${UNIT}.o$" | grep -v "_prof.o$")
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wall -Wno-unused-function -fno-slp-vectorize $flags -x hip -c ${UNIT}.hip -o variants/${UNIT}_$name.o \
+    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so $OTHERS variants/${UNIT}_$name.o && echo "built $name ($flags)" ) &
+done
+wait
+rm -f variants/*.o
