@@ -28,6 +28,16 @@
 // Same algorithm and the same reference lines as lcp_wave64.hip / lcp_generic.hip.
 #include "lcp_quad_prims.h"
 
+// Measured on the MI355X (profiles/r03_ab_occupancy.txt) and NOT the default: with its contact's rows of Jc / Jt read from LDS (LCP_Q_ROWL)
+// instead of held in 32 registers the pinned body-space kernel fits 239 registers - two wavefronts per SIMD (LCP_Q_OCC2 = 2) - but the
+// forward of 4096 scenes goes from 0.096 to 0.132 ms (one wave per SIMD waits out every LDS round trip), and at 32768 scenes, where
+// two waves do share a SIMD, 0.749 against 0.716 ms: a second wave does not buy back what the LDS reads cost.
+#ifndef LCP_Q_OCC2
+#define LCP_Q_OCC2 1          // wavefronts per SIMD the pinned body-space kernel is allocated for (2: at most 256 unified registers)
+#endif
+#ifndef LCP_Q_ROWL
+#define LCP_Q_ROWL 0          // 1: the pinned body-space kernel reads its contact's rows of Jc / Jt from LDS instead of keeping them in registers
+#endif
 #ifndef LCP_Q_BEST_LDS
 #define LCP_Q_BEST_LDS 1      // 0: the pinned body-space kernel keeps its best iterate in registers (A/B aid)
 #endif
@@ -53,11 +63,11 @@ constexpr int WL_ELEMS = NRED * (NRED + 1) / 2;
 // `xh` = x-space halves: 1 (nz <= 16, one entry per lane) or 2 (nz <= 32, entries j and 16 + j per lane); it is the row
 // length of GL / GTL / AtL in units of 16
 template <typename TI, typename TC>
-__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, bool with_w, int xh = 1) {
+__host__ __device__ inline size_t carve_q(LdsQ<TI, TC>& L, unsigned char* smem, bool with_w, int xh = 1, bool with_gal = true) {
   unsigned char* q = smem;
   auto take = [&](size_t bytes) { unsigned char* r = q; q += (bytes + 15) & ~(size_t)15; return r; };
-  L.GAL = (TC*)take(sizeof(TC) * NCQ * 2 * EQ);
-  L.S11 = (TC*)take(sizeof(TC) * EQ * EQ);
+  L.GAL = with_gal ? (TC*)take(sizeof(TC) * NCQ * 2 * EQ) : nullptr;      // (contact-space pre-factorisation; scratch of the backward kernels)
+  L.S11 = with_gal ? (TC*)take(sizeof(TC) * EQ * EQ) : nullptr;
   L.GL = (TI*)take(sizeof(TI) * NCQ * 16 * xh);
   L.GTL = (TI*)take(sizeof(TI) * NCQ * 16 * xh);
   L.AtL = (TI*)take(sizeof(TI) * EQ * 16 * xh);
@@ -104,13 +114,17 @@ template <int C0> __device__ __forceinline__ void gtw8_dpp(double& a0, double& a
 // XH = 2: nz <= 32, six to ten bodies).
 template <typename TC, int XH> struct XV { TC v[XH]; };
 
-template <typename TI, typename TC, int XH = 1>
+// ROWL: the lane's own rows of Jc / Jt are not kept in registers (32 of them) but read from their LDS copies at every use (the
+// pinned body-space kernel: its register budget is what decides how many wavefronts share a SIMD)
+template <typename TI, typename TC, int XH = 1, bool ROWL = false>
 struct SceneQ {
   static constexpr int RS = 16 * XH;     // row length of GL / GTL / AtL
   LdsQ<TI, TC> L;
   int nz, nc, e, l16;      // nc: live contacts of THIS scene (row-uniform)
   int ncw, ncap;          // ncw: max nc over the scenes of the wave (loop bound); ncap: contact capacity (array strides)
-  TI jc[RS], jt[RS];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
+  TI jc[ROWL ? 1 : RS], jt[ROWL ? 1 : RS];      // rows of Jc and Jt of this lane's contact (Jf rows are +jt, -jt: world.py:191-192)
+  template <int J> __device__ __forceinline__ TI jcv(int oz) const { if constexpr (ROWL) return L.GL[l16 * RS + J + oz]; else return launder(jc[J]); }
+  template <int J> __device__ __forceinline__ TI jtv(int oz) const { if constexpr (ROWL) return L.GTL[l16 * RS + J + oz]; else return launder(jt[J]); }
   TC gan[EQ], gat[EQ];    // (J Q^-1 A^T) rows of this contact
   TC s11row[EQ];          // row l16 of (A Q^-1 A^T)^-1
   TC qd[XH], qid[XH];     // Q[j][j], 1 / Q[j][j] for j = 16 h + l16
@@ -127,7 +141,8 @@ struct SceneQ {
       static_for<2>([&](auto Hh) LCP_INL {
         constexpr int J0 = 8 * Hh;
         double c[8], t[8];
-        static_for<8>([&](auto I) LCP_INL { c[I] = (double)launder(jc[J0 + I]); t[I] = (double)launder(jt[J0 + I]); });
+        const int ozr = ROWL ? lds_opaque_zero() : 0;
+        static_for<8>([&](auto I) LCP_INL { c[I] = (double)this->template jcv<J0 + I>(ozr); t[I] = (double)this->template jtv<J0 + I>(ozr); });
         gv8_dpp<J0>(n0, n1, t0, t1, v.v[0], c, t);
       });
       gn = n0 + n1; gt = t0 + t1;
@@ -135,8 +150,8 @@ struct SceneQ {
     }
     static_for<8 * XH>([&](auto H) LCP_INL {
       constexpr int J = 2 * H, hx = J >> 4;
-      fmac_bc<J & 15>(n0, v.v[hx], (TC)launder(jc[J])); fmac_bc<J & 15>(t0, v.v[hx], (TC)launder(jt[J]));
-      fmac_bc<(J + 1) & 15>(n1, v.v[hx], (TC)launder(jc[J + 1])); fmac_bc<(J + 1) & 15>(t1, v.v[hx], (TC)launder(jt[J + 1]));
+      fmac_bc<J & 15>(n0, v.v[hx], (TC)jcv<J>(0)); fmac_bc<J & 15>(t0, v.v[hx], (TC)jtv<J>(0));
+      fmac_bc<(J + 1) & 15>(n1, v.v[hx], (TC)jcv<J + 1>(0)); fmac_bc<(J + 1) & 15>(t1, v.v[hx], (TC)jtv<J + 1>(0));
     });
     gn = n0 + n1; gt = t0 + t1;
   }
@@ -422,8 +437,8 @@ struct PrimQ {
 // nz - neq rows of ONE row per lane (66 row updates instead of 360 on the headline config), the rows of the pinned coordinates
 // are never touched by it and stay S.  Same equations, fewer of them; detected per wave (all four scenes), any other A takes
 // the general path.
-template <typename TI, typename TC, typename PQ>
-__device__ __forceinline__ M4<TC> minv_pq(const PQ& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& t) {   // M^-1 t
+template <typename TI, typename TC, typename PQ, typename SQ>
+__device__ __forceinline__ M4<TC> minv_pq(const PQ& R, const SQ& S, const M4<TC>& t) {   // M^-1 t
   M4<TC> o;
   o.n = R.idn * t.n;
   o.g = R.kap * ((t.g - S.mu * o.n) + fma(R.i1, t.f1, R.i2 * t.f2));
@@ -431,8 +446,8 @@ __device__ __forceinline__ M4<TC> minv_pq(const PQ& R, const SceneQ<TI, TC, 1>& 
   o.f2 = R.i2 * (t.f2 - o.g);
   return o;
 }
-template <typename TI, typename TC, typename PQ>
-__device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, const SceneQ<TI, TC, 1>& S, const M4<TC>& D,
+template <typename TI, typename TC, typename PQ, typename SQ>
+__device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, const SQ& S, const M4<TC>& D,
                                           bool valid LCP_QPROF_ARG) {
   const int l16 = launder(S.l16), ncw = __builtin_amdgcn_readfirstlane(S.ncw);
   const int nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
@@ -442,8 +457,8 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, con
   const TC b10 = valid ? R.kap * (R.i1 - R.i2) * (S.mu * R.idn) : (TC)0;
   const TC b11 = valid ? R.kap * fma(R.i1 + R.i2, D.g, (TC)4 * (R.i1 * R.i2)) : (TC)0;   // = (i1 + i2) - kap (i1 - i2)^2, no cancellation
   TC p0[16], p1[16];
-  static_for<16>([&](auto J) LCP_INL { const TC c = (TC)launder(S.jc[J]), t = (TC)launder(S.jt[J]); p0[J] = b00 * c; p1[J] = fma(b10, c, b11 * t); });
   const int oz = lds_opaque_zero();
+  static_for<16>([&](auto J) LCP_INL { const TC c = (TC)S.template jcv<J>(oz), t = (TC)S.template jtv<J>(oz); p0[J] = b00 * c; p1[J] = fma(b10, c, b11 * t); });
   {
     const TI* at = S.L.AtL + oz;
     const TC dsel = (l16 < nz) ? S.qd[0] : (TC)1;
@@ -538,14 +553,14 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, con
 
 // solve_kkt (pdipm.py:325-354) in body space:  q = rs / d - rz,  K [dx; dy] = [-rx + G^T M^-1 q; -ry],
 // dz = M^-1 (G dx - q),  ds = (-rs - dz) / d
-template <typename TI, typename TC, typename PQ>
-__device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const TC (&xr)[20], const TC (&er)[20], const PQ& R,
+template <typename TI, typename TC, typename PQ, typename SQ>
+__device__ __forceinline__ void solve_kkt_pq(const SQ& S, const TC (&xr)[20], const TC (&er)[20], const PQ& R,
                                              const M4<TC>& di, bool valid, const XV<TC, 1>& rx, const M4<TC>& rs, const M4<TC>& rz, TC ry,
                                              XV<TC, 1>& ox, M4<TC>& os, M4<TC>& oz, TC& oy LCP_QPROF_ARG) {
   const int l16 = S.l16, nz = __builtin_amdgcn_readfirstlane(S.nz), e = __builtin_amdgcn_readfirstlane(S.e);
   M4<TC> q = m4<TC>(rs.n * di.n - rz.n, rs.f1 * di.f1 - rz.f1, rs.f2 * di.f2 - rz.f2, rs.g * di.g - rz.g);
   if (!valid) q = m4<TC>(0, 0, 0, 0);
-  const M4<TC> u = minv_pq<TI, TC, PQ>(R, S, q);
+  const M4<TC> u = minv_pq<TI, TC, PQ, SQ>(R, S, q);
   const XV<TC, 1> gu = S.template Gtw<true>(valid ? u.n : (TC)0, valid ? u.f1 - u.f2 : (TC)0);
   TC wx = (l16 < nz) ? gu.v[0] - rx.v[0] : (TC)0;
   TC we = (l16 < e) ? -ry : (TC)0;
@@ -573,7 +588,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
     oy = (l16 < e) ? wx : (TC)0;
     TC gn, gt;
     S.template Gv<true>(ox, gn, gt);
-    oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+    oz = minv_pq<TI, TC, PQ, SQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
     if (!valid) oz = m4<TC>(0, 0, 0, 0);
     os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
     if (!valid) os = m4<TC>(0, 0, 0, 0);
@@ -609,7 +624,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SceneQ<TI, TC, 1>& S, const T
   oy = (l16 < e) ? we * R.ude : (TC)0;
   TC gn, gt;
   S.template Gv<true>(ox, gn, gt);
-  oz = minv_pq<TI, TC, PQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
+  oz = minv_pq<TI, TC, PQ, SQ>(R, S, m4<TC>(gn - q.n, gt - q.f1, -gt - q.f2, -q.g));
   if (!valid) oz = m4<TC>(0, 0, 0, 0);
   os = m4<TC>((-rs.n - oz.n) * di.n, (-rs.f1 - oz.f1) * di.f1, (-rs.f2 - oz.f2) * di.f2, (-rs.g - oz.g) * di.g);   // :347,350
   if (!valid) os = m4<TC>(0, 0, 0, 0);
@@ -681,8 +696,8 @@ __device__ __forceinline__ void load_dense_q(SceneQ<TI, TC, 1>& S, const FwdArgs
 }
 
 // contact list -> per-lane rows (physics/engines.py:31-32,50-74; physics/world.py:144-234)
-template <typename TI, typename TC, int XH>
-__device__ __forceinline__ void assemble_q(SceneQ<TI, TC, XH>& S, const StepArgs& P, int scene, XV<TC, XH>& p, TC& hn, TC& b) {
+template <typename TI, typename TC, int XH, typename SQ>
+__device__ __forceinline__ void assemble_q(SQ& S, const StepArgs& P, int scene, XV<TC, XH>& p, TC& hn, TC& b) {
   constexpr int RS = 16 * XH;
   const int nb = P.nb, nc = S.ncap, nz = S.nz, e = S.e, l16 = S.l16;
   const bool vc = l16 < S.nc;
@@ -704,7 +719,8 @@ __device__ __forceinline__ void assemble_q(SceneQ<TI, TC, XH>& S, const StepArgs
     }
     hrow = r.h; mu = r.mu;
   }
-  static_for<RS>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * RS + J]; S.jt[J] = S.L.GTL[l16 * RS + J]; });   // own row only
+  if constexpr (sizeof(S.jc) == sizeof(TI) * RS)                                                        // (ROWL: the rows stay in LDS)
+    static_for<RS>([&](auto J) LCP_INL { S.jc[J] = S.L.GL[l16 * RS + J]; S.jt[J] = S.L.GTL[l16 * RS + J]; });   // own row only
   const TI* Je = (const TI*)P.Je + (size_t)scene * e * nz;
   static_for<RS>([&](auto K) LCP_INL {
     if (l16 < EQ) S.L.AtL[l16 * RS + K] = (l16 < e && K < nz) ? Je[l16 * nz + K] : (TI)0;
@@ -815,7 +831,7 @@ __device__ __forceinline__ int prefactor_q(SceneQ<TI, TC, XH>& S, const Ws<TI, T
 //          6 % faster.  A wave that does not qualify marks its scenes (meta[21]) and leaves; the ALG = 1 kernel, launched right
 //          behind with accept = 3, serves exactly the marked scenes - on the usual worlds it finds none and is gone in 2-3 us.
 template <typename TI, typename TC, bool FUSED, int XH, int ALG = 0>
-__global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
+__global__ void __launch_bounds__(64, (ALG == 2 ? LCP_Q_OCC2 : 1)) lcp_fwd_quad(FwdArgs P, StepArgs SP, int lds_per_scene, int accept) {
   static_assert(XH == 1 || FUSED, "the dense loader is written for nz <= 16");
   static_assert(ALG == 0 || XH == 1, "the body-space variant holds one x-row per lane");
   static_assert(ALG != 2 || FUSED, "the pinned-only kernel is launched by the contact-list entry points");
@@ -834,8 +850,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
   if (!FUSED) live = live && ((int)W.meta[0] == accept);
   if (FUSED && ALG == 1 && accept == 3) live = live && ((int)W.meta[21] == 1);   // second pass: the scenes the pinned-only kernel left
   if (!__any(live)) return;
-  SceneQ<TI, TC, XH> S;
-  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0, XH);
+  SceneQ<TI, TC, XH, (ALG == 2) && (LCP_Q_ROWL != 0)> S;
+  carve_q(S.L, smem_all + (size_t)row * lds_per_scene, LCP_Q_LDSW != 0, XH, ALG == 0);
   // per-scene contact count (solve_dynamics with detection); a scene without contacts takes the
   // direct KKT solve of engines.py:36-50, which is what the initialisation solve computes
   int ncs = nc;
@@ -899,6 +915,8 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
     bestL[384] = s_.n; bestL[448] = s_.f1; bestL[512] = s_.f2; bestL[576] = s_.g;
   };
   if constexpr (BEST_LDS) park(bx, by, bz, bs);
+  // ... and so is the affine direction while the corrector solve runs (pdipm.py:138-163): ten more doubles per lane
+  TC* const stashL = bestL + 640;
   bool have_best = false, done = !live;
   int n_not = 0, iters = 0;
   const TC mf = (TC)(4 * ncs);                                           // nineq of this scene
@@ -991,6 +1009,11 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         }
       } else if (pass == 0) {
         ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
+        if constexpr (BEST_LDS) {
+          stashL[0] = ax.v[0]; stashL[64] = ay;
+          stashL[128] = as_.n; stashL[192] = as_.f1; stashL[256] = as_.f2; stashL[320] = as_.g;
+          stashL[384] = az.n; stashL[448] = az.f1; stashL[512] = az.f2; stashL[576] = az.g;
+        }
         const TC alpha = pmin(step_pair_q(z, az, s, as_, vc), (TC)1);        // (:142-144)
         auto sc = [&](TC sv, TC dsv, TC zv, TC dzv) { return (sv + alpha * dsv) * (zv + alpha * dzv); };
         const TC t3 = row_sum(vc ? (sc(s.n, as_.n, z.n, az.n) + sc(s.f1, as_.f1, z.f1, az.f1)) + (sc(s.f2, as_.f2, z.f2, az.f2) + sc(s.g, as_.g, z.g, az.g)) : (TC)0);
@@ -1002,6 +1025,10 @@ __global__ void __launch_bounds__(64) lcp_fwd_quad(FwdArgs P, StepArgs SP, int l
         rs = vc ? m4<TC>(qdiv(ms + as_.n * az.n, s.n), qdiv(ms + as_.f1 * az.f1, s.f1), qdiv(ms + as_.f2 * az.f2, s.f2), qdiv(ms + as_.g * az.g, s.g))
                 : m4<TC>(0, 0, 0, 0);                                         // (:153)
       } else {
+        if constexpr (BEST_LDS) {
+          ax.v[0] = stashL[0]; ay = stashL[64];
+          as_ = m4<TC>(stashL[128], stashL[192], stashL[256], stashL[320]); az = m4<TC>(stashL[384], stashL[448], stashL[512], stashL[576]);
+        }
         XVt cx;
         static_for<XH>([&](auto HX) LCP_INL { cx.v[HX] = ox.v[HX] + ax.v[HX]; });
         const TC cy = oy + ay;                                                // (:160-163)
@@ -1448,9 +1475,9 @@ bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <
 // same banks).  Measured: SQ_LDS_BANK_CONFLICT 273 k -> 169 k cycles per launch; no change of the kernel time - the
 // single wave waits out the LDS latency either way.
 template <typename TC, typename TI = float>
-static size_t q16_lds(bool with_w, int xh = 1) {
+static size_t q16_lds(bool with_w, int xh = 1, bool with_gal = true) {
   q16::LdsQ<TI, TC> L;
-  size_t n = q16::carve_q<TI, TC>(L, nullptr, with_w, xh);
+  size_t n = q16::carve_q<TI, TC>(L, nullptr, with_w, xh, with_gal);
   while (n % 256 != 64) n += 16;
   return n;
 }
@@ -1497,14 +1524,16 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int
   const bool wide = 3 * SP.nb > 16;
   if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0, wide ? 2 : 1);
+    const int lb = (int)q16_lds<double>(LCP_Q_LDSW != 0, 1, false);          // body-space kernels: no contact-space tables
     if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
     else if (body_space && (solo > 0 || (solo < 0 && SP.B <= LCP_SOLO_MAX_B))) {
       int rc = solo_step(SP, stream);                                                                             // pinned leading coordinates, one scene per wave
       if (rc) return rc;
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 3);   // whatever that one left
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
     } else if (body_space) {
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * ls + 10 * 64 * sizeof(double), st, P, SP, ls, 2);   // pinned leading coordinates (+ the parked best iterate)
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * ls, st, P, SP, ls, 3);   // whatever that one left
+      // (+ the parked best iterate and affine direction: 2 x 10 doubles per lane)
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * lb + 20 * 64 * sizeof(double), st, P, SP, lb, 2);   // pinned leading coordinates
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
     }
     else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {
