@@ -55,6 +55,12 @@ extern "C" {
  * follows either). */
 #define LCP_PATH_QUAD 0x8000
 #define LCP_PATH_SOLO 0x10000
+/* May be OR-ed into the `compute` argument of the contact-list forwards (lcp_step_fused_f32, lcp_solve_dynamics_f32): the caller
+ * asserts that the equality rows of EVERY scene pin the leading coordinates - Je = [I 0], the TotalConstraint that fixes the floor of
+ * the reference's demo worlds (physics/constraints.py:175-192) - or that there are none.  The four-scenes-per-wave family then skips
+ * the launch that serves scenes with other equality rows (it finds nothing to do on such batches and costs 2-5 us).  A scene that
+ * breaks the promise is NOT solved: its new velocities are NaN and LCP_ST_NAN is set. */
+#define LCP_HINT_PINNED 0x20000
 /* OR-ed into the `compute` argument of lcp_workspace_bytes by callers of the fp64-I/O entry points (lcp_pdipm_forward_f64 /
  * lcp_pdipm_backward_f64): their workspace also keeps an fp64 copy of F. */
 #define LCP_IO_F64 0x400

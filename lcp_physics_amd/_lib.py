@@ -21,6 +21,7 @@ PATH_CONTACT_SPACE = 0x2000
 PATH_PRIMAL = 0x4000
 PATH_QUAD = 0x8000
 PATH_SOLO = 0x10000
+HINT_PINNED = 0x20000
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2

@@ -16,14 +16,16 @@ thread_local int g_path = 0;              // this thread's DEFAULT kernel path f
                                           // 0 = automatic, 1 = generic kernels, 3 = contact-space kernels instead of the body-space ones,
                                           // 4 = one wave per scene (lcp_primal.hip) at every size (A/B aids)
 
-constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL | LCP_PATH_QUAD | LCP_PATH_SOLO;
+constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL | LCP_PATH_QUAD | LCP_PATH_SOLO |
+                          LCP_HINT_PINNED;
 
 // `compute` word of an entry point -> arithmetic type and kernel path.  The path is a function of the WORD whenever the word
 // names one (LCP_PATH_*): a forward and its backward that carry the same word pick the same kernel family on any two host
 // threads.  Only a word without path bits falls back on the calling thread's lcp_debug_set_path default.
 // *path: 0 automatic, 1 generic, 3 contact space, 4 primal;  *generic = (path == 1)
 inline int split_compute(int compute, bool* generic, int* path = nullptr, int* solo = nullptr) {
-  if (solo) *solo = (compute & LCP_PATH_SOLO) ? 1 : ((compute & LCP_PATH_QUAD) ? 0 : -1);   // (same workspace layout either way: forward only)
+  // (same workspace layout either way: forward only; bit 2 of the value: LCP_HINT_PINNED)
+  if (solo) *solo = ((compute & LCP_PATH_SOLO) ? 1 : ((compute & LCP_PATH_QUAD) ? 0 : -1)) + ((compute & LCP_HINT_PINNED) ? 16 : 0);
   int p = g_path;
   if (compute & LCP_PATH_GENERIC) p = 1;
   else if (compute & LCP_PATH_CONTACT_SPACE) p = 3;
@@ -351,7 +353,7 @@ static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int 
   P.tag = trailer_of(P.ws, P.B, scene_bytes(nz, m, e, compute, 0));
   P.tag_value = step_tag(fam, nz, compute, path);
   switch (fam) {
-    case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3, solo);
+    case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3, solo >= 8 ? solo - 16 : solo, solo >= 8);
     case FAM_PRIMAL: return lcp::primal_step(P, stream);
     case FAM_BIG: return lcp::big_step(P, stream);
     case FAM_WAVE64: return lcp::wave64_step(P, compute, stream);

@@ -881,7 +881,13 @@ __global__ void __launch_bounds__(64, (ALG == 2 ? LCP_Q_OCC2 : 1)) lcp_fwd_quad(
     R.pin_rt = __all(okl) != 0;
     if constexpr (ALG == 2) {
       if (live && l16 == 0) W.meta[21] = R.pin_rt ? (TC)0 : (TC)1;
-      if (!R.pin_rt) return;                                             // the general kernel behind this one takes the wave
+      if (!R.pin_rt) {                                                   // the general kernel behind this one takes the wave ...
+        if (accept == 4 && live) {                                       // ... unless the caller promised there was no such wave (LCP_HINT_PINNED)
+          if (l16 < nz) ((TI*)SP.v_new)[(size_t)scene * nz + l16] = nan_of<TI>();
+          if (l16 == 0 && SP.status) SP.status[scene] = LCP_ST_NAN;
+        }
+        return;
+      }
     }
   }
   if (blockIdx.x == 0 && lane == 0) { int32_t* tg = FUSED ? SP.tag : P.tag; if (tg) *tg = FUSED ? SP.tag_value : P.tag_value; }
@@ -1517,7 +1523,7 @@ bool quad_step_is_body_space(int nz, int compute, int body_space) { return body_
 #ifndef LCP_SOLO_MAX_B
 #define LCP_SOLO_MAX_B 1024
 #endif
-int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int solo) {
+int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int solo, bool pinned) {
   FwdArgs P = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
@@ -1527,13 +1533,14 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int
     const int lb = (int)q16_lds<double>(LCP_Q_LDSW != 0, 1, false);          // body-space kernels: no contact-space tables
     if (wide) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 2>), grid, blk, 4 * ls, st, P, SP, ls, 2);
     else if (body_space && (solo > 0 || (solo < 0 && SP.B <= LCP_SOLO_MAX_B))) {
-      int rc = solo_step(SP, stream);                                                                             // pinned leading coordinates, one scene per wave
+      int rc = solo_step(SP, stream, pinned);                                                                     // pinned leading coordinates, one scene per wave
       if (rc) return rc;
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
+      if (!pinned) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
     } else if (body_space) {
       // (+ the parked best iterate and affine direction: 2 x 10 doubles per lane)
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * lb + 20 * 64 * sizeof(double), st, P, SP, lb, 2);   // pinned leading coordinates
-      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
+      // (accept 4 = LCP_HINT_PINNED: nothing is launched behind; a wave that does not qualify returns NaN velocities)
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2>), grid, blk, 4 * lb + 20 * 64 * sizeof(double), st, P, SP, lb, pinned ? 4 : 2);   // pinned leading coordinates
+      if (!pinned) hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
     }
     else hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1>), grid, blk, 4 * ls, st, P, SP, ls, 2);
   } else {

@@ -156,7 +156,7 @@ template <int K0> __device__ __forceinline__ void form4x4(double (&x)[4], const 
 #ifndef LCP_SOLO_OCC
 #define LCP_SOLO_OCC 1      // wavefronts per SIMD the register allocation allows (2: at most 256 unified registers, fp32 tables)
 #endif
-__global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP) {
+__global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, int pinned_hint) {
   using TI = float;
   using TC = double;
   __shared__ TI GL[NCQ * 16], GTL[NCQ * 16], AtL[EQ * 16];
@@ -235,7 +235,13 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP) {
     W.meta[21] = pin ? (TC)0 : (TC)1;
     W.meta[0] = (TC)2; W.meta[18] = (TC)1; W.meta[19] = (TC)ncs;
   }
-  if (!pin) return;
+  if (!pin) {                                                       // (LCP_HINT_PINNED: nothing is launched behind - the broken promise is loud)
+    if (pinned_hint && c0) {
+      if (l16 < nz) ((TI*)SP.v_new)[(size_t)scene * nz + l16] = nan_of<TI>();
+      if (l16 == 0 && SP.status) SP.status[scene] = LCP_ST_NAN;
+    }
+    return;
+  }
   if (c0 && vc) W.meta[1 + l16] = mu_c;
   int status = truncated;
   if (row_any(l16 < nz && !(qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
@@ -476,8 +482,8 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP) {
 
 // sizes lcp_fwd_solo takes (the body-space four-scenes-per-wave sizes with nz <= 16)
 bool solo_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
-int solo_step(const StepArgs& SP, void* stream) {
-  hipLaunchKernelGGL(solo::lcp_fwd_solo, dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP);
+int solo_step(const StepArgs& SP, void* stream, bool pinned) {
+  hipLaunchKernelGGL(solo::lcp_fwd_solo, dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, pinned ? 1 : 0);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 

@@ -61,11 +61,38 @@ def assemble_contacts(sc):
     return Q, p, G, h, A, b, F
 
 
-def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto"):
+def rows_pin_leading_coordinates(Je):
+    """Host check (synchronises once): every scene's equality rows are Je = [I 0] - the TotalConstraint that fixes the floor of
+    the reference's demo worlds (`constraints.py:175-192`) -, or there are none.  What `LCP_HINT_PINNED` promises."""
+    if Je is None or Je.numel() == 0:
+        return True
+    e, nz = Je.shape[1], Je.shape[2]
+    if e > nz:
+        return False
+    eye = torch.zeros(e, nz, dtype=Je.dtype, device=Je.device)
+    eye[:, :e] = torch.eye(e, dtype=Je.dtype, device=Je.device)
+    return bool((Je == eye).all())
+
+
+def _pinned_hint(sc, pinned):
+    """`pinned=None`: decided once per SceneBatch from its Je (cached on the object; Je must not be edited in place afterwards)."""
+    if pinned is None:
+        pinned = getattr(sc, "_rows_pinned", None)
+        if pinned is None:
+            pinned = rows_pin_leading_coordinates(sc.Je)
+            try:
+                sc._rows_pinned = pinned
+            except AttributeError:
+                pass
+    return _lib.HINT_PINNED if pinned else 0
+
+
+def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=None):
     """One fused simulation step for every scene of `sc` (float32 CUDA `SceneBatch`).
 
     Returns a dict with v_new, p_new [B,nb,3], z, s [B,4nc], y [B,e], iters, status [B] and the
-    workspace `ws` (re-usable; it also feeds `lcp_backward`)."""
+    workspace `ws` (re-usable; it also feeds `lcp_backward`).  `pinned`: the equality rows of every scene pin the leading
+    coordinates (`LCP_HINT_PINNED`: one launch less); None = checked once per SceneBatch on the host."""
     lib = _lib.load()
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
@@ -73,7 +100,7 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
     dev = sc.v.device
     comp = _COMPUTE[compute]
     need = _lib.workspace_bytes(B, nz, m, e, comp)
-    comp |= _lib.path_bits(path)
+    comp |= _lib.path_bits(path) | _pinned_hint(sc, pinned)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
@@ -224,7 +251,7 @@ class BatchedWorld:
 
 
 def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, eps=1e-12, not_improved_lim=3,
-                   max_iter=10, compute="f64", ws=None, out=None, path="auto"):
+                   max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=False):
     """`PdipmEngine.solve_dynamics` (`engines.py:26-78`) for B scenes with per-scene contact counts
     (`count` [B] int32, contact records in `cb`, a `contacts.ContactBuffers`): one launch of
     `lcp_solve_dynamics_f32`.  Returns dict(v_new, z, s, y, iters, status, ws)."""
@@ -233,7 +260,7 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
     comp = _COMPUTE[compute]
     nz, m = 3 * nb, 4 * maxc
     need = _lib.workspace_bytes(B, nz, m, e, comp)
-    comp |= _lib.path_bits(path)
+    comp |= _lib.path_bits(path) | (_lib.HINT_PINNED if pinned else 0)      # (pinned: LCP_HINT_PINNED, the caller checked its Je)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
@@ -506,6 +533,9 @@ class ContactWorld:
         else:
             self.e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
             self.Je = f32(Je) if self.e else None
+        # a constant Je that pins the leading coordinates (the fixed floor of the demo worlds) or no Je at all: LCP_HINT_PINNED,
+        # checked once here on the host
+        self._pinned = joints is None and rows_pin_leading_coordinates(self.Je)
         self.dt, self.eps, self.tol, self.strict = float(dt), float(eps), float(tol), bool(strict_no_penetration)
         self.maxc, self.max_iter, self.compute = int(maxc), int(max_iter), compute
         self.solver_eps, self.lim, self.max_trials = solver_eps, not_improved_lim, max_trials
@@ -681,7 +711,7 @@ class ContactWorld:
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
         out = solve_dynamics(self.B, self.nb, self.maxc, self.e, cb.count, self.Mdiag, self.v, f, self.rest,
                              self.fric, cb, self.Je, self.dt, eps=self.solver_eps, not_improved_lim=self.lim,
-                             max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out)
+                             max_iter=self.max_iter, compute=self.compute, ws=self._ws, out=self._out, pinned=self._pinned)
         self._ws, self._out = out["ws"], out
         torch.bitwise_or(self.sticky_status, out["status"], out=self.sticky_status)
         self.v, out["v_new"] = out["v_new"], self.v                      # world.py:87 set_v(new_v)

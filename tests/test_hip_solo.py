@@ -99,3 +99,31 @@ def test_backward_kernels_follow_a_solo_forward():
         assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * max(float(gb[k].abs().max()), 1e-12)
     for k in ("Mdiag", "v", "f"):
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-4 * max(float(pb[k].abs().max()), 1e-12), k
+
+
+def test_pinned_hint_skips_the_general_pass_and_a_broken_promise_is_loud():
+    """LCP_HINT_PINNED: the caller asserts Je = [I 0] (checked once per SceneBatch on the host by the wrappers) - same results,
+    one launch less; a scene that breaks an explicit promise gets NaN velocities and LCP_ST_NAN, not a silently stale output."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import fused_step
+    from lcp_physics_amd.physics.batched_world import rows_pin_leading_coordinates
+    B = 16
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=5, dtype=torch.float32)
+    assert rows_pin_leading_coordinates(sc.Je)
+    scg = sc.to(device=DEV)
+    for path in ("quad", "solo"):
+        a = fused_step(scg, path=path, pinned=True)
+        b = fused_step(scg, path=path, pinned=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a["v_new"], b["v_new"]) and torch.equal(a["z"], b["z"]) and torch.equal(a["iters"], b["iters"])
+    Je = sc.Je.clone()
+    Je[5] *= 2.0                                               # scene 5 (wave 1 of the four-scenes kernel) is not in the pinned form
+    sc2 = scenes.SceneBatch(**{**{f: getattr(sc, f) for f in ("p", "v", "Mdiag", "f", "rest", "fric", "c_n", "c_p1", "c_p2", "c_i1", "c_i2")},
+                               "Je": Je, "dt": sc.dt}).to(device=DEV)
+    assert not rows_pin_leading_coordinates(sc2.Je)
+    ok = fused_step(sc2)                                        # the default: detected, the general pass runs
+    bad = fused_step(sc2, path="solo", pinned=True)             # an explicit (wrong) promise
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ok["v_new"]).all())
+    assert bool(torch.isnan(bad["v_new"][5]).all()) and int(bad["status"][5]) & 8
+    assert bool(torch.isfinite(bad["v_new"][:5]).all()) and bool(torch.isfinite(bad["v_new"][6:]).all())
