@@ -222,13 +222,19 @@ __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs 
 // Hull vertices are R(rot) v_local, so d/d(rot) reaches normals, incident edges and clipped points the way the reference's
 // incrementally rotated `verts` do (bodies.py:211-214).  One thread per scene walks the body pairs in the detection kernel's
 // order (so the running contact index is the list's), pairs without a contact cost one value-only pass; fixed summation order.
-__global__ void __launch_bounds__(64) lcp_contact_frame_backward_kernel(int B, int nb, int maxc, const int32_t* kind, const double* radius,
+constexpr int FB_T = 32;       // scenes (threads) per workgroup of the frame backward: its per-thread geometry lives in LDS (43 KB)
+__global__ void __launch_bounds__(FB_T) lcp_contact_frame_backward_kernel(int B, int nb, int maxc, const int32_t* kind, const double* radius,
                                                                         const double* verts_local, const int32_t* nverts,
                                                                         const uint8_t* no_contact, const double* p, double eps,
                                                                         const int32_t* count, const float* g_n, const float* g_p1,
                                                                         const float* g_p2, double* dp) {
   using V2 = ad::V2; using Body = ad::Body; using Pt = ad::Pt; using Dual = ad::Dual;      // (functions: found through their arguments)
-  const int scene = blockIdx.x * 64 + threadIdx.x;
+  // the pair's rotated vertices, edge normals and edge lengths (dual numbers, indexed by run-time vertex numbers): per-thread
+  // slices of LDS - as local arrays they were 1296 B of scratch memory per lane.  (+1 element per slice: the threads' slices start
+  // on different banks)
+  __shared__ V2 s_v[4][FB_T][NV + 1];
+  __shared__ Dual s_e[2][FB_T][NV + 1];
+  const int scene = blockIdx.x * FB_T + threadIdx.x;
   if (scene >= B) return;
   double* out = dp + (size_t)scene * nb * 3;
   for (int i = 0; i < nb * 3; ++i) out[i] = 0.0;
@@ -258,8 +264,8 @@ __global__ void __launch_bounds__(64) lcp_contact_frame_backward_kernel(int B, i
   for (int bi = 0; bi < nb && base < ntot; ++bi) {
     for (int bj = bi + 1; bj < nb && base < ntot; ++bj) {
       if (no_contact && no_contact[((size_t)scene * nb + bi) * nb + bj]) continue;
-      V2 v1[NV], n1[NV], v2_[NV], n2[NV];
-      Dual e1[NV], e2[NV];
+      V2 *v1 = s_v[0][threadIdx.x], *n1 = s_v[1][threadIdx.x], *v2_ = s_v[2][threadIdx.x], *n2 = s_v[3][threadIdx.x];
+      Dual *e1 = s_e[0][threadIdx.x], *e2 = s_e[1][threadIdx.x];
       Body b1, b2;
       Pt pt0, pt1;
       build(bi, -1, v1, n1, e1, b1); build(bj, -1, v2_, n2, e2, b2);
@@ -346,7 +352,7 @@ int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, 
                                   const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,
                                   void* stream) {
   if (nb > ct::MAXB) return LCP_E_TOOLARGE;
-  hipLaunchKernelGGL(ct::lcp_contact_frame_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, maxc, kind,
+  hipLaunchKernelGGL(ct::lcp_contact_frame_backward_kernel, dim3((B + ct::FB_T - 1) / ct::FB_T), dim3(ct::FB_T), 0, (hipStream_t)stream, B, nb, maxc, kind,
                      radius, verts_local, nverts, no_contact, p, eps, count, g_n, g_p1, g_p2, dp);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

@@ -4,6 +4,10 @@
 #pragma once
 #include "lcp_wave_scene.h"
 
+#ifndef LCP_PRIMAL_OCC40
+#define LCP_PRIMAL_OCC40 2     // wavefronts per SIMD the 40-column instantiations are allocated for (A/B: 1 = no scratch, one wave per SIMD)
+#endif
+
 namespace lcp {
 namespace primal {
 
