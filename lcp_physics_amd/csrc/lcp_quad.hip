@@ -502,8 +502,11 @@ __device__ __forceinline__ bool factor_pq(TC (&xr)[20], TC (&er)[20], PQ& R, con
       if (k >= e && k < nz) {
         if (!primed) { pivv = bc<k>(xr[k]); inv = fast_rcp(pivv); primed = true; }
         singular = singular || (pivv == (TC)0);
-        const TC lx = keep_if(xr[k] * inv, l16 > k);                                   // (numerically zero on the rows above: one v_cndmask)
-        xr[k] = (l16 > k) ? lx : xr[k];
+        // column k scaled by 1 / U[k][k] on every row but k: the multipliers below the diagonal, and above it U[i][k] / U[k][k] - the
+        // backward sweep then needs no multiplication on its dependent chain (w_i -= (U_ik / U_kk) w_k, x_k = w_k / U_kk at the end)
+        const TC sk = xr[k] * inv;
+        const TC lx = keep_if(sk, l16 > k);                                            // (numerically zero on the rows above: one v_cndmask)
+        xr[k] = (l16 == k) ? xr[k] : sk;
         R.udx = (l16 == k) ? inv : R.udx;
         if constexpr (k + 1 < 16) {
           fnmac_bc<k>(xr[k + 1], xr[k + 1], lx);
@@ -579,8 +582,7 @@ __device__ __forceinline__ void solve_kkt_pq(const SQ& S, const TC (&xr)[20], co
       constexpr int Gq = 3 - GR;
       if (4 * Gq < nz) static_for<4>([&](auto KR) LCP_INL {
         constexpr int k = 4 * Gq + 3 - KR;
-        const TC xs = wx * R.udx;
-        fnmac_bc<k>(wx, xs, keep_if(xr[k], l16 < k));
+        fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 < k));                        // (xr[k] = U[i][k] / U[k][k] above the diagonal)
       });
     });
     LCP_QTICK(pr, 4)                                                       // triangular sweeps

@@ -324,8 +324,9 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       if (k >= es && k < nzs) {
         if (!primed) { pivv = bc<k>(xr[k]); inv = fast_rcp(pivv); primed = true; }
         singular = singular || (pivv == (TC)0);
-        const TC lx = keep_if(xr[k] * inv, ll > k);
-        xr[k] = (ll > k) ? lx : xr[k];
+        const TC sk = xr[k] * inv;                                          // (column k scaled on every row but k: lcp_quad.hip factor_pq)
+        const TC lx = keep_if(sk, ll > k);
+        xr[k] = (ll == k) ? xr[k] : sk;
         udx = (ll == k) ? inv : udx;
         if constexpr (k + 1 < 16) {
           fnmac_bc<k>(xr[k + 1], xr[k + 1], lx);
@@ -354,8 +355,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       constexpr int Gq = 3 - GR;
       if (4 * Gq < nzs) static_for<4>([&](auto KR) LCP_INL {
         constexpr int k = 4 * Gq + 3 - KR;
-        const TC xs = wx * udx;
-        fnmac_bc<k>(wx, xs, keep_if(xr[k], l16 < k));
+        fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 < k));
       });
     });
     ox = (l16 < es) ? we : ((l16 < nzs) ? wx * udx : (TC)0);
