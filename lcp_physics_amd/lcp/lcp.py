@@ -46,7 +46,7 @@ def _prep(t, B, ndim, device, dtype):
 
 class LCPSolution:
     """Result of one batched solve; keeps the workspace the backward kernel needs."""
-    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype", "all_contact")
+    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype", "all_contact", "_bwd_plan")
 
 
 def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64",
@@ -99,10 +99,19 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
 
 def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
     """Implicit-differentiation backward for a previous `lcp_solve` (lcp.py:37-64).
-    Returns [dQ, dp, dG, dh, dA, db, dF] (None where not needed / no equalities)."""
+    Returns [dQ, dp, dG, dh, dA, db, dF] (None where not needed / no equalities).  Called again with the `out` it returned and
+    the same tensors it re-uses the validated argument list (one ctypes call)."""
     lib = _lib.load()
     B, nz, m, e = sol.sizes
     dev, dtype = sol.G.device, sol.dtype
+    plan = getattr(sol, "_bwd_plan", None)
+    if (plan is not None and out is not None and plan[0] is out and dl_dx.dtype == dtype and dl_dx.is_contiguous()
+            and plan[1] == (dl_dx.data_ptr(), sol.G.data_ptr(), sol.ws.data_ptr(), sol.compute)):
+        from ..physics.batched_world import _on_device
+        with _on_device(dev):
+            rc = plan[2](*plan[3], _lib.stream_ptr(dev))
+        _lib.check(rc, "lcp_pdipm_backward")
+        return out
     dl_dx = _lib.require_gpu_tensor(dl_dx.to(dtype).contiguous(), "dl_dx", dtype)
     shapes = [(B, nz, nz), (B, nz), (B, m, nz), (B, m), (B, e, nz), (B, e), (B, m, m)]
     if out is None:
@@ -117,8 +126,9 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
                                                 *[P(o) for o in out], P(sol.ws), st)
         else:
             hint = _lib.HINT_ALL_CONTACT if getattr(sol, "all_contact", False) else 0
-            rc = lib.lcp_pdipm_backward_f32(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint,
-                                            *[P(o) for o in out], P(sol.ws), st)
+            args = (B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint, *[P(o) for o in out], P(sol.ws))
+            rc = lib.lcp_pdipm_backward_f32(*args, st)
+            sol._bwd_plan = (out, (dl_dx.data_ptr(), sol.G.data_ptr(), sol.ws.data_ptr(), sol.compute), lib.lcp_pdipm_backward_f32, args)
     _lib.check(rc, "lcp_pdipm_backward")
     return out
 

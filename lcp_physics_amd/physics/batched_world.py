@@ -87,17 +87,38 @@ def _pinned_hint(sc, pinned):
     return _lib.HINT_PINNED if pinned else 0
 
 
+def _on_device(dev):
+    """`with torch.cuda.device(dev)` costs several microseconds per call: entered only when `dev` is not already current."""
+    import contextlib
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev)
+
+
+_SCENE_FIELDS = ("p", "Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2", "c_i1", "c_i2")
+
+
 def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=None):
     """One fused simulation step for every scene of `sc` (float32 CUDA `SceneBatch`).
 
     Returns a dict with v_new, p_new [B,nb,3], z, s [B,4nc], y [B,e], iters, status [B] and the
     workspace `ws` (re-usable; it also feeds `lcp_backward`).  `pinned`: the equality rows of every scene pin the leading
-    coordinates (`LCP_HINT_PINNED`: one launch less); None = checked once per SceneBatch on the host."""
+    coordinates (`LCP_HINT_PINNED`: one launch less); None = checked once per SceneBatch on the host.
+    Calling it again with the `out` / `ws` it returned and the same tensors re-uses the validated argument list (the host side of
+    a step is then one ctypes call: at small batches the step is otherwise bound by this wrapper, not by the GPU)."""
     lib = _lib.load()
+    dev = sc.v.device
+    key = (tuple(getattr(sc, k).data_ptr() for k in _SCENE_FIELDS), 0 if sc.Je is None else sc.Je.data_ptr(), float(sc.dt),
+           float(eps), int(not_improved_lim), int(max_iter), compute, path, pinned, _lib.path_bits(path))
+    plan = None if out is None else out.get("_plan")
+    if plan is not None and plan[0] == key and (ws is None or ws is out["ws"]):
+        with _on_device(dev):
+            rc = lib.lcp_step_fused_f32(*plan[1], _lib.stream_ptr(dev))
+        _lib.check(rc, "lcp_step_fused_f32")
+        return out
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
     nz, m = 3 * nb, 4 * nc
-    dev = sc.v.device
     comp = _COMPUTE[compute]
     need = _lib.workspace_bytes(B, nz, m, e, comp)
     comp |= _lib.path_bits(path) | _pinned_hint(sc, pinned)
@@ -111,15 +132,14 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
                "status": torch.empty(B, dtype=torch.int32, device=dev)}
     out["ws"] = ws
     P = _lib.ptr
-    with torch.cuda.device(dev):
-        rc = lib.lcp_step_fused_f32(B, nb, nc, e, P(sc.p), P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest),
-                                    P(sc.fric), P(sc.c_n), P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2),
-                                    P(sc.Je) if e else None, float(sc.dt), float(eps), int(max_iter),
-                                    int(not_improved_lim), comp, P(out["v_new"]), P(out["p_new"]),
-                                    P(out["z"]), P(out["s"]), P(out["y"]), P(out["iters"]),
-                                    P(out["status"]), P(ws), _lib.stream_ptr(dev))
+    args = (B, nb, nc, e, P(sc.p), P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n), P(sc.c_p1), P(sc.c_p2),
+            P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None, float(sc.dt), float(eps), int(max_iter), int(not_improved_lim), comp,
+            P(out["v_new"]), P(out["p_new"]), P(out["z"]), P(out["s"]), P(out["y"]), P(out["iters"]), P(out["status"]), P(ws))
+    with _on_device(dev):
+        rc = lib.lcp_step_fused_f32(*args, _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_step_fused_f32")
     out["compute"] = comp                 # the word the backward must carry: arithmetic + kernel path (a family per word, any thread)
+    out["_plan"] = (key, args)            # (the output tensors and the workspace are the ones in `out`: same pointers next time)
     return out
 
 

@@ -2,7 +2,7 @@
 # One GPU call that refreshes every measured artefact of a round: bench lines of all BASELINE configs, the worlds with contact
 # detection, config 5 through both boundaries, rocprofv3 kernel trace + PMC passes (profile_all.sh / profile_config5.sh).
 # Outputs land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out
 mkdir -p $O
@@ -22,6 +22,13 @@ run bench_world python tools/bench_world.py --cpu-scenes 2
 run bench_world_graph python tools/bench_world.py --cpu-scenes 0 --graph
 run bench_world_11bodies python tools/bench_world.py --nbox 10 --box 24 --maxc 32 --cpu-scenes 0
 run bench_world_6bodies python tools/bench_world.py --nbox 5 --box 40 --cpu-scenes 0
+run batch_curve_2box python tools/bench_batch_curve.py 2
+run batch_curve_4box python tools/bench_batch_curve.py 4
 EXTRA="" bash tools/profile_all.sh $TAG > $O/${TAG}_profile_all.log 2>&1
 bash tools/profile_config5.sh $TAG > $O/${TAG}_profile_config5.log 2>&1
 ls $O | grep "^prof_${TAG}\|^${TAG}_" | head -60
+# in-kernel phase profile of the headline forward (needs `make -C lcp_physics_amd/csrc quadprof`)
+if [ -f tools/liblcp_quadprof.so ]; then
+  LCP_HIP_LIB=$ROOT/tools/liblcp_quadprof.so timeout 200 python tools/gpu_phase_profile_quad.py 4096 4 > $O/${TAG}_quad_phase_profile.txt 2>&1
+  LCP_HIP_LIB=$ROOT/tools/liblcp_quadprof.so timeout 200 python tools/gpu_phase_profile_quad.py 32768 4 >> $O/${TAG}_quad_phase_profile.txt 2>&1
+fi
