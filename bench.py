@@ -349,10 +349,11 @@ class HipStackWorkload:
         st = status.cpu()
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
-                "kernel": "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
+                "kernel": ("lcp_fwd_solo (one scene per wavefront: batches of at most 1024 scenes; PDIPM forward%s)" % (
+                    ", fused assembly + integrate",)) if (body_space and B <= 1024) else "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
                     "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
-                    ", fused assembly + integrate; the event-timed forward also contains the (empty) second pass lcp_fwd_quad<...,1,1> for "
-                    "scenes whose equality rows do not pin the leading coordinates" if a.mode == "fused"
+                    ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
+                    "the launch for other equality rows is skipped" if a.mode == "fused"
                     else "; the event-timed forward call also contains the classify launch"),
                 "achieved": tf(fl_exec, fwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(fl_exec, fwd_ms) / peak,
                 "flops": "executed",
@@ -386,7 +387,10 @@ class HipStackWorkload:
             bkey = key + ("_bwd" if dense_bwd else "_bwd_physical")
             btj = _quoted("traffic", bkey)
             btraffic = (2 * btj["fetch_kb"] + btj["write_kb"]) * 1024.0 if btj else None
-            balg = (flops.bytes_backward(nz, m, e) if dense_bwd else 4 * (14 * nb + 7 * nc + 3 * nb) + 4 * (11 * nb + 6 * nc)) * B
+            # what the backward must move: G, A, the cotangent and the fp64 iterate in, the seven dense gradients out (SURVEY 8d's
+            # figure also counts Q and F as reads: lcp.py:37-64 does not touch them and neither does the kernel)
+            balg = ((4 * (m * nz + e * nz + nz) + 8 * (nz + e + 2 * m) + 4 * (nz * nz + nz + m * nz + m + e * nz + e + m * m)) if dense_bwd
+                    else 4 * (14 * nb + 7 * nc + 3 * nb) + 4 * (11 * nb + 6 * nc)) * B
             used = btraffic if btraffic else balg
             roof["bwd"] = {"bound": "hbm",
                            "kernel": ("lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
