@@ -156,13 +156,16 @@ template <int K0> __device__ __forceinline__ void form4x4(double (&x)[4], const 
 #ifndef LCP_SOLO_OCC
 #define LCP_SOLO_OCC 1      // wavefronts per SIMD the register allocation allows (2: at most 256 unified registers, fp32 tables)
 #endif
+// NZF, EF: the scene's nz and neq as compile-time constants (0, 0: read from the arguments) - the guards of the LU and the sweeps
+// and the lane masks of the x-space fold; lcp_quad.hip (quad_step) has the measurement
+template <int NZF, int EF>
 __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, int pinned_hint) {
   using TI = float;
   using TC = double;
   __shared__ TI GL[NCQ * 16], GTL[NCQ * 16], AtL[EQ * 16];
   const int lane = threadIdx.x, l16 = lane & 15, comp = lane >> 4;
   const int scene = blockIdx.x;
-  const int nb = SP.nb, nz = 3 * nb, nc = SP.nc, e = SP.e, m = 4 * nc;
+  const int nb = SP.nb, nz = NZF > 0 ? NZF : 3 * nb, nc = SP.nc, e = NZF > 0 ? EF : SP.e, m = 4 * nc;
   const int max_iter = SP.max_iter, lim = SP.lim;
   const TC eps = SP.eps;
   Ws<TI, TC> W(SP.ws, scene);
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
 
   // factor: formation of Q + G^T M^-1 G (this row's four columns, then exchanged) and the pivot-free LU over the free coordinates
   auto factor = [&](TC di) -> bool {
-    const int ll = launder(l16), nzs = __builtin_amdgcn_readfirstlane(nz), es = __builtin_amdgcn_readfirstlane(e);
+    const int ll = launder(l16), nzs = NZF > 0 ? NZF : __builtin_amdgcn_readfirstlane(nz), es = NZF > 0 ? EF : __builtin_amdgcn_readfirstlane(e);
     const int ncw = __builtin_amdgcn_readfirstlane(ncs);
     const M4<TC> D = gather4(di);
     idn = fast_rcp(D.n); i1 = fast_rcp(D.f1); i2 = fast_rcp(D.f2);
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
 
   // solve_kkt (pdipm.py:325-354) in body space with pinned coordinates (lcp_quad.hip solve_kkt_pq): rs, rz, os, oz per (component, contact)
   auto solve = [&](TC di, TC rx, TC rs, TC rz, TC ry, TC& ox, TC& os, TC& oz, TC& oy) {
-    const int nzs = __builtin_amdgcn_readfirstlane(nz), es = __builtin_amdgcn_readfirstlane(e);
+    const int nzs = NZF > 0 ? NZF : __builtin_amdgcn_readfirstlane(nz), es = NZF > 0 ? EF : __builtin_amdgcn_readfirstlane(e);
     const TC q = vc ? rs * di - rz : (TC)0;
     const M4<TC> u4 = minv(gather4(q));
     const TC gu = Gtw(vc ? pick(u4) : (TC)0);
@@ -483,7 +486,13 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
 // sizes lcp_fwd_solo takes (the body-space four-scenes-per-wave sizes with nz <= 16)
 bool solo_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <= q16::NCQ) && nz <= 16 && e <= q16::EQ; }
 int solo_step(const StepArgs& SP, void* stream, bool pinned) {
-  hipLaunchKernelGGL(solo::lcp_fwd_solo, dim3(SP.B), dim3(64), 0, (hipStream_t)stream, SP, pinned ? 1 : 0);
+  const int nz = 3 * SP.nb, e = SP.e, ph = pinned ? 1 : 0;
+  const dim3 grid(SP.B), blk(64);
+  hipStream_t st = (hipStream_t)stream;
+  // the stack shapes of the BASELINE configs (floor pinned by a TotalConstraint: neq 3) get their sizes at compile time
+  if (nz == 9 && e == 3) hipLaunchKernelGGL((solo::lcp_fwd_solo<9, 3>), grid, blk, 0, st, SP, ph);
+  else if (nz == 15 && e == 3) hipLaunchKernelGGL((solo::lcp_fwd_solo<15, 3>), grid, blk, 0, st, SP, ph);
+  else hipLaunchKernelGGL((solo::lcp_fwd_solo<0, 0>), grid, blk, 0, st, SP, ph);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
