@@ -2,4 +2,5 @@
 // (a floor and three bodies; see lcp_quad_sized.inc)
 #define LCP_QS_NZ 12
 #define LCP_QS_E 3
+#define LCP_QS_NC 12
 #include "lcp_quad_sized.inc"

@@ -2,4 +2,5 @@
 // (a floor and one body; see lcp_quad_sized.inc)
 #define LCP_QS_NZ 6
 #define LCP_QS_E 3
+#define LCP_QS_NC 4
 #include "lcp_quad_sized.inc"
