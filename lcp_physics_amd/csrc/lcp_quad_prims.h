@@ -334,5 +334,86 @@ template <int K, int J0> __device__ __forceinline__ void pq_form8(float (&xr)[20
   static_for<8>([&](auto JJ) LCP_INL { constexpr int j = J0 + JJ; xr[j] = fmaf(bc<K>(p0[j]), a, xr[j]); xr[j] = fmaf(bc<K>(p1[j]), b, xr[j]); });
 }
 
+#ifndef LCP_DPP_FULL_EARLY
+#define LCP_DPP_FULL_EARLY "row_mask:0xf bank_mask:0xf"
+#endif
+#ifndef LCP_GV_ONE
+#define LCP_GV_ONE(ACC, M, K) "v_fmac_f64_dpp %[" #ACC "], %[v], %[" #M "] row_newbcast:%[" #K "] " LCP_DPP_FULL_EARLY "\n\t"
+#endif
+// ---------------------------------------------------------------- N-column forms of the two blocks above (compile-time sizes: only the
+// columns of the free coordinates are formed / multiplied) - generated, same rules: `s_nop 1` first, DPP sources read-only
+template <int K, int J0, int N> struct PqFormN;
+template <int J0, int N> struct GvN;
+template <int K, int J0> struct PqFormN<K, J0, 1> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x0, q0, b) 
+      : [x0] "+v"(xr[J0 + 0])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 2> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 3> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 4> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 5> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x4, p4, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) LCP_PQF_ONE(x4, q4, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3]), [x4] "+v"(xr[J0 + 4])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [p4] "v"(p0[J0 + 4]), [q4] "v"(p1[J0 + 4]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 6> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x4, p4, a) LCP_PQF_ONE(x5, p5, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) LCP_PQF_ONE(x4, q4, b) LCP_PQF_ONE(x5, q5, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3]), [x4] "+v"(xr[J0 + 4]), [x5] "+v"(xr[J0 + 5])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [p4] "v"(p0[J0 + 4]), [q4] "v"(p1[J0 + 4]), [p5] "v"(p0[J0 + 5]), [q5] "v"(p1[J0 + 5]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 7> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x4, p4, a) LCP_PQF_ONE(x5, p5, a) LCP_PQF_ONE(x6, p6, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) LCP_PQF_ONE(x4, q4, b) LCP_PQF_ONE(x5, q5, b) LCP_PQF_ONE(x6, q6, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3]), [x4] "+v"(xr[J0 + 4]), [x5] "+v"(xr[J0 + 5]), [x6] "+v"(xr[J0 + 6])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [p4] "v"(p0[J0 + 4]), [q4] "v"(p1[J0 + 4]), [p5] "v"(p0[J0 + 5]), [q5] "v"(p1[J0 + 5]), [p6] "v"(p0[J0 + 6]), [q6] "v"(p1[J0 + 6]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int K, int J0> struct PqFormN<K, J0, 8> { static __device__ __forceinline__ void run(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  asm("s_nop 1\n\t" LCP_PQF_ONE(x0, p0, a) LCP_PQF_ONE(x1, p1, a) LCP_PQF_ONE(x2, p2, a) LCP_PQF_ONE(x3, p3, a) LCP_PQF_ONE(x4, p4, a) LCP_PQF_ONE(x5, p5, a) LCP_PQF_ONE(x6, p6, a) LCP_PQF_ONE(x7, p7, a) LCP_PQF_ONE(x0, q0, b) LCP_PQF_ONE(x1, q1, b) LCP_PQF_ONE(x2, q2, b) LCP_PQF_ONE(x3, q3, b) LCP_PQF_ONE(x4, q4, b) LCP_PQF_ONE(x5, q5, b) LCP_PQF_ONE(x6, q6, b) LCP_PQF_ONE(x7, q7, b) 
+      : [x0] "+v"(xr[J0 + 0]), [x1] "+v"(xr[J0 + 1]), [x2] "+v"(xr[J0 + 2]), [x3] "+v"(xr[J0 + 3]), [x4] "+v"(xr[J0 + 4]), [x5] "+v"(xr[J0 + 5]), [x6] "+v"(xr[J0 + 6]), [x7] "+v"(xr[J0 + 7])
+      : [p0] "v"(p0[J0 + 0]), [q0] "v"(p1[J0 + 0]), [p1] "v"(p0[J0 + 1]), [q1] "v"(p1[J0 + 1]), [p2] "v"(p0[J0 + 2]), [q2] "v"(p1[J0 + 2]), [p3] "v"(p0[J0 + 3]), [q3] "v"(p1[J0 + 3]), [p4] "v"(p0[J0 + 4]), [q4] "v"(p1[J0 + 4]), [p5] "v"(p0[J0 + 5]), [q5] "v"(p1[J0 + 5]), [p6] "v"(p0[J0 + 6]), [q6] "v"(p1[J0 + 6]), [p7] "v"(p0[J0 + 7]), [q7] "v"(p1[J0 + 7]), [a] "v"(a), [b] "v"(b), [k] "n"(K)); } };
+template <int J0> struct GvN<J0, 1> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0)); } };
+template <int J0> struct GvN<J0, 2> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1)); } };
+template <int J0> struct GvN<J0, 3> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2)); } };
+template <int J0> struct GvN<J0, 4> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2), [c3] "v"(c[3]), [t3_] "v"(t[3]), [k3] "n"(J0 + 3)); } };
+template <int J0> struct GvN<J0, 5> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3) LCP_GV_ONE(n0, c4, k4) LCP_GV_ONE(t0, t4_, k4) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2), [c3] "v"(c[3]), [t3_] "v"(t[3]), [k3] "n"(J0 + 3), [c4] "v"(c[4]), [t4_] "v"(t[4]), [k4] "n"(J0 + 4)); } };
+template <int J0> struct GvN<J0, 6> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3) LCP_GV_ONE(n0, c4, k4) LCP_GV_ONE(t0, t4_, k4) LCP_GV_ONE(n1, c5, k5) LCP_GV_ONE(t1, t5_, k5) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2), [c3] "v"(c[3]), [t3_] "v"(t[3]), [k3] "n"(J0 + 3), [c4] "v"(c[4]), [t4_] "v"(t[4]), [k4] "n"(J0 + 4), [c5] "v"(c[5]), [t5_] "v"(t[5]), [k5] "n"(J0 + 5)); } };
+template <int J0> struct GvN<J0, 7> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3) LCP_GV_ONE(n0, c4, k4) LCP_GV_ONE(t0, t4_, k4) LCP_GV_ONE(n1, c5, k5) LCP_GV_ONE(t1, t5_, k5) LCP_GV_ONE(n0, c6, k6) LCP_GV_ONE(t0, t6_, k6) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2), [c3] "v"(c[3]), [t3_] "v"(t[3]), [k3] "n"(J0 + 3), [c4] "v"(c[4]), [t4_] "v"(t[4]), [k4] "n"(J0 + 4), [c5] "v"(c[5]), [t5_] "v"(t[5]), [k5] "n"(J0 + 5), [c6] "v"(c[6]), [t6_] "v"(t[6]), [k6] "n"(J0 + 6)); } };
+template <int J0> struct GvN<J0, 8> { static __device__ __forceinline__ void run(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  asm("s_nop 1\n\t" LCP_GV_ONE(n0, c0, k0) LCP_GV_ONE(t0, t0_, k0) LCP_GV_ONE(n1, c1, k1) LCP_GV_ONE(t1, t1_, k1) LCP_GV_ONE(n0, c2, k2) LCP_GV_ONE(t0, t2_, k2) LCP_GV_ONE(n1, c3, k3) LCP_GV_ONE(t1, t3_, k3) LCP_GV_ONE(n0, c4, k4) LCP_GV_ONE(t0, t4_, k4) LCP_GV_ONE(n1, c5, k5) LCP_GV_ONE(t1, t5_, k5) LCP_GV_ONE(n0, c6, k6) LCP_GV_ONE(t0, t6_, k6) LCP_GV_ONE(n1, c7, k7) LCP_GV_ONE(t1, t7_, k7) 
+      : [n0] "+v"(n0), [n1] "+v"(n1), [t0] "+v"(t0), [t1] "+v"(t1)
+      : [v] "v"(v), [c0] "v"(c[0]), [t0_] "v"(t[0]), [k0] "n"(J0 + 0), [c1] "v"(c[1]), [t1_] "v"(t[1]), [k1] "n"(J0 + 1), [c2] "v"(c[2]), [t2_] "v"(t[2]), [k2] "n"(J0 + 2), [c3] "v"(c[3]), [t3_] "v"(t[3]), [k3] "n"(J0 + 3), [c4] "v"(c[4]), [t4_] "v"(t[4]), [k4] "n"(J0 + 4), [c5] "v"(c[5]), [t5_] "v"(t[5]), [k5] "n"(J0 + 5), [c6] "v"(c[6]), [t6_] "v"(t[6]), [k6] "n"(J0 + 6), [c7] "v"(c[7]), [t7_] "v"(t[7]), [k7] "n"(J0 + 7)); } };
+template <int K, int J0, int N> __device__ __forceinline__ void pq_formN(double (&xr)[20], const double (&p0)[16], const double (&p1)[16], double a, double b) {
+  if constexpr (N > 0) PqFormN<K, J0, N>::run(xr, p0, p1, a, b);
+}
+template <int J0, int N> __device__ __forceinline__ void gvN_dpp(double& n0, double& n1, double& t0, double& t1, double v, const double (&c)[8], const double (&t)[8]) {
+  if constexpr (N > 0) GvN<J0, N>::run(n0, n1, t0, t1, v, c, t);
+}
+
 }  // namespace q16
 }  // namespace lcp
