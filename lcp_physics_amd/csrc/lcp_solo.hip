@@ -152,27 +152,99 @@ template <int K0> __device__ __forceinline__ void form4x4(double (&x)[4], const 
         [k0] "n"(K0), [k1] "n"(K0 + 1), [k2] "n"(K0 + 2), [k3] "n"(K0 + 3));
 }
 
+// ---- generated: the same two blocks over a WINDOW (compile-time sizes: columns neq .. nz-1 of x-space, contacts 0 .. nc-1)
+template <int LO, int N> struct DotW;
+template <int K0, int NS> struct FormW;
+template <int LO> struct DotW<LO, 1> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0)); } };
+template <int LO> struct DotW<LO, 2> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1)); } };
+template <int LO> struct DotW<LO, 3> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2)); } };
+template <int LO> struct DotW<LO, 4> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3)); } };
+template <int LO> struct DotW<LO, 5> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4)); } };
+template <int LO> struct DotW<LO, 6> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5)); } };
+template <int LO> struct DotW<LO, 7> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6)); } };
+template <int LO> struct DotW<LO, 8> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7)); } };
+template <int LO> struct DotW<LO, 9> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8)); } };
+template <int LO> struct DotW<LO, 10> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9)); } };
+template <int LO> struct DotW<LO, 11> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10)); } };
+template <int LO> struct DotW<LO, 12> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c11] row_newbcast:%[k11] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10), [c11] "v"(c[LO + 11]), [k11] "n"(LO + 11)); } };
+template <int LO> struct DotW<LO, 13> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c11] row_newbcast:%[k11] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c12] row_newbcast:%[k12] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10), [c11] "v"(c[LO + 11]), [k11] "n"(LO + 11), [c12] "v"(c[LO + 12]), [k12] "n"(LO + 12)); } };
+template <int LO> struct DotW<LO, 14> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c11] row_newbcast:%[k11] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c12] row_newbcast:%[k12] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c13] row_newbcast:%[k13] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10), [c11] "v"(c[LO + 11]), [k11] "n"(LO + 11), [c12] "v"(c[LO + 12]), [k12] "n"(LO + 12), [c13] "v"(c[LO + 13]), [k13] "n"(LO + 13)); } };
+template <int LO> struct DotW<LO, 15> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c11] row_newbcast:%[k11] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c12] row_newbcast:%[k12] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c13] row_newbcast:%[k13] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c14] row_newbcast:%[k14] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10), [c11] "v"(c[LO + 11]), [k11] "n"(LO + 11), [c12] "v"(c[LO + 12]), [k12] "n"(LO + 12), [c13] "v"(c[LO + 13]), [k13] "n"(LO + 13), [c14] "v"(c[LO + 14]), [k14] "n"(LO + 14)); } };
+template <int LO> struct DotW<LO, 16> { static __device__ __forceinline__ void run(double& a0, double& a1, double v, const double (&c)[16]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c4] row_newbcast:%[k4] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c5] row_newbcast:%[k5] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c6] row_newbcast:%[k6] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c7] row_newbcast:%[k7] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c8] row_newbcast:%[k8] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c9] row_newbcast:%[k9] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c10] row_newbcast:%[k10] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c11] row_newbcast:%[k11] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c12] row_newbcast:%[k12] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c13] row_newbcast:%[k13] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a0], %[v], %[c14] row_newbcast:%[k14] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[a1], %[v], %[c15] row_newbcast:%[k15] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [v] "v"(v), [c0] "v"(c[LO + 0]), [k0] "n"(LO + 0), [c1] "v"(c[LO + 1]), [k1] "n"(LO + 1), [c2] "v"(c[LO + 2]), [k2] "n"(LO + 2), [c3] "v"(c[LO + 3]), [k3] "n"(LO + 3), [c4] "v"(c[LO + 4]), [k4] "n"(LO + 4), [c5] "v"(c[LO + 5]), [k5] "n"(LO + 5), [c6] "v"(c[LO + 6]), [k6] "n"(LO + 6), [c7] "v"(c[LO + 7]), [k7] "n"(LO + 7), [c8] "v"(c[LO + 8]), [k8] "n"(LO + 8), [c9] "v"(c[LO + 9]), [k9] "n"(LO + 9), [c10] "v"(c[LO + 10]), [k10] "n"(LO + 10), [c11] "v"(c[LO + 11]), [k11] "n"(LO + 11), [c12] "v"(c[LO + 12]), [k12] "n"(LO + 12), [c13] "v"(c[LO + 13]), [k13] "n"(LO + 13), [c14] "v"(c[LO + 14]), [k14] "n"(LO + 14), [c15] "v"(c[LO + 15]), [k15] "n"(LO + 15)); } };
+template <int K0> struct FormW<K0, 1> { static __device__ __forceinline__ void run(double (&x)[4], const double (&p0)[4], const double (&p1)[4], const double (&a)[4], const double (&b)[4]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t"
+      : [x0] "+v"(x[0]) : [p0] "v"(p0[0]), [q0] "v"(p1[0]), [a0] "v"(a[0]), [b0] "v"(b[0]), [k0] "n"(K0 + 0), [a1] "v"(a[1]), [b1] "v"(b[1]), [k1] "n"(K0 + 1), [a2] "v"(a[2]), [b2] "v"(b[2]), [k2] "n"(K0 + 2), [a3] "v"(a[3]), [b3] "v"(b[3]), [k3] "n"(K0 + 3)); } };
+template <int K0> struct FormW<K0, 2> { static __device__ __forceinline__ void run(double (&x)[4], const double (&p0)[4], const double (&p1)[4], const double (&a)[4], const double (&b)[4]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t"
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]) : [p0] "v"(p0[0]), [q0] "v"(p1[0]), [p1] "v"(p0[1]), [q1] "v"(p1[1]), [a0] "v"(a[0]), [b0] "v"(b[0]), [k0] "n"(K0 + 0), [a1] "v"(a[1]), [b1] "v"(b[1]), [k1] "n"(K0 + 1), [a2] "v"(a[2]), [b2] "v"(b[2]), [k2] "n"(K0 + 2), [a3] "v"(a[3]), [b3] "v"(b[3]), [k3] "n"(K0 + 3)); } };
+template <int K0> struct FormW<K0, 3> { static __device__ __forceinline__ void run(double (&x)[4], const double (&p0)[4], const double (&p1)[4], const double (&a)[4], const double (&b)[4]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t"
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]) : [p0] "v"(p0[0]), [q0] "v"(p1[0]), [p1] "v"(p0[1]), [q1] "v"(p1[1]), [p2] "v"(p0[2]), [q2] "v"(p1[2]), [a0] "v"(a[0]), [b0] "v"(b[0]), [k0] "n"(K0 + 0), [a1] "v"(a[1]), [b1] "v"(b[1]), [k1] "n"(K0 + 1), [a2] "v"(a[2]), [b2] "v"(b[2]), [k2] "n"(K0 + 2), [a3] "v"(a[3]), [b3] "v"(b[3]), [k3] "n"(K0 + 3)); } };
+template <int K0> struct FormW<K0, 4> { static __device__ __forceinline__ void run(double (&x)[4], const double (&p0)[4], const double (&p1)[4], const double (&a)[4], const double (&b)[4]) {
+  asm("s_nop 1\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[p3], %[a0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[q3], %[b0] row_newbcast:%[k0] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[p3], %[a1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[q3], %[b1] row_newbcast:%[k1] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[p3], %[a2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[q3], %[b2] row_newbcast:%[k2] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[p0], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[p1], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[p2], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[p3], %[a3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x0], %[q0], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x1], %[q1], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x2], %[q2], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t" "v_fmac_f64_dpp %[x3], %[q3], %[b3] row_newbcast:%[k3] row_mask:0xf bank_mask:0xf\n\t"
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]) : [p0] "v"(p0[0]), [q0] "v"(p1[0]), [p1] "v"(p0[1]), [q1] "v"(p1[1]), [p2] "v"(p0[2]), [q2] "v"(p1[2]), [p3] "v"(p0[3]), [q3] "v"(p1[3]), [a0] "v"(a[0]), [b0] "v"(b[0]), [k0] "n"(K0 + 0), [a1] "v"(a[1]), [b1] "v"(b[1]), [k1] "n"(K0 + 1), [a2] "v"(a[2]), [b2] "v"(b[2]), [k2] "n"(K0 + 2), [a3] "v"(a[3]), [b3] "v"(b[3]), [k3] "n"(K0 + 3)); } };
+template <int LO, int N> __device__ __forceinline__ void dot_dpp(double& a0, double& a1, double v, const double (&c)[16]) { if constexpr (N > 0) DotW<LO, N>::run(a0, a1, v, c); }
+
 // ---------------------------------------------------------------- the kernel
 #ifndef LCP_SOLO_OCC
 #define LCP_SOLO_OCC 1      // wavefronts per SIMD the register allocation allows (2: at most 256 unified registers, fp32 tables)
 #endif
 // NZF, EF: the scene's nz and neq as compile-time constants (0, 0: read from the arguments) - the guards of the LU and the sweeps
 // and the lane masks of the x-space fold; lcp_quad.hip (quad_step) has the measurement
-template <int NZF, int EF>
+// NCF: the contact count of every scene as a compile-time constant (full lists, no per-scene counts; 0: run time).
+// With compile-time sizes only the columns neq .. nz-1 exist for the forward (x_p is identically zero, see lcp_quad_kernels.inc
+// factor_pq): they are dealt round-robin to the four DPP rows (column neq + 4 j + r in slot j of row r), the products run over the
+// window of live columns / contacts only.
+template <int NZF, int EF, int NCF = 0>
 __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, int pinned_hint) {
+  constexpr bool TRIM = NZF > 0;
+  constexpr int CLO = TRIM ? EF : 0, CHI = TRIM ? NZF : 16, NCOLS = CHI - CLO, NS = TRIM ? (NCOLS + 3) / 4 : 4;
+  constexpr int KHI = NCF > 0 ? NCF : 16;                              // contacts the products visit
   using TI = float;
   using TC = double;
   __shared__ TI GL[NCQ * 16], GTL[NCQ * 16], AtL[EQ * 16];
   const int lane = threadIdx.x, l16 = lane & 15, comp = lane >> 4;
   const int scene = blockIdx.x;
-  const int nb = SP.nb, nz = NZF > 0 ? NZF : 3 * nb, nc = SP.nc, e = NZF > 0 ? EF : SP.e, m = 4 * nc;
+  const int nb = SP.nb, nz = NZF > 0 ? NZF : 3 * nb, nc = NCF > 0 ? NCF : SP.nc, e = NZF > 0 ? EF : SP.e, m = 4 * nc;
   const int max_iter = SP.max_iter, lim = SP.lim;
   const TC eps = SP.eps;
   Ws<TI, TC> W(SP.ws, scene);
   if (blockIdx.x == 0 && lane == 0 && SP.tag) *SP.tag = SP.tag_value;
   int ncs = nc, truncated = 0;
-  if (SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; truncated = c > nc ? LCP_ST_TRUNCATED : 0; }
-  const bool vc = l16 < ncs;                                       // this lane's contact is live
+  if (NCF == 0 && SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; truncated = c > nc ? LCP_ST_TRUNCATED : 0; }
+  const bool vc = (NCF == 16) ? true : (l16 < ncs);                // this lane's contact is live
   const bool c0 = comp == 0, c1 = comp == 1, c2 = comp == 2, c3 = comp == 3;
   auto pick = [&](const M4<TC>& a) -> TC { return c0 ? a.n : (c1 ? a.f1 : (c2 ? a.f2 : a.g)); };
 
@@ -222,7 +294,12 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   // formation operands: the lane's contact at the row's four columns 4 comp + jj; the weights jc_c[l16], jt_c[l16] of matrix row l16
   // over the contacts c are read from LDS per group of four contacts
   TI jcq[4], jtq[4];
-  static_for<4>([&](auto JJ) LCP_INL { jcq[JJ] = GL[l16 * 16 + 4 * comp + JJ]; jtq[JJ] = GTL[l16 * 16 + 4 * comp + JJ]; });
+  auto colof = [&](int j) { return TRIM ? CLO + 4 * j + comp : 4 * comp + j; };     // matrix column in slot j of this DPP row
+  static_for<NS>([&](auto JJ) LCP_INL {
+    const int col = colof(JJ);
+    const bool okc = col < CHI;
+    jcq[JJ] = okc ? GL[l16 * 16 + (okc ? col : 0)] : (TI)0; jtq[JJ] = okc ? GTL[l16 * 16 + (okc ? col : 0)] : (TI)0;
+  });
   const TC qd = (l16 < nz) ? (TC)Md[l16] : (TC)0;
   const TC qid = (l16 < nz) ? (TC)1 / (TC)Md[l16] : (TC)0;
   const TC p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16 < nz ? l16 : 0], vv[l16 < nz ? l16 : 0], (TI)SP.dt, ff[l16 < nz ? l16 : 0]) : (TC)0;   // engines.py:32
@@ -264,14 +341,16 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   auto Gv = [&](TC v) -> TC {
     TC a0 = 0, a1 = 0, cf[16];
     static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(Grow[J]); else cf[J] = Grow[J]; });
-    dot16_dpp(a0, a1, v, cf);
+    if constexpr (TRIM) dot_dpp<CLO, NCOLS>(a0, a1, v, cf);             // (v is zero on the pinned lanes, absent beyond nz)
+    else dot16_dpp(a0, a1, v, cf);
     return a0 + a1;
   };
   // J^T w: every row sums its component over the contacts, then the rows are added (result replicated)
   auto Gtw = [&](TC w) -> TC {
     TC a0 = 0, a1 = 0, cf[16];
     static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(GTc[J]); else cf[J] = GTc[J]; });
-    dot16_dpp(a0, a1, w, cf);
+    if constexpr (NCF > 0) dot_dpp<0, KHI>(a0, a1, w, cf);
+    else dot16_dpp(a0, a1, w, cf);
     return rows_sum(a0 + a1);
   };
   // M^-1 t for the contact's gathered components (lcp_quad.hip minv_pq)
@@ -287,7 +366,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   // factor: formation of Q + G^T M^-1 G (this row's four columns, then exchanged) and the pivot-free LU over the free coordinates
   auto factor = [&](TC di) -> bool {
     const int ll = launder(l16), nzs = NZF > 0 ? NZF : __builtin_amdgcn_readfirstlane(nz), es = NZF > 0 ? EF : __builtin_amdgcn_readfirstlane(e);
-    const int ncw = __builtin_amdgcn_readfirstlane(ncs);
+    const int ncw = NCF > 0 ? NCF : __builtin_amdgcn_readfirstlane(ncs);
     const M4<TC> D = gather4(di);
     idn = fast_rcp(D.n); i1 = fast_rcp(D.f1); i2 = fast_rcp(D.f2);
     kap = fast_rcp(D.g + (i1 + i2));
@@ -295,10 +374,10 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const TC b10 = vc ? kap * (i1 - i2) * (mu_c * idn) : (TC)0;
     const TC b11 = vc ? kap * fma(i1 + i2, D.g, (TC)4 * (i1 * i2)) : (TC)0;
     TC p0[4], p1[4], x4[4];
-    static_for<4>([&](auto JJ) LCP_INL {
+    static_for<NS>([&](auto JJ) LCP_INL {
       const TC jc_ = (TC)launder(jcq[JJ]), jt_ = (TC)launder(jtq[JJ]);
       p0[JJ] = b00 * jc_; p1[JJ] = fma(b10, jc_, b11 * jt_);
-      x4[JJ] = (ll == 4 * comp + JJ) ? ((ll < nzs) ? qd : (TC)1) : (TC)0;
+      x4[JJ] = (ll == colof(JJ)) ? ((ll < nzs) ? qd : (TC)1) : (TC)0;
     });
     {
       const int oz = lds_opaque_zero();
@@ -310,13 +389,20 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
           static_for<4>([&](auto Kq) LCP_INL { av[Kq] = gl[(4 * Gq + Kq) * 16]; bv[Kq] = gtl[(4 * Gq + Kq) * 16]; });
           TC ad[4], bd[4];
           static_for<4>([&](auto Kq) LCP_INL { ad[Kq] = (TC)av[Kq]; bd[Kq] = (TC)bv[Kq]; });
-          form4x4<4 * Gq>(x4, p0, p1, ad, bd);
+          if constexpr (NS == 4) form4x4<4 * Gq>(x4, p0, p1, ad, bd);
+          else FormW<4 * Gq, NS>::run(x4, p0, p1, ad, bd);
         }
       });
     }
-    static_for<4>([&](auto JJ) LCP_INL {
+    static_for<NS>([&](auto JJ) LCP_INL {
       const M4<TC> g = gather4(x4[JJ]);
-      xr[JJ] = g.n; xr[4 + JJ] = g.f1; xr[8 + JJ] = g.f2; xr[12 + JJ] = g.g;
+      if constexpr (TRIM) {                                              // slot JJ of row r holds column CLO + 4 JJ + r
+        constexpr int c0_ = CLO + 4 * JJ;
+        if constexpr (c0_ < CHI) xr[c0_] = g.n;
+        if constexpr (c0_ + 1 < CHI) xr[c0_ + 1] = g.f1;
+        if constexpr (c0_ + 2 < CHI) xr[c0_ + 2] = g.f2;
+        if constexpr (c0_ + 3 < CHI) xr[c0_ + 3] = g.g;
+      } else { xr[JJ] = g.n; xr[4 + JJ] = g.f1; xr[8 + JJ] = g.f2; xr[12 + JJ] = g.g; }
     });
     bool singular = false;
     udx = 1;
@@ -338,7 +424,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         }
       }
     });
-    static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; sp[a] = xr[a]; xr[a] = (a < es) ? (TC)0 : xr[a]; });
+    if constexpr (!TRIM) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; sp[a] = xr[a]; xr[a] = (a < es) ? (TC)0 : xr[a]; });
     return row_any(singular);
   };
 
@@ -350,6 +436,10 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const TC gu = Gtw(vc ? pick(u4) : (TC)0);
     TC wx = (l16 < nzs) ? gu - rx : (TC)0;
     const TC we = (l16 < es) ? -ry : (TC)0;
+    if constexpr (TRIM) {                                                  // (we = -x_p is identically zero; free coordinates only)
+      static_for<NCOLS>([&](auto Kq) LCP_INL { constexpr int k = CLO + Kq; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k)); });
+      static_for<NCOLS>([&](auto KR) LCP_INL { constexpr int k = CHI - 1 - KR; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 < k)); });
+    } else {
     if (es > 0) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; fnmac_bc<a>(wx, we, keep_if(sp[a], a < es)); });
     static_for<4>([&](auto Gq) LCP_INL {                                   // L y = rhs (the steps of the pinned columns meet zeros)
       if (4 * Gq < nzs) static_for<4>([&](auto Kq) LCP_INL { constexpr int k = 4 * Gq + Kq; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k)); });
@@ -361,6 +451,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 < k));
       });
     });
+    }
     ox = (l16 < es) ? we : ((l16 < nzs) ? wx * udx : (TC)0);
     oy = (l16 < es) ? wx : (TC)0;
     const TC t = Gv(ox) - q;                                               // (cone row: G is zero there)
@@ -490,7 +581,10 @@ int solo_step(const StepArgs& SP, void* stream, bool pinned) {
   const dim3 grid(SP.B), blk(64);
   hipStream_t st = (hipStream_t)stream;
   // the stack shapes of the BASELINE configs (floor pinned by a TotalConstraint: neq 3) get their sizes at compile time
-  if (nz == 9 && e == 3) hipLaunchKernelGGL((solo::lcp_fwd_solo<9, 3>), grid, blk, 0, st, SP, ph);
+  const bool full = !SP.c_count;                                   // full contact lists: the contact count is a constant too
+  if (nz == 9 && e == 3 && full && SP.nc == 8) hipLaunchKernelGGL((solo::lcp_fwd_solo<9, 3, 8>), grid, blk, 0, st, SP, ph);
+  else if (nz == 9 && e == 3) hipLaunchKernelGGL((solo::lcp_fwd_solo<9, 3>), grid, blk, 0, st, SP, ph);
+  else if (nz == 15 && e == 3 && full && SP.nc == 16) hipLaunchKernelGGL((solo::lcp_fwd_solo<15, 3, 16>), grid, blk, 0, st, SP, ph);
   else if (nz == 15 && e == 3) hipLaunchKernelGGL((solo::lcp_fwd_solo<15, 3>), grid, blk, 0, st, SP, ph);
   else hipLaunchKernelGGL((solo::lcp_fwd_solo<0, 0>), grid, blk, 0, st, SP, ph);
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
