@@ -189,6 +189,7 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (!G || !dl_dx || !ws) return LCP_E_BADARG;
   if (e > 0 && !A) return LCP_E_BADARG;
   const int hint = compute & LCP_HINT_ALL_CONTACT;
+  const bool pinned = (compute & LCP_HINT_PINNED) != 0;      // (the forward's word: its promise holds for the backward too)
   bool generic;
   int path;
   compute = split_compute(compute, &generic, &path);
@@ -216,7 +217,7 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
     P.tag_value = step_tag(fam, nz, compute, path);
     if (fam == FAM_QUAD) {
       if (!lcp::quad_supported(nz, m, e)) return LCP_E_TOOLARGE;             // (nz 17..32: the physical backward only)
-      return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY);
+      return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY, pinned);
     }
     if (fam == FAM_WAVE64) return lcp::wave64_backward(P, compute, false, stream, 0);
     if (fam != FAM_GENERIC) return LCP_E_TOOLARGE;                            // (lcp_primal / lcp_big: lcp_step_backward_f32 is their backward)
@@ -313,6 +314,7 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
                              float* dfric, float* dc_n, float* dc_p1, float* dc_p2, float* dJe, void* ws, void* stream) {
   bool generic;
   int path;
+  const bool pinned = (compute & LCP_HINT_PINNED) != 0;
   compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
@@ -329,7 +331,7 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
   P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * nc, e, compute, 0));
   P.tag_value = step_tag(fam, 3 * nb, compute, path);
   switch (fam) {
-    case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream, path != 3);
+    case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream, path != 3, pinned);
     case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream);
     case FAM_BIG: return lcp::big_step_backward(P, G, stream);
     default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read

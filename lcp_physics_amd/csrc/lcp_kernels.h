@@ -139,12 +139,12 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body = 0);   // body: workspace of a body-space forward
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body = 0, bool pinned = false);   // body: workspace of a body-space forward; pinned: LCP_HINT_PINNED
 int quad_step(const StepArgs& P, int compute, void* stream, int body_space = 1, int solo = -1, bool pinned = false);   // solo: -1 by batch size, 0 never, 1 always; pinned: LCP_HINT_PINNED
 // one scene per wavefront, small batches (the body-space sizes with nz <= 16) - lcp_solo.hip
 bool solo_supported(int nz, int m, int e);
 int solo_step(const StepArgs& P, void* stream, bool pinned = false);
-int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream, int body_space = 1);
+int quad_step_backward(const StepArgs& P, const StepBwdArgs& G, int compute, void* stream, int body_space = 1, bool pinned = false);
 bool quad_step_is_body_space(int nz, int compute, int body_space);   // does quad_step run the body-space kernels for these arguments ?
 
 // workgroup-per-scene contact-structured forward for up to 64 contacts (fused step, forward only) - lcp_big.hip

@@ -38,8 +38,8 @@ bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <
 // ---- size-specialised instantiations (lcp_quad_n*e*.hip): the pinned body-space kernels with nz / neq at compile time
 #define LCP_QS_DECL(NZ, E)                                                                                       \
   int quad_sized_fwd_##NZ##_##E(const StepArgs& SP, int ls, size_t lds_bytes, int accept, void* stream);        \
-  int quad_sized_bwd_##NZ##_##E(const BwdArgs& P, int ls, int accept, void* stream);                            \
-  int quad_sized_step_bwd_##NZ##_##E(const StepArgs& SP, const StepBwdArgs& Gd, int ls, void* stream);
+  int quad_sized_bwd_##NZ##_##E(const BwdArgs& P, int ls, int accept, bool pinned, void* stream);               \
+  int quad_sized_step_bwd_##NZ##_##E(const StepArgs& SP, const StepBwdArgs& Gd, int ls, bool pinned, void* stream);
 LCP_QS_DECL(15, 3) LCP_QS_DECL(9, 3) LCP_QS_DECL(12, 3) LCP_QS_DECL(6, 3)
 #ifndef LCP_Q_SIZED
 #define LCP_Q_SIZED 1         // 0: always the run-time-size kernels (A/B aid)
@@ -137,13 +137,13 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64, int body) {
+int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64, int body, bool pinned) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
   if (body) {                                    // workspace of a body-space forward (fp32 I/O, fp64 arithmetic)
     if (io_f64 || compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
     const int ls = (int)q16_lds<double>(false);
-#define LCP_QS_CALL(NZ, E) quad_sized_bwd_##NZ##_##E(P, ls, accept, stream)
+#define LCP_QS_CALL(NZ, E) quad_sized_bwd_##NZ##_##E(P, ls, accept, pinned, stream)
     LCP_QS_FOR_EACH(P.nz, P.e, LCP_QS_CALL)
 #undef LCP_QS_CALL
     hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, ls, accept);
@@ -160,7 +160,7 @@ int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int i
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream, int body_space) {
+int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, void* stream, int body_space, bool pinned) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((SP.B + 3) / 4), blk(64);
   const bool wide = 3 * SP.nb > 16;
@@ -168,7 +168,7 @@ int quad_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, int compute, v
     const int ls = (int)q16_lds<double>(false, wide ? 2 : 1);
     if (wide) hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 2>), grid, blk, 4 * ls, st, SP, Gd, ls);
     else if (body_space) {
-#define LCP_QS_CALL(NZ, E) quad_sized_step_bwd_##NZ##_##E(SP, Gd, ls, stream)
+#define LCP_QS_CALL(NZ, E) quad_sized_step_bwd_##NZ##_##E(SP, Gd, ls, pinned, stream)
       LCP_QS_FOR_EACH(3 * SP.nb, SP.e, LCP_QS_CALL)
 #undef LCP_QS_CALL
       hipLaunchKernelGGL((q16::lcp_bwd_step_quad<float, double, 1, true>), grid, blk, 4 * ls, st, SP, Gd, ls);
