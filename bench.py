@@ -350,16 +350,17 @@ class HipStackWorkload:
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
                 "kernel": ("lcp_fwd_solo (one scene per wavefront: batches of at most 1024 scenes; PDIPM forward%s)" % (
-                    ", fused assembly + integrate",)) if (body_space and B <= 1024) else "lcp_fwd_quad<float,%s,%s,1,%d> (PDIPM forward%s)" % (
+                    ", fused assembly + integrate",)) if (body_space and B <= 1024) else "lcp_fwd_quad<float,%s,%s,1,%d%s> (PDIPM forward%s)" % (
                     "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
+                    (",%d,%d,%d" % (nz, e, nc)) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
                     ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
                     "the launch for other equality rows is skipped" if a.mode == "fused"
                     else "; the event-timed forward call also contains the classify launch"),
                 "achieved": tf(fl_exec, fwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(fl_exec, fwd_ms) / peak,
                 "flops": "executed",
                 "executed_flops_per_launch": fl_exec,
-                "executed_model": ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True): per iteration formation of "
-                                   "Q + G^T M^-1 G (4 nc nz^2) + LU of nz - neq rows + 2 KKT solves + residuals" if body_space
+                "executed_model": ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True; trimmed for the size-specialised shapes): per "
+                                   "iteration formation of Q + G^T M^-1 G (4 nc nz (nz - neq)) + LU of nz - neq rows + 2 KKT solves + residuals" if body_space
                                    else "flops.flops_forward_executed: the reduced 2 nc contact-space system"),
                 "kernel_ms": fwd_ms,
                 "traffic": traffic,

@@ -33,19 +33,25 @@ def flops_forward_executed(nz, nc, e, it):
     return P + Fk + S_full + it * I
 
 
-def flops_forward_executed_body_space(nz, nc, e, it, pinned=True):
+SIZED_SHAPES = {(15, 3), (9, 3), (12, 3), (6, 3)}       # (nz, neq) with compile-time instantiations (lcp_quad_n*e*.hip): columns trimmed
+
+
+def flops_forward_executed_body_space(nz, nc, e, it, pinned=True, trimmed=None):
     """FLOPs the body-space variant executes per scene (lcp_quad.hip ALG = 1 / 2, lcp_primal.hip).  Per factorisation: the
-    formation of Q + G^T M^-1 G (dense over the nz columns in the quad kernel: per contact the two rows P = B [jc; jt] - 4 nz flops -
-    and two rank-1 updates of an nz x nz block - 4 nz^2 -, plus the closed-form 2 x 2 block B of the contact, ~30) and the LU:
-    `pinned` (ALG = 2: the equality rows are A = [I 0], the TotalConstraint on the floor) factors the nz - e free rows only,
-    otherwise the (nz + e)-square system.  Per KKT solve: one J^T w and one J v (4 nc nz each, dense rows), the two triangular
-    sweeps, the pinned-column correction and the closed-form 4 x 4 block inverses (~60 per contact).  Nothing of the contact-space
-    pre-factorisation is formed (round 3: the backward kernels of this path factor in body space too)."""
+    formation of Q + G^T M^-1 G (per contact the two rows P = B [jc; jt] and two rank-1 updates of the matrix block, plus the
+    closed-form 2 x 2 block B of the contact, ~30) and the LU: `pinned` (ALG = 2: the equality rows are A = [I 0], the TotalConstraint
+    on the floor) factors the nz - e free rows only, otherwise the (nz + e)-square system.  Per KKT solve: one J^T w and one J v,
+    the two triangular sweeps and the closed-form 4 x 4 block inverses (~60 per contact).  `trimmed` (the size-specialised
+    instantiations: compile-time nz / neq, pinned): only the columns e .. nz-1 are formed and multiplied - nz rows x (nz - e)
+    columns per contact in the formation, nz - e terms in J v.  Nothing of the contact-space pre-factorisation is formed."""
+    if trimmed is None:
+        trimmed = pinned and (nz, e) in SIZED_SHAPES
     n = (nz - e) if pinned else (nz + e)
-    Fk = 4 * nc * nz * nz + 4 * nc * nz + (2.0 / 3) * n ** 3 + 30 * nc
-    prod = 4 * nc * nz                                  # one J v or J^T w product (dense rows)
-    S = 2 * prod + 2 * n * n + (2 * e * nz if pinned else 0) + 60 * nc + 2 * nz
-    Rk = 2 * prod + (0 if pinned else 4 * e * nz) + 2 * nz + 30 * nc
+    cols = (nz - e) if trimmed else nz
+    Fk = 4 * nc * nz * cols + 4 * nc * cols + (2.0 / 3) * n ** 3 + 30 * nc
+    prod_t, prod_v = 4 * nc * nz, 4 * nc * cols          # J^T w (dense rows), J v (live columns)
+    S = prod_t + prod_v + 2 * n * n + (2 * e * nz if (pinned and not trimmed) else 0) + 60 * nc + 2 * nz
+    Rk = prod_t + prod_v + (0 if pinned else 4 * e * nz) + 2 * nz + 30 * nc
     I = Fk + 2 * S + Rk + 60 * nc
     return Fk + S + it * I
 

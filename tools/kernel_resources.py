@@ -5,7 +5,8 @@ import json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
-FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_primal_chain.hip": [], "lcp_primal_poststab.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
+FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_quad_n15e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n9e3.hip": ["-fno-slp-vectorize"],
+         "lcp_solo.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_primal_chain.hip": [], "lcp_primal_poststab.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
 KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
         "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_static_bytes",
         "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills", "TotalSGPRs": "sgpr"}
@@ -36,12 +37,16 @@ def main():
     pick = lambda sub: next((dict(v, kernel=k) for k, v in nice.items() if sub in k), None)
     out = {
         # the keys bench.py quotes in its roofline object
-        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 2>"),        # body-space, pinned leading coordinates (contact-list entries)
-        "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1>"),
-        "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0>"),
-        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 0>"),
-        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0>"),
-        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0>"),
+        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 2, 15, 3, 16>"),   # the headline: body space, pinned floor, sizes at compile time
+        "lcp_fwd_quad_f64_fused_runtime_sizes": pick("lcp_fwd_quad<float, double, true, 1, 2, 0, 0, 0>"),
+        "lcp_bwd_quad_f64_body": pick("lcp_bwd_quad<float, double, true, 15, 3, true>"),
+        "lcp_bwd_step_quad_f64_body": pick("lcp_bwd_step_quad<float, double, 1, true, 15, 3, true>"),
+        "lcp_fwd_solo_9_3_8": pick("lcp_fwd_solo<9, 3, 8>"),
+        "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1, 0, 0, 0>"),
+        "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0, 0, 0, 0>"),
+        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 0, 0, 0, 0>"),
+        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0, 0, 0, 0>"),
+        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0, 0, 0, 0>"),
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
         "lcp_primal_kernel_40_fwd": pick("lcp_primal_kernel<40, false, false, 4>"),
         "lcp_primal_kernel_40_bwd": pick("lcp_primal_kernel<40, true, false, 4>"),
