@@ -341,7 +341,10 @@ class HipStackWorkload:
         tj = _quoted("traffic", key)
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
-        rj = _quoted("kernel_resources", "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))   # (the variant this mode runs)
+        sized = body_space and (nz, e) in flops.SIZED_SHAPES
+        rj = _quoted("kernel_resources", "lcp_fwd_solo_9_3_8" if (body_space and B <= 1024 and (nz, e, nc) == (9, 3, 8)) else
+                     "lcp_fwd_quad_f64_fused_two_waves" if (sized and B > 4096) else
+                     "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))   # (the variant this mode runs)
         # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
         cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
             (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
@@ -352,7 +355,7 @@ class HipStackWorkload:
                 "kernel": ("lcp_fwd_solo (one scene per wavefront: batches of at most 1024 scenes; PDIPM forward%s)" % (
                     ", fused assembly + integrate",)) if (body_space and B <= 1024) else "lcp_fwd_quad<float,%s,%s,1,%d%s> (PDIPM forward%s)" % (
                     "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
-                    (",%d,%d,%d" % (nz, e, nc)) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
+                    (",%d,%d,%d,%s" % (nz, e, nc, "true" if B <= 4096 else "false")) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
                     ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
                     "the launch for other equality rows is skipped" if a.mode == "fused"
                     else "; the event-timed forward call also contains the classify launch"),

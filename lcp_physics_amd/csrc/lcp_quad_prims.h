@@ -117,7 +117,9 @@ __device__ __forceinline__ double launder(double f) { asm volatile("" : "+v"(f))
 // Phase timing (build with -DLCP_Q_PROFILE; the dense forward then writes cycle totals to the debug trace buffer)
 #ifdef LCP_Q_PROFILE
 struct Prof { long long t[10]; long long last; };
-#define LCP_QTICK(pr, i) { const long long now_ = clock64(); (pr).t[i] += now_ - (pr).last; (pr).last = now_; }
+// (the scheduling barriers keep the straight-line phases of the size-specialised kernels on their own side of the clock read)
+#define LCP_QTICK(pr, i) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); __builtin_amdgcn_sched_barrier(0); \
+                           (pr).t[i] += now_ - (pr).last; (pr).last = now_; }
 #define LCP_QPROF_ARG , Prof& pr
 #define LCP_QPROF_PASS , pr
 #else
