@@ -332,7 +332,7 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
   P.tag_value = step_tag(fam, 3 * nb, compute, path);
   switch (fam) {
     case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream, path != 3, pinned);
-    case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream);
+    case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream, pinned);
     case FAM_BIG: return lcp::big_step_backward(P, G, stream);
     default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read
   }
@@ -356,7 +356,7 @@ static int launch_step(lcp::StepArgs& P, int nz, int m, int e, int compute, int 
   P.tag_value = step_tag(fam, nz, compute, path);
   switch (fam) {
     case FAM_QUAD: return lcp::quad_step(P, compute, stream, path != 3, solo >= 8 ? solo - 16 : solo, solo >= 8);
-    case FAM_PRIMAL: return lcp::primal_step(P, stream);
+    case FAM_PRIMAL: return lcp::primal_step(P, stream, solo >= 8);
     case FAM_BIG: return lcp::big_step(P, stream);
     case FAM_WAVE64: return lcp::wave64_step(P, compute, stream);
     default: break;

@@ -125,8 +125,10 @@ int wave64_step(const StepArgs& P, int compute, void* stream);
 bool primal_supported(int nz, int m, int e);          // contact-list entry points: up to 24 equality rows
 bool primal_dense_supported(int nz, int m, int e);    // dense boundary, post-stabilisation: up to 4
 size_t primal_ws_bytes();
-int primal_step(const StepArgs& P, void* stream);
-int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
+int primal_step(const StepArgs& P, void* stream, bool pinned = false);      // pinned: LCP_HINT_PINNED (lcp_primal_pin.hip)
+int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream, bool pinned = false);
+bool primal_pin_supported(int nz, int e);             // lcp_primal_pin.hip: nz - neq pivots when the equality rows pin the leading coordinates
+int primal_pin_launch(const StepArgs& P, const StepBwdArgs& G, int backward, void* stream);
 int primal_chain_launch(const StepArgs& P, const StepBwdArgs& G, int backward, void* stream);   // lcp_primal_chain.hip: 5 .. 24 equality rows
 int primal_post_stab_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);   // lcp.py:37-64 on that LCP, contracted through engines.py:84-112
 int primal_post_stab(const StepArgs& P, void* stream);                                         // engines.py:80-116 in body space

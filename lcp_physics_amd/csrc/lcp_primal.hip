@@ -28,8 +28,9 @@
 // through the assembly), behind lcp_solve_dynamics_f32 / lcp_step_backward_f32; the same solve behind the dense LCPFunction
 // boundary (DENSE: lcp_pdipm_forward_f32 / _backward_f32 at 17..64 contacts); post-stabilisation (engines.py:80-116,
 // lcp_poststab_primal_kernel behind lcp_post_stabilization_f32).
-// Translation units: this file (the step and the dense boundary, up to 4 equality rows), lcp_primal_chain.hip (the step with 5 .. 24
-// equality rows), lcp_primal_poststab.hip (post-stabilisation); the kernel template lives in lcp_primal_step.inc.
+// Translation units: this file (the step and the dense boundary, up to 4 equality rows), lcp_primal_pin.hip (the step when the
+// equality rows are known to pin the leading coordinates: nz - neq pivots), lcp_primal_chain.hip (the step with 5 .. 24 equality
+// rows), lcp_primal_poststab.hip (post-stabilisation); the kernel template lives in lcp_primal_step.inc.
 #include "lcp_primal_common.h"
 
 namespace lcp {
@@ -60,8 +61,16 @@ static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stre
   if (n <= 40) return primal_launch<40, BWD, DENSE>(SP, Gd, stream, DN);
   return primal_launch<56, BWD, DENSE>(SP, Gd, stream, DN);
 }
-int primal_step(const StepArgs& SP, void* stream) { StepBwdArgs Gd = {}; return primal_dispatch<false>(SP, Gd, stream); }
-int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream) { return primal_dispatch<true>(SP, Gd, stream); }
+// pinned: LCP_HINT_PINNED came with the call (the forward's word travels with its backward): lcp_primal_pin.hip where its sizes allow
+int primal_step(const StepArgs& SP, void* stream, bool pinned) {
+  StepBwdArgs Gd = {};
+  if (pinned && primal_pin_supported(3 * SP.nb, SP.e)) return primal_pin_launch(SP, Gd, 0, stream);
+  return primal_dispatch<false>(SP, Gd, stream);
+}
+int primal_step_backward(const StepArgs& SP, const StepBwdArgs& Gd, void* stream, bool pinned) {
+  if (pinned && primal_pin_supported(3 * SP.nb, SP.e)) return primal_pin_launch(SP, Gd, 1, stream);
+  return primal_dispatch<true>(SP, Gd, stream);
+}
 
 // dense boundary: the scenes lcp_classify_big marked 3 (launched next to the contact-space and generic kernels, which take 2 and 0)
 int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {

@@ -154,7 +154,8 @@ def test_large_scene_backward_matches_generic_dense_and_oracle():
     cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
     cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
     count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
-    out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+    # (pinned=True: the LCP_HINT_PINNED that fused_step derives from the scene's Je itself - the same word, the same kernels)
+    out = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt, pinned=True)
     pg = {k: v.double().cpu() for k, v in fused_step_backward(scg, out, cot.to(DEV)).items()}
     # either forward entry picks the same kernel family for these sizes: same workspace, same gradients
     pg2 = fused_step_backward(scg, fused_step(scg), cot.to(DEV))

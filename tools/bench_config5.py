@@ -4,15 +4,17 @@ import sys, time
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lcp_physics_amd import _lib, scenes
-from lcp_physics_amd.physics.batched_world import solve_dynamics
+from lcp_physics_amd.physics.batched_world import solve_dynamics, rows_pin_leading_coordinates
 from lcp_physics_amd.physics.contacts import ContactBuffers
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sc = scenes.make_pile_scenes(B=B, seed=5, dtype=torch.float32).to('cuda')
 cb = ContactBuffers(B, sc.nb, sc.nc, 'cuda')
 cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
 count = torch.full((B,), sc.nc, dtype=torch.int32, device='cuda')
+# LCP_HINT_PINNED: checked once on the host, as ContactWorld / fused_step do (argument "nohint": the general form, for the A/B)
+PINNED = rows_pin_leading_coordinates(sc.Je) and "nohint" not in sys.argv
 run = lambda out=None: solve_dynamics(B, sc.nb, sc.nc, 3, count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb, sc.Je, sc.dt,
-                                      ws=None if out is None else out["ws"], out=out)
+                                      ws=None if out is None else out["ws"], out=out, pinned=PINNED)
 out = run(); torch.cuda.synchronize()
 nchk = min(B, 64)
 _lib.set_path("generic")
@@ -73,7 +75,8 @@ print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts
                   "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),
                   "kernel": "lcp::big::lcp_big_kernel<64> (contact space, 128 x 128: blocked LU, trailing updates on v_mfma_f64_16x16x4_f64)"
                             if len(sys.argv) > 2 and sys.argv[2] == "big" else
-                            "lcp::primal::lcp_primal_kernel<40> (body space, 36 x 36 systems, one wave per scene)"}))
+                            ("lcp::primal::lcp_primal_kernel<32, ..., PIN> (body space, the 30 free coordinates' system, one wave per scene; LCP_HINT_PINNED)"
+                             if PINNED else "lcp::primal::lcp_primal_kernel<40> (body space, 36 x 36 systems, one wave per scene)")}))
 if "primalprof" in os.environ.get("LCP_HIP_LIB", ""):
     pc = out["s"][:, 248:254].double().mean(dim=0).tolist()
     print("cycles per scene: residuals %.0f  formation %.0f  LU %.0f  bookkeeping %.0f  solve_kkt %.0f  steps + update %.0f  total %.0f"
