@@ -8,6 +8,10 @@
 #define LCP_PRIMAL_OCC40 2     // wavefronts per SIMD the 40-column instantiations are allocated for (A/B: 1 = no scratch, one wave per SIMD)
 #endif
 
+#ifndef LCP_PRIMAL_CPERM
+#define LCP_PRIMAL_CPERM 1     // 1: contact 4 (lane % 16) + lane / 16 on a lane (neighbours in the list -> different 16-lane rows); 0: contact = lane (A/B)
+#endif
+
 namespace lcp {
 namespace primal {
 

@@ -21,6 +21,7 @@ bool primal_pin_supported(int nz, int e) { return e == 3 && nz - e <= 40; }
 int primal_pin_launch(const StepArgs& SP, const StepBwdArgs& Gd, int backward, void* stream) {
   const int n = 3 * SP.nb - SP.e;
   if (n <= 24) return backward ? pin_launch<24, true>(SP, Gd, stream) : pin_launch<24, false>(SP, Gd, stream);
+  if (n == 30) return backward ? pin_launch<32, true>(SP, Gd, stream) : pin_launch<30, false>(SP, Gd, stream);   // (BASELINE config 5: exactly its ten free bodies)
   if (n <= 32) return backward ? pin_launch<32, true>(SP, Gd, stream) : pin_launch<32, false>(SP, Gd, stream);
   return backward ? pin_launch<40, true>(SP, Gd, stream) : pin_launch<40, false>(SP, Gd, stream);
 }
