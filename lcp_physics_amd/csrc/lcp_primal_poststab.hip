@@ -13,7 +13,7 @@ namespace primal {
 // workgroup-per-scene kernel on this path (4.2 ms for 4096 x 16 contacts).
 template <int NCOL, bool BWD, int EQC>
 __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_kernel(StepArgs SP, StepBwdArgs Gd) {
-  constexpr int LDK = NCOL + 1;
+  constexpr int LDK = ((NCOL + 1) % 32 == 31) ? NCOL + 3 : NCOL + 1;     // (never -1 mod 32: lcp_primal_step.inc)
   __shared__ __attribute__((aligned(16))) double Kl[NCOL * LDK];
   __shared__ double xv[LX];
   constexpr int ASZ = (EQC <= 4) ? EQC * LX : at_cap(NCOL, EQC);    // the A image: rows of 64 (few rows) or packed e x nz (many rows)
@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   else if (SP.c_count) ncs = SP.c_count[scene];
   const int truncated = (ncs > ncap) ? LCP_ST_TRUNCATED : 0;
   ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
-  const bool vc = lane < ncs, vx = lane < nz, ve = lane >= nz && lane < n;
+  const int ci = (LCP_PRIMAL_CPERM && ncap > 16) ? (4 * (lane & 15) + (lane >> 4)) : lane;   // the lane's contact (lcp_primal_step.inc: neighbours of the list in different 16-lane rows)
+  const bool vc = ci < ncs, vx = lane < nz, ve = lane >= nz && lane < n;
   const float* Md = (const float*)SP.Mdiag + (size_t)scene * nz;
   const float* vv = (const float*)SP.v + (size_t)scene * nz;
   float jn[6] = {0, 0, 0, 0, 0, 0};
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
     const ContactRows<float> r = make_contact<float>((const float*)SP.c_n + (size_t)scene * ncap * 2, (const float*)SP.c_p1 + (size_t)scene * ncap * 2,
                                                      (const float*)SP.c_p2 + (size_t)scene * ncap * 2, SP.c_i1 + (size_t)scene * ncap,
                                                      SP.c_i2 + (size_t)scene * ncap, (const float*)SP.rest + (size_t)scene * nb,
-                                                     (const float*)SP.rest + (size_t)scene * nb, vv, lane);
+                                                     (const float*)SP.rest + (size_t)scene * nb, vv, ci);
 #pragma unroll
     for (int q = 0; q < 6; ++q) jn[q] = r.jn[q];
     c0 = 3 * r.b1; c1 = 3 * r.b2;
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
       double cr = 0, dnx = 0, dny = 0, d1x = 0, d1y = 0, d2x = 0, d2y = 0;
       int b1 = 0, b2 = 0;
       if (vc) {
-        const size_t cb = (size_t)scene * ncap + lane;
+        const size_t cb = (size_t)scene * ncap + ci;
         const double nx = ((const float*)SP.c_n)[cb * 2], ny = ((const float*)SP.c_n)[cb * 2 + 1];
         const double p1x = ((const float*)SP.c_p1)[cb * 2], p1y = ((const float*)SP.c_p1)[cb * 2 + 1];
         const double p2x = ((const float*)SP.c_p2)[cb * 2], p2y = ((const float*)SP.c_p2)[cb * 2 + 1];
@@ -270,9 +271,9 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
         d2x = -gjn[3] * ny; d2y = gjn[3] * nx;
       }
       wsync();
-      CR[lane] = cr; B12[lane] = b1; B12[LX + lane] = b2;
-      if (lane < ncap) {
-        const size_t cb = (size_t)scene * ncap + lane;
+      CR[ci] = cr; B12[ci] = b1; B12[LX + ci] = b2;
+      if (ci < ncap) {
+        const size_t cb = (size_t)scene * ncap + ci;
         if (Gd.dcn) { ((float*)Gd.dcn)[cb * 2] = (float)dnx; ((float*)Gd.dcn)[cb * 2 + 1] = (float)dny; }
         if (Gd.dcp1) { ((float*)Gd.dcp1)[cb * 2] = (float)d1x; ((float*)Gd.dcp1)[cb * 2 + 1] = (float)d1y; }
         if (Gd.dcp2) { ((float*)Gd.dcp2)[cb * 2] = (float)d2x; ((float*)Gd.dcp2)[cb * 2 + 1] = (float)d2y; }
