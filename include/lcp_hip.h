@@ -306,6 +306,28 @@ int lcp_joint_jacobian_f64(int B, int nb, int nj, int e,
                            const float* v, const double* dt_scene, double dt, double vscale,
                            float* Je, void* stream);
 
+/* Backward of lcp_joint_jacobian_f64 with respect to the pose and the revolute joints' angles: what the reference obtains by autograd
+ * through Joint.J() / FixedJoint.J() with update_pos (physics/constraints.py:26-50, 64-85) when a roll-out with joints is
+ * back-propagated (experiments/inference.py:55-61).  jrot1[B,nj]: the angles the Jacobian was evaluated at (a copy taken then - the
+ * forward advances its jrot1 in place);  gJe[B,e,3 nb] float32 = d(loss)/dJe (lcp_step_backward_je_f32's dJe).
+ *   out: g_p[B,nb,3] float64 (written, not accumulated; only the x / y columns of the joints' bodies are non-zero), g_rot[B,nj]. */
+int lcp_joint_jacobian_backward_f64(int B, int nb, int nj, int e,
+                                    const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                                    const double* jr1, const double* jrot1, const float* gJe,
+                                    double* g_p, double* g_rot, void* stream);
+
+/* Backward of the state update that ends a differentiable step - Body.move (physics/bodies.py:80-82), the vertex turn it skips for a
+ * zero rotation increment (bodies.py:199-202) and Joint.move (constraints.py:39-43) - with respect to the velocities moved by:
+ *   p_new = p + scale v dt_k (cotangent g_p);  the pose the geometry is differentiated at, geo_new = p_geo + the same increment where
+ *   it is non-zero or the coordinate is x / y (cotangent g_g);  rot_new = rot + scale v[body1][0] dt_k for revolute joints (g_rot).
+ * g_p / g_g [B,nb,3] float64 and g_rot [B,nj] float64 may be NULL (no such cotangent);  v[B,nb,3] float32 the velocities of the move
+ * (new_v, or the post-stabilisation dp with scale = 0.5, world.py:112);  dt_scene[B] > 0 the dt each scene's step accepted;
+ * jtype / jb1 [B,nj] as in lcp_joint_jacobian_f64 (needed with g_rot).   out: g_v[B,nb,3] float32 = d(loss)/dv. */
+int lcp_state_update_backward_f64(int B, int nb, int nj,
+                                  const double* g_p, const double* g_g, const double* g_rot,
+                                  const float* v, const double* dt_scene, double scale,
+                                  const int32_t* jtype, const int32_t* jb1, float* g_v, void* stream);
+
 /* Backward of the contact frame with respect to the poses: what the reference obtains by autograd through
  * DiffContactHandler (physics/contacts.py:57-352 - every operation of the contact tuple is a differentiable torch op,
  * including the rotated hull vertices of bodies.py:211-214), needed to back-propagate through a roll-out

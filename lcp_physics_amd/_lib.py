@@ -58,6 +58,8 @@ SIGNATURES = {
                                                           _c.c_double] + [_P] * 12 + [_P]),
     "lcp_joint_jacobian_f64": (_I, [_I] * 4 + [_P] * 8 + [_c.c_double, _c.c_double, _P, _P]),
     "lcp_contact_frame_backward_f64": (_I, [_I] * 3 + [_P] * 6 + [_c.c_double] + [_P] * 5 + [_P]),
+    "lcp_joint_jacobian_backward_f64": (_I, [_I] * 4 + [_P] * 6 + [_P, _P, _P]),
+    "lcp_state_update_backward_f64": (_I, [_I] * 3 + [_P] * 5 + [_c.c_double] + [_P] * 3 + [_P]),
     "lcp_debug_set_trace": (None, [_P]),
     "lcp_debug_set_path": (None, [_I]),
 }

@@ -476,6 +476,21 @@ int lcp_joint_jacobian_f64(int B, int nb, int nj, int e, const int32_t* jtype, c
   return lcp::joint_jacobian_launch(B, nb, nj, e, jtype, jb1, jb2, jr1, jrot1, p, v, dt_scene, dt, vscale, Je, stream);
 }
 
+int lcp_joint_jacobian_backward_f64(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                                    const double* jr1, const double* jrot1, const float* gJe, double* g_p, double* g_rot, void* stream) {
+  if (B <= 0 || nb <= 0 || nj <= 0 || e <= 0) return LCP_E_BADARG;
+  if (!jtype || !jb1 || !jb2 || !jr1 || !jrot1 || !gJe || !g_p || !g_rot) return LCP_E_BADARG;
+  return lcp::joint_jacobian_backward_launch(B, nb, nj, e, jtype, jb1, jb2, jr1, jrot1, gJe, g_p, g_rot, stream);
+}
+
+int lcp_state_update_backward_f64(int B, int nb, int nj, const double* g_p, const double* g_g, const double* g_rot, const float* v,
+                                  const double* dt_scene, double scale, const int32_t* jtype, const int32_t* jb1, float* g_v, void* stream) {
+  if (B <= 0 || nb <= 0 || nj < 0) return LCP_E_BADARG;
+  if (!v || !dt_scene || !g_v) return LCP_E_BADARG;
+  if (g_rot && (nj <= 0 || !jtype || !jb1)) return LCP_E_BADARG;
+  return lcp::state_update_backward_launch(B, nb, nj, g_p, g_g, g_rot, v, dt_scene, scale, jtype, jb1, g_v, stream);
+}
+
 int lcp_contact_frame_backward_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* verts_local,
                                    const int32_t* nverts, const uint8_t* no_contact, const double* p, double eps,
                                    const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,

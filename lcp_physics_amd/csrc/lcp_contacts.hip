@@ -337,7 +337,88 @@ __global__ void __launch_bounds__(64) lcp_joint_jacobian_kernel(int B, int nb, i
   }
 }
 
+// Backward of lcp_joint_jacobian_kernel with respect to the pose and the revolute joints' angles - what the reference's autograd
+// computes through Joint.J() / FixedJoint.J() and update_pos (constraints.py:26-50, 64-85): the four pose-dependent entries of a
+// joint's rows are e0 = -pos1_y, e1 = pos1_x (columns of body 1's angle) and e2 = pos2_y, e3 = -pos2_x (body 2's), with
+// pos1 = r1 (cos rot1, sin rot1), pos2 = body1.pos + pos1 - body2.pos.  jrot1: the angles Je was evaluated at.  One thread per scene.
+__global__ void __launch_bounds__(64) lcp_joint_jacobian_backward_kernel(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1,
+                                                                         const int32_t* jb2, const double* jr1, const double* jrot1,
+                                                                         const float* gJe, double* g_p, double* g_rot) {
+  const int scene = blockIdx.x * 64 + threadIdx.x;
+  if (scene >= B) return;
+  const int nz = 3 * nb;
+  const float* G = gJe + (size_t)scene * e * nz;
+  double* gq = g_p + (size_t)scene * nz;
+  for (int i = 0; i < nz; ++i) gq[i] = 0.0;
+  int row = 0;
+  for (int k = 0; k < nj; ++k) {
+    const size_t o = (size_t)scene * nj + k;
+    const int t = jtype[o], b1 = jb1[o], b2 = jb2[o];
+    double gr = 0.0;
+    if (t == 1 || t == 2) {
+      if (row + 1 < e) {
+        const double a0 = (double)G[(size_t)row * nz + 3 * b1], a1 = (double)G[(size_t)(row + 1) * nz + 3 * b1];
+        double a2 = 0, a3 = 0;
+        if (b2 >= 0) {
+          a2 = (double)G[(size_t)row * nz + 3 * b2]; a3 = (double)G[(size_t)(row + 1) * nz + 3 * b2];
+          gq[b1 * 3 + 1] += -a3; gq[b1 * 3 + 2] += a2;                       // pos2 = body1.pos + pos1 - body2.pos
+          gq[b2 * 3 + 1] += a3; gq[b2 * 3 + 2] += -a2;
+        }
+        if (t == 1) {                                                        // (a FixedJoint's anchor is body 1 itself: pos1 = 0)
+          const double rot = jrot1[o];
+          gr = jr1[o] * (-sin(rot) * (a1 - a3) + cos(rot) * (a2 - a0));
+        }
+      }
+      row += (t == 2) ? 3 : 2;
+    } else if (t == 3 || t == 4 || t == 5) row += 1;
+    else if (t == 6) row += 3;
+    g_rot[o] = gr;
+  }
+}
+
+// Backward of the state update of a differentiable step - Body.move and Joint.move (bodies.py:80-82, 199-202;
+// constraints.py:39-43) - with respect to the velocities the move used:
+//   p_new   = p + scale v dt_k                                         cotangent g_p
+//   geo_new = p_geo + [scale v dt_k where it is non-zero or the coordinate is x / y]   cotangent g_g (the reference turns a hull's
+//             vertices by the increment and skips the turn when it is zero: no vertex path through such a step)
+//   rot_new = rot + scale v[body1][0] dt_k  for revolute joints        cotangent g_rot
+// out: g_v = d(loss)/dv (float32).  dt_k > 0 (the step_dt loop stops at dt / 4): the increment is zero exactly where v is.
+// scale = 1 for the dynamics move, 0.5 for the post-stabilisation move (world.py:112).  One thread per scene.
+__global__ void __launch_bounds__(64) lcp_state_update_backward_kernel(int B, int nb, int nj, const double* g_p, const double* g_g,
+                                                                       const double* g_rot, const float* v, const double* dt_scene,
+                                                                       double scale, const int32_t* jtype, const int32_t* jb1, float* g_v) {
+  const int scene = blockIdx.x * 64 + threadIdx.x;
+  if (scene >= B) return;
+  const double k = scale * dt_scene[scene];
+  const size_t base = (size_t)scene * nb * 3;
+  for (int b = 0; b < nb; ++b) {
+    double rot_extra = 0.0;
+    if (g_rot) for (int j = 0; j < nj; ++j) { const size_t o = (size_t)scene * nj + j; if (jtype[o] == 1 && jb1[o] == b) rot_extra += g_rot[o]; }
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = base + b * 3 + c;
+      double tot = g_p ? g_p[i] : 0.0;
+      if (g_g && (c > 0 || v[i] != 0.0f)) tot += g_g[i];
+      if (c == 0) tot += rot_extra;
+      g_v[i] = (float)(tot * k);
+    }
+  }
+}
+
 }  // namespace ct
+
+int joint_jacobian_backward_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                                   const double* jr1, const double* jrot1, const float* gJe, double* g_p, double* g_rot, void* stream) {
+  hipLaunchKernelGGL(ct::lcp_joint_jacobian_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, nj, e, jtype, jb1,
+                     jb2, jr1, jrot1, gJe, g_p, g_rot);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
+int state_update_backward_launch(int B, int nb, int nj, const double* g_p, const double* g_g, const double* g_rot, const float* v,
+                                 const double* dt_scene, double scale, const int32_t* jtype, const int32_t* jb1, float* g_v, void* stream) {
+  hipLaunchKernelGGL(ct::lcp_state_update_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, nb, nj, g_p, g_g, g_rot, v,
+                     dt_scene, scale, jtype, jb1, g_v);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
 
 int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2, const double* jr1,
                           double* jrot1, const double* p, const float* v, const double* dt_scene, double dt, double vscale, float* Je,

@@ -164,6 +164,10 @@ int contacts_launch(const ContactArgs& P, void* stream);
 int joint_jacobian_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2, const double* jr1,
                           double* jrot1, const double* p, const float* v, const double* dt_scene, double dt, double vscale, float* Je,
                           void* stream);
+int joint_jacobian_backward_launch(int B, int nb, int nj, int e, const int32_t* jtype, const int32_t* jb1, const int32_t* jb2,
+                                   const double* jr1, const double* jrot1, const float* gJe, double* g_p, double* g_rot, void* stream);
+int state_update_backward_launch(int B, int nb, int nj, const double* g_p, const double* g_g, const double* g_rot, const float* v,
+                                 const double* dt_scene, double scale, const int32_t* jtype, const int32_t* jb1, float* g_v, void* stream);
 int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, const double* radius, const double* verts_local,
                                   const int32_t* nverts, const uint8_t* no_contact, const double* p, double eps,
                                   const int32_t* count, const float* g_n, const float* g_p1, const float* g_p2, double* dp,

@@ -336,7 +336,7 @@ class _ValueOf(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lin, value):
-        return value.detach().clone()
+        return value.detach().clone()                 # (`value` may be a buffer the next launch overwrites)
 
     @staticmethod
     def backward(ctx, g):
@@ -349,6 +349,66 @@ class _Frame:
 
     def __init__(self, c_n, c_p1, c_p2, c_i1, c_i2):
         self.c_n, self.c_p1, self.c_p2, self.c_i1, self.c_i2 = c_n, c_p1, c_p2, c_i1, c_i2
+
+
+class _StateUpdate(torch.autograd.Function):
+    """The state a differentiable step ends with, as ONE node:
+
+        p_new, geo_new[, rot_new] = _StateUpdate.apply(p, p_geo, rot, v, p_out, rot_value, dt_used, scale, joints)
+
+    values: `p_out`, the pose the kernels accepted (bitwise: the next contact list was detected at exactly these values), twice, and
+    `rot_value`, the revolute joints' angles after the move; gradients: those of
+
+        p_new   = p + scale v dt_used                                                          (bodies.py:80-82)
+        geo_new = p_geo + [scale v dt_used where the increment is non-zero or the coordinate is x / y]   (bodies.py:199-202)
+        rot_new = rot + scale v[body1][0] dt_used  for revolute joints                         (constraints.py:39-43)
+
+    Nothing is launched in the forward pass (the sums are never evaluated, only differentiated); the backward is one launch of
+    `lcp_state_update_backward_f64`.  `p_out`, `rot_value` and `dt_used` belong to the step (a differentiable step retires its contact
+    buffers instead of re-using them).  `rot` / `rot_value` / `joints` are None for worlds without pose-dependent joints."""
+
+    @staticmethod
+    def forward(ctx, p, p_geo, rot, v, p_out, rot_value, dt_used, scale, joints):
+        ctx.save_for_backward(v, dt_used)
+        ctx.scale, ctx.joints = float(scale), joints
+        if rot is None:
+            return p_out.detach(), p_out.detach()
+        return p_out.detach(), p_out.detach(), rot_value.detach()
+
+    @staticmethod
+    def backward(ctx, g_p, g_g, g_rot=None):
+        v, dt_used = ctx.saved_tensors
+        lib = _lib.load()
+        B, nb = v.shape[0], v.shape[1]
+        js = ctx.joints
+        c64 = lambda g: None if g is None else g.to(torch.float64).contiguous()
+        g_p, g_g, g_rot = c64(g_p), c64(g_g), (c64(g_rot) if js is not None else None)
+        g_v = torch.empty(B, nb, 3, dtype=torch.float32, device=v.device)
+        P = _lib.ptr
+        with _on_device(v.device):
+            rc = lib.lcp_state_update_backward_f64(B, nb, 0 if g_rot is None else js.jtype.shape[1], P(g_p), P(g_g), P(g_rot), P(v), P(dt_used),
+                                                   ctx.scale, P(js.jtype) if g_rot is not None else None,
+                                                   P(js.jb1) if g_rot is not None else None, P(g_v), _lib.stream_ptr(v.device))
+        _lib.check(rc, "lcp_state_update_backward_f64")
+        return g_p, g_g, g_rot, g_v, None, None, None, None, None
+
+
+class _JointJacobianFn(torch.autograd.Function):
+    """Je = the joint Jacobian the kernel computed at pose `p` and revolute angles `rot` (`JointSet.jacobian`; its values), with the
+    gradient of `Joint.J()` / `FixedJoint.J()` (constraints.py:26-50, 64-85): backward = one launch of
+    `lcp_joint_jacobian_backward_f64`.  `Je_value` belongs to the step (a fresh tensor per `jacobian()` call)."""
+
+    @staticmethod
+    def forward(ctx, p, rot, joints, Je_value):
+        ctx.joints, ctx.nb = joints, p.shape[1]
+        ctx.save_for_backward(rot)
+        return Je_value.detach()
+
+    @staticmethod
+    def backward(ctx, gJe):
+        (rot,) = ctx.saved_tensors
+        g_p, g_rot = ctx.joints.jacobian_backward(ctx.nb, rot, gJe)
+        return g_p, g_rot, None, None
 
 
 class SolveDynamicsFunction(torch.autograd.Function):
@@ -395,7 +455,7 @@ class SolveDynamicsFunction(torch.autograd.Function):
         frame = _Frame(c_n, c_p1, c_p2, c_i1, c_i2)
         out = solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, frame, Je if e else None, float(dt),
                              eps=opts.get("eps", 1e-12), not_improved_lim=opts.get("not_improved_lim", 3),
-                             max_iter=opts.get("max_iter", 10), compute=opts.get("compute", "f64"))
+                             max_iter=opts.get("max_iter", 10), compute=opts.get("compute", "f64"), pinned=bool(opts.get("pinned", False)))
         ctx.save_for_backward(Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2)
         ctx.Je, ctx.out, ctx.dims, ctx.dt, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), float(dt), opts.get("compute", "f64")
         opts["last"] = out
@@ -481,7 +541,10 @@ class PostStabilizationFunction(torch.autograd.Function):
         for name, t in (("Mdiag", Mdiag), ("v", v), ("rest", rest), ("c_n", c_n), ("c_p1", c_p1), ("c_p2", c_p2)):
             _lib.require_gpu_tensor(t, name, torch.float32)
         frame = _Frame(c_n, c_p1, c_p2, c_i1, c_i2)
-        out = post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, frame, Je if e else None, compute=opts.get("compute", "f64"))
+        # opts["ps_pose"] = (p, dt_scene, p_out): the kernel also makes the correction move of world.py:110-117, p_out = p + (dp / 2) dt_scene
+        pose = opts.get("ps_pose") or (None, None, None)
+        out = post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, frame, Je if e else None, p=pose[0], dt_scene=pose[1], p_out=pose[2],
+                                 compute=opts.get("compute", "f64"))
         ctx.save_for_backward(Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2)
         ctx.Je, ctx.out, ctx.dims, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), opts.get("compute", "f64")
         opts["last_post_stab"] = out
@@ -651,8 +714,11 @@ class ContactWorld:
         revolute / fixed joints is differentiated through the pose and the joint angle (dL/dJe: lcp_step_backward_je_f32);
         with `post_stab` the correction move is one more node (`PostStabilizationFunction`, world.py:109-121)."""
         ct = self._contacts_mod
-        cb = self.contacts
-        frame = ct.snapshot_frame(cb)
+        # the contact buffers at the current pose become this step's frame (kept for its backward); the detection below fills a
+        # fresh set - no copies
+        frame = self.contacts
+        cb = self.contacts = ct.ContactBuffers(self.B, self.nb, self.maxc, self.p.device)
+        self._autograd_owned = True
         # the pose the GEOMETRY is differentiated at: the same values as self.p, but a rotation increment that is exactly
         # zero carries no gradient - the reference turns its hulls' vertices by the increment and skips the turn when the
         # increment is zero (bodies.py:199-202 `if rot.item() != 0: self.rotate_verts(rot)`), so its autograd has no
@@ -660,7 +726,8 @@ class ContactWorld:
         p_geo = self._p_geom if getattr(self, "_p_geom_src", None) is self.p else self.p
         c_n, c_p1, c_p2 = ct.ContactFrameFunction.apply(p_geo, self.geom, frame, self.eps)
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()
-        opts = {"max_iter": self.max_iter, "eps": self.solver_eps, "not_improved_lim": self.lim, "compute": self.compute}
+        opts = {"max_iter": self.max_iter, "eps": self.solver_eps, "not_improved_lim": self.lim, "compute": self.compute,
+                "pinned": self._pinned}
         Je = self.Je
         js = self.joints
         if js is not None and js.pose_dependent:
@@ -668,8 +735,7 @@ class ContactWorld:
             # kernel's values, the gradient of the torch expression; lcp_step_backward_je_f32 returns dL/dJe
             if getattr(self, "_jrot_src", None) is not self.p:
                 self._jrot_ad, self._jrot_src = js.jrot1.clone(), self.p
-            Jt = js.jacobian_torch(self.p, self._jrot_ad).to(torch.float32)
-            Je = self.Je + (Jt - Jt.detach())
+            Je = _JointJacobianFn.apply(self.p, self._jrot_ad, js, self.Je)
         v_new = SolveDynamicsFunction.apply(self.Mdiag, self.v.contiguous(), f, self.rest, self.fric, c_n, c_p1, c_p2, frame.c_i1,
                                             frame.c_i2, frame.count, Je, self.dt, opts)
         out = opts["last"]
@@ -677,45 +743,42 @@ class ContactWorld:
         p_start = self.p
         ct.move_and_find_contacts(self.geom, p_start.detach(), v_new.detach(), self.dt, eps=self.eps, tol=self.tol,
                                   strict=self.strict, dt_floor=self.dt / 4, max_trials=self.max_trials, t=self.t, out=cb)
-        # the accepted pose: the kernel's value, the gradient of p + v dt_used
-        dp = v_new.to(torch.float64) * cb.dt_used.clone().reshape(-1, 1, 1)
-        p_lin = p_start + dp
-        self.p = _ValueOf.apply(p_lin, cb.p_out)
-        g_lin = p_geo + torch.where((dp != 0) | self._xy_mask, dp, dp.detach())       # (a zero rotation increment carries no gradient)
-        self._p_geom, self._p_geom_src = _ValueOf.apply(g_lin, cb.p_out), self.p
+        # the accepted pose: the kernel's value, the gradient of p + v dt_used (a zero rotation increment carries no gradient to the geometry)
         self.v = v_new
         if js is not None:                                                 # joint.move(dt): rot1 += body1.v[0] dt (constraints.py:39-43)
-            self.Je = js.jacobian(self.p.detach(), v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
-            if js.pose_dependent:
-                w1 = v_new[:, :, 0].gather(1, js.jb1.long()).to(torch.float64) * cb.dt_used.clone().reshape(-1, 1)
-                r_lin = self._jrot_ad + w1 * js.revolute_mask
-                self._jrot_ad, self._jrot_src = _ValueOf.apply(r_lin, js.jrot1), self.p
+            self.Je = js.jacobian(cb.p_out, v=v_new.detach().contiguous(), dt_scene=cb.dt_used)
+        if js is not None and js.pose_dependent:
+            self.p, self._p_geom, self._jrot_ad = _StateUpdate.apply(p_start, p_geo, self._jrot_ad, v_new, cb.p_out, js.jrot1.clone(),
+                                                                     cb.dt_used, 1.0, js)
+            self._jrot_src = self.p
+        else:
+            self.p, self._p_geom = _StateUpdate.apply(p_start, p_geo, None, v_new, cb.p_out, None, cb.dt_used, 1.0, None)
+        self._p_geom_src = self.p
         if self.post_stab:
             # world.py:109-121: dp = engine.post_stabilization(world) at the moved pose with the contacts found there and the
             # NEW velocities; dp /= 2; the bodies (and the joints) move by dp dt; contacts are detected again
-            frame2 = ct.snapshot_frame(cb)
-            dt_used = cb.dt_used.clone()
+            frame2 = cb                                                    # (retired like `frame`: the detection at the end fills a fresh set)
+            dt_used = cb.dt_used
             g_n, g_p1, g_p2 = ct.ContactFrameFunction.apply(self._p_geom, self.geom, frame2, self.eps)
-            Je2 = self.Je
-            if js is not None and js.pose_dependent:
-                Jt = js.jacobian_torch(self.p, self._jrot_ad).to(torch.float32)
-                Je2 = self.Je + (Jt - Jt.detach())
+            pose_dep = js is not None and js.pose_dependent
+            Je2 = _JointJacobianFn.apply(self.p, self._jrot_ad, js, self.Je) if pose_dep else self.Je
+            p_corr = torch.empty_like(cb.p_out)                            # the corrected pose: the kernel's own move, as in step()
+            opts["ps_pose"] = (cb.p_out, dt_used, p_corr)
             dp_s = PostStabilizationFunction.apply(self.Mdiag, v_new.contiguous(), self.rest, g_n, g_p1, g_p2, frame2.c_i1, frame2.c_i2,
                                                    frame2.count, Je2, opts)
             ps = opts["last_post_stab"]
             torch.bitwise_or(self.sticky_status, ps["status"], out=self.sticky_status)
-            mv = (dp_s.to(torch.float64) * 0.5) * dt_used.reshape(-1, 1, 1)
             p_mid, g_mid = self.p, self._p_geom
-            self.p = p_mid + mv
-            self._p_geom = g_mid + torch.where((mv != 0) | self._xy_mask, mv, mv.detach())         # (bodies.py:199-202, as above)
+            if js is not None:                                             # the joints follow the correction move (world.py:112-116)
+                self.Je = js.jacobian(p_corr, v=dp_s.detach().contiguous(), dt_scene=dt_used, vscale=0.5)
+            if pose_dep:
+                self.p, self._p_geom, self._jrot_ad = _StateUpdate.apply(p_mid, g_mid, self._jrot_ad, dp_s, p_corr, js.jrot1.clone(), dt_used,
+                                                                         0.5, js)
+                self._jrot_src = self.p
+            else:
+                self.p, self._p_geom = _StateUpdate.apply(p_mid, g_mid, None, dp_s, p_corr, None, dt_used, 0.5, None)
             self._p_geom_src = self.p
-            if js is not None:
-                self.Je = js.jacobian(self.p.detach().contiguous(), v=dp_s.detach().contiguous(), dt_scene=dt_used, vscale=0.5)
-                if js.pose_dependent:
-                    w1 = 0.5 * dp_s[:, :, 0].gather(1, js.jb1.long()).to(torch.float64) * dt_used.reshape(-1, 1)
-                    r_lin = self._jrot_ad + w1 * js.revolute_mask
-                    self._jrot_ad, self._jrot_src = _ValueOf.apply(r_lin, js.jrot1), self.p
-            ct.find_contacts(self.geom, self.p.detach().contiguous(), maxc=self.maxc, eps=self.eps, out=cb)   # world.py:121
+            self.contacts = ct.find_contacts(self.geom, p_corr, maxc=self.maxc, eps=self.eps)   # world.py:121
             out = dict(out)
             out["post_stab"] = ps
         ret = dict(out)
@@ -726,6 +789,10 @@ class ContactWorld:
         """`World.step()` = `step_dt(self.dt)` (`world.py:72-122`) for every scene."""
         if differentiable:
             return self.step_autograd()
+        if getattr(self, "_autograd_owned", False):
+            # the state tensors are outputs of the autograd graph (their storage belongs to the retired contact buffers of the last
+            # differentiable step): the double buffering below must not hand them to a kernel as an output slot
+            self.p, self.v, self._autograd_owned = self.p.detach().clone(), self.v.detach().clone(), False
         self._phase ^= 1
         cb = self.contacts
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()

@@ -107,6 +107,23 @@ class JointSet:
         _lib.check(rc, "lcp_joint_jacobian_f64")
         return out
 
+    def jacobian_backward(self, nb, rot, gJe):
+        """d(loss)/d(pose) [B,nb,3] and d(loss)/d(revolute angles) [B,nj] (float64) from d(loss)/dJe [B,e,3nb] (float32): the
+        backward of `jacobian()` at the angles `rot` [B,nj] it was evaluated at - one launch of `lcp_joint_jacobian_backward_f64`
+        (the reference's autograd through `Joint.J()` / `update_pos`, constraints.py:26-50)."""
+        lib = _lib.load()
+        B, nj = self.jtype.shape[0], self.jtype.shape[1]
+        gJe = _lib.require_gpu_tensor(gJe.to(torch.float32).contiguous(), "gJe", torch.float32)
+        rot = _lib.require_gpu_tensor(rot.contiguous(), "rot", torch.float64)
+        g_p = torch.empty(B, nb, 3, dtype=torch.float64, device=gJe.device)
+        g_rot = torch.empty(B, nj, dtype=torch.float64, device=gJe.device)
+        P = _lib.ptr
+        with torch.cuda.device(gJe.device):
+            rc = lib.lcp_joint_jacobian_backward_f64(B, nb, nj, self.e, P(self.jtype), P(self.jb1), P(self.jb2), P(self.jr1), P(rot),
+                                                     P(gJe), P(g_p), P(g_rot), _lib.stream_ptr(gJe.device))
+        _lib.check(rc, "lcp_joint_jacobian_backward_f64")
+        return g_p, g_rot
+
     def _torch_plan(self, B, nb, dtype, dev):
         """What `jacobian_torch` needs that does not change with the pose: the constant entries of Je ([B,e,3nb]) and, for the
         revolute / fixed joints, the (batch, row, column) indices of their four pose-dependent entries - built once."""

@@ -1146,3 +1146,90 @@ def test_grad_demo_rollout_from_one_hip_graph_equals_the_eager_run_and_the_refer
     err = np.abs(gr - d["grad"]).max(axis=1) / np.abs(d["grad"]).max(axis=1)
     assert err.max() <= 1e-4, err
     assert np.abs(loss_g.detach().cpu().numpy()[::rep] - d["loss"]).max() <= 1e-5 * np.abs(d["loss"]).max()
+
+
+def test_joint_jacobian_backward_matches_autograd_of_the_torch_expression():
+    """`lcp_joint_jacobian_backward_f64` (the backward of the joint Jacobian a differentiable step uses) against torch autograd through
+    `JointSet.jacobian_torch`, the torch restatement of Joint.J() / FixedJoint.J() (constraints.py:26-50, 64-85): revolute joints with
+    and without a second body, a fixed joint, one-row constraints and a pinned body in between (row bookkeeping)."""
+    from lcp_physics_amd.physics.joints import JointSet
+    B, nb = 33, 6
+    g = torch.Generator().manual_seed(21)
+    p0 = torch.zeros(nb, 3, dtype=torch.float64)
+    p0[:, 1] = 40.0 * torch.arange(nb, dtype=torch.float64)
+    p0[:, 2] = 25.0 * torch.rand(nb, generator=g, dtype=torch.float64)
+    joints = [("total", 0), ("joint", 1, 0, (20.0, 3.0)), ("x", 2), ("joint", 2, None, (75.0, 11.0)), ("fixed", 3, 2), ("joint", 4, 3, (140.0, -6.0)),
+              ("rot", 5), ("fixed", 5, None)]
+    js = JointSet.from_list(joints, p0, B).to(DEV)
+    p = (p0.unsqueeze(0) + 2.0 * torch.randn(B, nb, 3, generator=g, dtype=torch.float64)).to(DEV)
+    rot = (js.jrot1 + 0.3 * torch.randn(B, js.jrot1.shape[1], generator=g, dtype=torch.float64).to(DEV))
+    gJe = torch.randn(B, js.e, 3 * nb, generator=g, dtype=torch.float32).to(DEV)
+    g_p, g_rot = js.jacobian_backward(nb, rot, gJe)
+    pt, rt = p.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+    (js.jacobian_torch(pt, rt) * gJe.double()).sum().backward()
+    torch.cuda.synchronize()
+    assert float((g_p - pt.grad).abs().max()) <= 1e-12 * max(1.0, float(pt.grad.abs().max()))
+    rev = js.revolute_mask
+    assert float((g_rot - rt.grad * rev).abs().max()) <= 1e-12 * max(1.0, float(rt.grad.abs().max()))
+    assert float((g_rot * (1 - rev)).abs().max()) == 0.0
+    # the Jacobian the kernel computes at those angles is the one the expression describes
+    js2 = JointSet(js.jtype, js.jb1, js.jb2, js.jr1, rot.clone(), js.e)
+    assert float((js2.jacobian(p).double() - js.jacobian_torch(p, rot)).abs().max()) <= 1e-5
+
+
+def test_state_update_backward_matches_autograd():
+    """`lcp_state_update_backward_f64` (`_StateUpdate`: Body.move, the skipped vertex turn of a zero rotation increment, Joint.move -
+    bodies.py:80-82, 199-202, constraints.py:39-43) against torch autograd of the three sums, both scales, with and without joints,
+    missing cotangents."""
+    from lcp_physics_amd.physics.batched_world import _StateUpdate
+    from lcp_physics_amd.physics.joints import JointSet
+    B, nb = 40, 5
+    g = torch.Generator().manual_seed(8)
+    p0 = torch.zeros(nb, 3, dtype=torch.float64)
+    p0[:, 1] = 30.0 * torch.arange(nb, dtype=torch.float64)
+    js = JointSet.from_list([("total", 0), ("joint", 1, 0, (10.0, 2.0)), ("joint", 3, 1, (50.0, 1.0)), ("fixed", 4, 3), ("joint", 1, 2, (40.0, 0.0))], p0, B).to(DEV)
+    rn = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    v = rn(B, nb, 3).float()
+    v[:, 2, 0] = 0.0                                     # a body that does not turn: no geometry gradient through its angle
+    v[::3, 4] = 0.0
+    dt = (0.01 + 0.02 * torch.rand(B, generator=g, dtype=torch.float64)).to(DEV)
+    for scale, with_joints, drop in ((1.0, True, None), (0.5, True, "g_g"), (1.0, False, None), (0.5, False, "g_p")):
+        p, pg, rot = rn(B, nb, 3).to(DEV).requires_grad_(True), rn(B, nb, 3).to(DEV).requires_grad_(True), rn(B, js.jtype.shape[1]).to(DEV).requires_grad_(True)
+        vv = v.to(DEV).clone().requires_grad_(True)
+        p_out, rot_val = rn(B, nb, 3).to(DEV), rn(B, js.jtype.shape[1]).to(DEV)
+        cot = [rn(B, nb, 3).to(DEV), rn(B, nb, 3).to(DEV), rn(B, js.jtype.shape[1]).to(DEV)]
+        outs = _StateUpdate.apply(p, pg, rot if with_joints else None, vv, p_out, rot_val if with_joints else None, dt, scale, js if with_joints else None)
+        assert torch.equal(outs[0], p_out) and torch.equal(outs[1], p_out) and (not with_joints or torch.equal(outs[2], rot_val))
+        loss = 0
+        if drop != "g_p":
+            loss = loss + (outs[0] * cot[0]).sum()
+        if drop != "g_g":
+            loss = loss + (outs[1] * cot[1]).sum()
+        if with_joints:
+            loss = loss + (outs[2] * cot[2]).sum()
+        loss.backward()
+        got = [t.grad.clone() if t.grad is not None else None for t in (p, pg, rot, vv)]
+        # the same three sums in torch
+        p2, pg2, rot2, v2 = [t.detach().clone().requires_grad_(True) for t in (p, pg, rot, vv)]
+        dp = v2.double() * scale * dt.view(-1, 1, 1)
+        xy = (torch.arange(3, device=DEV) > 0).view(1, 1, 3)
+        a = p2 + dp
+        b = pg2 + torch.where((dp != 0) | xy, dp, dp.detach())
+        ref = 0
+        if drop != "g_p":
+            ref = ref + (a * cot[0]).sum()
+        if drop != "g_g":
+            ref = ref + (b * cot[1]).sum()
+        if with_joints:
+            w1 = v2[:, :, 0].gather(1, js.jb1.long()).double() * scale * dt.view(-1, 1)
+            ref = ref + ((rot2 + w1 * js.revolute_mask) * cot[2]).sum()
+        ref.backward()
+        torch.cuda.synchronize()
+        assert float((got[3].double() - v2.grad.double()).abs().max()) <= 2e-6 * float(v2.grad.abs().max()), (scale, with_joints, drop)
+        for k, t in ((0, p2), (1, pg2)):
+            if t.grad is None:
+                assert got[k] is None or float(got[k].abs().max()) == 0.0
+            else:
+                assert torch.equal(got[k], t.grad)
+        if with_joints:
+            assert torch.equal(got[2], rot2.grad)

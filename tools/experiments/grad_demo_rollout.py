@@ -48,6 +48,18 @@ def main():
         eager(); eager()
     torch.cuda.current_stream().wait_stream(side)
     t_eager = timed(eager)
+    # device launches (kernels + copies + memsets) of one eager iteration, per simulated step
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        eager(); torch.cuda.synchronize()
+    launches = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+    names = {}
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            names[e.name[:60]] = names.get(e.name[:60], 0) + 1
+    if "--names" in a:
+        for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:25]:
+            print("%6d  %s" % (v, k), file=sys.stderr)
     ref = force0.grad.clone()
     force0.grad = None
     g = torch.cuda.CUDAGraph()
@@ -57,6 +69,7 @@ def main():
     B = force0.shape[0]
     err = np.abs(force0.grad.cpu().numpy()[::rep] - d["grad"]).max(axis=1) / np.abs(d["grad"]).max(axis=1)
     print(json.dumps({"experiment": "batched grad_demo: %d steps forward + backward" % nsteps, "batch": B, "s_per_iteration_eager": t_eager,
+                      "device_launches_per_step_fwd_bwd_eager": launches / nsteps,
                       "s_per_iteration_hip_graph": t_graph, "sim_steps_fwd_bwd_per_s_eager": B * nsteps / t_eager,
                       "sim_steps_fwd_bwd_per_s_hip_graph": B * nsteps / t_graph, "graph_equals_eager_bitwise": bool(torch.equal(force0.grad, ref)),
                       "worst_relative_gradient_error_vs_reference_autograd": float(err.max())}))

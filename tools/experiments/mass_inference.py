@@ -82,6 +82,22 @@ def main():
         hist.append(float(loss.detach().mean()))
         if os.environ.get("LCP_VERBOSE"):
             print(it, hist[-1], log_m.detach().exp()[:4].cpu().tolist(), log_m.grad[:4].cpu().tolist())
+    launches = None
+    if "--count" in a and g is None:                  # device launches (kernels, copies, memsets) of one eager iteration, per simulated step
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            optim.zero_grad()
+            poses, world = rollout(log_m.exp())
+            ((poses - observed) ** 2).mean(dim=(1, 2, 3)).sum().backward()
+            torch.cuda.synchronize()
+        ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+        launches = len(ev) / steps
+        if "--names" in a:
+            names = {}
+            for e in ev:
+                names[e.name[:90]] = names.get(e.name[:90], 0) + 1
+            for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:40]:
+                print("%7.1f  %s" % (v / steps, k), file=sys.stderr)
     m = log_m.detach().exp().cpu()
     times = sorted(times[2:])
     print(json.dumps({"experiment": "mass inference through the simulator (experiments/inference.py), batched", "batch": B, "links": links,
@@ -89,6 +105,7 @@ def main():
                       "start_mass_min_max": [float(start.min()), float(start.max())],
                       "recovered_mass_median": float(m.median()), "recovered_within_2pct": float(((m - true_mass).abs() < 0.02 * true_mass).float().mean()),
                       "loss_first_last": [hist[0], hist[-1]], "s_per_iteration_median": times[len(times) // 2],
+                      "device_launches_per_step_fwd_bwd_eager": launches,
                       "sim_steps_fwd_bwd_per_s": B * steps / times[len(times) // 2], "status_flags": int(world.sticky_status.max()), "hip_graph": bool(graph)}))
 
 
