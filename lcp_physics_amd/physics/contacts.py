@@ -76,19 +76,31 @@ class ContactBuffers:
     differentiable step, which keeps the previous set as that step's contact snapshot).  ONE zero-filled allocation, carved into
     the typed arrays: a single memset launch instead of twelve."""
 
+    _LAYOUTS = {}                                                    # (B, nb, maxc) -> total bytes, [(name, dtype, shape, offset, bytes)]
+
+    @classmethod
+    def _layout(cls, B, nb, maxc):
+        key = (B, nb, maxc)
+        lay = cls._LAYOUTS.get(key)
+        if lay is None:
+            spec = (("p_out", torch.float64, (B, nb, 3)), ("c_pen", torch.float64, (B, maxc)), ("max_pen", torch.float64, (B,)),
+                    ("dt_used", torch.float64, (B,)), ("c_n", torch.float32, (B, maxc, 2)), ("c_p1", torch.float32, (B, maxc, 2)),
+                    ("c_p2", torch.float32, (B, maxc, 2)), ("c_i1", torch.int32, (B, maxc)), ("c_i2", torch.int32, (B, maxc)),
+                    ("count", torch.int32, (B,)), ("trials", torch.int32, (B,)))
+            off, items = 0, []
+            for name, dt, sh in spec:
+                n = int(np.prod(sh)) * (8 if dt == torch.float64 else 4)
+                items.append((name, dt, sh, off, n))
+                off += (n + 15) // 16 * 16
+            lay = cls._LAYOUTS[key] = (off, items)
+        return lay
+
     def __init__(self, B, nb, maxc, device):
         self.maxc = maxc
-        spec = (("p_out", torch.float64, (B, nb, 3)), ("c_pen", torch.float64, (B, maxc)), ("max_pen", torch.float64, (B,)),
-                ("dt_used", torch.float64, (B,)), ("c_n", torch.float32, (B, maxc, 2)), ("c_p1", torch.float32, (B, maxc, 2)),
-                ("c_p2", torch.float32, (B, maxc, 2)), ("c_i1", torch.int32, (B, maxc)), ("c_i2", torch.int32, (B, maxc)),
-                ("count", torch.int32, (B,)), ("trials", torch.int32, (B,)))
-        size = lambda dt, shape: (int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() + 15) // 16 * 16
-        backing = torch.zeros(sum(size(dt, sh) for _, dt, sh in spec), dtype=torch.uint8, device=device)
-        off = 0
-        for name, dt, sh in spec:
-            n = int(np.prod(sh)) * torch.empty((), dtype=dt).element_size()
-            setattr(self, name, backing[off:off + n].view(dt).view(*sh))
-            off += size(dt, sh)
+        total, items = self._layout(B, nb, maxc)
+        backing = torch.zeros(total, dtype=torch.uint8, device=device)
+        for name, dt, sh, off, n in items:
+            setattr(self, name, backing[off:off + n].view(dt).view(sh))
 
 
 def move_and_find_contacts(geom, p_start, v, dt, maxc=16, eps=EPSILON, tol=TOL, strict=True, dt_floor=None,
