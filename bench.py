@@ -281,7 +281,10 @@ class HipStackWorkload:
         G, A = self.lcp[2], self.lcp[4]
         self.sol = lcp_solve(*self.lcp, compute=args.compute)
         self.grads = lcp_backward(self.sol, self.cot)
-        self.step_out = fused_step(self.sc, compute=args.compute) if args.mode == "fused" else None
+        # the timed step asks for what the reference's step returns - new_v (and the moved pose): engines.py:76-77, bodies.py:80-82; the
+        # multipliers stay in the workspace for the backward (fp64).  host_side_checks() repeats the call WITH z, s for the parity object
+        # and requires its new_v / iteration counts to be bitwise those of the timed call.
+        self.step_out = fused_step(self.sc, compute=args.compute, multipliers=False) if args.mode == "fused" else None
         torch.cuda.synchronize()
         # (the output buffers and the workspace are re-used every step, so the handle the backward takes is built once)
         self.step_sol = solution_of_step(self.sc, self.step_out, G, A, compute=args.compute) if args.mode == "fused" else None
@@ -408,8 +411,10 @@ class HipStackWorkload:
                 roof["bwd"]["traffic_source"] = btj["source"]
         return {
             "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
-                                   "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s"
-                                   % (cfg, B, nc, a.nbox, a.pts, nz, m, e, what, a.mode, "none" if a.fwd_only else a.bwd),
+                                   "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s%s"
+                                   % (cfg, B, nc, a.nbox, a.pts, nz, m, e, what, a.mode, "none" if a.fwd_only else a.bwd,
+                                      "; step outputs: new_v and the moved pose (engines.py:76-77, bodies.py:80-82), multipliers kept in the "
+                                      "workspace in fp64" if a.mode == "fused" else ""),
                        "mean_pdipm_iters": float(iters.mean()), "nonzero_status": int((st != 0).sum()),
                        "status_bits": {name: int(((st & bit) != 0).sum()) for name, bit in
                                        (("singular_Q", 1), ("singular_S11", 2), ("singular_T", 4), ("nan", 8), ("truncated", 16))}},
@@ -423,10 +428,22 @@ class HipStackWorkload:
         x_gpu = self.sol.x if a.mode == "dense" else -self.step_out["v_new"].reshape(B, nz)
         dp_gpu = None if (a.fwd_only or a.bwd == "physical") else self.grads[1]
         src = self.sol if a.mode == "dense" else None
-        z_gpu = src.z if src is not None else self.step_out["z"]
-        s_gpu = src.s if src is not None else self.step_out["s"]
+        if src is None:
+            # the same call with the multipliers written out (the timed one keeps them in the workspace only)
+            from lcp_physics_amd.physics import fused_step
+            chk = fused_step(self.sc, compute=a.compute)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(chk["v_new"], self.step_out["v_new"]) and torch.equal(chk["iters"], self.step_out["iters"])
+                        and torch.equal(chk["p_new"], self.step_out["p_new"]))
+            if not same:
+                raise SystemExit("bench.py: the step with multipliers differs from the timed step")
+        z_gpu = src.z if src is not None else chk["z"]
+        s_gpu = src.s if src is not None else chk["s"]
         it_gpu = src.iters if src is not None else self.step_out["iters"]
         out["parity"] = parity_vs_oracle(self.lcp, self.cot_cpu, x_gpu, z_gpu, s_gpu, it_gpu, dp_gpu)
+        if src is None:
+            out["parity"]["multipliers"] = ("z, s of a repeat of the timed call that writes them out (the timed step returns new_v and the pose "
+                                            "only, as the reference's step does); new_v, pose and iteration counts of the two calls: bitwise equal")
         return out
 
 

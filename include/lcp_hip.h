@@ -150,7 +150,9 @@ int lcp_assemble_contacts_f32(int B, int nb, int nc, int e,
  * integrator p <- p + new_v dt of Body.move (physics/bodies.py:80-82).  Dense LCP data
  * never leaves the chip.  Leaves the same workspace as the forward so that
  * lcp_pdipm_backward_f32 can follow (with G from lcp_assemble_contacts_f32).
- *   out: v_new[B,nb,3]  p_new[B,nb,3]  z[B,m]  s[B,m]  y[B,e]  iters[B]  status[B] */
+ *   out: v_new[B,nb,3]  p_new[B,nb,3]  z[B,m]  s[B,m]  y[B,e]  iters[B]  status[B]
+ *        z, s, y may be NULL: the multipliers are then not written out (the reference's step returns new_v only, engines.py:76-77;
+ *        the backward reads them, in fp64, from the workspace either way). */
 int lcp_step_fused_f32(int B, int nb, int nc, int e,
                        const float* pos, const float* Mdiag, const float* v, const float* f,
                        const float* rest, const float* fric,

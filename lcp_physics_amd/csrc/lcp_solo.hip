@@ -301,7 +301,6 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     jcq[JJ] = okc ? GL[l16 * 16 + (okc ? col : 0)] : (TI)0; jtq[JJ] = okc ? GTL[l16 * 16 + (okc ? col : 0)] : (TI)0;
   });
   const TC qd = (l16 < nz) ? (TC)Md[l16] : (TC)0;
-  const TC qid = (l16 < nz) ? (TC)1 / (TC)Md[l16] : (TC)0;
   const TC p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16 < nz ? l16 : 0], vv[l16 < nz ? l16 : 0], (TI)SP.dt, ff[l16 < nz ? l16 : 0]) : (TC)0;   // engines.py:32
   // F z of the contact structure (engines.py:69-73) with the contact's gathered multipliers: (F z)_comp = fn z_n + f1 (z_f1 + z_f2) + fg z_g
   const TC fzn = c3 ? mu_c : (TC)0, fz12 = c3 ? (TC)-1 : (TC)0, fzg = (c1 || c2) ? (TC)1 : (TC)0;
@@ -325,7 +324,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   if (c0 && vc) W.meta[1 + l16] = mu_c;
   int status = truncated;
   if (row_any(l16 < nz && !(qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
-  if (c0) { W.Qit[l16] = qid; W.Qit[128 + l16] = qd; }
+  if (c0) W.Qit[128 + l16] = qd;                                    // (Q's diagonal: the backward takes the reciprocals itself)
 
   // ---- state: x-space entry l16 (replicated in the rows), m-space scalar of (comp, contact)
   TC x = 0, y = 0, s = 1, z = 1, dinv = 1;

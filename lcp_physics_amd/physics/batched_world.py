@@ -98,12 +98,15 @@ def _on_device(dev):
 _SCENE_FIELDS = ("p", "Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2", "c_i1", "c_i2")
 
 
-def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=None):
+def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=None,
+               multipliers=True):
     """One fused simulation step for every scene of `sc` (float32 CUDA `SceneBatch`).
 
     Returns a dict with v_new, p_new [B,nb,3], z, s [B,4nc], y [B,e], iters, status [B] and the
     workspace `ws` (re-usable; it also feeds `lcp_backward`).  `pinned`: the equality rows of every scene pin the leading
-    coordinates (`LCP_HINT_PINNED`: one launch less); None = checked once per SceneBatch on the host.
+    coordinates (`LCP_HINT_PINNED`: one launch less); None = checked once per SceneBatch on the host.  `multipliers=False`: z, s (and
+    y) are not written out - the reference's step returns new_v only (`engines.py:76-77`; its multipliers stay inside the op for the
+    backward, here: in fp64 in the workspace) - which saves the step a third of its HBM writes.
     Calling it again with the `out` / `ws` it returned and the same tensors re-uses the validated argument list (the host side of
     a step is then one ctypes call: at small batches the step is otherwise bound by this wrapper, not by the GPU)."""
     lib = _lib.load()
@@ -126,8 +129,8 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     if out is None:
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        out = {"v_new": new(B, nb, 3), "p_new": new(B, nb, 3), "z": new(B, m), "s": new(B, m),
-               "y": new(B, e) if e else None,
+        out = {"v_new": new(B, nb, 3), "p_new": new(B, nb, 3), "z": new(B, m) if multipliers else None,
+               "s": new(B, m) if multipliers else None, "y": new(B, e) if (e and multipliers) else None,
                "iters": torch.empty(B, dtype=torch.int32, device=dev),
                "status": torch.empty(B, dtype=torch.int32, device=dev)}
     out["ws"] = ws
