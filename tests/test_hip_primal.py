@@ -81,7 +81,7 @@ def test_forward_matches_the_oracle_on_piles():
         assert ex <= 1e-5, (k, n, ex)
 
 
-@pytest.mark.parametrize("kind", ["pile", (6, 4), (8, 4), (11, 1), (11, 2), (12, 2)])
+@pytest.mark.parametrize("kind", ["pile", (6, 4), (8, 4), (9, 2), (11, 1), (11, 2), (12, 2)])     # free coordinates: 30 | 18, 24 -> 24 columns | 27 -> 32 | 33, 33, 36 -> 40
 def test_pinned_form_matches_the_general_form(kind):
     """LCP_HINT_PINNED on the one-wave-per-scene sizes (`lcp_primal_pin.hip`): the free coordinates' system (nz - neq pivots: 30
     instead of 36 on the piles of BASELINE config 5) against the full KKT system of `lcp_primal.hip` - same iterates up to
