@@ -3,11 +3,15 @@
 // post-stabilisation): constants, the workspace layout, small device helpers.
 #pragma once
 #include "lcp_wave_scene.h"
+#include "lcp_quad_prims.h"      // (row_newbcast moves and fused multiply-adds for the lane-grid LU of the pinned form)
 
 #ifndef LCP_PRIMAL_OCC40
 #define LCP_PRIMAL_OCC40 2     // wavefronts per SIMD the 40-column instantiations are allocated for (A/B: 1 = no scratch, one wave per SIMD)
 #endif
 
+#ifndef LCP_PRIMAL_GRIDLU
+#define LCP_PRIMAL_GRIDLU 1    // pinned form, <= 32 columns: LU on a 4 x 16 lane grid (pivot rows by row_newbcast) instead of row per lane (v_readlane) - 1: backward kernels, 2: forward too, 0: none (A/B)
+#endif
 #ifndef LCP_PRIMAL_CPERM
 #define LCP_PRIMAL_CPERM 1     // 1: contact 4 (lane % 16) + lane / 16 on a lane (neighbours in the list -> different 16-lane rows); 0: contact = lane (A/B)
 #endif
@@ -39,6 +43,16 @@ constexpr int ZO = WsLayout::ZO;     // offset of z in the iterate block
 
 // keeps a wave-uniform value in scalar registers at this point (the batches of pivot-row broadcasts stay batches)
 __device__ __forceinline__ void sgpr_pin(double& v) { asm volatile("" : "+s"(v)); }
+// a double of DPP row R to the same lane of all four rows: copies through v_permlane16_swap / v_permlane32_swap (gfx950)
+template <int R> __device__ __forceinline__ double rows_bcast(double x) {
+  auto one = [](uint32_t v) -> uint32_t {
+    auto s16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // -> [v0 v0 v2 v2] and [v1 v1 v3 v3] (by row)
+    const uint32_t h = (R & 1) ? s16[1] : s16[0];
+    auto s32 = __builtin_amdgcn_permlane32_swap(h, h, false, false);     // -> [h0 h1 h0 h1] and [h2 h3 h2 h3]
+    return (R & 2) ? s32[1] : s32[0];
+  };
+  return __hiloint2double((int)one((uint32_t)__double2hiint(x)), (int)one((uint32_t)__double2loint(x)));
+}
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);     // ds_add_f64 (no return)
 }
