@@ -58,7 +58,9 @@ extern "C" {
 /* May be OR-ed into the `compute` argument of the contact-list forwards (lcp_step_fused_f32, lcp_solve_dynamics_f32): the caller
  * asserts that the equality rows of EVERY scene pin the leading coordinates - Je = [I 0], the TotalConstraint that fixes the floor of
  * the reference's demo worlds (physics/constraints.py:175-192) - or that there are none.  The four-scenes-per-wave family then skips
- * the launch that serves scenes with other equality rows (it finds nothing to do on such batches and costs 2-5 us).  A scene that
+ * the launch that serves scenes with other equality rows (it finds nothing to do on such batches and costs 2-5 us); the
+ * one-wave-per-scene family (17..64 contacts) forms and factors the free coordinates' system only (three pinned rows: 30 pivots
+ * instead of 36 on BASELINE config 5).  The word travels with the op: the backward entry points take the same hint.  A scene that
  * breaks the promise is NOT solved: its new velocities are NaN and LCP_ST_NAN is set. */
 #define LCP_HINT_PINNED 0x20000
 /* OR-ed into the `compute` argument of lcp_workspace_bytes by callers of the fp64-I/O entry points (lcp_pdipm_forward_f64 /
