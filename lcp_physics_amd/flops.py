@@ -56,6 +56,20 @@ def flops_forward_executed_body_space(nz, nc, e, it, pinned=True, trimmed=None):
     return Fk + S + it * I
 
 
+def flops_forward_executed_primal(nz, nc, e, it, pinned=True):
+    """FLOPs the one-wave-per-scene body-space kernel executes per scene (lcp_primal_step.inc).  Its formation is SPARSE - every
+    contact adds its 6 x 6 block (two bodies) to the matrix image: 12 products for the two rows P = B [jc; jt], then 3 per entry -,
+    the LU runs over the nz - e free coordinates in the pinned form (nz + e otherwise); per KKT solve: J^T w and J v over the
+    contact's six entries, the two sweeps, two closed-form 4 x 4 block inverses (~30 each); per iteration one factorisation, two
+    solves, the residuals (one J^T w, one J v, ~30 per contact) and the step lengths (~100 per contact: 20 divisions)."""
+    n = (nz - e) if pinned else (nz + e)
+    Fk = nc * (12 + 36 * 3 + 30) + (2.0 / 3) * n ** 3
+    S = nc * (6 * 3 + 6 * 4 + 60) + 2 * n * n
+    Rk = nc * (6 * 3 + 6 * 4 + 30) + 2 * nz
+    I = Fk + 2 * S + Rk + 100 * nc
+    return Fk + S + it * I
+
+
 def flops_backward_executed_body_space(nz, nc, e, refine=2, pinned=True):
     """The body-space backward solve (lcp_quad.hip bwd_solve_body): one formation + LU, 1 + `refine` KKT solves and the residual
     products of the refinement steps; the outer products of lcp.py:52-61 are counted with the dense gradient sizes."""

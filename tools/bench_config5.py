@@ -3,7 +3,7 @@ generic kernels on a few scenes and timed.   python tools/bench_config5.py [B]""
 import sys, time
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lcp_physics_amd import _lib, scenes
+from lcp_physics_amd import _lib, flops, scenes
 from lcp_physics_amd.physics.batched_world import solve_dynamics, rows_pin_leading_coordinates
 from lcp_physics_amd.physics.contacts import ContactBuffers
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -73,6 +73,9 @@ print(json.dumps({"metric": "sim steps/s, BASELINE config 5 (batch x 64 contacts
                   "value": B / dt, "unit": "sim steps/s", "batch": B, "ms_per_step": dt * 1e3,
                   "backward_ms": dtb * 1e3, "fwd_bwd_value": B / (dt + dtb),
                   "mean_pdipm_iters": float(out["iters"].float().mean()), "max_abs_diff_vs_generic_kernels": float(d),
+                  "executed_flops_per_scene": flops.flops_forward_executed_primal(3 * sc.nb, sc.nc, 3, float(out["iters"].float().mean()), PINNED),
+                  "frac_of_fp64_vector_peak": flops.flops_forward_executed_primal(3 * sc.nb, sc.nc, 3, float(out["iters"].float().mean()), PINNED) * B / dt / 78.6e12,
+                  "algorithmic_flops_per_scene_survey_8d": flops.flops_forward(3 * sc.nb, 4 * sc.nc, 3, float(out["iters"].float().mean())),
                   "kernel": "lcp::big::lcp_big_kernel<64> (contact space, 128 x 128: blocked LU, trailing updates on v_mfma_f64_16x16x4_f64)"
                             if len(sys.argv) > 2 and sys.argv[2] == "big" else
                             ("lcp::primal::lcp_primal_kernel<32, ..., PIN> (body space, the 30 free coordinates' system, one wave per scene; LCP_HINT_PINNED)"
