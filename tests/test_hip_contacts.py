@@ -1233,3 +1233,31 @@ def test_state_update_backward_matches_autograd():
                 assert torch.equal(got[k], t.grad)
         if with_joints:
             assert torch.equal(got[2], rot2.grad)
+
+
+@pytest.mark.parametrize("post_stab", [False, True])
+def test_plain_steps_after_differentiable_steps_match_plain_steps(post_stab):
+    """A differentiable step runs the kernels of a plain step (the state update is the kernels' own output, `_StateUpdate`), and the
+    plain steps that follow it must not hand autograd-owned storage to a kernel as an output slot: 3 differentiable + 3 plain
+    steps against 6 plain steps, bitwise, and the gradient of the third pose is still intact afterwards."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    B = 16
+    w = scenes.make_drop_world(B, nbox=4, box=40.0, seed=3)
+    geom = _geom([w["shapes"]] * B)
+    g = lambda k: w[k].to(DEV)
+    mk = lambda: ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=16, post_stab=post_stab)
+    a, b = mk(), mk()
+    b.f = b.f.clone().requires_grad_(True)
+    for _ in range(6):
+        a.step()
+    for _ in range(3):
+        b.step(differentiable=True)
+    p3 = b.p
+    for _ in range(3):
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.p, b.p.detach()) and torch.equal(a.v, b.v.detach()) and torch.equal(a.t, b.t)
+    assert torch.equal(a.contacts.count, b.contacts.count)
+    p3.sum().backward()                                  # the graph of the differentiable steps was not disturbed
+    assert bool(torch.isfinite(b.f.grad).all()) and float(b.f.grad.abs().max()) > 0
