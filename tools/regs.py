@@ -4,7 +4,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
 f = sys.argv[1]
-extra = sys.argv[2:] + (["-fno-slp-vectorize"] if f == "lcp_quad.hip" else [])
+extra = sys.argv[2:] + (["-fno-slp-vectorize"] if (f.startswith("lcp_quad") or f == "lcp_solo.hip") and "-fslp-vectorize" not in sys.argv else [])   # (the Makefile's flags for these units)
 obj = os.path.join(CSRC, f.replace(".hip", ".o")) if "--keep" in extra else "/dev/null"
 extra = [x for x in extra if x != "--keep"]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-Wall",
