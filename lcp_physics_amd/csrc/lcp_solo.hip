@@ -464,6 +464,12 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
     const TC az = -zv / dz, as = -sv / ds;
     const uint32_t nz_ = key_is_nan<TC>(nan_key(az)) ? 1u : 0u, ns_ = key_is_nan<TC>(nan_key(as)) ? 2u : 0u;
+    {
+      // the fill max(1, a.max()) is at least every entry: with an entry it does not replace (dv <= 0) in both vectors and no NaN,
+      // a.min() is the minimum over those entries - no maxima needed (lcp_quad_kernels.inc, step_pair_q: same value bit for bit)
+      const uint32_t f = wave_or(vc ? ((!(dz > (TC)0) ? 1u : 0u) | (!(ds > (TC)0) ? 2u : 0u) | ((nz_ | ns_) ? 4u : 0u)) : 0u);
+      if (f == 3u) return wave_fmin(vc ? fmin_((dz > (TC)0) ? pinf : az, (ds > (TC)0) ? pinf : as) : pinf);
+    }
     const uint32_t kf = wave_or(vc ? (nz_ | ns_) : 0u);                    // a.max(): NaN if any entry is NaN ...
     TC mz = vc ? az : ninf, ms = vc ? as : ninf;
     wave_fmax2(mz, ms);
