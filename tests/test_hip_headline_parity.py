@@ -114,3 +114,29 @@ def test_timed_kernel_full_batch_properties_configs2():
     assert float(ex.max()) <= 1e-5, float(ex.max())
     d = (a["iters"] - sol.iters).abs()
     assert int(d.max()) <= 2
+
+
+@pytest.mark.parametrize("path,nbox", [("quad", 4), ("quad", 2), ("solo", 4), ("auto", 10)])
+def test_a_nan_scene_takes_the_general_step_length_form_and_leaves_its_neighbours_alone(path, nbox):
+    """`get_step` (pdipm.py:182-186) runs without the fill's reductions wherever the fill cannot be the minimum; a NaN among the
+    quotients sends the whole wavefront to the general form (a uniform branch).  One poisoned scene per batch: it reports
+    LCP_ST_NAN, and every other scene - in the four-scenes-per-wave kernel three of them share its wavefront and take the general
+    form with it - returns bit for bit what it returns in a clean batch."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics import fused_step
+    B, bad = 64, 21
+    mk = (lambda: scenes.make_pile_scenes(B=B, seed=9, dtype=torch.float32)) if nbox == 10 else \
+         (lambda: scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=4, seed=77, dtype=torch.float32))
+    sc = mk()
+    clean = fused_step(sc.to(device=DEV), path=path)
+    sc2 = mk()
+    sc2.v = sc2.v.clone()
+    sc2.v[bad, 1, 1] = float("nan")
+    dirty = fused_step(sc2.to(device=DEV), path=path)
+    torch.cuda.synchronize()
+    assert int(dirty["status"][bad]) & 8
+    keep = torch.ones(B, dtype=torch.bool)
+    keep[bad] = False
+    keep = keep.to(DEV)
+    for k in ("v_new", "z", "s", "iters", "status"):
+        assert torch.equal(clean[k][keep], dirty[k][keep]), k
