@@ -795,7 +795,9 @@ class ContactWorld:
         if getattr(self, "_autograd_owned", False):
             # the state tensors are outputs of the autograd graph (their storage belongs to the retired contact buffers of the last
             # differentiable step): the double buffering below must not hand them to a kernel as an output slot
+            # - and the contact buffers of the last differentiable step (dt_used, the accepted pose) are saved in that graph
             self.p, self.v, self._autograd_owned = self.p.detach().clone(), self.v.detach().clone(), False
+            self.contacts = self.contacts.clone()
         self._phase ^= 1
         cb = self.contacts
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()

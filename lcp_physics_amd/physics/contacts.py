@@ -98,9 +98,22 @@ class ContactBuffers:
     def __init__(self, B, nb, maxc, device):
         self.maxc = maxc
         total, items = self._layout(B, nb, maxc)
-        backing = torch.zeros(total, dtype=torch.uint8, device=device)
+        self._carve(torch.zeros(total, dtype=torch.uint8, device=device), items)
+
+    def _carve(self, backing, items):
+        self._backing, self._dims = backing, None
         for name, dt, sh, off, n in items:
             setattr(self, name, backing[off:off + n].view(dt).view(sh))
+
+    def clone(self):
+        """A copy in storage of its own (one device copy): what a world keeps when the original became part of an autograd graph."""
+        B, nb = self.p_out.shape[0], self.p_out.shape[1]
+        new = ContactBuffers.__new__(ContactBuffers)
+        new.maxc = self.maxc
+        new._carve(self._backing.clone(), self._layout(B, nb, self.maxc)[1])
+        if self.p_out.data_ptr() != self._backing.data_ptr():          # (ContactWorld.step swaps p_out with its pose buffer)
+            new.p_out = self.p_out.clone()
+        return new
 
 
 def move_and_find_contacts(geom, p_start, v, dt, maxc=16, eps=EPSILON, tol=TOL, strict=True, dt_floor=None,
