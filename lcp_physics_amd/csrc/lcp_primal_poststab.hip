@@ -195,6 +195,12 @@ __global__ void __launch_bounds__(64, (NCOL <= 40 ? 2 : 1)) lcp_poststab_primal_
   auto step_pair = [&](double z, double dz, double s, double ds) -> double {
     const double ninf = -inf_of<double>(), pinf = inf_of<double>();
     const double az = -z / dz, as = -s / ds;
+    {
+      // (lcp_primal_step.inc: the fill cannot be the minimum where both vectors keep an entry and nothing is NaN - same value)
+      const bool nn = key_is_nan(umax(nan_key(az), nan_key(as)));
+      const uint32_t fz_ = wave_umax(vc ? (nn ? 8u : (!(dz > 0.0) ? 1u : 0u)) : 0u), fs_ = wave_umax((vc && !(ds > 0.0)) ? 1u : 0u);
+      if (fz_ == 1u && fs_ == 1u) return wave_min(vc ? __builtin_fmin((dz > 0.0) ? pinf : az, (ds > 0.0) ? pinf : as) : pinf);
+    }
     const uint32_t kmz = wave_umax(vc ? nan_key(az) : 0u), kms = wave_umax(vc ? nan_key(as) : 0u);
     const double mz = wave_max(vc ? az : ninf), ms = wave_max(vc ? as : ninf);
     const double fz = key_is_nan(kmz) ? 1.0 : __builtin_fmax(mz, 1.0), fs = key_is_nan(kms) ? 1.0 : __builtin_fmax(ms, 1.0);
