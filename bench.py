@@ -8,7 +8,15 @@ step   : one pass of the hot path over one batch of synthetic scenes already res
          new velocities and poses) + lcp_pdipm_backward_f32, for B = 4096 scenes per GPU (floor + 4-box
          stack, 4 contact points per interface: nz 15, nineq 64, neq 3).  `--mode dense` times the dense
          LCPFunction boundary instead (lcp_pdipm_forward_f32 on pre-assembled (Q,p,G,h,A,b,F) + backward).
-N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling, config 4 = 8 x 4096); no
+         `--config N` selects BASELINE.json `configs[N]`: 1 = 1024 x 8 forward only, 2 = the default (the config the
+         metric is quoted on), 3 = 32768 x 16 over the ranks, 4 = 4096 x 64 contacts (the ten-box pile, nineq 256:
+         lcp_step_fused_f32 -> lcp_primal_kernel<30, ..., PIN>, backward lcp_step_backward_f32 - gradients w.r.t. the
+         physical inputs; the dense gradients of a 256-row LCP are 302 KB per scene and no world asks for them).
+launch : the forward + backward pair of one step is captured ONCE into a HIP graph (the library is capture-safe: it
+         launches on the caller's stream and keeps no host state) and the timed region replays it K times
+         (`--launch graph`, the default; `config.launch` says so).  `eager_ms_per_step` = the same K steps issued as two
+         ctypes calls per step.
+N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling, config 3 = 8 x 4096); no
          collective on the solve path - torch.distributed (RCCL) is only used for the barriers and the
          MAX-over-ranks wall time.  `python bench.py --gpus N` started WITHOUT a launcher starts the N ranks
          itself (torch.distributed.run on 127.0.0.1, one per visible device) and refuses when fewer than N
@@ -17,23 +25,30 @@ N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling,
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      - dominant kernel (the forward PDIPM kernel).  `achieved` / `frac` = the FLOPs the kernel really EXECUTES
-                  (lcp_physics_amd/flops.py: body-space system of the pinned variant - formation + LU of nz - neq rows per
-                  iteration, two KKT solves, residuals - with the iteration counts the kernel reports) divided by its average
-                  launch duration, measured with HIP events on the launch stream inside the timed region, over the FP64 VECTOR
-                  rate (the kernel issues no MFMA: `bound` says "valu_fp64").  `frac_algorithmic` = SURVEY.md §8d's count of
-                  the REFERENCE's dense formulation over the same time and peak: it exceeds 1 because the kernel factors
-                  nz - neq = 12 rows where the reference factors nineq = 64 - a different algorithm with the same answers,
-                  not an efficiency.  `insts_per_useful_fma` cross-checks the executed model against the SQ_INSTS_VALU counter;
-                  `traffic` = HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE counters; counters and registers are
-                  quoted from the committed rocprofv3 / compiler reports under profiles/ (bench.py cannot run --pmc itself).
-                  `roofline.bwd` = the backward kernel against the HBM roofline (it is bound by the 21.6 KB of dense
-                  gradients it writes per scene): `achieved` = measured traffic (else algorithmic bytes) / its event time.
+                  (lcp_physics_amd/flops.py, with the iteration counts the kernel reports) divided by its average launch
+                  duration - HIP events on the launch stream around >= 128 eager launches right after the timed region
+                  (`event_timed_steps`; events inside the timed region would cost the stream 2-3 us each) - over the FP64
+                  VECTOR rate (the kernels issue no MFMA: `bound` says "valu_fp64").  `frac_necessary` = the same with the
+                  formation counted SPARSE (a contact touches two bodies: 6 x 6 block): what a kernel that multiplied no
+                  structural zero would execute.  `frac_algorithmic` = SURVEY.md §8d's count of the REFERENCE's dense
+                  formulation over the same time and peak: it exceeds 1 because the kernel factors nz - neq rows where the
+                  reference factors nineq - a different algorithm with the same answers, not an efficiency.
+                  `insts_per_useful_fma` cross-checks the executed model against the SQ_INSTS_VALU counter; `traffic` = HBM
+                  bytes per launch from the FETCH_SIZE / WRITE_SIZE counters; counters and registers are quoted from the
+                  committed rocprofv3 / compiler reports under profiles/ (bench.py cannot run --pmc itself).
+                  `roofline.bwd` = the backward kernel: the dense backward against the HBM roofline (it is bound by the
+                  21.6 KB of dense gradients it writes per scene), the physical one against the FP64 vector rate.
+  companions    - (rank 0, N = 1) the same workload timed three more ways, K steps each: `eager` (two ctypes launches per step),
+                  `general_kernel` (lcp_solve_dynamics_f32 with a contact count per scene: the instantiation a ContactWorld
+                  gets) and `with_multipliers` (z, s, y written out every step: the form rounds 1 and 2 timed).
   cpu_baseline  - the oracle (a port, torch CPU fp64) timed on this host's cores on the same workload (rank 0,
-                  N=1 only);  cpu_reference - the UNMODIFIED reference timed in the build container
-                  (profiles/r01_reference_cpu_timing.json; /root/reference does not exist on the GPU box).
+                  N=1 only);  cpu_reference - the UNMODIFIED reference's own timing of the workload (newest
+                  profiles/r*_reference_cpu_timing.json; /root/reference does not exist on the GPU box).
+  parity        - the metric's second half: tests/parity.py::headline_report on 512 scenes sampled over the batch.
   sustained     - the same step repeated for >= 1 s after the timed region (independent evidence of GPU work).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -44,7 +59,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-EVENT_STRIDE = 8
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X FP64 / FP32 vector = matrix rates (datasheet; MI355X_MICROARCH.md lists FP32)
 HBM_PEAK_GBS = 8000.0
 
@@ -56,51 +70,71 @@ def parse(argv=None):
     # timed region of ~40 ms; the whole default run still takes seconds
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=4096, help="scenes per GPU")
-    ap.add_argument("--nbox", type=int, default=4)
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[N]: sets --batch / --nbox / --pile / --fwd-only (2 = the default run)")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default 4096)")
+    ap.add_argument("--nbox", type=int, default=None)
     ap.add_argument("--pts", type=int, default=4)
+    ap.add_argument("--pile", action="store_true", help="BASELINE configs[4]: the ten-box pyramid, 64 contacts (nz 33, nineq 256)")
     ap.add_argument("--compute", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default="fused", choices=["dense", "fused"])
-    ap.add_argument("--bwd", default="dense", choices=["dense", "physical"],
+    ap.add_argument("--bwd", default=None, choices=["dense", "physical"],
                     help="backward timed in the step: 'dense' = LCPFunction.backward (7 dense gradients, lcp.py:37-64); "
-                         "'physical' (fused mode only) = lcp_step_backward_f32, gradients w.r.t. the physical inputs")
+                         "'physical' (fused mode only) = lcp_step_backward_f32, gradients w.r.t. the physical inputs "
+                         "(default: dense for the stacks, physical for the pile)")
     ap.add_argument("--fwd-only", action="store_true",
                     help="time the forward only (BASELINE configs[1] is forward-only); the default is the headline fwd+bwd")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="how the timed region issues a step: one replay of a captured HIP graph (fwd + bwd), or two eager launches")
+    ap.add_argument("--event-samples", type=int, default=128, help="eager launches bracketed by HIP events for roofline.kernel_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of the untimed sustained loop after the timed steps (0 = off)")
     ap.add_argument("--share-devices", action="store_true",
                     help="TESTING AID: let several ranks use one GPU (gloo instead of RCCL); the line then says devices_used < n_gpus")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.config == 1:
+        a.batch, a.nbox, a.fwd_only = a.batch or 1024, a.nbox or 2, True
+    elif a.config == 3:
+        a.batch, a.nbox = a.batch or max(1, 32768 // max(1, a.gpus)), a.nbox or 4
+    elif a.config == 4:
+        a.pile = True
+    a.batch = a.batch or 4096
+    if a.pile:
+        a.nbox, a.pts = 10, 4
+        if a.mode != "fused":
+            raise SystemExit("bench.py: --pile runs the contact-list entry points (--mode fused)")
+        if a.bwd == "dense":
+            raise SystemExit("bench.py: the pile's backward is lcp_step_backward_f32 (--bwd physical)")
+        a.bwd = "physical"
+    a.nbox = a.nbox or 4
+    a.bwd = a.bwd or "dense"
+    return a
 
 
 # ------------------------------------------------------------------------------------------------ rank protocol
-def timed_steps(work, steps, warmup, sync, reduce_dev):
+def timed_steps(work, steps, warmup, sync):
     """The contract's timing rule: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier +
-    device synchronisation on both sides; returns the MAX wall time over the ranks and the per-step events."""
+    device synchronisation on both sides.  Returns (this rank's wall time incl. the closing barrier, its own wall time before it
+    waits for the others).  Nothing but `work.step()` runs inside the timed region (no event records)."""
     from lcp_physics_amd import shard
     for _ in range(warmup):
         work.step()
-    # HIP events bracket the kernels of every EVENT_STRIDE-th timed step only: an event record is a packet of its own in the queue
-    # and costs the stream 2-3 us - three of them on every step were 4 % of the headline step and 15 % of a configs[1] step
-    # (never the first timed step: the queue is empty after the barrier, and the gap between its event record and the arrival of its
-    #  first launch would be booked as kernel time - 0.089 against 0.068 ms measured on the headline)
-    sampled = set(range(EVENT_STRIDE - 1, steps, EVENT_STRIDE)) or {steps - 1}
-    events = [work.new_events() if k in sampled else None for k in range(steps)]
     sync()
     shard.barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
-        work.step(events[k])
+    for _ in range(steps):
+        work.step()
     sync()
     own = time.perf_counter() - t0                   # this rank's K steps, device work included, before it waits for the others
     shard.barrier()
     wall = time.perf_counter() - t0
-    return shard.max_over_ranks(wall, device=reduce_dev), events, own
+    return wall, own
 
 
 def run_rank(args, make_work, device=None):
-    """Everything one rank does.  `make_work(args, rank, device)` builds the workload (HipStackWorkload below; the CPU
+    """Everything one rank does.  `make_work(args, rank, device)` builds the workload (HipWorkload below; the CPU
     test of the N > 1 protocol passes a stand-in whose step launches nothing).  Returns the JSON object on rank 0."""
     from lcp_physics_amd import shard
     rank, local_rank, world = shard.env_rank()
@@ -114,7 +148,10 @@ def run_rank(args, make_work, device=None):
     rdev = shard.reduce_device(dev)
     sync = torch.cuda.synchronize if is_gpu else (lambda: None)
     work = make_work(args, rank, dev)
-    wall, events, own_wall = timed_steps(work, args.steps, args.warmup, sync, rdev)
+    own_wall_all, own_wall = timed_steps(work, args.steps, args.warmup, sync)
+    wall = shard.max_over_ranks(own_wall_all, device=rdev)
+    # kernel durations: HIP events around eager launches, outside the timed region
+    samples = work.sample_kernels(args.event_samples) if hasattr(work, "sample_kernels") else None
     # how many ranks really ran, and on how many distinct devices
     reported = int(round(shard.sum_over_ranks(1.0, device=rdev)))
     dev_index = torch.device(dev).index or 0
@@ -154,7 +191,7 @@ def run_rank(args, make_work, device=None):
         "dtype": args.compute,
         "data": "synthetic",
     }
-    rep_ = work.report(events, world)                 # (every rank: its own kernel timings go into `per_rank`)
+    rep_ = work.report(samples, world)                # (every rank: its own kernel timings go into `per_rank`)
     out.update(rep_)
     # per-rank record, so that an N > 1 line can be audited rank by rank: this rank's own wall clock over the timed region (the
     # metric uses the MAX) and its event-timed kernel durations
@@ -170,6 +207,8 @@ def run_rank(args, make_work, device=None):
         out["devices_used"] = devices_used
     if sustained is not None:
         out["sustained"] = sustained
+    if rank == 0 and world == 1 and not args.no_companions and hasattr(work, "companions"):
+        out.update(work.companions(sync))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.update(work.host_side_checks())
     elif rank == 0:
@@ -199,9 +238,11 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
             O.lcp_backward(sol, *lcp, cot[:n].double())
         return time.perf_counter() - t0
 
-    run(32)                                             # warm-up
-    cal = run(128)
-    sample = int(max(128, min(sc_cpu.B, 128 * budget_s / max(cal, 1e-3))))
+    big = sc_cpu.nc > 32                                # (the piles: 256 x 256 dense systems per scene)
+    run(8 if big else 32)                               # warm-up
+    n0 = 32 if big else 128
+    cal = run(n0)
+    sample = int(max(n0, min(sc_cpu.B, n0 * budget_s / max(cal, 1e-3))))
     total, passes = 0.0, 0
     while total < budget_s * 0.66 and passes < 64:      # repeat passes over the sample up to ~10 s of CPU work
         total += run(sample)
@@ -211,41 +252,24 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
                       % (sample, passes, "forward only" if fwd_only else "fwd+bwd", total)}
 
 
-def cpu_reference_quote():
-    """The unmodified reference's own timing of this workload (build container; it cannot run on the GPU box)."""
-    path = os.path.join(ROOT, "profiles", "r01_reference_cpu_timing.json")
-    if not os.path.exists(path):
-        return None
-    j = json.load(open(path))
-    r = j["runs"][0]
-    return {"value": r["value"], "unit": r["unit"], "cores": r["cpu_threads"], "kind": "reference", "dtype": r["dtype"],
-            "machine": r.get("machine", "build container"), "what": r["what"], "workload": r["workload"],
-            "measured_in_this_run": False, "source": "profiles/r01_reference_cpu_timing.json (" + j["source"] + ")"}
-
-
-def parity_vs_oracle(lcp_gpu, cot, x_gpu, z_gpu, s_gpu, iters_gpu, dp_gpu, n=512):
-    """The metric's second half ("fwd+bwd rel-err vs ref"): the step just timed against the fp64 oracle on `n` scenes sampled
-    over the batch, on IDENTICAL inputs - the fp32 LCP data the HIP assembly produced for the kernel (all assembling kernels
-    share one contraction-free builder; tests/test_hip_parity.py::test_assembly_kernel_matches_oracle), solved by the oracle in
-    fp64.  Fields: tests/parity.py::headline_report - err_x (SURVEY 8d), contact index sets UNMASKED and on the decisive rows,
-    the histogram of iteration-count differences, dl/dp on the scenes whose backward system is well posed; the same report
-    tests/test_hip_headline_parity.py gates at configs[1] / [2] / [3]."""
-    from oracle import pdipm_oracle as O
-    from tests import parity
-    B = x_gpu.shape[0]
-    n = min(n, B)
-    idx = torch.arange(0, B, max(1, B // n))[:n]
-    di = idx.to(x_gpu.device)
-    lcp64 = [None if t is None else t[di].double().cpu() for t in lcp_gpu]
-    rep, _ = parity.headline_report(O, lcp64, x_gpu[di].cpu(), z_gpu[di].cpu(), s_gpu[di].cpu(), iters_gpu[di].cpu(),
-                                    dp=None if dp_gpu is None else dp_gpu[di].cpu(), cot=cot[idx])
-    rep["sample"] = "every %d-th scene of the batch" % max(1, B // n)
-    return rep
+def cpu_reference_quote(nc=16):
+    """The unmodified reference's own timing of this workload (it cannot run inside this process on the GPU box: /root/reference
+    is not there): the newest committed profiles/r*_reference_cpu_timing.json, the run whose workload matches."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu_timing.json")), reverse=True)
+    for path in paths:
+        j = json.load(open(path))
+        for r in j["runs"]:
+            if int(r.get("nc", 16)) != nc:
+                continue
+            return {"value": r["value"], "unit": r["unit"], "cores": r["cpu_threads"], "kind": "reference", "dtype": r["dtype"],
+                    "machine": r.get("machine", j.get("machine", "build container")), "what": r.get("what"), "workload": r.get("workload"),
+                    "measured_in_this_run": False, "source": os.path.relpath(path, ROOT) + " (" + j["source"] + ")"}
+    return None
 
 
 def _quoted(name, key):
     """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             j = json.load(open(path)).get(key)
@@ -257,88 +281,208 @@ def _quoted(name, key):
 
 
 # ------------------------------------------------------------------------------------------------ the HIP workload
-class HipStackWorkload:
-    """B stack scenes per rank resident in HBM; step = fused step kernel (or the dense operator) + backward."""
+class HipWorkload:
+    """B scenes per rank resident in HBM (4-box stacks, or the ten-box piles of configs[4]); step = fused step kernel (or the
+    dense operator) + backward, replayed from one HIP graph or issued eagerly."""
 
     def __init__(self, args, rank, dev):
         from lcp_physics_amd import scenes
         from lcp_physics_amd.lcp import lcp_backward, lcp_solve
         from lcp_physics_amd.physics import assemble_contacts, fused_step
-        from lcp_physics_amd.physics.batched_world import solution_of_step
+        from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step
         if torch.device(dev).type != "cuda":
             raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
         if args.bwd == "physical" and args.mode != "fused":
             raise SystemExit("--bwd physical needs --mode fused")
         self.args, self.rank, self.dev = args, rank, dev
+        self.pile = bool(args.pile)
         B = self.B = self.units_per_step = args.batch
-        self.nb, self.nc = args.nbox + 1, args.nbox * args.pts
-        self.nz, self.m, self.e = 3 * self.nb, 4 * self.nc, 3
         # synthetic scenes, generated on the host, then resident in HBM before any timing
-        self.sc_cpu = scenes.make_stack_scenes(B=B, nbox=args.nbox, pts_per_interface=args.pts, seed=1236 + 1000 * rank,
-                                               dtype=torch.float32)
+        if self.pile:
+            self.sc_cpu = scenes.make_pile_scenes(B=B, seed=5 + 1000 * rank, dtype=torch.float32)
+        else:
+            self.sc_cpu = scenes.make_stack_scenes(B=B, nbox=args.nbox, pts_per_interface=args.pts, seed=1236 + 1000 * rank,
+                                                   dtype=torch.float32)
+        self.nb, self.nc = self.sc_cpu.nb, self.sc_cpu.nc
+        self.nz, self.m, self.e = 3 * self.nb, 4 * self.nc, 3
         self.sc = self.sc_cpu.to(device=dev)
         g = torch.Generator().manual_seed(4321 + rank)
         self.cot_cpu = torch.randn(B, self.nz, generator=g, dtype=torch.float32)
         self.cot = self.cot_cpu.to(dev)
-        self.lcp = assemble_contacts(self.sc)   # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel
-        G, A = self.lcp[2], self.lcp[4]
-        self.sol = lcp_solve(*self.lcp, compute=args.compute)
-        self.grads = lcp_backward(self.sol, self.cot)
+        self.cot_v = (-self.cot).reshape(B, self.nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
+        self.lcp = self.sol = self.grads = self.step_sol = self.pgrads = None
+        if not self.pile:
+            # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel (the dense backward reads G and A; --mode dense solves it)
+            self.lcp = assemble_contacts(self.sc)
+            self.sol = lcp_solve(*self.lcp, compute=args.compute)
+            self.grads = lcp_backward(self.sol, self.cot)
         # the timed step asks for what the reference's step returns - new_v (and the moved pose): engines.py:76-77, bodies.py:80-82; the
         # multipliers stay in the workspace for the backward (fp64).  host_side_checks() repeats the call WITH z, s for the parity object
         # and requires its new_v / iteration counts to be bitwise those of the timed call.
         self.step_out = fused_step(self.sc, compute=args.compute, multipliers=False) if args.mode == "fused" else None
         torch.cuda.synchronize()
         # (the output buffers and the workspace are re-used every step, so the handle the backward takes is built once)
-        self.step_sol = solution_of_step(self.sc, self.step_out, G, A, compute=args.compute) if args.mode == "fused" else None
-        self.cot_v = (-self.cot).reshape(B, self.nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
-        self.pgrads = None
+        if args.mode == "fused" and not self.pile:
+            self.step_sol = solution_of_step(self.sc, self.step_out, self.lcp[2], self.lcp[4], compute=args.compute)
+        if args.bwd == "physical" and not args.fwd_only:
+            self.pgrads = fused_step_backward(self.sc, self.step_out, self.cot_v, compute=args.compute)
+        torch.cuda.synchronize()
+        self.graph = None
+        if args.launch == "graph":
+            for _ in range(3):
+                self.eager_step()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.eager_step()
+            torch.cuda.synchronize()
 
-    def new_events(self):
-        return [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-
-    def step(self, ev=None):
-        from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+    # ---- one step
+    def forward(self):
+        from lcp_physics_amd.lcp import lcp_solve
         from lcp_physics_amd.physics import fused_step
-        from lcp_physics_amd.physics.batched_world import fused_step_backward
         a = self.args
-        if ev is not None:
-            ev[0].record()
         if a.mode == "dense":
             lcp_solve(*self.lcp, compute=a.compute, ws=self.sol.ws, out=self.sol)
-            s_ = self.sol
         else:
-            self.step_out = fused_step(self.sc, compute=a.compute, ws=self.step_out["ws"], out=self.step_out)
-            s_ = self.step_sol
-        if ev is not None:
-            ev[1].record()
+            self.step_out = fused_step(self.sc, compute=a.compute, ws=self.step_out["ws"], out=self.step_out, multipliers=False)
+
+    def backward(self):
+        from lcp_physics_amd.lcp import lcp_backward
+        from lcp_physics_amd.physics.batched_world import fused_step_backward
+        a = self.args
         if a.fwd_only:
-            pass
-        elif a.bwd == "physical":
+            return
+        if a.bwd == "physical":
             self.pgrads = fused_step_backward(self.sc, self.step_out, self.cot_v, compute=a.compute, grads=self.pgrads)
         else:
-            lcp_backward(s_, self.cot, out=self.grads)
-        if ev is not None:
+            lcp_backward(self.sol if a.mode == "dense" else self.step_sol, self.cot, out=self.grads)
+
+    def eager_step(self):
+        self.forward()
+        self.backward()
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.eager_step()
+
+    def sample_kernels(self, n):
+        """HIP events on the launch stream around `n` eager forward / backward launches (the first one is dropped: the queue is
+        empty when it arrives, and the gap between its event record and the launch would be booked as kernel time)."""
+        n = max(2, n)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        torch.cuda.synchronize()
+        for ev in evs:
+            ev[0].record()
+            self.forward()
+            ev[1].record()
+            self.backward()
             ev[2].record()
+        torch.cuda.synchronize()
+        return [(ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])) for ev in evs[1:]]
+
+    def _time(self, fn, sync):
+        a = self.args
+        for _ in range(min(a.warmup, 10)):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / a.steps
+
+    def companions(self, sync):
+        """The same workload timed other ways (K steps each, this rank's clock): see the module docstring."""
+        from lcp_physics_amd.lcp import lcp_backward
+        from lcp_physics_amd.physics import fused_step
+        from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step, solve_dynamics
+        from lcp_physics_amd.physics.contacts import ContactBuffers
+        a, B = self.args, self.B
+        out = {}
+        rate = lambda dt: {"ms_per_step": dt * 1e3, "value": B / dt, "unit": "sim steps/s"}
+        if self.graph is not None:
+            dt = self._time(self.eager_step, sync)
+            out["eager_ms_per_step"] = dt * 1e3
+            out["eager_value"] = B / dt
+        if a.mode != "fused":
+            return out
+        sc = self.sc
+        # (1) per-scene contact counts: lcp_solve_dynamics_f32 - what ContactWorld.step() calls (LCP_HINT_PINNED checked on the host)
+        cb = ContactBuffers(B, self.nb, self.nc, self.dev)
+        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2
+        count = torch.full((B,), self.nc, dtype=torch.int32, device=self.dev)
+        st = {"o": None}
+
+        def sd():
+            o = st["o"]
+            st["o"] = solve_dynamics(B, self.nb, self.nc, self.e, count, sc.Mdiag, sc.v, sc.f, sc.rest, sc.fric, cb, sc.Je, sc.dt,
+                                     compute=a.compute, ws=None if o is None else o["ws"], out=o, pinned=True)
+        sd()
+        sync()
+        same = bool(torch.equal(st["o"]["v_new"], self.step_out["v_new"]))
+        if a.fwd_only:
+            gen = sd
+        elif a.bwd == "physical":
+            pg = {"g": None}
+
+            def gen():
+                sd()
+                pg["g"] = fused_step_backward(sc, st["o"], self.cot_v, compute=a.compute, grads=pg["g"])
+        else:
+            gsol = solution_of_step(sc, st["o"], self.lcp[2], self.lcp[4], compute=a.compute)
+            gg = lcp_backward(gsol, self.cot)
+
+            def gen():
+                sd()
+                lcp_backward(gsol, self.cot, out=gg)
+        r = rate(self._time(gen, sync))
+        r.update({"launch": "eager", "new_v_bitwise_equal_to_the_timed_kernel": same,
+                  "what": "lcp_solve_dynamics_f32 with c_count[B] (= the full list here) + the same backward: the run-time-count "
+                          "instantiation a ContactWorld gets"})
+        out["general_kernel"] = r
+        out["general_kernel_value"] = r["value"]
+        # (2) multipliers written out every step (z, s, y to HBM in fp32): the step rounds 1-2 timed
+        mo = {"o": fused_step(sc, compute=a.compute)}
+        msol = None if (self.pile or a.bwd == "physical" or a.fwd_only) else \
+            solution_of_step(sc, mo["o"], self.lcp[2], self.lcp[4], compute=a.compute)
+        mg = {"g": None if msol is None else lcp_backward(msol, self.cot), "p": None}
+
+        def withm():
+            mo["o"] = fused_step(sc, compute=a.compute, ws=mo["o"]["ws"], out=mo["o"])
+            if a.fwd_only:
+                return
+            if a.bwd == "physical":
+                mg["p"] = fused_step_backward(sc, mo["o"], self.cot_v, compute=a.compute, grads=mg["p"])
+            else:
+                lcp_backward(msol, self.cot, out=mg["g"])
+        r = rate(self._time(withm, sync))
+        r.update({"launch": "eager", "what": "the same step with z, s, y written out (multipliers=True)"})
+        out["with_multipliers"] = r
+        return out
 
     def metric_name(self):
         return "sim steps/sec at batch=%dx%d contacts, %s" % (self.B, self.nc, "fwd" if self.args.fwd_only else "fwd+bwd")
 
-    def report(self, events, world):
+    def report(self, samples, world):
         from lcp_physics_amd import flops
         a, B, nb, nc, nz, m, e = self.args, self.B, self.nb, self.nc, self.nz, self.m, self.e
-        events = [ev for ev in events if ev is not None]                       # (the sampled steps of the timed region)
-        fwd_ms = sum(ev[0].elapsed_time(ev[1]) for ev in events) / len(events)
-        bwd_ms = sum(ev[1].elapsed_time(ev[2]) for ev in events) / len(events)
+        fwd_ms = sum(s[0] for s in samples) / len(samples)
+        bwd_ms = sum(s[1] for s in samples) / len(samples)
         iters = (self.sol.iters if a.mode == "dense" else self.step_out["iters"]).double()
         status = (self.sol.status if a.mode == "dense" else self.step_out["status"])
         it_list = iters.cpu().tolist()
         fl_alg = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
         # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic; the stack scenes pin
-        # their floor: ALG = 2), the dense boundary the contact-space one
+        # their floor: ALG = 2), the one-wave-per-scene lcp_primal_kernel for the piles, the dense boundary the contact-space one
         body_space = a.mode == "fused" and a.compute == "f64" and nz <= 16
-        fl_exec = float(sum((flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)(nz, nc, e, it)
-                            for it in it_list))
+        primal = self.pile and a.compute == "f64"
+        model = (flops.flops_forward_executed_primal if primal else
+                 flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)
+        fl_exec = float(sum(model(nz, nc, e, it) for it in it_list))
+        fl_nec = float(sum(flops.flops_forward_executed_primal(nz, nc, e, it, True) for it in it_list)) if (body_space or primal) else None
         peak = PEAK_TFLOPS[a.compute]
         alg_bytes = (flops.bytes_fused_step(nb, nc) if a.mode == "fused" else flops.bytes_forward(nz, m, e)) * B
         key = "%s_B%d_nc%d_%s" % (a.mode, B, nc, a.compute)
@@ -348,29 +492,46 @@ class HipStackWorkload:
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
         sized = body_space and (nz, e) in flops.SIZED_SHAPES
-        rj = _quoted("kernel_resources", "lcp_fwd_solo_9_3_8" if (body_space and B <= 1024 and (nz, e, nc) == (9, 3, 8)) else
+        rj = _quoted("kernel_resources", "lcp_primal_kernel_30_pin" if primal else
+                     "lcp_fwd_solo_9_3_8" if (body_space and B <= 1024 and (nz, e, nc) == (9, 3, 8)) else
                      "lcp_fwd_quad_f64_fused_two_waves" if (sized and B > 4096) else
                      "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))   # (the variant this mode runs)
         # which BASELINE.json config the flags amount to (the default run is configs[2], the one the metric is quoted on)
-        cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU"}.get(
+        cfg = {(1024, 8): "configs[1]", (4096, 16): "configs[2]", (32768, 16): "configs[3] on one GPU", (4096, 64): "configs[4]"}.get(
             (B, nc), "configs[3]" if (B * world, nc) == (32768, 16) else "variant")
         what = "forward only" if a.fwd_only else "forward + backward (implicit diff)"
         st = status.cpu()
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+        if primal:
+            kname = ("lcp_primal_kernel<30, false, false, 4, PIN = 3> (one wavefront per scene, body space: the 30 free coordinates' system; "
+                     "fused assembly + integrate; LCP_HINT_PINNED)")
+            emodel = ("flops.flops_forward_executed_primal(nz, nc, neq, iters, pinned=True): per iteration the SPARSE formation (6 x 6 block per "
+                      "contact) + LU of nz - neq rows + 2 KKT solves + residuals + step lengths")
+        elif body_space and B <= 1024:
+            kname = "lcp_fwd_solo (one scene per wavefront: batches of at most 1024 scenes; PDIPM forward, fused assembly + integrate)"
+            emodel = None
+        else:
+            kname = "lcp_fwd_quad<float,%s,%s,1,%d%s> (PDIPM forward%s)" % (
+                "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
+                (",%d,%d,%d,%s" % (nz, e, nc, "true" if B <= 4096 else "false")) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
+                ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
+                "the launch for other equality rows is skipped" if a.mode == "fused"
+                else "; the event-timed forward call also contains the classify launch")
+            emodel = None
+        if emodel is None:
+            emodel = ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True; trimmed for the size-specialised shapes): per "
+                      "iteration formation of Q + G^T M^-1 G (4 nc nz (nz - neq)) + LU of nz - neq rows + 2 KKT solves + residuals" if body_space
+                      else "flops.flops_forward_executed: the reduced 2 nc contact-space system")
         roof = {"bound": "valu_fp64" if a.compute == "f64" else "valu_fp32",
-                "kernel": ("lcp_fwd_solo (one scene per wavefront: batches of at most 1024 scenes; PDIPM forward%s)" % (
-                    ", fused assembly + integrate",)) if (body_space and B <= 1024) else "lcp_fwd_quad<float,%s,%s,1,%d%s> (PDIPM forward%s)" % (
-                    "double" if a.compute == "f64" else "float", "true" if a.mode == "fused" else "false", 2 if body_space else 0,
-                    (",%d,%d,%d,%s" % (nz, e, nc, "true" if B <= 4096 else "false")) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
-                    ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
-                    "the launch for other equality rows is skipped" if a.mode == "fused"
-                    else "; the event-timed forward call also contains the classify launch"),
+                "kernel": kname,
                 "achieved": tf(fl_exec, fwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(fl_exec, fwd_ms) / peak,
                 "flops": "executed",
                 "executed_flops_per_launch": fl_exec,
-                "executed_model": ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True; trimmed for the size-specialised shapes): per "
-                                   "iteration formation of Q + G^T M^-1 G (4 nc nz (nz - neq)) + LU of nz - neq rows + 2 KKT solves + residuals" if body_space
-                                   else "flops.flops_forward_executed: the reduced 2 nc contact-space system"),
+                "executed_model": emodel,
+                "frac_necessary": (tf(fl_nec, fwd_ms) / peak) if fl_nec else None,
+                "necessary_flops_per_launch": fl_nec,
+                "necessary_model": "flops.flops_forward_executed_primal: the same solve with the formation and the J v / J^T w products "
+                                   "counted over the contact's two bodies only (no structural zero multiplied)" if fl_nec else None,
                 "kernel_ms": fwd_ms,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -379,10 +540,16 @@ class HipStackWorkload:
                 "frac_algorithmic": tf(fl_alg, fwd_ms) / peak,
                 "algorithmic_flops_per_launch": fl_alg,
                 "note_algorithmic": "SURVEY 8d counts the reference's dense formulation (LU of nineq = %d rows per iteration); the kernel "
-                                    "factors %d rows: a fraction above 1 is the algorithmic saving, not an efficiency" % (m, (nz - e) if body_space else 2 * nc),
-                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "event_timed_steps": len(events)}
+                                    "factors %d rows: a fraction above 1 is the algorithmic saving, not an efficiency"
+                                    % (m, (nz - e) if (body_space or primal) else 2 * nc),
+                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "event_timed_steps": len(samples),
+                "event_timing": "HIP events on the launch stream around eager launches right after the timed region"}
+        if primal:
+            ph = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config5_primal_phases.txt")), reverse=True)
+            if ph:
+                roof["phases_source"] = os.path.relpath(ph[0], ROOT) + " (in-kernel cycle counters per phase: make primalprof)"
         if cj:
-            waves = (B + 3) // 4
+            waves = B if primal else (B + 3) // 4
             useful = fl_exec / 2.0 / waves / 64.0                               # wave-wide FMA instructions' worth of executed FLOPs
             roof.update({"valu_active": cj.get("valu_active"), "wait_frac": cj.get("wait_frac"),
                          "valu_insts_per_wave": cj.get("valu_insts_per_wave"),
@@ -401,23 +568,38 @@ class HipStackWorkload:
             # figure also counts Q and F as reads: lcp.py:37-64 does not touch them and neither does the kernel)
             balg = ((4 * (m * nz + e * nz + nz) + 8 * (nz + e + 2 * m) + 4 * (nz * nz + nz + m * nz + m + e * nz + e + m * m)) if dense_bwd
                     else 4 * (14 * nb + 7 * nc + 3 * nb) + 4 * (11 * nb + 6 * nc)) * B
-            used = btraffic if btraffic else balg
-            roof["bwd"] = {"bound": "hbm",
-                           "kernel": ("lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
-                                      % ("true" if body_space else "false")) if dense_bwd else "lcp_bwd_step_quad (gradients w.r.t. the physical inputs)",
-                           "achieved": used / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": used / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "bytes": "measured traffic" if btraffic else "algorithmic",
-                           "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
-                           "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if body_space else None}
+            if dense_bwd:
+                used = btraffic if btraffic else balg
+                roof["bwd"] = {"bound": "hbm",
+                               "kernel": "lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
+                                         % ("true" if body_space else "false"),
+                               "achieved": used / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": used / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "bytes": "measured traffic" if btraffic else "algorithmic",
+                               "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
+                               "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if body_space else None}
+            else:
+                # the physical backward moves ~1 KB per scene: it is bound by its one factorisation + 1 + 2 KKT solves (fp64 VALU)
+                bfl = (flops.flops_forward_executed_primal(nz, nc, e, 0, True) + 2 * (nc * 102 + 2 * (nz - e) ** 2) if primal
+                       else flops.flops_backward_executed_body_space(nz, nc, e) - (2 * nz * nz + 3 * m * nz + m * m + 3 * e * nz)) * B
+                roof["bwd"] = {"bound": "valu_fp64",
+                               "kernel": ("lcp_primal_kernel<30, true, ...> behind lcp_step_backward_f32" if primal else "lcp_bwd_step_quad")
+                                         + " (lcp.py:37-64 contracted through the assembly: gradients w.r.t. the physical inputs)",
+                               "achieved": tf(bfl, bwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(bfl, bwd_ms) / peak,
+                               "flops": "executed (one formation + LU at the best iterate, 1 + 2 KKT solves)",
+                               "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
+                               "executed_flops_per_launch": bfl}
             if btj:
                 roof["bwd"]["traffic_source"] = btj["source"]
+        shape = ("ten-box pile (4-3-2-1 pyramid), %d pts/interface" % a.pts) if self.pile else "%d-box stack, %d pts/interface" % (a.nbox, a.pts)
         return {
-            "config": {"workload": "%s: batch=%d x %d contacts (%d-box stack, %d pts/interface; nz %d, nineq %d, "
+            "config": {"workload": "%s: batch=%d x %d contacts (%s; nz %d, nineq %d, "
                                    "neq %d) per GPU, fp32 I/O, LCP %s, mode=%s, bwd=%s%s"
-                                   % (cfg, B, nc, a.nbox, a.pts, nz, m, e, what, a.mode, "none" if a.fwd_only else a.bwd,
+                                   % (cfg, B, nc, shape, nz, m, e, what, a.mode, "none" if a.fwd_only else a.bwd,
                                       "; step outputs: new_v and the moved pose (engines.py:76-77, bodies.py:80-82), multipliers kept in the "
                                       "workspace in fp64" if a.mode == "fused" else ""),
+                       "launch": ("one HIP graph replay per step (forward + backward captured once)" if self.graph is not None
+                                  else "eager: one ctypes call per kernel launch"),
                        "mean_pdipm_iters": float(iters.mean()), "nonzero_status": int((st != 0).sum()),
                        "status_bits": {name: int(((st & bit) != 0).sum()) for name, bit in
                                        (("singular_Q", 1), ("singular_S11", 2), ("singular_T", 4), ("nan", 8), ("truncated", 16))}},
@@ -425,29 +607,63 @@ class HipStackWorkload:
         }
 
     def host_side_checks(self):
+        """cpu_baseline, cpu_reference and the parity object (512 scenes sampled over the batch)."""
+        from lcp_physics_amd.physics import assemble_contacts, fused_step
+        from oracle import pdipm_oracle as O
+        from tests import parity
         a, B, nz = self.args, self.B, self.nz
         out = {"cpu_baseline": cpu_baseline(self.sc_cpu, self.cot_cpu, a.cpu_budget, a.fwd_only),
-               "cpu_reference": cpu_reference_quote()}
-        x_gpu = self.sol.x if a.mode == "dense" else -self.step_out["v_new"].reshape(B, nz)
-        dp_gpu = None if (a.fwd_only or a.bwd == "physical") else self.grads[1]
-        src = self.sol if a.mode == "dense" else None
-        if src is None:
+               "cpu_reference": cpu_reference_quote(self.nc)}
+        n = min(512, B)
+        idx = torch.arange(0, B, max(1, B // n))[:n]
+        di = idx.to(self.dev)
+        take = lambda t: None if t is None else t[di].cpu()
+        sub_cpu = self.sc_cpu.slice(0, B)
+        for fl in ("p", "v", "Mdiag", "f", "rest", "fric", "c_n", "c_p1", "c_p2", "c_i1", "c_i2", "Je"):
+            setattr(sub_cpu, fl, getattr(self.sc_cpu, fl)[idx])
+        kw = {"phys": sub_cpu.phys_dict(), "dt": sub_cpu.dt}
+        if a.mode == "dense":
+            x_gpu, z_gpu, s_gpu, it_gpu = self.sol.x, self.sol.z, self.sol.s, self.sol.iters
+        else:
             # the same call with the multipliers written out (the timed one keeps them in the workspace only)
-            from lcp_physics_amd.physics import fused_step
             chk = fused_step(self.sc, compute=a.compute)
             torch.cuda.synchronize()
             same = bool(torch.equal(chk["v_new"], self.step_out["v_new"]) and torch.equal(chk["iters"], self.step_out["iters"])
                         and torch.equal(chk["p_new"], self.step_out["p_new"]))
             if not same:
                 raise SystemExit("bench.py: the step with multipliers differs from the timed step")
-        z_gpu = src.z if src is not None else chk["z"]
-        s_gpu = src.s if src is not None else chk["s"]
-        it_gpu = src.iters if src is not None else self.step_out["iters"]
-        out["parity"] = parity_vs_oracle(self.lcp, self.cot_cpu, x_gpu, z_gpu, s_gpu, it_gpu, dp_gpu)
-        if src is None:
-            out["parity"]["multipliers"] = ("z, s of a repeat of the timed call that writes them out (the timed step returns new_v and the pose "
-                                            "only, as the reference's step does); new_v, pose and iteration counts of the two calls: bitwise equal")
+            x_gpu, z_gpu, s_gpu, it_gpu = -self.step_out["v_new"].reshape(B, nz), chk["z"], chk["s"], self.step_out["iters"]
+        if not a.fwd_only:
+            if a.bwd == "physical":
+                kw["phys_grads"] = {k: take(v) for k, v in self.pgrads.items()}
+            else:
+                kw["grads"] = {k: take(t) for k, t in zip("QpGhAbF", self.grads)}
+        # identical inputs: the fp32 LCP data the HIP assembly kernel produces for these scenes (all assembling kernels share one
+        # contraction-free builder), solved by the oracle in fp64
+        lcp_s = assemble_contacts(sub_cpu.to(device=self.dev)) if self.lcp is None else [None if t is None else t[di] for t in self.lcp]
+        lcp64 = [None if t is None else t.double().cpu() for t in lcp_s]
+        rep, _ = parity.headline_report(O, lcp64, take(x_gpu), take(z_gpu), take(s_gpu), take(it_gpu),
+                                        cot=None if a.fwd_only else self.cot_cpu[idx], **kw)
+        rep["sample"] = "every %d-th scene of the batch" % max(1, B // n)
+        # ... and the oracle's OWN assembly of the same scenes (engines.py:31-32, 50-74 restated; fp32 like the kernel's): the LCP
+        # data compared entry by entry, and the kernel's new_v against the oracle's solve of what the oracle assembled
+        lcp_o = O.assemble_lcp(*sub_cpu.assembly_args())
+        worst = 0.0
+        for t_hip, t_o in zip(lcp_s, lcp_o):
+            if t_o is not None:
+                worst = max(worst, float((t_hip.cpu().double() - t_o.double()).abs().max() / max(1e-30, float(t_o.abs().max()))))
+        lo64 = [None if t is None else t.double() for t in lcp_o]
+        ref_o = O.lcp_forward(*lo64)
+        rep["assembly_max_rel_diff_vs_oracle_assembly"] = worst
+        rep["fwd_err_x_max_oracle_assembled"] = float(parity.err_x(take(x_gpu).double(), ref_o.x, lo64[0], lo64[1]).max())
+        if a.mode == "fused":
+            rep["multipliers"] = ("z, s of a repeat of the timed call that writes them out (the timed step returns new_v and the pose "
+                                  "only, as the reference's step does); new_v, pose and iteration counts of the two calls: bitwise equal")
+        out["parity"] = rep
         return out
+
+
+HipStackWorkload = HipWorkload          # (the name rounds 1-3 used)
 
 
 def main(argv=None):
@@ -464,7 +680,7 @@ def main(argv=None):
             raise SystemExit(rc)
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    run_rank(args, HipStackWorkload)
+    run_rank(args, HipWorkload)
 
 
 if __name__ == "__main__":

@@ -219,7 +219,16 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
       if (!lcp::quad_supported(nz, m, e)) return LCP_E_TOOLARGE;             // (nz 17..32: the physical backward only)
       return lcp::quad_backward(P, compute, 2, stream, 0, P.tag_value == TAG_STEP_QUAD_BODY, pinned);
     }
-    if (fam == FAM_WAVE64) return lcp::wave64_backward(P, compute, false, stream, 0);
+    if (fam == FAM_WAVE64) {
+      // lcp_solve_dynamics_f32 (contact counts per scene) runs these sizes on the generic step kernel (launch_step), the full-list
+      // lcp_step_fused_f32 on the wave64 one: the `compute` word cannot tell, the tag the forward left can.  Both backwards are
+      // launched; the one whose family did not run the forward finds its partner's tag and leaves without writing.
+      P.skip_tag = TAG_STEP_GENERIC;
+      int rc = lcp::wave64_backward(P, compute, false, stream, 0);
+      if (rc) return rc;
+      P.tag_value = TAG_STEP_GENERIC; P.skip_tag = TAG_STEP_WAVE64;
+      return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
+    }
     if (fam != FAM_GENERIC) return LCP_E_TOOLARGE;                            // (lcp_primal / lcp_big: lcp_step_backward_f32 is their backward)
     return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
   }

@@ -766,6 +766,7 @@ __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int scene = blockIdx.x, tid = threadIdx.x;
   if (P.cls && P.cls[scene] >= 2) return;
+  if (P.tag && P.skip_tag && *P.tag == P.skip_tag) return;        // (see BwdArgs::skip_tag: the partner family's backward serves this call)
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
   Scene<TC> S;

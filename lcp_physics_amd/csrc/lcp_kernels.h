@@ -43,6 +43,8 @@ struct BwdArgs {
   const int32_t* cls;  // as FwdArgs::cls
   const int32_t* tag;  // workspace trailer word the forward left; a backward that finds another value than `tag_value` (a workspace
   int tag_value;       // laid out by another kernel family) returns NaN gradients instead of reading it
+  int skip_tag;        // 0, or the tag of the OTHER kernel family the forward may have fallen back on (wave64 step -> generic step
+                       // when contact counts are given): a backward that finds it leaves without writing, its partner serves the call
 };
 
 // dense (Q, p, G, h, A, b, F) boundary of lcp_big.hip: LCPFunction sizes beyond the wave-per-scene kernels (nineq <= 256)

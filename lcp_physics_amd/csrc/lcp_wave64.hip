@@ -1121,6 +1121,7 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int scene = blockIdx.x * WPB + wave;
   if (scene >= P.B) return;
+  if (P.tag && P.skip_tag && *P.tag == P.skip_tag) return;        // the forward fell back on the partner family: its backward serves this call
   unsigned char* smem = smem_all + (size_t)wave * lds_per_wave;
   const int nz = P.nz, m = P.m, e = P.e;
   Ops<TI, TC> O;

@@ -97,16 +97,24 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
     return sol
 
 
+def _bwd_key(sol, dl_dx, out):
+    return (dl_dx.data_ptr(), sol.G.data_ptr(), 0 if sol.A is None else sol.A.data_ptr(), sol.ws.data_ptr(), sol.compute,
+            bool(getattr(sol, "all_contact", False)), tuple(0 if o is None else o.data_ptr() for o in out))
+
+
 def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
     """Implicit-differentiation backward for a previous `lcp_solve` (lcp.py:37-64).
     Returns [dQ, dp, dG, dh, dA, db, dF] (None where not needed / no equalities).  Called again with the `out` it returned and
-    the same tensors it re-uses the validated argument list (one ctypes call)."""
+    the same tensors it re-uses the validated argument list (one ctypes call; keyed on every pointer it holds).  With `out`
+    given, `out` decides which gradients are written (its None entries are skipped); `need` only shapes a NEW `out`."""
     lib = _lib.load()
     B, nz, m, e = sol.sizes
     dev, dtype = sol.G.device, sol.dtype
     plan = getattr(sol, "_bwd_plan", None)
+    # the cached argument list holds raw pointers: it is valid only while EVERY tensor behind it is the same - the cotangent, G, A,
+    # the workspace and each gradient tensor of `out` (an entry the caller replaced gets a fresh list, not a write to the old tensor)
     if (plan is not None and out is not None and plan[0] is out and dl_dx.dtype == dtype and dl_dx.is_contiguous()
-            and plan[1] == (dl_dx.data_ptr(), sol.G.data_ptr(), sol.ws.data_ptr(), sol.compute)):
+            and plan[1] == _bwd_key(sol, dl_dx, out)):
         from ..physics.batched_world import _on_device
         with _on_device(dev):
             rc = plan[2](*plan[3], _lib.stream_ptr(dev))
@@ -128,7 +136,7 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
             hint = _lib.HINT_ALL_CONTACT if getattr(sol, "all_contact", False) else 0
             args = (B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint, *[P(o) for o in out], P(sol.ws))
             rc = lib.lcp_pdipm_backward_f32(*args, st)
-            sol._bwd_plan = (out, (dl_dx.data_ptr(), sol.G.data_ptr(), sol.ws.data_ptr(), sol.compute), lib.lcp_pdipm_backward_f32, args)
+            sol._bwd_plan = (out, _bwd_key(sol, dl_dx, out), lib.lcp_pdipm_backward_f32, args)
     _lib.check(rc, "lcp_pdipm_backward")
     return out
 

@@ -96,6 +96,8 @@ def _on_device(dev):
 
 
 _SCENE_FIELDS = ("p", "Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2", "c_i1", "c_i2")
+_STEP_OUTPUTS = ("v_new", "p_new", "z", "s", "y", "iters", "status")
+_STEP_KEY_LEN = 10                       # entries of fused_step's plan key before the output pointers
 
 
 def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws=None, out=None, path="auto", pinned=None,
@@ -108,11 +110,18 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
     y) are not written out - the reference's step returns new_v only (`engines.py:76-77`; its multipliers stay inside the op for the
     backward, here: in fp64 in the workspace) - which saves the step a third of its HBM writes.
     Calling it again with the `out` / `ws` it returned and the same tensors re-uses the validated argument list (the host side of
-    a step is then one ctypes call: at small batches the step is otherwise bound by this wrapper, not by the GPU)."""
+    a step is then one ctypes call: at small batches the step is otherwise bound by this wrapper, not by the GPU); the list is
+    keyed on every pointer it holds - scene, outputs, workspace - and on the options.  With `out` given, `out` decides what is
+    written (its `z` / `s` / `y` entries, tensors or None); `multipliers` only shapes a NEW `out`."""
     lib = _lib.load()
     dev = sc.v.device
     key = (tuple(getattr(sc, k).data_ptr() for k in _SCENE_FIELDS), 0 if sc.Je is None else sc.Je.data_ptr(), float(sc.dt),
            float(eps), int(not_improved_lim), int(max_iter), compute, path, pinned, _lib.path_bits(path))
+    if out is not None:
+        # ... and on the OUTPUT tensors the caller hands back: an entry of `out` that was replaced (to keep the old result) or a
+        # different workspace gets a fresh argument list, never a write through a stale pointer
+        key += (tuple(0 if out.get(k) is None else out[k].data_ptr() for k in _STEP_OUTPUTS),
+                0 if out.get("ws") is None else out["ws"].data_ptr())
     plan = None if out is None else out.get("_plan")
     if plan is not None and plan[0] == key and (ws is None or ws is out["ws"]):
         with _on_device(dev):
@@ -142,7 +151,8 @@ def fused_step(sc, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64", ws
         rc = lib.lcp_step_fused_f32(*args, _lib.stream_ptr(dev))
     _lib.check(rc, "lcp_step_fused_f32")
     out["compute"] = comp                 # the word the backward must carry: arithmetic + kernel path (a family per word, any thread)
-    out["_plan"] = (key, args)            # (the output tensors and the workspace are the ones in `out`: same pointers next time)
+    key = key[:_STEP_KEY_LEN] + (tuple(0 if out.get(k) is None else out[k].data_ptr() for k in _STEP_OUTPUTS), ws.data_ptr())
+    out["_plan"] = (key, args)            # (valid while the scene, the options, the output tensors and the workspace are the same)
     return out
 
 
@@ -720,8 +730,12 @@ class ContactWorld:
         # the contact buffers at the current pose become this step's frame (kept for its backward); the detection below fills a
         # fresh set - no copies
         frame = self.contacts
+        frame.retired = True                                               # (nothing writes these records again: no copy in ContactFrameFunction)
         cb = self.contacts = ct.ContactBuffers(self.B, self.nb, self.maxc, self.p.device)
         self._autograd_owned = True
+        # HIP graphs captured by an earlier run(graph=True) hold raw pointers to the buffers retired here (they now belong to this
+        # step's backward) and to the old state tensors: a later run() must capture again on the new ones
+        self._graphs, self._phase = {}, 0
         # the pose the GEOMETRY is differentiated at: the same values as self.p, but a rotation increment that is exactly
         # zero carries no gradient - the reference turns its hulls' vertices by the increment and skips the turn when the
         # increment is zero (bodies.py:199-202 `if rot.item() != 0: self.rotate_verts(rot)`), so its autograd has no
@@ -761,6 +775,7 @@ class ContactWorld:
             # world.py:109-121: dp = engine.post_stabilization(world) at the moved pose with the contacts found there and the
             # NEW velocities; dp /= 2; the bodies (and the joints) move by dp dt; contacts are detected again
             frame2 = cb                                                    # (retired like `frame`: the detection at the end fills a fresh set)
+            frame2.retired = True
             dt_used = cb.dt_used
             g_n, g_p1, g_p2 = ct.ContactFrameFunction.apply(self._p_geom, self.geom, frame2, self.eps)
             pose_dep = js is not None and js.pose_dependent
@@ -798,6 +813,7 @@ class ContactWorld:
             # - and the contact buffers of the last differentiable step (dt_used, the accepted pose) are saved in that graph
             self.p, self.v, self._autograd_owned = self.p.detach().clone(), self.v.detach().clone(), False
             self.contacts = self.contacts.clone()
+            self._graphs, self._phase = {}, 0                            # (no graph captured before these buffers existed may replay)
         self._phase ^= 1
         cb = self.contacts
         f = self.f if self.force_fn is None else self.force_fn(self.t).to(torch.float32).contiguous()

@@ -188,9 +188,14 @@ class ContactFrameFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, geom, frame, eps=EPSILON):
+        # The kernels write contact buffers through raw pointers (autograd's version counters never see it), so the records this node
+        # hands out and keeps for its backward must belong to nobody else: a `snapshot_frame()`, or the ContactBuffers a
+        # differentiable step RETIRED (`ContactWorld.step_autograd` marks them `retired`: the world detects into a fresh set from
+        # then on) are used as they are; a LIVE buffer set (e.g. `world.contacts`) is copied first.
+        if isinstance(frame, ContactBuffers) and not getattr(frame, "retired", False):
+            frame = snapshot_frame(frame)
         ctx.geom, ctx.frame, ctx.eps = geom, frame, eps
         ctx.save_for_backward(p)
-        # (the frame owns its records: a snapshot, or the ContactBuffers a differentiable step retired - nothing writes them again)
         return frame.c_n.detach(), frame.c_p1.detach(), frame.c_p2.detach()
 
     @staticmethod

@@ -172,9 +172,15 @@ def err_physical(pg, pg_ref, phys, floor, keys=None):
 # one report for "the kernel the metric times against the oracle" (tests/test_hip_headline_parity.py and
 # bench.py's `parity` object print the same fields)
 # ----------------------------------------------------------------------------
-def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4)):
+def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4), grads=None, phys=None, dt=None,
+                    phys_grads=None):
     """`lcp64`: the LCP the kernel solved (fp64 copies of the fp32 data the HIP assembly produced: identical inputs),
     `x, z, s, iters`: what the kernel returned for those scenes, `dp` (optional): its dl/dp for the cotangent `cot`.
+    `grads` (optional): the kernel's dense gradients, dict over "QpGhAbF" (lcp.py:52-61); `phys` + `dt`: the scenes' physical
+    description (`SceneBatch.phys_dict()`, CPU) - the dense gradients are then also contracted through the engine assembly and
+    compared there; `phys_grads`: gradients w.r.t. the physical inputs the kernel returned DIRECTLY (`lcp_step_backward_f32`,
+    dict over PHYS_KEYS) - compared with the oracle's dense gradients contracted through the assembly, and dl/dp is read off
+    d(loss)/df = dt dl/dp (engines.py:32: p = M v + dt f).
     Returns (report dict, oracle solution).  Fields:
       fwd_err_x_*                      SURVEY 8d err_x per scene
       index_set_mismatches_unmasked    rows where (z_i > s_i) differs from the oracle's, NO mask
@@ -183,7 +189,13 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
       index_set_mismatches_floor_1e-4 / masked_frac_floor_1e-4   with the looser floor the body-space kernels are gated on
       iters_delta_hist                 histogram of iters - iters_oracle (pdipm.py:80-136 loop iterations per scene)
       iters_differ_frac                share of scenes with a non-zero delta
-      bwd_*                            dl/dp against lcp.py:52 on the scenes whose backward system is well posed"""
+      bwd_err_dp_*                     dl/dp against lcp.py:52 on the scenes whose backward system is well posed
+      bwd_err_dQ_max / dA / db         the other outputs of lcp.py:52-61 that are defined on degenerate contact LCPs (see the note
+                                       above `kkt_backward_residual`), same scenes, `grad_floors` scaling
+      bwd_kkt_resid_max                residual of the kernel's (dx, dlam, dnu) = (dp, -dh, -db) in the system lcp.py:47-50 solves,
+                                       at the oracle's iterate (fp64 z, s); bwd_kkt_resid_own_iterate_max: at the kernel's own fp32
+                                       outputs z, s
+      bwd_err_phys_max                 `err_physical` over Mdiag, v, f (the parameters that enter through Q and p)"""
     Q, p, G, h, A, b, F = lcp64
     ref = oracle.lcp_forward(*lcp64)
     n = Q.shape[0]
@@ -204,14 +216,42 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
     out["iters_delta_hist"] = {str(int(k)): int((d == k).sum()) for k in torch.unique(d)}
     out["iters_differ_frac"] = float((d != 0).sum()) / n
     out["iters_max_abs_delta"] = int(d.abs().max())
+    if grads is not None and dp is None:
+        dp = grads["p"]
+    if phys_grads is not None and dp is None:
+        dp = phys_grads["f"].double().reshape(n, -1) / dt              # d(loss)/df = dt dl/dp
     if dp is not None:
         c64 = cot.double()
         gref = oracle.lcp_backward(ref, *lcp64, c64)
         ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
         eg = err_grads({"p": dp.double()}, {"p": gref["dp"]}, fl)["p"]
-        if bool(ok.any()):
+        if bool(ok.any()):           # (callers gate bwd_well_posed_frac; without a well-posed scene the bwd_err_* keys are ABSENT and a gate on them fails loudly)
             out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})
         out["bwd_well_posed_scenes"] = int(ok.sum())
         out["bwd_well_posed_frac"] = float(ok.sum()) / n
+        gr = {k: gref["d" + k] for k in "QpGhAbF"}
+        if grads is not None and bool(ok.any()):
+            g64 = {k: (None if grads.get(k) is None else grads[k].double()) for k in "QpGhAbF"}
+            keys = [k for k in "QAb" if g64.get(k) is not None and gr[k] is not None]
+            errs = err_grads({k: g64[k] for k in keys}, {k: gr[k] for k in keys}, fl)
+            for k in keys:
+                out["bwd_err_d%s_max" % k] = float(errs[k][ok].max())
+            dnu = None if (A is None or g64.get("b") is None) else -g64["b"]
+            for name, zz, ss in (("bwd_kkt_resid_max", ref.z, ref.s), ("bwd_kkt_resid_own_iterate_max", z, s)):
+                res = kkt_backward_residual(Q, G, A, F, zz, ss, c64, g64["p"], -g64["h"], dnu)
+                out[name] = max(float(v[ok].max()) for v in res.values())
+        if phys is not None and bool(ok.any()) and (grads is not None or phys_grads is not None):
+            ph = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
+            keys = ["Mdiag", "v", "f"]
+            pg_ref = physical_grads(ph, dt, gr, oracle)
+            pg = ({k: phys_grads[k].double() for k in keys} if phys_grads is not None
+                  else physical_grads(ph, dt, {k: g64[k] for k in "QpGhF"}, oracle))
+            scl = free_scales(Q, p, c64)
+            floor = _n(c64) * torch.maximum(scl["x_free"], _n(ref.x))
+            ep = err_physical(pg, pg_ref, ph, floor, keys=keys)
+            out["bwd_err_phys_max"] = float(ep[ok].max())
+            out["bwd_err_phys_median"] = float(ep[ok].median())
+            out["bwd_phys_source"] = ("the kernel's own physical gradients (lcp_step_backward_f32)" if phys_grads is not None
+                                      else "the kernel's dense gradients contracted through the assembly (engines.py:31-32,50-74)")
     return out, ref

@@ -336,6 +336,35 @@ def test_contact_world_graph_replay_is_bitwise_the_eager_run(name):
     assert float(a.t.min()) > 0.3
 
 
+def test_graphs_captured_before_a_differentiable_step_are_not_replayed_after_it():
+    """run(graph) -> step(differentiable=True) -> run(graph) -> backward.  The differentiable step retires the contact buffers into
+    its backward and replaces the state tensors; a graph captured earlier holds raw pointers to all of them.  The second run() must
+    capture again: it advances the VISIBLE state exactly as eager steps do, and the gradient of the differentiable step is the one
+    computed without any run() after it (a stale replay used to overwrite the contact records saved for the backward)."""
+    rec = load_world_traj()["stack3"]
+    B = 4
+
+    def play(second_run):
+        w = _world_of(rec, B)
+        w.run(6, graph=True)
+        w.f = w.f.clone().requires_grad_(True)
+        out = w.step(differentiable=True)
+        v_diff, p_diff = w.v, w.p
+        assert not w._graphs                                               # nothing captured on the retired buffers may replay
+        second_run(w)
+        torch.cuda.synchronize()
+        (v_diff.double().pow(2).sum() + p_diff.pow(2).sum()).backward()
+        return w, w.f.grad.clone()
+
+    a, ga = play(lambda w: w.run(6, graph=True))
+    b, gb = play(lambda w: [w.step() for _ in range(6)])
+    c, gc = play(lambda w: None)
+    assert torch.equal(a.p, b.p) and torch.equal(a.v, b.v) and torch.equal(a.t, b.t)
+    assert torch.equal(a.contacts.count, b.contacts.count)
+    assert bool(torch.isfinite(ga).all()) and float(ga.abs().max()) > 0
+    assert torch.equal(ga, gc) and torch.equal(gb, gc)
+
+
 def test_post_stabilization_matches_oracle_with_ragged_counts():
     """`lcp_post_stabilization_f32` on stack scenes with random velocities and per-scene contact counts (0 = the direct
     KKT solve, engines.py:92-103) against oracle/pdipm_oracle.post_stabilization per scene, and the correction move
@@ -495,9 +524,11 @@ def test_mid_size_scenes_match_generic_and_oracle():
 
 
 def test_config5_pile_solve_dynamics_matches_oracle():
-    """BASELINE config 5 shape (11 bodies, 64 contacts, nineq 256) through lcp_solve_dynamics_f32 = the register-tiled
-    workgroup-per-scene kernel (lcp_big.hip), with ragged contact counts: new_v within 1e-4 (scaled) of the fp64 oracle
-    on the same fp32 inputs, and identical to the generic kernels' answer."""
+    """BASELINE config 5 shape (11 bodies, 64 contacts, nineq 256) through lcp_solve_dynamics_f32 without hints = the
+    one-wave-per-scene body-space kernel `lcp_primal_kernel<40>` (lcp_primal.hip; the contact-space `lcp_big.hip` is the A/B
+    partner behind path "big", tests/test_hip_primal.py), with ragged contact counts: new_v within 1e-4 (scaled) of the fp64
+    oracle on the same fp32 inputs, and the generic kernels' answer to 1e-5.  The pinned instantiation at the BASELINE batch is
+    gated in tests/test_hip_headline_parity.py (configs4_4096x64_pile)."""
     from lcp_physics_amd import _lib, scenes
     from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import ContactBuffers

@@ -1,16 +1,21 @@
-"""GPU parity of THE KERNEL THE METRIC TIMES, at the sizes the metric uses.
+"""GPU parity of THE KERNELS THE METRIC TIMES, at the sizes the metric uses.
 
 bench.py times `lcp_step_fused_f32` (the body-space four-scenes-per-wave forward: `lcp_fwd_quad<..., ALG = 2>` for scenes whose
-equality rows pin the floor, `ALG = 1` behind it for any other equality rows) followed by the dense `lcp_pdipm_backward_f32`.
-These tests run exactly that pair at BASELINE configs[1] (1024 x 8 contacts), configs[2] (4096 x 16) and one 4096-scene shard of
-configs[3] (rank 5 of 8: the seed bench.py gives that rank) and compare >= 512 sampled scenes with the fp64 oracle on identical
-inputs (pdipm.py:49-186, lcp.py:37-64):
+equality rows pin the floor, `ALG = 1` behind it for any other equality rows) followed by the dense `lcp_pdipm_backward_f32`;
+`bench.py --config 4` times the one-wave-per-scene body-space kernel (`lcp_primal_kernel<30, ..., PIN>`, `LCP_HINT_PINNED`) and its
+backward `lcp_step_backward_f32` on the 4096 x 64-contact piles of BASELINE configs[4].
+These tests run exactly those pairs at BASELINE configs[1] (1024 x 8 contacts), configs[2] (4096 x 16), one 4096-scene shard of
+configs[3] (rank 5 of 8: the seed bench.py gives that rank) - EVERY scene of the batch - and configs[4] (4096 x 64: 512 scenes
+sampled over the batch; the fp64 oracle factors 256 x 256 systems there) against the fp64 oracle on identical inputs
+(pdipm.py:49-186, lcp.py:37-64):
 
-  * SURVEY 8d err_x <= 1e-4 on every sampled scene;
+  * SURVEY 8d err_x <= 1e-4 on every compared scene;
   * contact index sets {i : z_i > s_i}: reported unmasked AND on the decisive rows (tests/parity.py::decisive_rows); at
-    configs[2] / [3] they must be identical on every row, no mask; gates per case below;
-  * loop iterations per scene (pdipm.py:80-136) against the oracle's: histogram printed, equal at configs[2] / [3];
-  * dl/dp of the dense backward on the scenes whose backward system is well posed.
+    configs[2] / [3] / [4] they must be identical on every row, no mask; gates per case below;
+  * loop iterations per scene (pdipm.py:80-136) against the oracle's: histogram printed, equal at configs[2] / [3] / [4];
+  * the backward on the scenes whose backward system is well posed: dl/dp, dQ, dA, db (lcp.py:52-61), the KKT residual of
+    (dx, dlam, dnu) in the system lcp.py:47-50 solves, and the gradients w.r.t. the physical inputs that enter through Q and p
+    (Mdiag, v, f: engines.py:31-32) - for configs[4] those are what its backward kernel returns, and dl/dp = (dl/df) / dt.
 
 The same report (tests/parity.py::headline_report) is what bench.py prints in its `parity` object.
 """
@@ -25,30 +30,38 @@ from tests import parity
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# (label, scenes, boxes, seed, equality rows, gates): the seeds are bench.py's (1236 + 1000 * rank).
-# Gates.  The 16-contact stacks (configs[2], [3]) are still on their way to convergence after ten iterations: the kernel's index
-# sets equal the oracle's on EVERY row (no mask at all) and so do its iteration counts.  The 8-contact stacks of configs[1]
-# converge to rounding inside the ten iterations: a fifth of the (z_i, s_i) pairs are two numbers that both went to zero - the
-# oracle's own z_i > s_i there is decided by the rounding of its last iteration - and the exit tests of pdipm.py:133 compare
-# rounding noise, so there the sets are required to be identical on the decisive rows, the unmasked count is bounded (1 % of
-# the rows) and reported, and the iteration counts may differ by one.
-STRICT = dict(unmasked_max=0, masked_max=0.03, iters_max_delta=0, well_posed_min=0.9)
-CONVERGED = dict(unmasked_max=0.01, masked_max=0.25, iters_max_delta=1, well_posed_min=0.5)
+# (label, kind, scenes, boxes, seed, equality rows, scenes compared, gates): the seeds are bench.py's (1236 + 1000 * rank; piles: 5).
+# Gates.  The 16-contact stacks (configs[2], [3]) and the piles (configs[4]) are still on their way to convergence after ten
+# iterations: the kernel's index sets equal the oracle's on EVERY row (no mask at all) and so do its iteration counts.  The
+# 8-contact stacks of configs[1] converge to rounding inside the ten iterations: a fifth of the (z_i, s_i) pairs are two numbers
+# that both went to zero - the oracle's own z_i > s_i there is decided by the rounding of its last iteration - and the exit tests
+# of pdipm.py:133 compare rounding noise, so there the sets are required to be identical on the decisive rows, the unmasked count
+# is bounded (1 % of the rows) and reported, and the iteration counts may differ by one.
+STRICT = dict(unmasked_max=0, masked_max=0.03, iters_max_delta=0, well_posed_min=0.9, kkt_max=1e-6)
+CONVERGED = dict(unmasked_max=0.01, masked_max=0.25, iters_max_delta=1, well_posed_min=0.5, kkt_max=1e-6)
 CASES = [
-    ("configs1_1024x8", 1024, 2, 1236, "pinned", CONVERGED),
-    ("configs2_4096x16", 4096, 4, 1236, "pinned", STRICT),
-    ("configs3_shard5_4096x16", 4096, 4, 1236 + 5000, "pinned", STRICT),
-    ("configs2_4096x16_general_rows", 4096, 4, 1236, "scaled", STRICT),       # A = 2 [I 0]: the same constraint, not the pinned form -> ALG = 1
-    ("configs1_1024x8_general_rows", 1024, 2, 1236, "coupled", CONVERGED),    # a row with a general entry -> ALG = 1
+    ("configs1_1024x8", "stack", 1024, 2, 1236, "pinned", 1024, CONVERGED),
+    ("configs2_4096x16", "stack", 4096, 4, 1236, "pinned", 4096, STRICT),
+    ("configs3_shard5_4096x16", "stack", 4096, 4, 1236 + 5000, "pinned", 4096, STRICT),
+    ("configs2_4096x16_general_rows", "stack", 4096, 4, 1236, "scaled", 4096, STRICT),    # A = 2 [I 0]: the same constraint, not the pinned form -> ALG = 1
+    ("configs1_1024x8_general_rows", "stack", 1024, 2, 1236, "coupled", 1024, CONVERGED), # a row with a general entry -> ALG = 1
+    ("configs4_4096x64_pile", "pile", 4096, 10, 5, "pinned", 512, STRICT),                # lcp_primal_kernel<30, ..., PIN> + lcp_step_backward_f32
 ]
 
 
-def _run_case(B, nbox, seed, rows, sample):
+def _sub(lcp, di):
+    return [None if t is None else t[di].double().cpu() for t in lcp]
+
+
+def _run_case(kind, B, nbox, seed, rows, sample):
     from lcp_physics_amd import scenes
     from lcp_physics_amd.lcp import lcp_backward
     from lcp_physics_amd.physics import assemble_contacts, fused_step
-    from lcp_physics_amd.physics.batched_world import solution_of_step
-    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=4, seed=seed, dtype=torch.float32)
+    from lcp_physics_amd.physics.batched_world import fused_step_backward, solution_of_step, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    pile = kind == "pile"
+    sc = (scenes.make_pile_scenes(B=B, seed=seed, dtype=torch.float32) if pile else
+          scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=4, seed=seed, dtype=torch.float32))
     if rows == "scaled":
         sc.Je = sc.Je * 2.0
     elif rows == "coupled":
@@ -57,25 +70,42 @@ def _run_case(B, nbox, seed, rows, sample):
     scg = sc.to(device=DEV)
     lcp = assemble_contacts(scg)
     out = fused_step(scg)                                      # the forward bench.py times
-    sol = solution_of_step(scg, out, lcp[2], lcp[4])
     nz = 3 * sc.nb
     cot = torch.randn(B, nz, generator=torch.Generator().manual_seed(4321), dtype=torch.float32)
-    grads = lcp_backward(sol, cot.to(DEV))                     # the backward bench.py times
-    torch.cuda.synchronize()
     idx = torch.arange(0, B, max(1, B // sample))[:sample]
-    lcp64 = [None if t is None else t[idx.to(DEV)].double().cpu() for t in lcp]
-    rep, ref = parity.headline_report(O, lcp64, -out["v_new"].reshape(B, nz)[idx.to(DEV)].cpu(), out["z"][idx.to(DEV)].cpu(),
-                                      out["s"][idx.to(DEV)].cpu(), out["iters"][idx.to(DEV)].cpu(),
-                                      dp=grads[1][idx.to(DEV)].cpu(), cot=cot[idx])
+    di = idx.to(DEV)
+    kw = dict(phys={k: (None if v is None else v[idx]) for k, v in sc.phys_dict().items()}, dt=sc.dt)
+    if pile:
+        assert out["compute"] & 0x20000                        # LCP_HINT_PINNED: the instantiation bench.py --config 4 times
+        # (d(loss)/d(v_new) = -d(loss)/dx: engines.py:76-77)
+        pg = fused_step_backward(scg, out, (-cot).reshape(B, sc.nb, 3).to(DEV))   # the backward bench.py --config 4 times
+        # lcp_solve_dynamics_f32 with a full count per scene and LCP_HINT_PINNED (what a ContactWorld calls): the same kernel
+        cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+        cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+        count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
+        sd = solve_dynamics(B, sc.nb, sc.nc, 3, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt, pinned=True)
+        torch.cuda.synchronize()
+        for k in ("v_new", "z", "s", "iters", "status"):
+            assert torch.equal(sd[k], out[k]), k
+        grads = None
+        kw["phys_grads"] = {k: v[di].cpu() for k, v in pg.items()}
+    else:
+        sol = solution_of_step(scg, out, lcp[2], lcp[4])
+        g7 = lcp_backward(sol, cot.to(DEV))                    # the backward bench.py times
+        torch.cuda.synchronize()
+        grads = g7
+        kw["grads"] = {k: (None if t is None else t[di].cpu()) for k, t in zip("QpGhAbF", g7)}
+    rep, ref = parity.headline_report(O, _sub(lcp, di), -out["v_new"].reshape(B, nz)[di].cpu(), out["z"][di].cpu(),
+                                      out["s"][di].cpu(), out["iters"][di].cpu(), cot=cot[idx], **kw)
     rep["status_nonzero"] = int((out["status"] & ~4 != 0).sum())
     return rep, out, grads, scg
 
 
-@pytest.mark.parametrize("label,B,nbox,seed,rows,gates", CASES, ids=[c[0] for c in CASES])
-def test_timed_kernel_against_oracle_at_metric_sizes(label, B, nbox, seed, rows, gates):
-    rep, out, grads, scg = _run_case(B, nbox, seed, rows, sample=512)
+@pytest.mark.parametrize("label,kind,B,nbox,seed,rows,sample,gates", CASES, ids=[c[0] for c in CASES])
+def test_timed_kernel_against_oracle_at_metric_sizes(label, kind, B, nbox, seed, rows, sample, gates):
+    rep, out, grads, scg = _run_case(kind, B, nbox, seed, rows, sample)
     print("\nheadline parity %s: %s" % (label, json.dumps(rep)))
-    assert rep["scenes"] >= 512
+    assert rep["scenes"] >= min(sample, 512)
     assert rep["status_nonzero"] == 0
     assert rep["fwd_err_x_max"] <= 1e-4, rep
     # index sets {i : z_i > s_i}: unmasked count, and identical on the decisive rows (the mask itself is gated)
@@ -85,6 +115,11 @@ def test_timed_kernel_against_oracle_at_metric_sizes(label, B, nbox, seed, rows,
     assert rep["iters_max_abs_delta"] <= gates["iters_max_delta"], rep
     assert rep["bwd_well_posed_frac"] >= gates["well_posed_min"], rep
     assert rep["bwd_err_dp_max"] <= 1e-4, rep
+    assert rep["bwd_err_phys_max"] <= 1e-4, rep                 # Mdiag, v, f
+    if kind != "pile":                                          # the dense outputs of lcp.py:52-61 that are defined here
+        for k in ("bwd_err_dQ_max", "bwd_err_dA_max", "bwd_err_db_max"):
+            assert rep[k] <= 1e-4, (k, rep)
+        assert rep["bwd_kkt_resid_max"] <= gates["kkt_max"], rep
 
 
 def test_timed_kernel_full_batch_properties_configs2():

@@ -703,8 +703,8 @@ def test_dense_boundary_reaches_the_big_kernel_at_config5_sizes(kernel_path):
     ok = parity.backward_well_posed(lcp64[0], lcp64[2], lcp64[4], lcp64[6], ref, cot.double(), gref)
     fl = parity.grad_floors(lcp64[0], lcp64[1], cot.double(), ref.x, ref.z, ref.y)
     errs = parity.err_grads({k: g for k, g in zip("QpGhAbF", grads) if k in "QpAb"}, {k: gref["d" + k] for k in "QpAb"}, fl)
-    if bool(ok.any()):
-        assert max(float(e[ok].max()) for e in errs.values()) < TOL_G32, {k: float(v[ok].max()) for k, v in errs.items()}
+    assert int(ok.sum()) >= B // 2, ("too few scenes whose backward system the oracle itself solves", int(ok.sum()), B)
+    assert max(float(e[ok].max()) for e in errs.values()) < TOL_G32, {k: float(v[ok].max()) for k, v in errs.items()}
     # the rank-1 structure of the dense gradients (lcp.py:53-56): dF = -dlam (x) lam, dh = -dlam
     dF, dh = grads[6], grads[3]
     lam = sol.z.double().cpu()

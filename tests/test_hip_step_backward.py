@@ -190,9 +190,9 @@ def test_large_scene_backward_matches_generic_dense_and_oracle():
     scl = parity.free_scales(Q, p, cx)
     floor = parity._n(cx) * torch.maximum(scl["x_free"], parity._n(refsol.x))
     ep = parity.err_physical(pg, pg_ref, ph, floor, keys=["Mdiag", "v", "f"])
-    if bool(ok.any()):
-        assert float(ep[ok].max()) < 1e-4, (float(ep[ok].max()), int(ok.sum()))
     print("well-posed scenes", int(ok.sum()), "of", B)
+    assert int(ok.sum()) >= B // 2, ("too few scenes whose backward system the oracle itself solves", int(ok.sum()), B)
+    assert float(ep[ok].max()) < 1e-4, (float(ep[ok].max()), int(ok.sum()))
 
 
 def test_batched_world_differentiable_step_is_the_same_backward_as_a_graph_node():
@@ -224,3 +224,56 @@ def test_batched_world_differentiable_step_is_the_same_backward_as_a_graph_node(
     (r2["p_new"] * cot).sum().backward()
     assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in leaves.values())
     assert float(leaves["f"].grad.abs().max()) > 0
+
+
+def test_dense_backward_follows_either_forward_entry_where_the_two_pick_different_kernels():
+    """fp32 arithmetic, nz <= 16 with 5..8 equality rows: `lcp_step_fused_f32` (full lists) runs the wave64 step kernel,
+    `lcp_solve_dynamics_f32` (a contact count per scene) the generic one - the `compute` word cannot tell the two apart, the tag in
+    the workspace trailer can.  `lcp_pdipm_backward_f32` + LCP_HINT_ALL_CONTACT after EITHER forward returns that forward's
+    gradients (it used to return NaN after the second); plan-cache hits must follow replaced output tensors."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward
+    from lcp_physics_amd.physics.batched_world import assemble_contacts, fused_step, solution_of_step, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 24
+    sc = scenes.make_stack_scenes(B=B, nbox=3, pts_per_interface=4, seed=61, dtype=torch.float32)
+    nz = 3 * sc.nb
+    Je = torch.zeros(B, 6, nz)
+    Je[:, :3, :3] = torch.eye(3)
+    Je[:, 3, 3], Je[:, 3, 6] = 1.0, -1.0                         # boxes 1 and 2 turn together
+    Je[:, 4, 6], Je[:, 4, 9] = 1.0, -1.0                         # boxes 2 and 3 turn together
+    Je[:, 5, 4], Je[:, 5, 7] = 1.0, -1.0                         # boxes 1 and 2 slide together
+    sc.Je = Je
+    scg = sc.to(device=DEV)
+    lcp = assemble_contacts(scg)
+    cot = torch.randn(B, nz, generator=torch.Generator().manual_seed(2), dtype=torch.float32).to(DEV)
+    a = fused_step(scg, compute="f32")
+    ga = lcp_backward(solution_of_step(scg, a, lcp[2], lcp[4], compute="f32"), cot)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.full((B,), sc.nc, dtype=torch.int32, device=DEV)
+    b = solve_dynamics(B, sc.nb, sc.nc, 6, count, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt, compute="f32")
+    sb = solution_of_step(scg, b, lcp[2], lcp[4], compute="f32")
+    gb = lcp_backward(sb, cot)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(a["v_new"]).all()) and bool(torch.isfinite(b["v_new"]).all())
+    vs = float(a["v_new"].abs().max())
+    assert float((a["v_new"] - b["v_new"]).abs().max()) <= 2e-3 * vs          # (all-fp32 arithmetic, two elimination orders)
+    for k, x, y in zip("QpGhAbF", ga, gb):
+        assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all()), k
+    dps = float(ga[1].abs().max())
+    assert float((ga[1] - gb[1]).abs().max()) <= 2e-2 * dps
+    # the cached argument list of the backward follows a replaced output tensor (it used to keep writing the old one)
+    keep = gb[1]
+    gb2 = list(gb)
+    gb2[1] = torch.zeros_like(keep)
+    sb._bwd_plan = (gb2,) + tuple(sb._bwd_plan[1:])                           # (the handle the first call cached, now with a new dp tensor)
+    lcp_backward(sb, cot, out=gb2)
+    torch.cuda.synchronize()
+    assert torch.equal(gb2[1], keep) and gb2[1].data_ptr() != keep.data_ptr()
+    # ... and so does the step's: replace v_new in the handle, the next call must fill the new tensor
+    old_v = a["v_new"]
+    a["v_new"] = torch.zeros_like(old_v)
+    a = fused_step(scg, compute="f32", ws=a["ws"], out=a)
+    torch.cuda.synchronize()
+    assert torch.equal(a["v_new"], old_v) and a["v_new"].data_ptr() != old_v.data_ptr()
