@@ -12,10 +12,11 @@ step   : one pass of the hot path over one batch of synthetic scenes already res
          metric is quoted on), 3 = 32768 x 16 over the ranks, 4 = 4096 x 64 contacts (the ten-box pile, nineq 256:
          lcp_step_fused_f32 -> lcp_primal_kernel<30, ..., PIN>, backward lcp_step_backward_f32 - gradients w.r.t. the
          physical inputs; the dense gradients of a 256-row LCP are 302 KB per scene and no world asks for them).
-launch : the forward + backward pair of one step is captured ONCE into a HIP graph (the library is capture-safe: it
-         launches on the caller's stream and keeps no host state) and the timed region replays it K times
-         (`--launch graph`, the default; `config.launch` says so).  `eager_ms_per_step` = the same K steps issued as two
-         ctypes calls per step.
+launch : two eager launches per step (one ctypes call each; `--launch eager`, the default).  `--launch graph` captures the
+         forward + backward pair ONCE into a HIP graph (the library is capture-safe: it launches on the caller's stream and keeps
+         no host state) and replays it K times: measured SLOWER on this stack (0.1006 against 0.0947 ms per step at the headline,
+         profiles/r04_ab_launch.txt - the eager queue already runs the two kernels back to back, 94.7 us per step against 93.6 us
+         of kernel time), so it is the companion figure `graph_ms_per_step`, not the timed form.
 N GPUs : one process per GPU, every rank owns its own 4096 scenes (weak scaling, config 3 = 8 x 4096); no
          collective on the solve path - torch.distributed (RCCL) is only used for the barriers and the
          MAX-over-ranks wall time.  `python bench.py --gpus N` started WITHOUT a launcher starts the N ranks
@@ -38,7 +39,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   committed rocprofv3 / compiler reports under profiles/ (bench.py cannot run --pmc itself).
                   `roofline.bwd` = the backward kernel: the dense backward against the HBM roofline (it is bound by the
                   21.6 KB of dense gradients it writes per scene), the physical one against the FP64 vector rate.
-  companions    - (rank 0, N = 1) the same workload timed three more ways, K steps each: `eager` (two ctypes launches per step),
+  companions    - (rank 0, N = 1) the same workload timed three more ways, K steps each (best of two repeats): `graph` (one HIP-graph replay per step),
                   `general_kernel` (lcp_solve_dynamics_f32 with a contact count per scene: the instantiation a ContactWorld
                   gets) and `with_multipliers` (z, s, y written out every step: the form rounds 1 and 2 timed).
   cpu_baseline  - the oracle (a port, torch CPU fp64) timed on this host's cores on the same workload (rank 0,
@@ -78,14 +79,20 @@ def parse(argv=None):
     ap.add_argument("--pile", action="store_true", help="BASELINE configs[4]: the ten-box pyramid, 64 contacts (nz 33, nineq 256)")
     ap.add_argument("--compute", default="f64", choices=["f64", "f32"])
     ap.add_argument("--mode", default="fused", choices=["dense", "fused"])
+    ap.add_argument("--contact-space", action="store_true",
+                    help="--mode dense: LCP_PATH_CONTACT_SPACE, the contact-space factorisation (the default until round 3) instead of the body-space kernels")
     ap.add_argument("--bwd", default=None, choices=["dense", "physical"],
                     help="backward timed in the step: 'dense' = LCPFunction.backward (7 dense gradients, lcp.py:37-64); "
                          "'physical' (fused mode only) = lcp_step_backward_f32, gradients w.r.t. the physical inputs "
                          "(default: dense for the stacks, physical for the pile)")
     ap.add_argument("--fwd-only", action="store_true",
                     help="time the forward only (BASELINE configs[1] is forward-only); the default is the headline fwd+bwd")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="how the timed region issues a step: one replay of a captured HIP graph (fwd + bwd), or two eager launches")
+    ap.add_argument("--launch", default="eager", choices=["graph", "eager"],
+                    help="how the timed region issues a step: two eager launches (default: measured faster, see `graph_ms_per_step`), or "
+                         "one replay of a captured HIP graph (fwd + bwd)")
+    ap.add_argument("--spinup", type=float, default=0.3,
+                    help="seconds of untimed launches while the workload is built, before the W warm-up steps: the first ~0.2 s of "
+                         "launches on a fresh process run at ramping clocks, which a 2 ms timed region (--steps 20) would otherwise measure")
     ap.add_argument("--event-samples", type=int, default=128, help="eager launches bracketed by HIP events for roofline.kernel_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true")
@@ -226,8 +233,15 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
     """Oracle (port of the reference algorithm, vectorised torch fp64) on the host cores: forward +
     backward on a bounded sample of the same scenes (sized from a calibration pass to ~budget_s)."""
     from oracle import pdipm_oracle as O
-    threads = max(1, min(os.cpu_count() or 1, 16))      # tiny batched ops: more threads only add overhead
-    torch.set_num_threads(threads)
+    big = sc_cpu.nc > 32                                # (the piles: 256 x 256 dense systems per scene)
+    if big:
+        # torch.set_num_threads() (whatever the value) turns on MKL's own threading inside ATen's batch-parallel LU, and the batched
+        # 256 x 256 getrf then fails in DLASWP or hangs (torch 2.10 + oneMKL 2024.2; the 64 x 64 systems of the stacks take MKL's
+        # sequential path and are not affected): the piles run with the thread settings the process started with
+        threads = torch.get_num_threads()
+    else:
+        threads = max(1, min(os.cpu_count() or 1, 16))  # tiny batched ops: more threads only add overhead
+        torch.set_num_threads(threads)
 
     def run(n):
         sub = sc_cpu.slice(0, n).to(dtype=torch.float64)
@@ -238,7 +252,6 @@ def cpu_baseline(sc_cpu, cot, budget_s=15.0, fwd_only=False):
             O.lcp_backward(sol, *lcp, cot[:n].double())
         return time.perf_counter() - t0
 
-    big = sc_cpu.nc > 32                                # (the piles: 256 x 256 dense systems per scene)
     run(8 if big else 32)                               # warm-up
     n0 = 32 if big else 128
     cal = run(n0)
@@ -314,7 +327,7 @@ class HipWorkload:
         if not self.pile:
             # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel (the dense backward reads G and A; --mode dense solves it)
             self.lcp = assemble_contacts(self.sc)
-            self.sol = lcp_solve(*self.lcp, compute=args.compute)
+            self.sol = lcp_solve(*self.lcp, compute=args.compute, path="big" if args.contact_space else "auto")
             self.grads = lcp_backward(self.sol, self.cot)
         # the timed step asks for what the reference's step returns - new_v (and the moved pose): engines.py:76-77, bodies.py:80-82; the
         # multipliers stay in the workspace for the backward (fp64).  host_side_checks() repeats the call WITH z, s for the parity object
@@ -328,14 +341,26 @@ class HipWorkload:
             self.pgrads = fused_step_backward(self.sc, self.step_out, self.cot_v, compute=args.compute)
         torch.cuda.synchronize()
         self.graph = None
+        self.spinup_s = 0.0
+        if args.spinup > 0:                                # (device clocks settle: part of building the workload, not of the W warm-up steps)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < args.spinup:
+                for _ in range(50):
+                    self.eager_step()
+                torch.cuda.synchronize()
+            self.spinup_s = time.perf_counter() - t0
         if args.launch == "graph":
-            for _ in range(3):
-                self.eager_step()
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.eager_step()
-            torch.cuda.synchronize()
+            self.graph = self.capture()
+
+    def capture(self):
+        for _ in range(3):
+            self.eager_step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.eager_step()
+        torch.cuda.synchronize()
+        return g
 
     # ---- one step
     def forward(self):
@@ -343,7 +368,7 @@ class HipWorkload:
         from lcp_physics_amd.physics import fused_step
         a = self.args
         if a.mode == "dense":
-            lcp_solve(*self.lcp, compute=a.compute, ws=self.sol.ws, out=self.sol)
+            lcp_solve(*self.lcp, compute=a.compute, ws=self.sol.ws, out=self.sol, path="big" if a.contact_space else "auto")
         else:
             self.step_out = fused_step(self.sc, compute=a.compute, ws=self.step_out["ws"], out=self.step_out, multipliers=False)
 
@@ -385,14 +410,18 @@ class HipWorkload:
 
     def _time(self, fn, sync):
         a = self.args
-        for _ in range(min(a.warmup, 10)):
-            fn()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            fn()
-        sync()
-        return (time.perf_counter() - t0) / a.steps
+        best = None
+        for _ in range(2):                                 # (best of two repeats of K steps: a companion figure, not the metric)
+            for _ in range(min(max(a.warmup, 2), 10)):
+                fn()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                fn()
+            sync()
+            dt = (time.perf_counter() - t0) / a.steps
+            best = dt if best is None else min(best, dt)
+        return best
 
     def companions(self, sync):
         """The same workload timed other ways (K steps each, this rank's clock): see the module docstring."""
@@ -407,6 +436,11 @@ class HipWorkload:
             dt = self._time(self.eager_step, sync)
             out["eager_ms_per_step"] = dt * 1e3
             out["eager_value"] = B / dt
+        else:
+            g = self.capture()
+            dt = self._time(g.replay, sync)
+            out["graph_ms_per_step"] = dt * 1e3
+            out["graph_value"] = B / dt
         if a.mode != "fused":
             return out
         sc = self.sc
@@ -477,7 +511,7 @@ class HipWorkload:
         fl_alg = float(sum(flops.flops_forward(nz, m, e, it) for it in it_list))
         # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic; the stack scenes pin
         # their floor: ALG = 2), the one-wave-per-scene lcp_primal_kernel for the piles, the dense boundary the contact-space one
-        body_space = a.mode == "fused" and a.compute == "f64" and nz <= 16
+        body_space = a.compute == "f64" and nz <= 16 and not (a.mode == "dense" and a.contact_space)
         primal = self.pile and a.compute == "f64"
         model = (flops.flops_forward_executed_primal if primal else
                  flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)
@@ -492,7 +526,8 @@ class HipWorkload:
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
         sized = body_space and (nz, e) in flops.SIZED_SHAPES
-        rj = _quoted("kernel_resources", "lcp_primal_kernel_30_pin" if primal else
+        rj = _quoted("kernel_resources", "lcp_primal_kernel_30_pinned_fwd" if primal else
+                     "lcp_fwd_quad_f64_dense_contact_space" if (a.mode == "dense" and a.contact_space) else
                      "lcp_fwd_solo_9_3_8" if (body_space and B <= 1024 and (nz, e, nc) == (9, 3, 8)) else
                      "lcp_fwd_quad_f64_fused_two_waves" if (sized and B > 4096) else
                      "lcp_fwd_quad_%s_%s" % ("f64" if a.compute == "f64" else "f32", a.mode))   # (the variant this mode runs)
@@ -516,7 +551,8 @@ class HipWorkload:
                 (",%d,%d,%d,%s" % (nz, e, nc, "true" if B <= 4096 else "false")) if (body_space and (nz, e) in flops.SIZED_SHAPES) else "",
                 ", fused assembly + integrate; LCP_HINT_PINNED: the wrappers checked on the host that every scene's Je pins the floor, "
                 "the launch for other equality rows is skipped" if a.mode == "fused"
-                else "; the event-timed forward call also contains the classify launch")
+                else "; the event-timed forward call also contains the classify launch (and, in body space, the general kernel's launch "
+                     "behind the pinned one: it finds no scene)")
             emodel = None
         if emodel is None:
             emodel = ("flops.flops_forward_executed_body_space(nz, nc, neq, iters, pinned=True; trimmed for the size-specialised shapes): per "
@@ -600,6 +636,7 @@ class HipWorkload:
                                       "workspace in fp64" if a.mode == "fused" else ""),
                        "launch": ("one HIP graph replay per step (forward + backward captured once)" if self.graph is not None
                                   else "eager: one ctypes call per kernel launch"),
+                       "device_spin_up_s": round(self.spinup_s, 3),
                        "mean_pdipm_iters": float(iters.mean()), "nonzero_status": int((st != 0).sum()),
                        "status_bits": {name: int(((st & bit) != 0).sum()) for name, bit in
                                        (("singular_Q", 1), ("singular_S11", 2), ("singular_T", 4), ("nan", 8), ("truncated", 16))}},

@@ -41,7 +41,8 @@ inline int split_compute(int compute, bool* generic, int* path = nullptr, int* s
 enum WsTag {
   TAG_DENSE_WAVE = 1, TAG_DENSE_BIG = 2, TAG_DENSE_GENERIC = 3,                       // lcp_pdipm_forward_*
   TAG_STEP_QUAD_BODY = 4, TAG_STEP_QUAD_CS = 5, TAG_STEP_PRIMAL = 6, TAG_STEP_BIG = 7, TAG_STEP_WAVE64 = 8, TAG_STEP_GENERIC = 9,
-  TAG_POSTSTAB_PRIMAL = 10, TAG_POSTSTAB_GENERIC = 11
+  TAG_POSTSTAB_PRIMAL = 10, TAG_POSTSTAB_GENERIC = 11,
+  TAG_DENSE_WAVE_BODY = 12                                                            // lcp_pdipm_forward_f32, class-2 scenes solved in body space (no W)
 };
 constexpr size_t TRAILER_BYTES = 256;
 
@@ -144,14 +145,17 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   const bool bigd = use_big_dense(io_f64, nz, m, e, compute, generic);
   lcp::FwdArgs P;
   memset(&P, 0, sizeof(P));
+  // the wave-per-scene sizes whose contact-structured scenes the four-scenes-per-wave kernels take: in body space unless the word
+  // asks for the contact-space formulation (LCP_PATH_CONTACT_SPACE) - a function of (sizes, word), the same in the backward
+  const int dense_body = (w64 && path != 3 && lcp::quad_supported(nz, m, e) && lcp::quad_dense_is_body_space(io_f64, compute, 1)) ? 1 : 0;
   P.tag = trailer_of(ws, B, per_scene_all);
-  P.tag_value = w64 ? TAG_DENSE_WAVE : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
+  P.tag_value = w64 ? (dense_body ? TAG_DENSE_WAVE_BODY : TAG_DENSE_WAVE) : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
   P.B = B; P.nz = nz; P.m = m; P.e = e;
   P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b; P.F = F;
   P.x = x; P.y = y; P.z = z; P.s = s; P.iters = iters; P.status = status;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.eps = eps; P.max_iter = max_iter; P.lim = lim;
   P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds; P.trace = g_trace;
-  if (w64) return lcp::wave64_forward(P, compute, stream, io_f64);
+  if (w64) return lcp::wave64_forward(P, compute, stream, io_f64, dense_body);
   if (bigd) {
     const size_t per_scene = per_scene_all;
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
@@ -202,8 +206,9 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   const bool bigd = use_big_dense(io_f64, nz, m, e, compute, generic);
   lcp::BwdArgs P;
   memset(&P, 0, sizeof(P));
+  const int dense_body = (w64 && path != 3 && lcp::quad_supported(nz, m, e) && lcp::quad_dense_is_body_space(io_f64, compute, 1)) ? 1 : 0;   // (as in forward_common)
   P.tag = trailer_of(ws, B, per_scene_all);
-  P.tag_value = w64 ? TAG_DENSE_WAVE : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
+  P.tag_value = w64 ? (dense_body ? TAG_DENSE_WAVE_BODY : TAG_DENSE_WAVE) : (bigd ? TAG_DENSE_BIG : TAG_DENSE_GENERIC);
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
@@ -232,7 +237,7 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
     if (fam != FAM_GENERIC) return LCP_E_TOOLARGE;                            // (lcp_primal / lcp_big: lcp_step_backward_f32 is their backward)
     return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
   }
-  if (w64) return lcp::wave64_backward(P, compute, false, stream, io_f64);
+  if (w64) return lcp::wave64_backward(P, compute, false, stream, io_f64, dense_body);
   if (bigd) {
     const size_t per_scene = per_scene_all;
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);

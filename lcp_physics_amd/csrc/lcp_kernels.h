@@ -119,8 +119,8 @@ int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, 
 // wave-per-scene register-resident path (nz <= 16, nineq <= 64, neq <= 8, fp32 I/O) - lcp_wave64.hip
 bool wave64_supported(int nz, int m, int e);
 size_t wave64_ws_bytes(int compute, int io_f64 = 0);
-int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64 = 0);
-int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64 = 0);
+int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64 = 0, int body_space = 0);   // body_space: see quad_forward
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64 = 0, int body_space = 0);
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
 // body-space (primal) contact-structured path: one wave per scene, <= 64 contacts, nz + neq <= 56 - lcp_primal.hip
@@ -142,7 +142,8 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
 // `accept`: classification flag value (workspace meta[0]) the launch serves
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
-int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0);
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body_space = 0);   // body_space: the dense boundary on the body-space kernels (fp32 tensors, fp64 arithmetic)
+bool quad_dense_is_body_space(int io_f64, int compute, int body_space);   // does quad_forward run the body-space kernels for these arguments ?
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body = 0, bool pinned = false);   // body: workspace of a body-space forward; pinned: LCP_HINT_PINNED
 int quad_step(const StepArgs& P, int compute, void* stream, int body_space = 1, int solo = -1, bool pinned = false);   // solo: -1 by batch size, 0 never, 1 always; pinned: LCP_HINT_PINNED
 // one scene per wavefront, small batches (the body-space sizes with nz <= 16) - lcp_solo.hip

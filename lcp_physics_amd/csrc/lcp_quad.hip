@@ -38,6 +38,7 @@ bool quad_step_supported(int nz, int m, int e) { return (m % 4 == 0) && (m / 4 <
 // ---- size-specialised instantiations (lcp_quad_n*e*.hip): the pinned body-space kernels with nz / neq at compile time
 #define LCP_QS_DECL(NZ, E)                                                                                       \
   int quad_sized_fwd_##NZ##_##E(const StepArgs& SP, int ls, size_t lds_bytes, int accept, void* stream);        \
+  int quad_sized_dense_fwd_##NZ##_##E(const FwdArgs& P, int ls, size_t lds_bytes, int accept, void* stream);    \
   int quad_sized_bwd_##NZ##_##E(const BwdArgs& P, int ls, int accept, bool pinned, void* stream);               \
   int quad_sized_step_bwd_##NZ##_##E(const StepArgs& SP, const StepBwdArgs& Gd, int ls, bool pinned, void* stream);
 LCP_QS_DECL(15, 3) LCP_QS_DECL(9, 3) LCP_QS_DECL(12, 3) LCP_QS_DECL(6, 3)
@@ -65,24 +66,49 @@ static size_t q16_lds(bool with_w, int xh = 1, bool with_gal = true) {
   return n;
 }
 
-// The dense LCPFunction boundary keeps the contact-space factorisation: it is the reference's own formulation, and with it the
-// exit tests of pdipm.py:133 fall where the reference's fall (iteration counts equal to the oracle's even where a solve converges
-// to rounding - tests/test_hip_parity.py).  The body-space variant takes the same Newton steps to ~1e-12 but can leave a converged
-// solve one iteration later; it serves the contact-list entry points (1 builds it here too, for profiling: the phase trace of
-// LCP_Q_PROFILE is written by the dense forward).
-#ifndef LCP_Q_DENSE_BODY_SPACE
-#define LCP_Q_DENSE_BODY_SPACE 0
-#endif
-int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64) {
+// The dense LCPFunction boundary (fp32 tensors, fp64 arithmetic) runs the BODY-space kernels by default since round 4: the pinned
+// variant (ALG = 2; size-specialised for the stack shapes) for the waves whose equality rows pin the leading coordinates, the
+// general body-space kernel (ALG = 1) right behind it for the scenes those waves marked - exactly what the contact-list entry
+// points launch, reading the rows of G instead of a contact list.  Nothing of the contact-space pre-factorisation is formed: no
+// W = J P J^T written (45 MB per launch at 4096 x 16 contacts) and re-read at every factorisation, 12 pivots instead of 32.
+// LCP_PATH_CONTACT_SPACE in the `compute` word keeps the contact-space factorisation - the reference's own formulation: with it
+// the exit tests of pdipm.py:133 fall where the reference's fall even on solves that converge to rounding inside the ten
+// iterations (the body-space kernels take the same Newton steps to ~1e-12 but can leave such a solve one iteration later; on
+// BASELINE configs[2] / [3] the iteration counts of both equal the oracle's on every scene - tests/test_hip_headline_parity.py).
+// fp64 tensors and fp32 arithmetic keep the contact-space kernels.
+bool quad_dense_is_body_space(int io_f64, int compute, int body_space) { return body_space && !io_f64 && compute == LCP_COMPUTE_F64; }
+int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64, int body_space) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
+  if (quad_dense_is_body_space(io_f64, compute, body_space)) {
+    const int lb = (int)q16_lds<double>(LCP_Q_LDSW != 0, 1, false);          // body-space kernels: no contact-space tables
+    const size_t lbytes = 4 * lb + 20 * 64 * sizeof(double);                 // (+ the parked best iterate and affine direction)
+    auto first = [&]() -> int {
+#define LCP_QS_CALL(NZ, E) quad_sized_dense_fwd_##NZ##_##E(P, lb, lbytes, accept, stream)
+      if (LCP_Q_SIZED && P.e == 3) {
+        int rc = 1;
+        if (P.nz == 15) rc = LCP_QS_CALL(15, 3);
+        else if (P.nz == 9) rc = LCP_QS_CALL(9, 3);
+        else if (P.nz == 12) rc = LCP_QS_CALL(12, 3);
+        else if (P.nz == 6) rc = LCP_QS_CALL(6, 3);
+        if (rc <= 0) return rc;                                              // (1: not the shape's contact count)
+      }
+#undef LCP_QS_CALL
+      hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1, 2>), grid, blk, lbytes, st, P, SP, lb, accept);
+      return 0;
+    };
+    const int rc = first();
+    if (rc) return rc;
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1, 1>), grid, blk, 4 * lb, st, P, SP, lb, accept | 16);   // whatever that one left
+    return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+  }
   if (io_f64) {                                  // the reference's native dtype (physics/utils.py:34): fp64 loads / stores
     const int ls = (int)q16_lds<double, double>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<double, double, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else if (compute == LCP_COMPUTE_F64) {
     const int ls = (int)q16_lds<double>(LCP_Q_LDSW != 0);
-    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1, LCP_Q_DENSE_BODY_SPACE>), grid, blk, 4 * ls, st, P, SP, ls, accept);
+    hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, false, 1, 0>), grid, blk, 4 * ls, st, P, SP, ls, accept);
   } else {
     const int ls = (int)q16_lds<float>(LCP_Q_LDSW != 0);
     hipLaunchKernelGGL((q16::lcp_fwd_quad<float, float, false, 1>), grid, blk, 4 * ls, st, P, SP, ls, accept);

@@ -1233,7 +1233,7 @@ static int w64_allow_lds(K kernel, size_t bytes) {
     hipLaunchKernelGGL(kfn, GRID, blk, (size_t)(LW) * w64::WPB, st, __VA_ARGS__);        \
   } while (0)
 
-int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64) {
+int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64, int body_space) {
   StepArgs SP = {};
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
@@ -1249,7 +1249,7 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64) {
   } else if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
-    if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
+    if (quad) { int rc = quad_forward(P, compute, 2, stream, 0, body_space); if (rc) return rc; }
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
     LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
   } else {
@@ -1277,11 +1277,12 @@ int wave64_step(const StepArgs& SP, int compute, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
-int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64) {
+int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, int io_f64, int body_space) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 blk(64 * w64::WPB);
   const int quad = quad_supported(P.nz, P.m, P.e) ? 1 : 0;
-  if (quad) { int rc = quad_backward(P, compute, 2, stream, io_f64); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
+  // (the class-2 scenes of a dense forward that ran in body space left no W: their backward factors in body space too)
+  if (quad) { int rc = quad_backward(P, compute, 2, stream, io_f64, quad_dense_is_body_space(io_f64, compute, body_space) ? 1 : 0); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
   if (io_f64) {
     const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
     LCP_W64_LAUNCH((w64::lcp_bwd_wave<double, double, true, true>), w64_grid(P.B), ls, P, ls, quad);

@@ -50,9 +50,12 @@ class LCPSolution:
 
 
 def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64",
-              ws=None, out=None):
+              ws=None, out=None, path="auto"):
     """Forward solve on GPU tensors (no autograd).  Q,p,G,h,A,b,F: contiguous CUDA tensors of
-    one dtype (float32 or float64), batched; A, b may be None.  Returns an `LCPSolution`."""
+    one dtype (float32 or float64), batched; A, b may be None.  Returns an `LCPSolution`.
+    `path`: "auto" (the library's choice: contact-structured scenes with a diagonal Q are factored in BODY space - nz - neq or
+    nz + neq rows), "big" (LCP_PATH_CONTACT_SPACE: the reference's own contact-space formulation, pdipm.py:357-454 - where a
+    solve converges to rounding inside max_iter its exit tests then fall exactly where the reference's do), "generic"."""
     lib = _lib.load()
     dtype = G.dtype
     dev = G.device
@@ -64,7 +67,7 @@ def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, c
         _lib.require_gpu_tensor(A, "A", dtype)
         _lib.require_gpu_tensor(b, "b", dtype)
     assert Q.shape == (B, nz, nz) and p.shape == (B, nz) and h.shape == (B, m) and F.shape == (B, m, m)
-    comp = (_lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]) | _lib.path_bits()
+    comp = (_lib.COMPUTE_F64 if dtype == torch.float64 else _COMPUTE[compute]) | _lib.path_bits(path)
     need = _lib.workspace_bytes(B, nz, m, e, comp | (_lib.IO_F64 if dtype == torch.float64 else 0))
     if need == 0:
         raise RuntimeError("invalid LCP sizes B=%d nz=%d nineq=%d neq=%d" % (B, nz, m, e))
@@ -158,7 +161,7 @@ class _LCPFn(torch.autograd.Function):
             dA, db_ = None, None
         sol = lcp_solve(dQ, dp_, dG, dh_, dA, db_, dF, eps=holder.eps,
                         not_improved_lim=holder.not_improved_lim, max_iter=holder.max_iter,
-                        compute=holder.compute)
+                        compute=holder.compute, path=holder.path)
         if holder.check:
             st = sol.status.cpu()
             if bool((st & _lib.ST_SINGULAR_Q).any()):
@@ -195,10 +198,13 @@ class LCPFunction:
 
     Extra keywords (not in the reference): `compute` - arithmetic used inside the kernels for
     float32 inputs ("f64" = parity path, "f32" = all-fp32 fast path); `check` - read the status
-    word back (one host sync) and raise on a singular Q like the reference does.
+    word back (one host sync) and raise on a singular Q like the reference does; `path` - kernel
+    family, see `lcp_solve` ("big" = the reference's contact-space formulation instead of the default
+    body-space factorisation of contact-structured scenes).
     """
 
-    def __init__(self, eps=1e-12, verbose=-1, not_improved_lim=3, max_iter=10, compute="f64", check=True):
+    def __init__(self, eps=1e-12, verbose=-1, not_improved_lim=3, max_iter=10, compute="f64", check=True, path="auto"):
+        self.path = path
         self.eps = eps
         self.verbose = verbose
         self.not_improved_lim = not_improved_lim

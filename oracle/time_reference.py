@@ -27,13 +27,16 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dtype", default="float64", choices=["float32", "float64"])
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--pile", action="store_true", help="BASELINE configs[4]: the ten-box piles (64 contacts, nineq 256)")
+    ap.add_argument("--machine", default="build container (not the GPU box)")
     args = ap.parse_args()
     from lcp_physics_amd import scenes
     ref_shim.load_reference()
     dt = getattr(torch, args.dtype)
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
-    sc = scenes.make_stack_scenes(B=args.batch, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32)
+    # (torch.set_num_threads breaks MKL's batched 256 x 256 getrf - see bench.py cpu_baseline: the process keeps its default threads)
+    threads = torch.get_num_threads()
+    sc = (scenes.make_pile_scenes(B=args.batch, seed=5, dtype=torch.float32) if args.pile else
+          scenes.make_stack_scenes(B=args.batch, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32))
     lcp = [None if t is None else t.to(dt) for t in O.assemble_lcp(*sc.assembly_args())]
     cot = torch.randn(args.batch, lcp[0].shape[1], generator=torch.Generator().manual_seed(4321), dtype=dt)
     best = None
@@ -47,9 +50,11 @@ def main():
         if best is None or t2 - t0 < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
     out = {"what": "unmodified reference pdipm (through oracle/ref_shim.py), fwd+bwd, batched call",
-           "workload": "first %d scenes of the headline workload (4-box stack, 16 contacts, nineq 64)" % args.batch,
-           "dtype": args.dtype, "cpu_threads": threads, "value": args.batch / best[0], "unit": "sim steps/s",
-           "fwd_s": best[1], "bwd_s": best[2], "machine": "build container (not the GPU box)"}
+           "workload": ("first %d scenes of the configs[4] workload (ten-box pile, 64 contacts, nineq 256)" if args.pile else
+                        "first %d scenes of the headline workload (4-box stack, 16 contacts, nineq 64)") % args.batch,
+           "nc": sc.nc, "batch": args.batch,
+           "dtype": args.dtype, "cpu_threads": threads, "host_cores": os.cpu_count(), "value": args.batch / best[0], "unit": "sim steps/s",
+           "fwd_s": best[1], "bwd_s": best[2], "machine": args.machine}
     print(json.dumps(out))
 
 

@@ -90,7 +90,15 @@ def backward_well_posed(Q, G, A, F, ref, cot, gref):
                                 None if gref.get("db") is None else -gref["db"])
     ok = torch.stack([v for v in res.values()]).max(dim=0)[0] < 1e-9
     zs, ss = ref.z.max(dim=1, keepdim=True)[0], ref.s.max(dim=1, keepdim=True)[0]
-    return ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
+    ok = ok & (torch.maximum(ref.z / zs, ref.s / ss).min(dim=1)[0] > 1e-6)
+    # ... and its dlam has the size the data allow: on a solve that converged to rounding (mu ~ 1e-15) the oracle's own solve can return
+    # dlam ~ 1e16 along a null direction of its singular matrix with a RELATIVE residual of 1e-17 (measured: configs[1] with a coupled
+    # equality row, scene 487 of seed 1236: |dlam| = 7.6e16, natural scale ~10; tools/experiments/bwd_outliers.py) - an answer no other
+    # elimination order reproduces and no gradient anybody could use
+    rown = G.double().norm(dim=2)                                                   # |G_i|; zero rows (the gamma rows) do not constrain dlam
+    gmin = torch.where(rown > 0, rown, torch.full_like(rown, float("inf"))).min(dim=1)[0].clamp(1e-300, 1e300)
+    sane = _n(gref["dh"]) <= 1e8 * _n(cot) / gmin                                   # (Q dx + G^T dlam = -cot: |dlam| ~ |cot| / |G_i| by nature)
+    return ok & sane
 
 
 # ----------------------------------------------------------------------------
@@ -192,9 +200,11 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
       bwd_err_dp_*                     dl/dp against lcp.py:52 on the scenes whose backward system is well posed
       bwd_err_dQ_max / dA / db         the other outputs of lcp.py:52-61 that are defined on degenerate contact LCPs (see the note
                                        above `kkt_backward_residual`), same scenes, `grad_floors` scaling
-      bwd_kkt_resid_max                residual of the kernel's (dx, dlam, dnu) = (dp, -dh, -db) in the system lcp.py:47-50 solves,
-                                       at the oracle's iterate (fp64 z, s); bwd_kkt_resid_own_iterate_max: at the kernel's own fp32
-                                       outputs z, s
+      bwd_kkt_resid_max                residual of the kernel's (dx, dlam, dnu) = (dp, -dh, -db) in the system lcp.py:47-50 solves at
+                                       the iterate the KERNEL returned (its fp32 outputs z, s; the iterate itself is what the forward
+                                       fields compare); bwd_kkt_resid_at_oracle_iterate_max: the same vectors in the system at the
+                                       ORACLE's iterate - informative only: where a solve converged to rounding s_i / z_i is a ratio of two
+                                       1e-17 numbers and the two systems are different matrices (configs[1]: O(1))
       bwd_err_phys_max                 `err_physical` over Mdiag, v, f (the parameters that enter through Q and p)"""
     Q, p, G, h, A, b, F = lcp64
     ref = oracle.lcp_forward(*lcp64)
@@ -238,7 +248,7 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
             for k in keys:
                 out["bwd_err_d%s_max" % k] = float(errs[k][ok].max())
             dnu = None if (A is None or g64.get("b") is None) else -g64["b"]
-            for name, zz, ss in (("bwd_kkt_resid_max", ref.z, ref.s), ("bwd_kkt_resid_own_iterate_max", z, s)):
+            for name, zz, ss in (("bwd_kkt_resid_max", z, s), ("bwd_kkt_resid_at_oracle_iterate_max", ref.z, ref.s)):
                 res = kkt_backward_residual(Q, G, A, F, zz, ss, c64, g64["p"], -g64["h"], dnu)
                 out[name] = max(float(v[ok].max()) for v in res.values())
         if phys is not None and bool(ok.any()) and (grads is not None or phys_grads is not None):

@@ -19,10 +19,11 @@ TOL_X32 = 1e-4
 TOL_G32 = 1e-4
 
 
-@pytest.fixture(autouse=True, params=["wave64", "generic"])
+@pytest.fixture(autouse=True, params=["wave64", "generic", "big"])
 def kernel_path(request):
-    """Every test runs twice: through the wave-per-scene kernels (where the sizes allow - the library
-    falls back to the generic kernels otherwise) and with the generic kernels forced."""
+    """Every test runs three times: through the library's own choice of kernels (wave-per-scene / four-scenes-per-wave where the
+    sizes allow - contact-structured scenes in body space -, the generic kernels otherwise), with the generic kernels forced, and
+    with LCP_PATH_CONTACT_SPACE ("big": the contact-space factorisation where the default is a body-space one)."""
     from lcp_physics_amd import _lib
     _lib.set_path(request.param)
     yield request.param
@@ -145,7 +146,7 @@ MIN_WELL_POSED = {"cfg2_stack2x4": 0.5, "cfg3_stack4x4": parity.MIN_WELL_POSED_F
 
 
 @pytest.mark.parametrize("name,nbox,pts,B", CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_stack_scenes_forward_parity(name, nbox, pts, B):
+def test_stack_scenes_forward_parity(name, nbox, pts, B, kernel_path):
     from lcp_physics_amd import scenes
     sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=1234 + nbox, dtype=torch.float32)
     lcp32 = O.assemble_lcp(*sc.assembly_args())
@@ -153,7 +154,14 @@ def test_stack_scenes_forward_parity(name, nbox, pts, B):
     sol = _solve(lcp32, torch.float32)
     _check_forward(sol, ref, lcp32[0], lcp32[1], TOL_X32, name, max_masked=MAX_MASKED[name])
     di = (sol.iters.cpu() - ref.iters).abs()
-    assert int(di.max()) <= 1 and float((di == 0).float().mean()) >= 0.97, (name, "iteration counts", di.tolist())
+    if kernel_path == "wave64" and name != "cfg3_stack4x4":
+        # the library's own choice since round 4: contact-structured scenes are factored in BODY space.  Stacks that converge to
+        # rounding inside the ten iterations (two or four points under one or two boxes) then meet the exit tests of pdipm.py:133 on
+        # rounding noise of another elimination order: same answers (err_x above), the loop may run an iteration or two longer.
+        # Equal counts are asserted where the oracle's formulation runs - kernel_path "big" (LCP_PATH_CONTACT_SPACE) and "generic".
+        assert int(di.max()) <= 2, (name, "iteration counts", di.tolist())
+    else:
+        assert int(di.max()) <= 1 and float((di == 0).float().mean()) >= 0.97, (name, "iteration counts", di.tolist())
 
 
 @pytest.mark.parametrize("name,nbox,pts,B", CONFIGS, ids=[c[0] for c in CONFIGS])

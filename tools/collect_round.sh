@@ -2,7 +2,7 @@
 # One GPU call that refreshes every measured artefact of a round: bench lines of all BASELINE configs, the worlds with contact
 # detection, config 5 through both boundaries, rocprofv3 kernel trace + PMC passes (profile_all.sh / profile_config5.sh).
 # Outputs land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out
 mkdir -p $O
@@ -14,8 +14,7 @@ run bench_fused_physical_bwd python bench.py --bwd physical --no-cpu-baseline
 run bench_config2_fwd_only python bench.py --batch 1024 --nbox 2 --fwd-only --no-cpu-baseline
 run bench_config4_on_1gpu python bench.py --batch 32768 --no-cpu-baseline
 run bench_fused_8contacts python bench.py --pts 2 --no-cpu-baseline
-run bench_config5 python tools/bench_config5.py
-run bench_config5_dense python tools/bench_config5.py 4096 dense
+run bench_config5 python bench.py --config 4
 run bench_midsize_24 python tools/bench_midsize.py 6 4
 run bench_midsize_32 python tools/bench_midsize.py 8 4
 run bench_world python tools/bench_world.py --cpu-scenes 2

@@ -1,0 +1,113 @@
+"""MEASUREMENT ONLY - the engine plug-in behind the REAL reference `World`, on a GPU.
+
+The build container has the reference but no GPU, the GPU box a GPU but no reference: the GPU tests replay recorded accessor
+outputs (tests/world_io.py::RecordedWorld).  This script closes that gap once per round: with a copy of the reference staged
+in untracked scratch for ONE gpurun call (`LCP_REFERENCE_ROOT`; never committed, never imported by the package - see
+tools/stage_reference.sh) it builds the reference's own `World` objects (lcp_physics/physics/world.py:19-122, unmodified, through
+oracle/ref_shim.py) twice per scene -
+
+    World(bodies, joints, ...)                                   the reference's PdipmEngine on the host CPU (engines.py:17-116)
+    World(bodies, joints, ..., engine=HipPdipmEngine)            lcp_physics_amd.physics.engines (a live `world.contacts` tuple list,
+                                                                 `apply_forces(t)` side effects, `Je()` of jointed worlds)
+
+- steps both and compares trajectories, contact counts and, for the differentiable scene, d(loss)/d(initial force) through
+`World.step()` (demos/grad_demo.py:19-83).  Prints one JSON object; the caller commits it as profiles/r04_reference_world_plugin.json.
+
+    LCP_REFERENCE_ROOT=/path/to/staged/reference python tools/experiments/reference_world_plugin.py
+"""
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+
+
+def main():
+    if not ref_shim.reference_available():
+        raise SystemExit("no reference tree at %s (stage one with tools/stage_reference.sh)" % ref_shim.REFERENCE_ROOT)
+    ref_only = os.environ.get("PLUGIN_REF_ONLY") == "1"      # (build container, no GPU: exercise the reference half of this script)
+    if not ref_only and not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    ref_shim.load_reference()
+    from lcp_physics.physics.world import World
+    from lcp_physics_amd.physics.engines import HipFusedEngine, HipPdipmEngine
+    from oracle.make_golden_world import _scenes
+    torch.set_default_dtype(torch.float64)
+    out = {"what": "unmodified reference World (physics/world.py) stepped with its own PdipmEngine (host CPU) and with "
+                   "lcp_physics_amd's HipPdipmEngine plugged in through World(engine=...) on the same box",
+           "device": "none (reference half only)" if ref_only else torch.cuda.get_device_name(0), "host_cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "scenes": {}}
+    worst = 0.0
+    for name, make in _scenes().items():
+        post_stab = name.endswith("_poststab")
+
+        def run(engine):
+            random.seed(0)
+            bodies, joints, nsteps, strict = make()
+            kw = {} if engine is None else {"engine": engine}
+            world = World(bodies, joints, dt=1.0 / 30, strict_no_penetration=strict, post_stab=post_stab, **kw)
+            P, NC = [], []
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                world.step()
+                P.append(torch.cat([b.p for b in world.bodies]).detach().clone())
+                NC.append(len(world.contacts or []))
+            return torch.stack(P), NC, float(world.t), (time.perf_counter() - t0) / nsteps
+
+        pr, nr, tr, dt_ref = run(None)
+        ph, nh, th, dt_hip = run(None if ref_only else HipPdipmEngine)
+        pf, nf, tf, dt_fused = run(None if ref_only else HipFusedEngine)
+        err = float((ph - pr).abs().max())
+        same_steps = sum(1 for a, b in zip(nr, nh) if a == b)
+        out["scenes"][name] = {"steps": len(nr), "max_abs_pose_diff": err, "max_abs_pose_diff_fused_engine": float((pf - pr).abs().max()),
+                               "pose_scale": float(pr.abs().max()), "contact_counts_equal_steps": same_steps,
+                               "clock_equal": abs(tr - th) < 1e-12, "max_contacts": max(nr),
+                               "ms_per_step_reference_engine": dt_ref * 1e3, "ms_per_step_hip_engine": dt_hip * 1e3,
+                               "ms_per_step_hip_fused_engine": dt_fused * 1e3}
+        worst = max(worst, err)
+    out["worst_max_abs_pose_diff"] = worst
+    out["note"] = ("fp32 device solves against the reference's fp64 host solves: the trajectories agree to the 1e-4 .. 1e-3 the fp32 "
+                   "velocities put into poses of magnitude ~500 over 30-60 steps; scenes with post-stabilisation amplify rounding "
+                   "(ten PDIPM iterations do not converge on the frictionless LCP of a resting contact - tests/test_world_oracle.py)")
+    # a gradient through World.step(): demos/grad_demo.py's pattern on a small scene - d(final x of the ball)/d(initial push)
+    def grad(engine):
+        from lcp_physics.physics.bodies import Circle, Rect
+        from lcp_physics.physics.constraints import TotalConstraint
+        from lcp_physics.physics.forces import ExternalForce, Gravity
+        random.seed(0)
+        push = torch.tensor([0.0, 35.0, -1.0], requires_grad=True)     # (ExternalForce multiplies by 100: forces.py:29-36)
+
+        def force(t):
+            return push if t < 0.1 else torch.zeros(3, dtype=push.dtype)
+        fl = Rect([500, 500], [900, 10])
+        c = Circle([300, 455], 30, restitution=0.5)
+        c.add_force(Gravity(g=100))
+        c.add_force(ExternalForce(force))
+        b = Rect([600, 465], [60, 60])
+        b.add_force(Gravity(g=100))
+        kw = {} if engine is None else {"engine": engine}
+        world = World([fl, c, b], [TotalConstraint(fl)], dt=1.0 / 30, **kw)
+        for _ in range(30):
+            world.step()
+        loss = ((c.pos - torch.tensor([600.0, 300.0])) ** 2).sum() + (b.pos ** 2).sum() * 1e-3
+        loss.backward()
+        return float(loss), push.grad.clone()
+
+    try:
+        lr, gr = grad(None)
+        lh, gh = grad(None if ref_only else HipPdipmEngine)
+        out["rollout_gradient"] = {"scene": "floor + pushed ball that hits a box, 30 steps, d(loss)/d(push) through World.step()",
+                                   "loss_reference": lr, "loss_hip": lh, "grad_reference": gr.tolist(), "grad_hip": gh.tolist(),
+                                   "rel_err": float((gh - gr).norm() / gr.norm().clamp_min(1e-30))}
+    except Exception as ex:                                  # (measurement script: report, do not hide)
+        out["rollout_gradient"] = {"error": repr(ex)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

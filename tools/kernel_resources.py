@@ -45,7 +45,8 @@ def main():
         "lcp_fwd_solo_9_3_8": pick("lcp_fwd_solo<9, 3, 8>"),
         "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1, 0, 0, 0, false>"),
         "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0, 0, 0, 0, false>"),
-        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 0, 0, 0, 0, false>"),
+        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 2, 15, 3, 16, true>"),   # the dense boundary, body space (round 4): the same kernel reading rows of G
+        "lcp_fwd_quad_f64_dense_contact_space": pick("lcp_fwd_quad<float, double, false, 1, 0, 0, 0, 0, false>"),   # LCP_PATH_CONTACT_SPACE
         "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0, 0, 0, 0, false>"),
         "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0, 0, 0, 0, false>"),
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),

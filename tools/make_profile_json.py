@@ -9,23 +9,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E",                 # the headline forward (body space, pinned floor)
            "fused_B4096_nc16_f64_bwd": "lcp_bwd_quadIfdLb1E",                      # the dense backward behind it (body space)
            "fused_B4096_nc16_f64_bwd_physical": "lcp_bwd_step_quadIfdLi1ELb1E",    # --bwd physical
-           "dense_B4096_nc16_f64": "lcp_fwd_quadIfdLb0ELi1E",
-           "dense_B4096_nc16_f64_bwd": "lcp_bwd_quadIfdLb0E"}
+           # --mode dense (round 4: body space): the forward CALL is classify + the pinned kernel + three launches that find no scene
+           # (general body-space kernel, the two wave-per-scene kernels) - traffic summed over all of them, counters of the solver
+           "dense_B4096_nc16_f64": ["lcp_fwd_quadIfdLb0ELi1ELi2E", "lcp_classify_wave", "lcp_fwd_quadIfdLb0ELi1ELi1E", "lcp_fwd_waveIfdLb1ELb0ELb1E",
+                                    "lcp_fwd_waveIfdLb1ELb0ELb0E"],
+           "dense_B4096_nc16_f64_bwd": ["lcp_bwd_quadIfdLb1E", "lcp_bwd_waveIfdLb1ELb1E", "lcp_bwd_waveIfdLb1ELb0E"],
+           # --config 4 (the piles): lcp_primal_kernel<30, fwd, PIN = 3> and its backward <32, bwd, PIN = 3>
+           "fused_B4096_nc64_f64": "lcp_primal_kernelILi30ELb0ELb0ELi4ELi3E",
+           "fused_B4096_nc64_f64_bwd_physical": "lcp_primal_kernelILi32ELb1ELb0ELi4ELi3E"}
 
 
-def main(path, tag):
+def main(paths, tag):
     rows = {}
-    for line in open(path):
+    path = paths[0]
+    for line in (l for p_ in paths for l in open(p_)):
         parts = line.split()
         if len(parts) >= 5 and parts[0].startswith("_ZN"):
             rows[(parts[0], parts[1])] = float(parts[-1])          # avg per launch (per counter instance)
     traffic, counters = {}, {}
     src = os.path.relpath(path, ROOT)
-    for key, sub in KERNELS.items():
-        get = lambda c: next((v for (k, cn), v in rows.items() if sub in k and cn == c), None)
+    for key, subs in KERNELS.items():
+        subs = [subs] if isinstance(subs, str) else list(subs)
+        sub = subs[0]                                                   # the kernel the counters describe; traffic sums the whole call
+        get = lambda c, sb=sub: next((v for (k, cn), v in rows.items() if sb in k and cn == c), None)
         if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
-            traffic[key] = {"kernel": sub, "fetch_kb": get("FETCH_SIZE"), "write_kb": get("WRITE_SIZE"),
-                            "source": src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, avg per launch)"}
+            tot = lambda c: sum(v for v in (get(c, sb) for sb in subs) if v is not None)
+            traffic[key] = {"kernel": sub, "fetch_kb": tot("FETCH_SIZE"), "write_kb": tot("WRITE_SIZE"),
+                            "source": src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, avg per launch"
+                                      + ("; summed over the %d kernels of the call" % len(subs) if len(subs) > 1 else "") + ")"}
         wc = get("SQ_WAVE_CYCLES")
         if wc:
             c = {"kernel": sub, "source": src + " (rocprofv3 --pmc, avg per launch and counter instance)"}
@@ -43,4 +54,4 @@ def main(path, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1:-1], sys.argv[-1])          # python tools/make_profile_json.py profiles/r04_pmc.txt [profiles/r04_pmc_dense.txt ...] r04

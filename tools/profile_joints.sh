@@ -11,7 +11,7 @@ python tools/experiments/chain_world.py generic 2>/dev/null | tail -1 >> $OUT/r0
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_chain -o trace -- python $ROOT/tools/experiments/chain_world.py > $OUT/prof_chain.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_inf -o trace -- python $ROOT/tools/experiments/mass_inference.py --batch 4096 --iters 3 > $OUT/prof_inf.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o trace -- python $ROOT/tools/bench_config5.py 4096 > $OUT/prof_c5.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_c5 -o trace -- python $ROOT/tools/config5_phases.py 4096 > $OUT/prof_c5.log 2>&1
 cd $ROOT
 for t in chain inf c5; do
   f=$(find $OUT/prof_$t -name "*.db" | head -1)
