@@ -4,13 +4,17 @@
 #pragma once
 #include "lcp_wave_scene.h"
 #include "lcp_quad_prims.h"      // (row_newbcast moves and fused multiply-adds for the lane-grid LU of the pinned form)
+#include "lcp_primal_gridlu.h"   // (generated: the trailing update of a pivot of the lane-grid LU as one asm block)
 
 #ifndef LCP_PRIMAL_OCC40
 #define LCP_PRIMAL_OCC40 2     // wavefronts per SIMD the 40-column instantiations are allocated for (A/B: 1 = no scratch, one wave per SIMD)
 #endif
 
 #ifndef LCP_PRIMAL_GRIDLU
-#define LCP_PRIMAL_GRIDLU 1    // pinned form, <= 32 columns: LU on a 4 x 16 lane grid (pivot rows by row_newbcast) instead of row per lane (v_readlane) - 1: backward kernels, 2: forward too, 0: none (A/B)
+#define LCP_PRIMAL_GRIDLU 2    // pinned form, <= 32 columns: LU on a 4 x 16 lane grid (pivot rows by row_newbcast) instead of row per lane (v_readlane) - 2: forward and backward kernels (round 4), 1: backward kernels only (round 3), 0: none (A/B)
+#endif
+#ifndef LCP_PRIMAL_GRIDLU_V2
+#define LCP_PRIMAL_GRIDLU_V2 2 // form of the lane-grid LU - 2: fused multiply-adds, multipliers through LDS, constant lane masks, software-pipelined (round 4); 1: the same without the pipelining; 0: round 3's form (v_mov_b64_dpp + v_fma pairs, v_permlane swaps) (A/B)
 #endif
 #ifndef LCP_PRIMAL_CPERM
 #define LCP_PRIMAL_CPERM 1     // 1: contact 4 (lane % 16) + lane / 16 on a lane (neighbours in the list -> different 16-lane rows); 0: contact = lane (A/B)

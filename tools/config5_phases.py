@@ -33,7 +33,7 @@ dt = (time.perf_counter() - t) / 20
 print("config 5 forward (%s%s): %.4f ms per launch of %d scenes = %.2f M sim steps/s, mean iterations %.2f" % (
     "lcp_big.hip, contact space" if "big" in sys.argv else "lcp_primal_kernel", ", LCP_HINT_PINNED" if PINNED else "", dt * 1e3, B, B / dt / 1e6,
     float(out["iters"].float().mean())))
-if "primalprof" in os.environ.get("LCP_HIP_LIB", ""):
+if "prof" in os.path.basename(os.environ.get("LCP_HIP_LIB", "")) and "bigprof" not in os.environ.get("LCP_HIP_LIB", ""):
     pc = out["s"][:, 248:254].double().mean(dim=0).tolist()
     print("cycles per scene: residuals %.0f  formation %.0f  LU %.0f  bookkeeping %.0f  solve_kkt %.0f  steps + update %.0f  total %.0f"
           % (pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], sum(pc)))
