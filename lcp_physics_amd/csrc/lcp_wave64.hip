@@ -908,17 +908,19 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
     const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
     // (the tests are accumulated with `&`, not `&&`: a short-circuit would make every load wait for the previous compare)
     int good = 1;
+    // (round 4: the kernel was bound by the LATENCY of its loads - eight in flight per wavefront, ~15 round trips, 24 us for the 88 MB
+    //  of a 4096 x 16-contact batch; with 32 rows of F and 16 of G in flight it is a handful of round trips)
     if (lane < nz) {
-#pragma unroll 4
+#pragma unroll 8
       for (int i = nc; i < 3 * nc; i += 2) good &= (G[(i + 1) * nz + lane] == -G[i * nz + lane]) ? 1 : 0;
-#pragma unroll 4
+#pragma unroll 16
       for (int i = 3 * nc; i < m; ++i) good &= (G[i * nz + lane] == (TI)0) ? 1 : 0;
     }
     // F: lane j holds column j of every row in turn (one coalesced 4 m-byte read per row)
     const TI* F = (const TI*)P.F + (size_t)scene * m * m;
     if (lane < m) {
       const int j = lane;
-#pragma unroll 8
+#pragma unroll 32
       for (int i = 0; i < m; ++i) {
         const TI v = F[(size_t)i * m + j];
         TI want = (TI)0;

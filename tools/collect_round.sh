@@ -9,9 +9,11 @@ mkdir -p $O
 cd $ROOT
 run() { name=$1; shift; timeout 300 "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err; tail -1 $O/${TAG}_$name.json | cut -c1-200; }
 run bench_fused python bench.py
-run bench_dense python bench.py --mode dense --no-cpu-baseline
+run bench_dense python bench.py --mode dense --cpu-budget 3
+run bench_dense_contact_space python bench.py --mode dense --contact-space --cpu-budget 3
+run bench_driver_form python bench.py --steps 20 --warmup 5
 run bench_fused_physical_bwd python bench.py --bwd physical --no-cpu-baseline
-run bench_config2_fwd_only python bench.py --batch 1024 --nbox 2 --fwd-only --no-cpu-baseline
+run bench_config2_fwd_only python bench.py --config 1 --no-cpu-baseline
 run bench_config4_on_1gpu python bench.py --batch 32768 --no-cpu-baseline
 run bench_fused_8contacts python bench.py --pts 2 --no-cpu-baseline
 run bench_config5 python bench.py --config 4
@@ -22,8 +24,11 @@ run bench_world_graph python tools/bench_world.py --cpu-scenes 0 --graph
 run bench_world_11bodies python tools/bench_world.py --nbox 10 --box 24 --maxc 32 --cpu-scenes 0
 run bench_world_6bodies python tools/bench_world.py --nbox 5 --box 40 --cpu-scenes 0
 run batch_curve_2box python tools/bench_batch_curve.py 2
+{ timeout 300 python tools/experiments/grad_demo_rollout.py --rep 128 --eager --count; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 128; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 512 --eager; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 512; } 2>/dev/null | grep "^{" > $O/${TAG}_grad_demo_rollout.json
+{ timeout 300 python tools/experiments/mass_inference.py --batch 4096 --count; timeout 300 python tools/experiments/mass_inference.py --batch 4096 --graph; } 2>/dev/null | grep "^{" > $O/${TAG}_mass_inference.json
 run batch_curve_4box python tools/bench_batch_curve.py 4
 EXTRA="" bash tools/profile_all.sh $TAG > $O/${TAG}_profile_all.log 2>&1
+EXTRA="--mode dense" bash tools/profile_all.sh ${TAG}dense > $O/${TAG}_profile_dense.log 2>&1
 bash tools/profile_config5.sh $TAG > $O/${TAG}_profile_config5.log 2>&1
 ls $O | grep "^prof_${TAG}\|^${TAG}_" | head -60
 # in-kernel phase profile of the headline forward (needs `make -C lcp_physics_amd/csrc quadprof`)

@@ -2,12 +2,12 @@
 # Collect the round's profiles on the GPU box: kernel trace + stats, then PMC counters in separate passes
 # (never combined with tracing domains).  Outputs land in gpurun_out/prof_<tag>/ ; summaries are made by
 # tools/rocprof_summary.py and tools/pmc_summary.py and copied into profiles/ by hand.
-TAG=${1:-r01}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline ${EXTRA}"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-companions --spinup 0 --event-samples 8 ${EXTRA}"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_trace -o trace -- $BENCH > $OUT/prof_${TAG}_trace.log 2>&1
 echo "trace rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT"; do
@@ -17,7 +17,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 done
 ls $OUT | grep prof_${TAG}
 # the world with contact detection (kernel trace only)
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_world -o trace -- python $ROOT/tools/bench_world.py --cpu-scenes 0 --steps 50 > $OUT/prof_${TAG}_world.log 2>&1
+[ -n "$EXTRA" ] || timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_world -o trace -- python $ROOT/tools/bench_world.py --cpu-scenes 0 --steps 50 > $OUT/prof_${TAG}_world.log 2>&1
 echo "world trace rc=$?"
 cd $ROOT
 for d in $OUT/prof_${TAG}_trace $OUT/prof_${TAG}_world; do
