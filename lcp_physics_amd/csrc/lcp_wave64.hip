@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(256) lcp_classify_wave(FwdArgs P) {
 // STRUCT = contact-structured path (reduced 2 nc system); FUSED implies STRUCT.  For dense inputs both
 // instantiations are launched and each scene is served by the one its classification flag selects.
 template <typename TI, typename TC, bool PIVOT, bool FUSED, bool STRUCT>
-__global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave, int skip2) {
+__device__ __forceinline__ void fwd_wave_body(const FwdArgs& P, const StepArgs& SP, int lds_per_wave, int skip2) {
   static_assert(STRUCT || !FUSED, "the fused step is always contact-structured");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1116,9 +1116,25 @@ __global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wa
   }
 }
 
+template <typename TI, typename TC, bool PIVOT, bool FUSED, bool STRUCT>
+__global__ void __launch_bounds__(64 * WPB, STRUCT ? LCP_W64_OCC : 1) lcp_fwd_wave(FwdArgs P, StepArgs SP, int lds_per_wave, int skip2) {
+  fwd_wave_body<TI, TC, PIVOT, FUSED, STRUCT>(P, SP, lds_per_wave, skip2);
+}
+// Dense inputs: ONE launch for the scenes the four-scenes-per-wave kernels do not take - a wave reads its scene's class and runs the
+// structured or the general body (round 4: the two were separate launches, and on the usual batches - every scene contact-structured
+// with a diagonal Q - each of them cost 4.7 us to find nothing to do)
+template <typename TI, typename TC>
+__global__ void __launch_bounds__(64 * WPB) lcp_fwd_wave_any(FwdArgs P, StepArgs SP, int lds_per_wave, int skip2) {
+  const int scene = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (scene >= P.B) return;
+  Ws<TI, TC> W(P.ws, scene);
+  if (W.meta[0] == (TC)0) fwd_wave_body<TI, TC, true, false, false>(P, SP, lds_per_wave, 0);
+  else fwd_wave_body<TI, TC, true, false, true>(P, SP, lds_per_wave, skip2);
+}
+
 // ---------------------------------------------------------------- the backward kernel (lcp.py:37-64)
 template <typename TI, typename TC, bool PIVOT, bool STRUCT>
-__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave, int skip2) {
+__device__ __forceinline__ void bwd_wave_body(const BwdArgs& P, int lds_per_wave, int skip2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int scene = blockIdx.x * WPB + wave;
@@ -1203,6 +1219,19 @@ __global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_
   }
 }
 
+template <typename TI, typename TC, bool PIVOT, bool STRUCT>
+__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave(BwdArgs P, int lds_per_wave, int skip2) {
+  bwd_wave_body<TI, TC, PIVOT, STRUCT>(P, lds_per_wave, skip2);
+}
+template <typename TI, typename TC>
+__global__ void __launch_bounds__(64 * WPB) lcp_bwd_wave_any(BwdArgs P, int lds_per_wave, int skip2) {   // (as lcp_fwd_wave_any)
+  const int scene = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (scene >= P.B) return;
+  Ws<TI, TC> W(P.ws, scene);
+  if (W.meta[0] == (TC)0) bwd_wave_body<TI, TC, true, false>(P, lds_per_wave, 0);
+  else bwd_wave_body<TI, TC, true, true>(P, lds_per_wave, skip2);
+}
+
 }  // namespace w64
 
 // ---------------------------------------------------------------- host-side launchers
@@ -1246,20 +1275,17 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64, int 
     const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<double, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream, 1); if (rc) return rc; }
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<double, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<double, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<double, double>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
   } else if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream, 0, body_space); if (rc) return rc; }
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, double, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<float, double>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
   } else {
     const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, true>), w64_grid(P.B), ls, P, SP, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_fwd_wave<float, float, true, false, false>), w64_grid(P.B), lw, P, SP, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<float, float>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
@@ -1287,16 +1313,13 @@ int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, 
   if (quad) { int rc = quad_backward(P, compute, 2, stream, io_f64, quad_dense_is_body_space(io_f64, compute, body_space) ? 1 : 0); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
   if (io_f64) {
     const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<double, double, true, true>), w64_grid(P.B), ls, P, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<double, double, true, false>), w64_grid(P.B), lw, P, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<double, double>), w64_grid(P.B), lw, P, lw, quad);
   } else if (compute == LCP_COMPUTE_F64) {
     const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, true>), w64_grid(P.B), ls, P, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, double, true, false>), w64_grid(P.B), lw, P, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<float, double>), w64_grid(P.B), lw, P, lw, quad);
   } else {
     const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, true>), w64_grid(P.B), ls, P, ls, quad);
-    LCP_W64_LAUNCH((w64::lcp_bwd_wave<float, float, true, false>), w64_grid(P.B), lw, P, lw, 0);
+    LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<float, float>), w64_grid(P.B), lw, P, lw, quad);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

@@ -170,7 +170,11 @@ class _LCPFn(torch.autograd.Function):
         holder.nus, holder.lams, holder.slacks = back(sol.y), back(sol.z), back(sol.s)   # lcp.py:29
         holder.neq, holder.nineq, holder.nz = neq, nineq, nz
         holder.iters, holder.status, holder.solution = sol.iters, sol.status, sol
-        ctx.sol = sol
+        # the handle the backward takes, WITHOUT x: `back(sol.x)` below is sol.x itself when no conversion is needed, autograd stamps
+        # this node on it, and a ctx that holds it would be a cycle the garbage collector cannot see (the workspace would never be freed)
+        import copy
+        ctx.sol = copy.copy(sol)
+        ctx.sol.x = None
         ctx.meta = [(t.device, t.dtype, tuple(t.shape)) for t in ins]
         ctx.neq = neq
         return back(sol.x)

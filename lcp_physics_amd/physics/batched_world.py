@@ -470,7 +470,11 @@ class SolveDynamicsFunction(torch.autograd.Function):
                              eps=opts.get("eps", 1e-12), not_improved_lim=opts.get("not_improved_lim", 3),
                              max_iter=opts.get("max_iter", 10), compute=opts.get("compute", "f64"), pinned=bool(opts.get("pinned", False)))
         ctx.save_for_backward(Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2)
-        ctx.Je, ctx.out, ctx.dims, ctx.dt, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), float(dt), opts.get("compute", "f64")
+        # what the backward reads - the workspace and the word - WITHOUT the tensor this function returns: autograd stamps its node on the
+        # returned tensor, and a ctx that holds that tensor is a cycle through C++ the garbage collector cannot see (node -> ctx -> v_new
+        # -> grad_fn -> node): until round 4 every differentiable step leaked its 58 KB-per-scene workspace (profiles/r04_rollout_leak.txt)
+        ctx.Je, ctx.dims, ctx.dt, ctx.compute = (Je if e else None), (B, nb, maxc, e), float(dt), opts.get("compute", "f64")
+        ctx.out = {k: v for k, v in out.items() if k != "v_new"}
         opts["last"] = out
         return out["v_new"]
 
@@ -559,7 +563,8 @@ class PostStabilizationFunction(torch.autograd.Function):
         out = post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, frame, Je if e else None, p=pose[0], dt_scene=pose[1], p_out=pose[2],
                                  compute=opts.get("compute", "f64"))
         ctx.save_for_backward(Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2)
-        ctx.Je, ctx.out, ctx.dims, ctx.compute = (Je if e else None), out, (B, nb, maxc, e), opts.get("compute", "f64")
+        ctx.Je, ctx.dims, ctx.compute = (Je if e else None), (B, nb, maxc, e), opts.get("compute", "f64")
+        ctx.out = {k: v for k, v in out.items() if k != "dp"}          # (not the returned tensor: see SolveDynamicsFunction)
         opts["last_post_stab"] = out
         return out["dp"]
 
