@@ -265,6 +265,11 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e,
                                         float* dc_n, float* dc_p1, float* dc_p2, float* dJe,
                                         void* ws, void* stream);
 
+/* Host-only: 1 when lcp_post_stabilization_backward_f32 can follow lcp_post_stabilization_f32 at these sizes and this `compute`
+ * word, else 0 (the host then differentiates the correction through the dense boundary, the way engines.py:80-116 itself does:
+ * lcp_physics_amd/physics/dense_step.py). */
+int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute);
+
 /* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the
  * contact generation it calls, for B independent scenes in one launch:
  *   Body.move (physics/bodies.py:80-82)         p_try = p_start + v dt
@@ -284,7 +289,7 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e,
  *   out: p_out[B,nb,3]  c_n/c_p1/c_p2[B,maxc,2]  c_pen[B,maxc]  c_i1/c_i2[B,maxc]  count[B] (contacts found,
  *        in the reference's order; > maxc means the list was truncated)  max_pen[B]  dt_used[B]
  *        t[B] (+= dt_used)  trials[B]   (c_pen, max_pen, dt_used, t, trials, p_out may be NULL)
- * nb <= 16, hulls of <= 8 vertices. */
+ * nb <= 32, hulls of <= 8 vertices. */
 int lcp_move_find_contacts_f64(int B, int nb, int maxc,
                                const int32_t* kind, const double* radius, const double* verts_local,
                                const int32_t* nverts, const uint8_t* no_contact,
@@ -339,7 +344,7 @@ int lcp_state_update_backward_f64(int B, int nb, int nj,
  * SAT), hull / hull (SAT, incident edge, clipping); the derivative follows the branches the detection took (as autograd does).
  *   in : the geometry and the pose `p` lcp_move_find_contacts_f64 detected the contact list at (its p_out), its `eps`,
  *        count[B], and g_n / g_p1 / g_p2 [B,maxc,2] = d(loss)/d(c_n, c_p1, c_p2) (what lcp_step_backward_f32 returns)
- *   out: dp[B,nb,3] = d(loss)/d(pose) through the contact frame (overwritten).   nb <= 16. */
+ *   out: dp[B,nb,3] = d(loss)/d(pose) through the contact frame (overwritten).   nb <= 32. */
 int lcp_contact_frame_backward_f64(int B, int nb, int maxc,
                                    const int32_t* kind, const double* radius, const double* verts_local,
                                    const int32_t* nverts, const uint8_t* no_contact,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "lcp_step_backward_f32": (_I, [_I] * 4 + [_P] * 11 + [_c.c_float, _P, _I] + [_P] * 8 + [_P, _P]),
     "lcp_step_backward_je_f32": (_I, [_I] * 4 + [_P] * 11 + [_c.c_float, _P, _I] + [_P] * 9 + [_P, _P]),
     "lcp_step_has_backward": (_I, [_I, _I, _I, _I]),
+    "lcp_post_stabilization_has_backward": (_I, [_I, _I, _I, _I]),
     "lcp_post_stabilization_backward_f32": (_I, [_I] * 4 + [_P] * 10 + [_I] + [_P] * 7 + [_P, _P]),
     "lcp_solve_dynamics_f32": (_I, [_I] * 4 + [_P] * 12 + [_c.c_float, _c.c_double, _I, _I, _I] + [_P] * 4
                                + [_P, _P, _P, _P]),

@@ -439,6 +439,15 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   return lcp::generic_post_stab(P, compute, pl.lds_bytes, stream);
 }
 
+int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute) {
+  if (nb <= 0 || maxc <= 0 || e < 0) return 0;
+  bool generic;
+  int path;
+  compute = split_compute(compute, &generic, &path);
+  // (the routing test of lcp_post_stabilization_backward_f32 below)
+  return (compute == LCP_COMPUTE_F64 && path == 0 && lcp::primal_supported(3 * nb, 4 * maxc, e)) ? 1 : 0;
+}
+
 int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const float* Mdiag, const float* v,
                                         const float* rest, const float* c_n, const float* c_p1, const float* c_p2,
                                         const int32_t* c_i1, const int32_t* c_i2, const float* Je, const float* dl_ddp,

@@ -29,7 +29,7 @@ namespace lcp {
 namespace ct {
 
 constexpr int NV = 8;          // max vertices of a hull
-constexpr int MAXB = 16;       // max bodies per scene handled by this kernel
+constexpr int MAXB = 32;       // max bodies per scene handled by the detection kernel (its LDS staging is sized by the NBMAX it is built for)
 
 #define LCP_S double
 #include "lcp_contacts_geom.inc"
@@ -68,10 +68,10 @@ __device__ __forceinline__ bool operator==(Dual a, Dual b) { return a.v == b.v; 
 // scene has at most 16 body pairs, i.e. nb <= 6 - the common case; the lanes of a scene are one DPP/shuffle row).
 // Scenes that share a wave advance in lock step: a scene whose step is accepted keeps recomputing the same accepted
 // trial (identical stores) until its neighbours are done.
-template <int LPS>
+template <int LPS, int NBMAX>
 __global__ void __launch_bounds__(64) lcp_move_find_contacts_kernel(ContactArgs P) {
   constexpr int SPW = 64 / LPS;                                 // scenes per wave
-  constexpr int NBMAX = (LPS == 64) ? MAXB : 6;
+  static_assert(NBMAX <= MAXB && (LPS == 64 || NBMAX * (NBMAX - 1) / 2 <= LPS), "bodies per scene");
   __shared__ V2 s_verts_all[SPW * NBMAX * NV];
   __shared__ V2 s_nrm_all[SPW * NBMAX * NV];
   __shared__ double s_elen_all[SPW * NBMAX * NV];
@@ -440,8 +440,9 @@ int contact_frame_backward_launch(int B, int nb, int maxc, const int32_t* kind, 
 
 int contacts_launch(const ContactArgs& P, void* stream) {
   if (P.nb > ct::MAXB) return LCP_E_TOOLARGE;
-  if (P.nb <= 6) hipLaunchKernelGGL(ct::lcp_move_find_contacts_kernel<16>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
-  else hipLaunchKernelGGL(ct::lcp_move_find_contacts_kernel<64>, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P);
+  if (P.nb <= 6) hipLaunchKernelGGL((ct::lcp_move_find_contacts_kernel<16, 6>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+  else if (P.nb <= 16) hipLaunchKernelGGL((ct::lcp_move_find_contacts_kernel<64, 16>), dim3(P.B), dim3(64), 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL((ct::lcp_move_find_contacts_kernel<64, ct::MAXB>), dim3(P.B), dim3(64), 0, (hipStream_t)stream, P);   // (15 KB of LDS per scene)
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 

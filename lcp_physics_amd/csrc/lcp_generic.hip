@@ -70,16 +70,22 @@ struct Scene {
 };
 
 // Carve the per-scene LDS block.  Called with smem == nullptr on the host to size it.
+// `level` (Plan::t_in_lds) - where the matrices live:
+//   1  everything in LDS
+//   0  the big-problem plan: T and the prefactor scratch (G Q^-1) in the HBM workspace (T_ws points at T, the scratch follows it)
+//   2  the huge-problem plan: Q, Q^-1 and G follow them there too; LDS keeps A, G A-terms and the vectors (any World the reference
+//      can hold: 32 bodies x 128 contacts in fp64 is 80 KB of vectors) - every access goes through the same pointers
 template <typename TC>
 __host__ __device__ inline size_t carve(Scene<TC>& S, unsigned char* smem, int nz, int m, int e, int ldT,
-                                        bool t_in_lds, TC* T_ws) {
-  // t_in_lds == false is the big-problem plan: T and the prefactor scratch (G Q^-1) both live in the
-  // HBM workspace (T_ws points at T, the scratch follows it).
+                                        int level, TC* T_ws) {
+  const bool t_in_lds = level == 1, mats_in_lds = level != 2;
   TC* q = reinterpret_cast<TC*>(smem);
   auto take = [&](size_t n) { TC* r = q; q += n; return r; };
   S.nz = nz; S.m = m; S.e = e; S.ldT = ldT; S.nc = 0;
-  S.Q = take((size_t)nz * nz); S.Qi = take((size_t)nz * nz);
-  S.G = take((size_t)m * nz); S.scr = t_in_lds ? take((size_t)m * nz) : T_ws + (size_t)m * ldT;
+  TC* far = T_ws + (size_t)m * ldT + (size_t)m * nz;                     // (level 2) behind T and the scratch
+  S.Q = mats_in_lds ? take((size_t)nz * nz) : far; S.Qi = mats_in_lds ? take((size_t)nz * nz) : far + (size_t)nz * nz;
+  S.G = mats_in_lds ? take((size_t)m * nz) : far + 2 * (size_t)nz * nz;
+  S.scr = t_in_lds ? take((size_t)m * nz) : T_ws + (size_t)m * ldT;
   S.A = take((size_t)e * nz); S.GA = take((size_t)m * e); S.S11i = take((size_t)e * e);
   S.T = t_in_lds ? take((size_t)m * ldT) : T_ws;
   S.mu_c = take(m);
@@ -97,7 +103,7 @@ __host__ __device__ inline size_t carve(Scene<TC>& S, unsigned char* smem, int n
   return (bytes + 15) & ~(size_t)15;
 }
 
-inline size_t lds_bytes_for(int nz, int m, int e, int ldT, bool t_in_lds, int csize) {
+inline size_t lds_bytes_for(int nz, int m, int e, int ldT, int t_in_lds, int csize) {
   if (csize == 8) { Scene<double> S; return carve<double>(S, nullptr, nz, m, e, ldT, t_in_lds, nullptr); }
   Scene<float> S; return carve<float>(S, nullptr, nz, m, e, ldT, t_in_lds, nullptr);
 }
@@ -583,9 +589,10 @@ __device__ void pdipm_loop(Scene<TC>& S, const FT& F, TC eps, int max_iter, int 
 
 // workspace layout per scene (TC elements): R[m*m] Qi[nz*nz] GA[m*e] S11i[e*e] x[nz] s[m] z[m] y[e] (T[m*ldT])
 template <typename TC>
-__host__ __device__ inline size_t ws_elems(int nz, int m, int e, int ldT, bool t_in_ws) {
+__host__ __device__ inline size_t ws_elems(int nz, int m, int e, int ldT, int level) {
   size_t n = (size_t)m * m + (size_t)nz * nz + (size_t)m * e + (size_t)e * e + nz + 2 * (size_t)m + e;
-  if (t_in_ws) n += (size_t)m * ldT + (size_t)m * nz;   // T and the prefactor scratch
+  if (level != 1) n += (size_t)m * ldT + (size_t)m * nz;   // T and the prefactor scratch
+  if (level == 2) n += 2 * (size_t)nz * nz + (size_t)m * nz;   // Q, Q^-1, G
   return (n + 31) & ~(size_t)31;
 }
 
@@ -624,7 +631,7 @@ __global__ void __launch_bounds__(NT) lcp_fwd_kernel(FwdArgs P) {
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
   Scene<TC> S;
-  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds, W.T);
   S.R = W.R;
   load_dense<TI, TC>(S, P, scene);
   FDense<TI, TC> F{(const TI*)P.F + (size_t)scene * m * m, m};
@@ -657,7 +664,7 @@ __global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
   const int nz = 3 * P.nb, m = ncs, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, 4 * ncap, e);
   Scene<TC> S;
-  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds, W.T);
   S.R = W.R;
   assemble_scene<TI, TC, true>(S, P, scene, ncs);
   FZero<TC> F;
@@ -696,7 +703,7 @@ __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   const int nz = 3 * P.nb, m = 4 * ncs, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, mcap, e);
   Scene<TC> S;
-  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds, W.T);
   S.R = W.R;
   assemble_scene<TI, TC>(S, P, scene, ncs);
   FContact<TC> F{S.mu_c, ncs};
@@ -770,7 +777,7 @@ __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
   const int nz = P.nz, m = P.m, e = P.e;
   WsView<TC> W(P.ws, P.ws_stride, scene, nz, m, e);
   Scene<TC> S;
-  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds != 0, W.T);
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds, W.T);
   S.R = W.R;
   const TI* G = (const TI*)P.G + (size_t)scene * m * nz;
   for (int i = tid; i < m * nz; i += NT) S.G[i] = (TC)G[i];
@@ -838,14 +845,14 @@ Plan make_plan(int nz, int m, int e, int csize) {
   Plan pl;
   pl.ldT = m | 1;                      // odd leading dimension: conflict-free column walks
   pl.t_in_lds = 1;
-  pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, true, csize);
-  if (pl.lds_bytes > LDS_LIMIT) {
-    pl.t_in_lds = 0;
-    pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, false, csize);
+  pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, 1, csize);
+  for (int level = 0; pl.lds_bytes > LDS_LIMIT && level <= 2; level += 2) {       // 1 -> 0 -> 2: see carve()
+    pl.t_in_lds = level;
+    pl.lds_bytes = lds_bytes_for(nz, m, e, pl.ldT, level, csize);
   }
   pl.ok = pl.lds_bytes <= LDS_LIMIT;
-  pl.ws_stride = (csize == 8) ? ws_elems<double>(nz, m, e, pl.ldT, !pl.t_in_lds)
-                              : ws_elems<float>(nz, m, e, pl.ldT, !pl.t_in_lds);
+  pl.ws_stride = (csize == 8) ? ws_elems<double>(nz, m, e, pl.ldT, pl.t_in_lds)
+                              : ws_elems<float>(nz, m, e, pl.ldT, pl.t_in_lds);
   return pl;
 }
 
@@ -914,7 +921,7 @@ int generic_step(const StepArgs& P, int compute, size_t lds, void* stream) {
 int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b, float* F,
                      void* stream) {
   const int nz = 3 * P.nb, m = 4 * P.nc;
-  size_t lds = lds_bytes_for(nz, m, P.e, m, false, 4);
+  size_t lds = lds_bytes_for(nz, m, P.e, m, 0, 4);
   if (lds > LDS_LIMIT) return LCP_E_TOOLARGE;
   auto k = lcp_assemble_kernel<float>;
   if (set_lds(k, lds)) return LCP_E_LAUNCH;

@@ -11,7 +11,7 @@ namespace lcp {
 struct Plan {
   int ok;            // fits the LDS budget
   int ldT;           // leading dimension of T
-  int t_in_lds;      // T = R + diag(s/z) lives in LDS (else in the workspace)
+  int t_in_lds;      // where the matrices live (lcp_generic.hip carve()): 1 = all in LDS, 0 = T = R + diag(s/z) and the prefactor scratch in the workspace, 2 = Q, Q^-1, G there too
   size_t lds_bytes;  // dynamic LDS per workgroup
   size_t ws_stride;  // workspace elements (compute precision) per scene
 };

@@ -441,18 +441,17 @@ class SolveDynamicsFunction(torch.autograd.Function):
 
     @classmethod
     def apply(cls, Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts):
-        # The generic kernels step any size forward but keep no iterate a fused backward could read: say so when the step is
-        # RECORDED, not with LCP_E_TOOLARGE in the middle of loss.backward().  (Checked here: inside forward() grad mode is off.)
+        # The generic kernels step any size forward but keep no iterate a fused backward could read.  A step that is being RECORDED at
+        # such a size goes through the dense boundary instead, the way the reference does at every size (physics/dense_step.py):
+        # decided here, when the step is recorded - not with LCP_E_TOOLARGE in the middle of loss.backward().  (Inside forward() grad
+        # mode is off.)
         args = (Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts)
         if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
             nb, maxc = v.shape[1], c_n.shape[1]
             e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
             if not _lib.load().lcp_step_has_backward(nb, maxc, e, _COMPUTE[opts.get("compute", "f64")] | _lib.path_bits()):
-                raise RuntimeError(
-                    "SolveDynamicsFunction: a differentiable step of %d bodies / %d contacts / %d joint rows (compute=%s) has no fused "
-                    "backward (limits: 64 contacts, 3 nb + e <= 56, fp64 arithmetic beyond 16 contacts); differentiate this size "
-                    "through the dense boundary - assemble_contacts() + lcp_physics_amd.lcp.LCPFunction (lcp/lcp.py:37-64) - or "
-                    "call under torch.no_grad()" % (nb, maxc, e, opts.get("compute", "f64")))
+                from .dense_step import solve_dynamics_dense
+                return solve_dynamics_dense(*args)
         return super(SolveDynamicsFunction, cls).apply(*args)
 
     @staticmethod
@@ -550,6 +549,18 @@ class PostStabilizationFunction(torch.autograd.Function):
     `post_stabilization` (`engines.py:80-116`) as an autograd node: forward `lcp_post_stabilization_f32` (no pose update),
     backward `lcp_post_stabilization_backward_f32`.  All tensors float32 on the GPU; every call owns its workspace."""
 
+    @classmethod
+    def apply(cls, Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts):
+        # (as SolveDynamicsFunction.apply: a recorded correction of a size without a fused backward goes through the dense boundary)
+        args = (Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts)
+        if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+            nb, maxc = v.shape[1], c_n.shape[1]
+            e = 0 if Je is None or Je.numel() == 0 else Je.shape[1]
+            if not _lib.load().lcp_post_stabilization_has_backward(nb, maxc, e, _COMPUTE[opts.get("compute", "f64")] | _lib.path_bits()):
+                from .dense_step import post_stabilization_dense
+                return post_stabilization_dense(*args)
+        return super(PostStabilizationFunction, cls).apply(*args)
+
     @staticmethod
     def forward(ctx, Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts):
         B, nb = v.shape[0], v.shape[1]
@@ -594,9 +605,10 @@ class ContactWorld:
     Forces: a constant `f` or `force_fn(t)` (time-dependent, `forces.py:29-48`).  `step(differentiable=True)` records the
     step in torch's autograd graph (roll-out gradients, `demos/grad_demo.py`).  Joints: a constant Jacobian `Je`
     (Total/X/Y/Rot constraints) or a `JointSet` (revolute / fixed joints, Jacobian rebuilt every step and differentiated);
-    at most 16 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the four-scenes-per-wave solver, up to
+    at most 32 bodies per scene.  Scenes with 3 nb <= 32, maxc <= 16, e <= 4 run on the four-scenes-per-wave solver, up to
     64 contacts and 24 equality rows (3 nb + e <= 56) on the wave-per-scene body-space solver (both with a fused backward),
-    anything else on the generic kernels (slower, forward only).
+    anything else on the generic kernels; a differentiable step of such a size goes through the dense boundary
+    (physics/dense_step.py: torch assembly on the device + `LCPFunction`, the reference's own route).
     `post_stab=True` (off by default, as in the reference: utils.py:30) adds the two launches of world.py:109-121 to a
     step: `lcp_post_stabilization_f32` (frictionless LCP + correction move) and a contact re-detection.
     """

@@ -1,0 +1,185 @@
+"""GPU: differentiable steps of sizes the fused kernels keep no backward for (3 nb + e > 56, > 64 contacts, fp32 arithmetic beyond
+16 contacts) - `SolveDynamicsFunction` / `PostStabilizationFunction` route them through the dense boundary
+(`lcp_physics_amd/physics/dense_step.py`: torch assembly on the device + `LCPFunction`, the reference's own route,
+`engines.py:26-116`, `lcp.py:20-64`).  Against the fp64 oracle end to end (forward, and `lcp.py:37-64` + autograd through the
+assembly for every physical gradient), against the fused no-grad step of the same scenes, and through `ContactWorld`."""
+import pytest
+import torch
+
+from oracle import pdipm_oracle as O
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KEYS = ("Mdiag", "v", "f", "rest", "fric", "c_n", "c_p1", "c_p2")
+
+
+def _tall_stack(B=6, nbox=19, pts=2, seed=11):
+    from lcp_physics_amd import scenes
+    return scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=seed, dtype=torch.float32)
+
+
+def _leaves(sc):
+    return {k: getattr(sc, k).to(DEV).clone().requires_grad_(True) for k in KEYS}
+
+
+def _oracle_step(sc, cot, count=None):
+    """fp64 oracle per scene with its own contact count: v_new and the physical gradients of sum(v_new * cot)."""
+    vs, gs = [], {k: [] for k in KEYS}
+    for i in range(sc.B):
+        one = sc.slice(i, i + 1)
+        nc = sc.nc if count is None else int(count[i])
+        L = {k: getattr(one, k).double().clone().requires_grad_(True) for k in KEYS}
+        cut = lambda t: t[:, :nc]
+        if nc == 0:
+            Md = L["Mdiag"].reshape(1, -1)
+            top = Md * L["v"].reshape(1, -1) + sc.dt * L["f"].reshape(1, -1)
+            Je = one.Je.double()
+            P = torch.cat([torch.cat([torch.diag_embed(Md), -Je.transpose(1, 2)], 2),
+                           torch.cat([Je, torch.zeros(1, Je.shape[1], Je.shape[1], dtype=torch.float64)], 2)], 1)
+            v_new = (torch.inverse(P) @ torch.cat([top, torch.zeros(1, Je.shape[1], dtype=torch.float64)], 1).unsqueeze(2))
+            v_new = v_new.squeeze(2)[:, :Md.shape[1]].reshape(1, sc.nb, 3)                     # engines.py:36-49
+            g = torch.autograd.grad((v_new * cot[i:i + 1].double()).sum(), [L[k] for k in KEYS], allow_unused=True)
+        else:
+            lcp = O.assemble_lcp(L["Mdiag"], L["v"], L["f"], sc.dt, cut(L["c_n"]), cut(L["c_p1"]), cut(L["c_p2"]), cut(one.c_i1),
+                                 cut(one.c_i2), L["rest"], L["fric"], one.Je.double())
+            det = [None if t is None else t.detach() for t in lcp]
+            sol = O.lcp_forward(*det)
+            v_new = (-sol.x).reshape(1, sc.nb, 3)
+            gl = O.lcp_backward(sol, *det, (-cot[i:i + 1].double()).reshape(1, -1))          # lcp.py:37-64
+            outs = [t for t, k in zip(lcp, "QpGhAbF") if k in "QpGhF"]
+            g = torch.autograd.grad(outs, [L[k] for k in KEYS], [gl["d" + k] for k in "QpGhF"], allow_unused=True)
+        vs.append(v_new.detach())
+        for k, gi in zip(KEYS, g):
+            gs[k].append(torch.zeros_like(L[k]) if gi is None else gi)
+    return torch.cat(vs), {k: torch.cat(v) for k, v in gs.items()}
+
+
+def _rel(a, b):
+    B = a.shape[0]
+    return ((a - b).abs().reshape(B, -1).max(dim=1)[0] / b.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("pts", [2, 3])
+def test_a_recorded_step_without_a_fused_backward_goes_through_the_dense_boundary(pts):
+    """20 bodies; 38 contacts (G, Q in LDS, T in the workspace) and 57 contacts (nineq 228: the matrices no longer fit the 160 KB of
+    LDS in fp64 - the generic kernels' workspace plan, lcp_generic.hip carve() level 2)."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, fused_step
+    sc = _tall_stack(pts=pts, B=6 if pts == 2 else 3)
+    assert not _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)
+    L = _leaves(sc)
+    scg = sc.to(device=DEV)
+    opts = {"max_iter": 10, "compute": "f64"}
+    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
+                                        None, scg.Je, sc.dt, opts)
+    assert opts["last"]["dense_boundary"] and v_new.dtype == torch.float32 and v_new.shape == (sc.B, sc.nb, 3)
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(4))
+    (v_new * cot.to(DEV)).sum().backward()
+    v_ref, g_ref = _oracle_step(sc, cot)
+    # forward: the oracle, and the fused (no-grad) step of the same scenes - the value must not depend on whether a step is recorded
+    assert float(_rel(v_new.detach().double().cpu(), v_ref).max()) < 2e-6
+    fused = fused_step(scg)["v_new"].double().cpu()
+    assert float(_rel(v_new.detach().double().cpu(), fused).max()) < 2e-6
+    assert torch.equal(opts["last"]["iters"].cpu(), fused_step(scg)["iters"].cpu())
+    # backward: every physical gradient against lcp.py:37-64 + autograd in fp64
+    worst = {k: float(_rel(L[k].grad.double().cpu(), g_ref[k]).max()) for k in KEYS}
+    print("dense-boundary step, worst relative gradient error per key:", worst)
+    for k in ("Mdiag", "v", "f"):
+        assert worst[k] < 1e-4, (k, worst)
+    for k in ("rest", "fric", "c_n", "c_p1", "c_p2") if pts == 2 else ():      # (three collinear points per interface: the multipliers,
+        assert worst[k] < 1e-3, (k, worst)                                       #  and with them these gradients, are not unique)
+
+
+def test_scenes_with_their_own_contact_counts_are_solved_with_exactly_those_contacts():
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    sc = _tall_stack(B=5, seed=12)
+    count = torch.tensor([sc.nc, 0, 20, 20, sc.nc + 3], dtype=torch.int32)
+    L = _leaves(sc)
+    scg = sc.to(device=DEV)
+    opts = {"max_iter": 10, "compute": "f64"}
+    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
+                                        count.to(DEV), scg.Je, sc.dt, opts)
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(5))
+    (v_new * cot.to(DEV)).sum().backward()
+    v_ref, g_ref = _oracle_step(sc, cot, count.clamp(max=sc.nc))
+    assert float(_rel(v_new.detach().double().cpu(), v_ref).max()) < 2e-6
+    from lcp_physics_amd import _lib
+    assert (opts["last"]["status"].cpu() & _lib.ST_TRUNCATED).bool().tolist() == [False, False, False, False, True]
+    # the fused step with the same counts (no grad): same velocities, same multipliers in the same row layout
+    cb = ContactBuffers(sc.B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    out = solve_dynamics(sc.B, sc.nb, sc.nc, 3, count.to(DEV), scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, scg.Je, sc.dt)
+    assert float(_rel(v_new.detach().double().cpu(), out["v_new"].double().cpu()).max()) < 2e-6
+    zs = out["z"].double().cpu().abs().max(dim=1, keepdim=True)[0].clamp_min(1e-30)
+    assert float(((opts["last"]["z"].double().cpu() - out["z"].double().cpu()).abs() / zs).max()) < 1e-4
+    for k in ("Mdiag", "v", "f"):
+        assert float(_rel(L[k].grad.double().cpu(), g_ref[k]).max()) < 1e-4, k
+    # padded contact slots receive no gradient
+    for i, c in enumerate(count.clamp(max=sc.nc).tolist()):
+        for k in ("c_n", "c_p1", "c_p2"):
+            assert float(L[k].grad[i, c:].abs().max() if c < sc.nc else 0.0) == 0.0
+
+
+def test_post_stabilization_of_a_size_without_a_fused_backward():
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import PostStabilizationFunction, post_stabilization
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    sc = _tall_stack(B=4, seed=13)
+    assert not _lib.load().lcp_post_stabilization_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)
+    assert _lib.load().lcp_post_stabilization_has_backward(5, 16, 3, _lib.COMPUTE_F64)
+    keys = ("Mdiag", "v", "rest", "c_n", "c_p1", "c_p2")
+    L = {k: getattr(sc, k).to(DEV).clone().requires_grad_(True) for k in keys}
+    scg = sc.to(device=DEV)
+    opts = {"max_iter": 10, "compute": "f64"}
+    dp = PostStabilizationFunction.apply(L["Mdiag"], L["v"], L["rest"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2, None, scg.Je, opts)
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(6))
+    (dp * cot.to(DEV)).sum().backward()
+    # oracle: engines.py:80-116 + lcp.py:37-64 + autograd
+    R = {k: getattr(sc, k).double().clone().requires_grad_(True) for k in keys}
+    lcp = O.assemble_post_stabilization(R["Mdiag"], R["v"], R["c_n"], R["c_p1"], R["c_p2"], sc.c_i1, sc.c_i2, R["rest"], sc.Je.double())
+    det = [None if t is None else t.detach() for t in lcp]
+    sol = O.lcp_forward(*det)
+    gl = O.lcp_backward(sol, *det, (-cot.double()).reshape(sc.B, -1))
+    pairs = [(t, gl["d" + k]) for t, k in zip(lcp, "QpGhAbF") if t is not None and t.requires_grad]
+    g_ref = torch.autograd.grad([t for t, _ in pairs], [R[k] for k in keys], [g for _, g in pairs], allow_unused=True)
+    assert float(_rel(dp.detach().double().cpu(), (-sol.x).reshape(sc.B, sc.nb, 3)).max()) < 1e-5
+    cb = ContactBuffers(sc.B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    full = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=DEV)
+    fused = post_stabilization(sc.B, sc.nb, sc.nc, 3, full, scg.Mdiag, scg.v, scg.rest, cb, scg.Je)["dp"].double().cpu()
+    assert float(_rel(dp.detach().double().cpu(), fused).max()) < 1e-5
+    worst = {k: float(_rel(L[k].grad.double().cpu(), torch.zeros_like(R[k]) if g is None else g).max()) for k, g in zip(keys, g_ref)}
+    print("dense-boundary post-stabilisation, worst relative gradient error per key:", worst)
+    for k in ("Mdiag", "v"):
+        assert worst[k] < 1e-3, (k, worst)
+
+
+def test_contact_world_records_steps_of_twenty_bodies():
+    """`ContactWorld.step(differentiable=True)` with 20 bodies (3 nb + e = 63): the recorded roll-out follows the plain one, and a loss
+    on the final pose reaches the initial velocities and the masses."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    B, nbox, steps = 4, 19, 4
+    w = scenes.make_drop_world(B, nbox=nbox, seed=77, gap=(0.02, 0.08))        # (inside the detection margin: in contact from the start)
+    geom = GeometryBatch.from_shapes(w["shapes"], B).to(DEV)
+    dev = lambda t: t.to(DEV)
+
+    def world(Mdiag, v):
+        return ContactWorld(geom, dev(w["p"]), v, Mdiag, dev(w["f"]), dev(w["rest"]), dev(w["fric"]), Je=dev(w["Je"]), maxc=48)
+
+    plain = world(dev(w["Mdiag"]), dev(w["v"]))
+    for _ in range(steps):
+        plain.step()
+    Mdiag, v0 = dev(w["Mdiag"]).requires_grad_(True), dev(w["v"]).requires_grad_(True)
+    rec = world(Mdiag, v0)
+    for _ in range(steps):
+        rec.step(differentiable=True)
+    assert float((rec.p.detach() - plain.p).abs().max()) < 1e-4
+    assert int(rec.contacts.count.max()) > 16
+    loss = (rec.p[:, 1:, 1:] ** 2).sum() * 1e-4
+    loss.backward()
+    for t in (Mdiag.grad, v0.grad):
+        assert t is not None and bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0

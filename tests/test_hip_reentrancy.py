@@ -194,23 +194,31 @@ def test_backward_planned_for_another_layout_returns_nan_not_garbage():
     assert bool(torch.isnan(nanp).all())
 
 
-def test_differentiable_step_without_a_fused_backward_fails_at_forward_time():
+def test_differentiable_step_without_a_fused_backward_is_decided_at_forward_time():
     """sizes the generic kernels step forward (no iterate kept for a fused backward) must not fail with LCP_E_TOOLARGE
-    in the middle of loss.backward(): SolveDynamicsFunction says so when the step is recorded."""
+    in the middle of loss.backward(): SolveDynamicsFunction decides when the step is RECORDED - since round 4 by taking the dense
+    boundary (physics/dense_step.py), whose gradients are those of the fused backward."""
     from lcp_physics_amd import _lib
     from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction
     sc = _scenes(23, B=8)
     Md = sc.Mdiag.clone().requires_grad_(True)
     count = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=DEV)
     args = (Md, sc.v, sc.f, sc.rest, sc.fric, sc.c_n, sc.c_p1, sc.c_p2, sc.c_i1, sc.c_i2, count, sc.Je, sc.dt)
-    v_new = SolveDynamicsFunction.apply(*args, {})
+    opts = {}
+    v_new = SolveDynamicsFunction.apply(*args, opts)
     v_new.sum().backward()                                       # the default path has one
-    assert Md.grad is not None and bool(torch.isfinite(Md.grad).all())
+    assert Md.grad is not None and bool(torch.isfinite(Md.grad).all()) and "dense_boundary" not in opts["last"]
+    fused, Md.grad = Md.grad.clone(), None
     _lib.set_path("generic")
     try:
-        with pytest.raises(RuntimeError, match="no fused backward"):
-            SolveDynamicsFunction.apply(*args, {})
+        opts = {}
+        v_dense = SolveDynamicsFunction.apply(*args, opts)
+        assert opts["last"]["dense_boundary"]
+        v_dense.sum().backward()
         with torch.no_grad():
-            SolveDynamicsFunction.apply(*args, {})               # forward only: fine
+            SolveDynamicsFunction.apply(*args, {})               # forward only: the fused generic step
     finally:
         _lib.set_path("auto")
+    assert float((v_dense.detach() - v_new.detach()).abs().max() / v_new.detach().abs().max()) < 1e-5
+    scale = fused.abs().reshape(sc.B, -1).max(dim=1)[0].clamp_min(1e-30)
+    assert float(((Md.grad - fused).abs().reshape(sc.B, -1).max(dim=1)[0] / scale).median()) < 1e-4

@@ -106,6 +106,43 @@ def main():
                                    "rel_err": float((gh - gr).norm() / gr.norm().clamp_min(1e-30))}
     except Exception as ex:                                  # (measurement script: report, do not hide)
         out["rollout_gradient"] = {"error": repr(ex)}
+    # the same through a world of TWENTY bodies (3 nb + e = 63 coordinates: beyond the fused backward kernels - the engine's recorded
+    # steps go through the dense boundary, lcp_physics_amd/physics/dense_step.py): a tower of 19 boxes, the top one pushed sideways
+    def grad_tower(engine, nbox=19, steps=6):
+        from lcp_physics.physics.bodies import Rect
+        from lcp_physics.physics.constraints import TotalConstraint
+        from lcp_physics.physics.forces import ExternalForce, Gravity
+        random.seed(0)
+        push = torch.tensor([0.0, 2.0, 0.0], requires_grad=True)
+
+        def force(t):
+            return push
+        fl = Rect([500, 500], [900, 10])
+        boxes = []
+        for k in range(nbox):
+            b = Rect([500 + 2.0 * ((k * 7) % 5 - 2), 485 - 20.05 * k - 0.05], [20, 20])
+            b.add_force(Gravity(g=100))
+            boxes.append(b)
+        boxes[-1].add_force(ExternalForce(force))
+        kw = {} if engine is None else {"engine": engine}
+        world = World([fl] + boxes, [TotalConstraint(fl)], dt=1.0 / 30, **kw)
+        ncs = []
+        for _ in range(steps):
+            world.step()
+            ncs.append(len(world.contacts or []))
+        loss = sum((b.pos ** 2).sum() for b in boxes[-3:]) * 1e-3
+        loss.backward()
+        return float(loss), push.grad.clone(), ncs
+
+    try:
+        lr, gr, nr_ = grad_tower(None)
+        lh, gh, nh_ = grad_tower(None if ref_only else HipPdipmEngine)
+        out["rollout_gradient_20_bodies"] = {"scene": "floor + tower of 19 boxes, the top one pushed; 6 steps, d(loss)/d(push) through World.step()",
+                                             "contacts_per_step_reference": nr_, "contacts_per_step_hip": nh_,
+                                             "loss_reference": lr, "loss_hip": lh, "grad_reference": gr.tolist(), "grad_hip": gh.tolist(),
+                                             "rel_err": float((gh - gr).norm() / gr.norm().clamp_min(1e-30))}
+    except Exception as ex:
+        out["rollout_gradient_20_bodies"] = {"error": repr(ex)}
     print(json.dumps(out))
 
 

@@ -14,6 +14,7 @@ try:
 except Exception as ex:
     print("ERR", ex)
 PY
+[ -n "$ONLY_PLUGIN" ] && exit 0                  # (the world comparison alone; the reference timings below take ~4 minutes)
 M="GPU box host ($(nproc) cores, same box as the bench)"
 timeout 600 python oracle/time_reference.py --batch 4096 --dtype float64 --reps 1 --machine "$M" > $O/r04_reference_cpu_timing_f64.json 2>/dev/null; cat $O/r04_reference_cpu_timing_f64.json
 timeout 600 python oracle/time_reference.py --batch 4096 --dtype float32 --reps 1 --machine "$M" > $O/r04_reference_cpu_timing_f32.json 2>/dev/null; cat $O/r04_reference_cpu_timing_f32.json

@@ -11,4 +11,4 @@ rm -rf $STAGE; mkdir -p $STAGE
 trap 'rm -rf oracle/_ref/stage' EXIT
 cp -r /root/reference/lcp_physics $STAGE/
 find $STAGE -name "__pycache__" -prune -exec rm -rf {} +
-/usr/local/graft/bin/gpurun --timeout ${TIMEOUT:-1500} -- 'bash tools/gpu_reference_measure.sh'
+/usr/local/graft/bin/gpurun --timeout ${TIMEOUT:-1500} -- "${CMD:-bash tools/gpu_reference_measure.sh}"
