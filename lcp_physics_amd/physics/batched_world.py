@@ -412,7 +412,7 @@ class _JointJacobianFn(torch.autograd.Function):
     `lcp_joint_jacobian_backward_f64`.  `Je_value` belongs to the step (a fresh tensor per `jacobian()` call)."""
 
     @staticmethod
-    def forward(ctx, p, rot, joints, Je_value):
+    def forward(ctx, p, rot, r1, joints, Je_value):
         ctx.joints, ctx.nb = joints, p.shape[1]
         ctx.save_for_backward(rot)
         return Je_value.detach()
@@ -421,7 +421,9 @@ class _JointJacobianFn(torch.autograd.Function):
     def backward(ctx, gJe):
         (rot,) = ctx.saved_tensors
         g_p, g_rot = ctx.joints.jacobian_backward(ctx.nb, rot, gJe)
-        return g_p, g_rot, None, None
+        # (r1 = the anchors' radii: constants unless the joints were created at poses that require grad, constraints.py:21-23)
+        g_r1 = ctx.joints.anchor_radius_backward(ctx.nb, rot, gJe) if ctx.needs_input_grad[2] else None
+        return g_p, g_rot, g_r1, None, None
 
 
 class SolveDynamicsFunction(torch.autograd.Function):
@@ -769,7 +771,7 @@ class ContactWorld:
             # kernel's values, the gradient of the torch expression; lcp_step_backward_je_f32 returns dL/dJe
             if getattr(self, "_jrot_src", None) is not self.p:
                 self._jrot_ad, self._jrot_src = js.jrot1.clone(), self.p
-            Je = _JointJacobianFn.apply(self.p, self._jrot_ad, js, self.Je)
+            Je = _JointJacobianFn.apply(self.p, self._jrot_ad, js.jr1, js, self.Je)
         v_new = SolveDynamicsFunction.apply(self.Mdiag, self.v.contiguous(), f, self.rest, self.fric, c_n, c_p1, c_p2, frame.c_i1,
                                             frame.c_i2, frame.count, Je, self.dt, opts)
         out = opts["last"]
@@ -796,7 +798,7 @@ class ContactWorld:
             dt_used = cb.dt_used
             g_n, g_p1, g_p2 = ct.ContactFrameFunction.apply(self._p_geom, self.geom, frame2, self.eps)
             pose_dep = js is not None and js.pose_dependent
-            Je2 = _JointJacobianFn.apply(self.p, self._jrot_ad, js, self.Je) if pose_dep else self.Je
+            Je2 = _JointJacobianFn.apply(self.p, self._jrot_ad, js.jr1, js, self.Je) if pose_dep else self.Je
             p_corr = torch.empty_like(cb.p_out)                            # the corrected pose: the kernel's own move, as in step()
             opts["ps_pose"] = (cb.p_out, dt_used, p_corr)
             dp_s = PostStabilizationFunction.apply(self.Mdiag, v_new.contiguous(), self.rest, g_n, g_p1, g_p2, frame2.c_i1, frame2.c_i2,

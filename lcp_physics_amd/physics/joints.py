@@ -55,13 +55,16 @@ class JointSet:
         p0 = torch.as_tensor(p0, dtype=torch.float64)
         if p0.dim() == 2:
             p0 = p0.unsqueeze(0).expand(B, -1, -1)
-        B = p0.shape[0]
+        B, dev = p0.shape[0], p0.device
         nj = len(joints)
-        jtype = torch.zeros(B, nj, dtype=torch.int32)
-        jb1 = torch.zeros(B, nj, dtype=torch.int32)
-        jb2 = torch.full((B, nj), -1, dtype=torch.int32)
-        jr1 = torch.zeros(B, nj, dtype=torch.float64)
-        jrot1 = torch.zeros(B, nj, dtype=torch.float64)
+        jtype = torch.zeros(B, nj, dtype=torch.int32, device=dev)
+        jb1 = torch.zeros(B, nj, dtype=torch.int32, device=dev)
+        jb2 = torch.full((B, nj), -1, dtype=torch.int32, device=dev)
+        # the anchors' polar coordinates are differentiable functions of `p0`, like the reference's (`pos - body1.pos` ->
+        # cart_to_polar, constraints.py:21-23): with a `p0` that requires grad a differentiable roll-out carries d(loss)/d(r1),
+        # d(loss)/d(rot1) back to it (ContactWorld.step_autograd -> _JointJacobianFn)
+        r_cols, rot_cols = [], []
+        zero = torch.zeros(B, dtype=torch.float64, device=dev)
         e = 0
         for k, j in enumerate(joints):
             t = _NAMES[j[0]]
@@ -69,12 +72,15 @@ class JointSet:
             if t in (JOINT, FIXED) and j[2] is not None:
                 jb2[:, k] = int(j[2])
             if t == JOINT:
-                d = torch.tensor(j[3], dtype=torch.float64).unsqueeze(0) - p0[:, int(j[1]), 1:]
-                jr1[:, k] = d.norm(dim=1)
+                d = torch.tensor(j[3], dtype=torch.float64, device=dev).unsqueeze(0) - p0[:, int(j[1]), 1:]
                 th = torch.atan2(d[:, 1], d[:, 0])
-                jrot1[:, k] = torch.where(th < 0, th + 2 * math.pi, th)
+                r_cols.append(d.norm(dim=1)); rot_cols.append(torch.where(th < 0, th + 2 * math.pi, th))
+            else:
+                r_cols.append(zero); rot_cols.append(zero)
             e += ROWS[t]
-        return JointSet(jtype, jb1, jb2, jr1, jrot1, e)
+        jr1 = torch.stack(r_cols, dim=1) if nj else torch.zeros(B, 0, dtype=torch.float64, device=dev)
+        jrot1 = torch.stack(rot_cols, dim=1) if nj else torch.zeros(B, 0, dtype=torch.float64, device=dev)
+        return JointSet(jtype, jb1, jb2, jr1.contiguous(), jrot1.contiguous(), e)
 
     @staticmethod
     def from_arrays(jtype, jb1, jb2, jr1, jrot1, B):
@@ -123,6 +129,23 @@ class JointSet:
                                                      P(gJe), P(g_p), P(g_rot), _lib.stream_ptr(gJe.device))
         _lib.check(rc, "lcp_joint_jacobian_backward_f64")
         return g_p, g_rot
+
+    def anchor_radius_backward(self, nb, rot, gJe):
+        """d(loss)/d(jr1) [B,nj] float64 from d(loss)/dJe: the one input of `Joint.J()` the kernel above does not differentiate (a
+        constant unless the joints were created at poses that require grad).  pos1 = r1 (cos rot1, sin rot1) enters four entries per
+        revolute joint (constraints.py:26-36 with pos2 = body1.pos + pos1 - body2.pos): a gather on the index plan of `jacobian_torch`."""
+        B, nj = self.jtype.shape[0], self.jtype.shape[1]
+        plan = self._torch_plan(B, nb, torch.float64, gJe.device)
+        out = torch.zeros(B, nj, dtype=torch.float64, device=gJe.device)
+        if not plan["ks"]:
+            return out
+        kk, has2, rev = plan["kk"], plan["has2"], plan["rev"]
+        ext = torch.cat([gJe.to(torch.float64), gJe.new_zeros(B, self.e, 1, dtype=torch.float64)], dim=2).reshape(B, -1)
+        gv = ext.gather(1, plan["flat"]).reshape(B, len(plan["ks"]), 4)       # d/d(-pos1_y), d/d(pos1_x), d/d(pos2_y), d/d(-pos2_x)
+        gx, gy = gv[..., 1] - has2 * gv[..., 3], -gv[..., 0] + has2 * gv[..., 2]
+        th = rot[:, kk]
+        out[:, kk] = rev * (gx * torch.cos(th) + gy * torch.sin(th))
+        return out
 
     def _torch_plan(self, B, nb, dtype, dev):
         """What `jacobian_torch` needs that does not change with the pose: the constant entries of Je ([B,e,3nb]) and, for the

@@ -136,14 +136,15 @@ K_FORCES = [([0.0, 30.0, 0.0], [0.0, 0.0, 0.0]), ([3.0, 36.0, 4.0], [0.0, -2.0, 
             ([5.0, 33.0, 6.0], [-0.3, -1.0, -1.0]), ([1.0, 40.0, -5.0], [0.0, 0.5, 2.0]), ([-4.0, 26.0, 2.0], [0.1, -1.5, 0.0])]
 
 
-def make_world_pendulum(f_first, f_ball):
+def make_world_pendulum(f_first, f_ball, pos0=None):
     from lcp_physics.physics.bodies import Circle
     from lcp_physics.physics.constraints import Joint
     from lcp_physics.physics.forces import ExternalForce, Gravity
     from lcp_physics.physics.world import World
-    bob = Circle([300, 300], 20, restitution=0.3, fric_coeff=0.4)
-    link = Circle([300, 372], 18, restitution=0.3, fric_coeff=0.4)
-    ball = Circle([390, 300], 22, restitution=0.5, fric_coeff=0.3)
+    pos0 = pos0 or ([300, 300], [300, 372], [390, 300])        # (tensors that require grad in the "a_" scenes: Body.__init__ keeps them)
+    bob = Circle(pos0[0], 20, restitution=0.3, fric_coeff=0.4)
+    link = Circle(pos0[1], 18, restitution=0.3, fric_coeff=0.4)
+    ball = Circle(pos0[2], 22, restitution=0.5, fric_coeff=0.3)
     bob.add_no_contact(link)
     for b in (bob, link):
         b.add_force(Gravity(g=100))
@@ -168,13 +169,17 @@ def make_world_dumbbell(f_first, f_ball):
     return world, [[0, 1]], []
 
 
-def run_joints(make, fb, fx):
+def run_joints(make, fb, fx, pos0=None):
+    """`pos0`: initial positions [nb][2] that REQUIRE GRAD ("a_" scenes) - the reference's `Joint.__init__` takes the anchor's polar
+    coordinates from `pos - body1.pos` (constraints.py:21-23), so d(loss)/d(initial position) has a path through (r1, rot1) and
+    every later `Joint.J()`; recorded as grad_p0 [nb,2]."""
     from lcp_physics.physics import constraints as C_
     from lcp_physics.physics.forces import ExternalForce
     f1 = torch.tensor(fb, dtype=torch.float64, requires_grad=True)
     f2 = torch.tensor(fx, dtype=torch.float64, requires_grad=True)
+    leaves = None if pos0 is None else [torch.tensor(q, dtype=torch.float64, requires_grad=True) for q in pos0]
     world, no_contact, heavy = make(lambda t: f1 if t < T_PUSH else ExternalForce.ZEROS,
-                                    lambda t: f2 if t < T_PUSH else ExternalForce.ZEROS)
+                                    lambda t: f2 if t < T_PUSH else ExternalForce.ZEROS, *([] if leaves is None else [leaves]))
     second, ball = world.bodies[1], world.bodies[2]
     nb = len(world.bodies)
     jt = {C_.Joint: 1, C_.FixedJoint: 2, C_.XConstraint: 3, C_.YConstraint: 4, C_.RotConstraint: 5, C_.TotalConstraint: 6}
@@ -198,6 +203,8 @@ def run_joints(make, fb, fx):
     dist.backward()
     rec.update(p_final=torch.stack([b.p for b in world.bodies]).detach().numpy().copy(), loss=np.float64(float(dist)),
                grad_first=f1.grad.numpy().copy(), grad_ball=f2.grad.numpy().copy(), ncontacts=np.array(ncs), t=np.array(ts))
+    if leaves is not None:
+        rec["grad_p0"] = np.stack([q.grad.numpy().copy() for q in leaves])
     return rec
 
 
@@ -283,8 +290,13 @@ def chain(prefix="c_", params=C_PARAMS, links=C_LINKS, nsteps=C_NSTEPS):
     return out
 
 
-def jointed(prefix, make, forces):
-    recs = [run_joints(make, a, b) for a, b in forces]
+# initial positions of the "a_" scenes (the pendulum of "j_" with its bodies moved a little; gradients with respect to them)
+A_POS0 = [([300.0, 300.0], [300.0, 372.0], [390.0, 300.0]), ([303.0, 298.0], [301.0, 371.0], [391.0, 302.0]),
+          ([296.0, 303.0], [298.0, 374.0], [388.0, 297.0]), ([301.0, 305.0], [304.0, 370.0], [392.0, 301.0])]
+
+
+def jointed(prefix, make, forces, pos0=None):
+    recs = [run_joints(make, a, b, None if pos0 is None else pos0[i]) for i, (a, b) in enumerate(forces)]
     out = {prefix + k: np.stack([r[k] for r in recs]) for k in recs[0]}
     out.update({prefix + "force_first": np.array([a for a, _ in forces]), prefix + "force_ball": np.array([b for _, b in forces]),
                 prefix + "nsteps": np.int64(J_NSTEPS)})
@@ -300,6 +312,7 @@ def main():
     torch.set_default_dtype(torch.float64)
     jout = jointed("j_", make_world_pendulum, J_FORCES)
     jout.update(jointed("k_", make_world_dumbbell, K_FORCES))
+    jout.update(jointed("a_", make_world_pendulum, J_FORCES[:len(A_POS0)], A_POS0))
     jout.update(chain())
     jout.update(chain("d_", D_PARAMS, D_LINKS, D_NSTEPS))
     hrecs = [run_hulls(a, b) for a, b in H_FORCES]

@@ -935,6 +935,63 @@ def test_rollout_gradient_through_pose_dependent_joints_matches_the_reference_au
         assert err[same].max() > 1e-2, err
 
 
+@pytest.mark.parametrize("anchors_follow_p0", [True, False])
+def test_rollout_gradient_reaches_the_initial_positions_through_the_joint_anchors(anchors_follow_p0):
+    """The reference's `Joint.__init__` takes the anchor's polar coordinates from `pos - body1.pos` (constraints.py:21-23,
+    utils.py:75-82): an initial position that requires grad reaches the loss through (r1, rot1) and every later `Joint.J()` as well as
+    through the state.  "a_" scenes of the fixture: the double pendulum of "j_" with its bodies' initial positions as leaves; four
+    scenes against the unmodified reference's autograd.  `JointSet.from_list(joints, p0)` keeps that graph; built from a detached
+    `p0` (`anchors_follow_p0=False`) the same comparison must FAIL - the test sees the path."""
+    from lcp_physics_amd.physics.batched_world import ContactWorld
+    from lcp_physics_amd.physics.contacts import GeometryBatch
+    from lcp_physics_amd.physics.joints import JointSet
+    d0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    d = {k[2:]: d0[k] for k in d0.files if k.startswith("a_")}
+    nv, rep = d["force_first"].shape[0], 16
+    B = nv * rep
+    rp = lambda a, dt_: torch.tensor(np.repeat(a, rep, axis=0), dtype=dt_, device=DEV)
+    nb = d["rad"].shape[1]
+    geom = GeometryBatch.from_shapes([("circle", float(r)) for r in d["rad"][0]], B)
+    nocon = torch.zeros(B, nb, nb, dtype=torch.uint8)
+    for i, j in d["no_contact"][0].tolist():
+        nocon[:, i, j] = nocon[:, j, i] = 1
+    geom.no_contact = nocon
+    geom = geom.to(DEV)
+    p0 = rp(d["p0"], torch.float64).requires_grad_(True)
+    # (oracle/make_golden_rollout.py::make_world_pendulum: Joint(bob, None, [300, 220]), Joint(bob, link, [300, 330]))
+    joints = JointSet.from_list([("joint", 0, None, (300.0, 220.0)), ("joint", 0, 1, (300.0, 330.0))], p0 if anchors_follow_p0 else p0.detach())
+    assert np.abs(joints.jr1.detach().cpu().numpy()[::rep] - d["jr1"]).max() < 1e-12
+    assert np.abs(joints.jrot1.detach().cpu().numpy()[::rep] - d["jrot1"]).max() < 1e-12
+    f1, f2, grav = rp(d["force_first"], torch.float32), rp(d["force_ball"], torch.float32), rp(d["gravity"], torch.float32)
+    mult, t_push = float(d0["mult"]), float(d0["t_push"])
+
+    def force_fn(t):
+        on = (t < t_push).to(torch.float32).unsqueeze(1)
+        z = torch.zeros(B, 1, 3, dtype=torch.float32, device=DEV)
+        return grav + torch.cat([(f1 * mult * on).unsqueeze(1), z, (f2 * mult * on).unsqueeze(1)], dim=1)
+
+    world = ContactWorld(geom, p0, rp(d["v0"], torch.float32), rp(d["Mdiag"], torch.float32), torch.zeros(B, nb, 3, device=DEV),
+                         rp(d["rest"], torch.float32), rp(d["fric"], torch.float32), joints=joints, dt=float(d0["dt"]), maxc=8, force_fn=force_fn)
+    assert np.abs(world.Je.cpu().numpy()[::rep] - d["Je"]).max() <= 1e-5
+    ncs = []
+    for _ in range(int(d["nsteps"])):
+        world.step(differentiable=True)
+        ncs.append(world.contacts.count.clone())
+    pos = world.p[:, :, 1:]
+    (pos[:, 2] - pos[:, 1]).norm(dim=1).sum().backward()
+    torch.cuda.synchronize()
+    same = (np.abs(world.t.cpu().numpy()[::rep] - d["t"][:, -1]) < 1e-12) & (torch.stack(ncs, 1).cpu().numpy()[::rep] == d["ncontacts"]).all(axis=1)
+    print("scenes on the reference's trajectory:", same.tolist())
+    assert same.sum() >= nv - 1
+    got, ref = p0.grad.cpu().numpy()[::rep, :, 1:].reshape(nv, -1), d["grad_p0"].reshape(nv, -1)
+    err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print("d(loss)/d(initial positions), anchors follow p0 = %s: relative error per scene" % anchors_follow_p0, np.array2string(err, precision=2))
+    if anchors_follow_p0:
+        assert err[same].max() <= 1e-4, err
+    else:
+        assert err[same].max() > 1e-2, err
+
+
 @pytest.mark.parametrize("nbox,pts,extra_rows", [(2, 2, 0), (4, 2, 0), (6, 2, 0), (4, 2, 4), (8, 2, 5)])
 def test_post_stabilization_backward_matches_oracle(nbox, pts, extra_rows):
     """`lcp_post_stabilization_backward_f32` against the fp64 oracle end to end: per scene, the oracle solves the frictionless LCP

@@ -166,6 +166,33 @@ def test_jointset_torch_jacobian_matches_oracle_and_reference_and_is_differentia
         assert (fd - g).abs().max() < 1e-6, (fd - g).abs().max()
 
 
+def test_joint_anchors_are_differentiable_functions_of_the_poses_they_were_created_at():
+    """`Joint.__init__` (constraints.py:21-23): r1, rot1 = cart_to_polar(pos - body1.pos) - with poses that require grad the reference's
+    anchors carry a graph.  `JointSet.from_list` keeps it (values = the "a_" records of the fixture), and the backward of the one
+    input of `Joint.J()` the kernels do not differentiate - r1 - equals autograd through `jacobian_torch`."""
+    import os
+    import numpy as np
+    import torch
+    from lcp_physics_amd.physics.joints import JointSet
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rollout_grad.npz"))
+    p0 = torch.tensor(d["a_p0"], dtype=torch.float64, requires_grad=True)
+    js = JointSet.from_list([("joint", 0, None, (300.0, 220.0)), ("joint", 0, 1, (300.0, 330.0))], p0)
+    assert js.jr1.requires_grad and js.jrot1.requires_grad
+    assert np.abs(js.jr1.detach().numpy() - d["a_jr1"]).max() < 1e-12 and np.abs(js.jrot1.detach().numpy() - d["a_jrot1"]).max() < 1e-12
+    g = torch.autograd.grad(js.jr1.sum() + js.jrot1.sum(), p0)[0]
+    assert float(g[:, 0, 1:].abs().max(dim=1)[0].min()) > 0 and float(g[:, 1:].abs().max()) == 0 and float(g[:, :, 0].abs().max()) == 0
+    # r1's backward against autograd, with a welded pair in the list
+    B = 3
+    p = torch.randn(B, 3, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    js = JointSet.from_list([("joint", 0, None, (1.0, 2.0)), ("joint", 0, 1, (3.0, -1.0)), ("fixed", 1, 2)], p)
+    r1, rot = js.jr1.clone().requires_grad_(True), js.jrot1.clone().requires_grad_(True)
+    js = JointSet(js.jtype, js.jb1, js.jb2, r1, rot, js.e)
+    Je = js.jacobian_torch(p, rot)
+    gJe = torch.randn(Je.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    ref = torch.autograd.grad(Je, r1, gJe)[0]
+    assert torch.allclose(js.anchor_radius_backward(3, rot.detach(), gJe), ref, rtol=1e-13, atol=1e-13) and float(ref[:, :2].abs().min()) > 0
+
+
 @pytest.mark.parametrize("scene", ["j_", "k_", "c_", "d_"])
 def test_world_oracle_follows_the_reference_rollouts_with_joints_and_post_stabilization(scene):
     """The oracle's `step_dt` against the roll-outs the unmodified reference recorded for the gradient fixtures
