@@ -5,6 +5,7 @@
 #include "lcp_wave_scene.h"
 #include "lcp_quad_prims.h"      // (row_newbcast moves and fused multiply-adds for the lane-grid LU of the pinned form)
 #include "lcp_primal_gridlu.h"   // (generated: the trailing update of a pivot of the lane-grid LU as one asm block)
+#include "lcp_primal_bsweep.h"   // (generated: the triangular sweeps behind the lane-grid LU, in block layout on three DPP rows)
 
 #ifndef LCP_PRIMAL_OCC40
 #define LCP_PRIMAL_OCC40 2     // wavefronts per SIMD the 40-column instantiations are allocated for (A/B: 1 = no scratch, one wave per SIMD)
@@ -15,6 +16,9 @@
 #endif
 #ifndef LCP_PRIMAL_GRIDLU_V2
 #define LCP_PRIMAL_GRIDLU_V2 2 // form of the lane-grid LU - 2: fused multiply-adds, multipliers through LDS, constant lane masks, software-pipelined (round 4); 1: the same without the pipelining; 0: round 3's form (v_mov_b64_dpp + v_fma pairs, v_permlane swaps) (A/B)
+#endif
+#ifndef LCP_PRIMAL_BSWEEP
+#define LCP_PRIMAL_BSWEEP 1    // kernels with the lane-grid LU (second form): triangular sweeps in block layout on three DPP rows - solution entries by row_newbcast inside the multiply-add, blocks across the rows by lane swaps - instead of row per lane with v_readlane broadcasts (0: A/B)
 #endif
 #ifndef LCP_PRIMAL_CPERM
 #define LCP_PRIMAL_CPERM 1     // 1: contact 4 (lane % 16) + lane / 16 on a lane (neighbours in the list -> different 16-lane rows); 0: contact = lane (A/B)
