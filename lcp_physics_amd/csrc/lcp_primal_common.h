@@ -17,6 +17,9 @@
 #ifndef LCP_PRIMAL_GRIDLU_V2
 #define LCP_PRIMAL_GRIDLU_V2 2 // form of the lane-grid LU - 2: fused multiply-adds, multipliers through LDS, constant lane masks, software-pipelined (round 4); 1: the same without the pipelining; 0: round 3's form (v_mov_b64_dpp + v_fma pairs, v_permlane swaps) (A/B)
 #endif
+#ifndef LCP_PRIMAL_GRIDLU_XROW
+#define LCP_PRIMAL_GRIDLU_XROW 0   // lane-grid LU (pipelined form): a pivot's multipliers reach the other DPP rows by lane swaps (1) instead of through LDS (0) (A/B)
+#endif
 #ifndef LCP_PRIMAL_BSWEEP
 #define LCP_PRIMAL_BSWEEP 1    // kernels with the lane-grid LU (second form): triangular sweeps in block layout on three DPP rows - solution entries by row_newbcast inside the multiply-add, blocks across the rows by lane swaps - instead of row per lane with v_readlane broadcasts (0: A/B)
 #endif
