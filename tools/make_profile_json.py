@@ -10,10 +10,9 @@ KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E",               
            "fused_B4096_nc16_f64_bwd": "lcp_bwd_quadIfdLb1E",                      # the dense backward behind it (body space)
            "fused_B4096_nc16_f64_bwd_physical": "lcp_bwd_step_quadIfdLi1ELb1E",    # --bwd physical
            # --mode dense (round 4: body space): the forward CALL is classify + the pinned kernel + three launches that find no scene
-           # (general body-space kernel, the two wave-per-scene kernels) - traffic summed over all of them, counters of the solver
-           "dense_B4096_nc16_f64": ["lcp_fwd_quadIfdLb0ELi1ELi2E", "lcp_classify_wave", "lcp_fwd_quadIfdLb0ELi1ELi1E", "lcp_fwd_waveIfdLb1ELb0ELb1E",
-                                    "lcp_fwd_waveIfdLb1ELb0ELb0E"],
-           "dense_B4096_nc16_f64_bwd": ["lcp_bwd_quadIfdLb1E", "lcp_bwd_waveIfdLb1ELb1E", "lcp_bwd_waveIfdLb1ELb0E"],
+           # (general body-space kernel, the wave-per-scene fallbacks - one launch since the merge of round 4) - traffic summed over all of them, counters of the solver
+           "dense_B4096_nc16_f64": ["lcp_fwd_quadIfdLb0ELi1ELi2E", "lcp_classify_wave", "lcp_fwd_quadIfdLb0ELi1ELi1E", "lcp_fwd_wave_any"],
+           "dense_B4096_nc16_f64_bwd": ["lcp_bwd_quadIfdLb1E", "lcp_bwd_wave_any"],
            # --config 4 (the piles): lcp_primal_kernel<30, fwd, PIN = 3> and its backward <32, bwd, PIN = 3>
            "fused_B4096_nc64_f64": "lcp_primal_kernelILi30ELb0ELb0ELi4ELi3E",
            "fused_B4096_nc64_f64_bwd_physical": "lcp_primal_kernelILi32ELb1ELb0ELi4ELi3E"}
