@@ -183,3 +183,39 @@ def test_contact_world_records_steps_of_twenty_bodies():
     loss.backward()
     for t in (Mdiag.grad, v0.grad):
         assert t is not None and bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0
+
+
+@pytest.mark.parametrize("compute,with_joints", [("f64", False), ("f32", True)])
+def test_dense_boundary_route_without_joints_and_in_fp32_arithmetic(compute, with_joints):
+    """The same route with no equality rows at all (A, b empty - `engines.py:59-60`) and in fp32 arithmetic (`compute="f32"`: no fused
+    backward beyond 16 contacts at any number of bodies): forward against the fused step of the same word, gradients against the fp64
+    oracle at the tolerance of the arithmetic."""
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, solve_dynamics
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    sc = _tall_stack(B=4, seed=15) if compute == "f64" else _tall_stack(B=4, nbox=6, pts=4, seed=16)     # (fp32: 7 bodies, 24 contacts)
+    e = 3 if with_joints else 0
+    assert not _lib.load().lcp_step_has_backward(sc.nb, sc.nc, e, _lib.COMPUTE_F64 if compute == "f64" else _lib.COMPUTE_F32)
+    L = _leaves(sc)
+    scg = sc.to(device=DEV)
+    Je = scg.Je if with_joints else None
+    opts = {"max_iter": 10, "compute": compute}
+    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
+                                        None, Je, sc.dt, opts)
+    assert opts["last"]["dense_boundary"]
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(8))
+    (v_new * cot.to(DEV)).sum().backward()
+    cb = ContactBuffers(sc.B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    full = torch.full((sc.B,), sc.nc, dtype=torch.int32, device=DEV)
+    fused = solve_dynamics(sc.B, sc.nb, sc.nc, e, full, scg.Mdiag, scg.v, scg.f, scg.rest, scg.fric, cb, Je, sc.dt, compute=compute)
+    # (fp32 arithmetic on four collinear points per interface: the two routes round the assembly differently and the solve amplifies it)
+    tol = 2e-6 if compute == "f64" else 2e-2
+    assert float(_rel(v_new.detach().double().cpu(), fused["v_new"].double().cpu()).max()) < tol
+    import dataclasses
+    ref_sc = sc if with_joints else dataclasses.replace(sc, Je=torch.zeros(sc.B, 0, 3 * sc.nb))
+    v_ref, g_ref = _oracle_step(ref_sc, cot)
+    assert float(_rel(v_new.detach().double().cpu(), v_ref).max()) < tol
+    for k in ("Mdiag", "v", "f"):
+        err = _rel(L[k].grad.double().cpu(), g_ref[k])
+        assert float(err.median()) < (1e-4 if compute == "f64" else 5e-2), (k, err)
