@@ -167,21 +167,21 @@ def test_contact_world_records_steps_of_twenty_bodies():
     geom = GeometryBatch.from_shapes(w["shapes"], B).to(DEV)
     dev = lambda t: t.to(DEV)
 
-    def world(Mdiag, v):
-        return ContactWorld(geom, dev(w["p"]), v, Mdiag, dev(w["f"]), dev(w["rest"]), dev(w["fric"]), Je=dev(w["Je"]), maxc=48)
+    def world(Mdiag, v, p=None):
+        return ContactWorld(geom, dev(w["p"]) if p is None else p, v, Mdiag, dev(w["f"]), dev(w["rest"]), dev(w["fric"]), Je=dev(w["Je"]), maxc=48)
 
     plain = world(dev(w["Mdiag"]), dev(w["v"]))
     for _ in range(steps):
         plain.step()
-    Mdiag, v0 = dev(w["Mdiag"]).requires_grad_(True), dev(w["v"]).requires_grad_(True)
-    rec = world(Mdiag, v0)
+    Mdiag, v0, p0 = dev(w["Mdiag"]).requires_grad_(True), dev(w["v"]).requires_grad_(True), dev(w["p"]).requires_grad_(True)
+    rec = world(Mdiag, v0, p0)
     for _ in range(steps):
         rec.step(differentiable=True)
     assert float((rec.p.detach() - plain.p).abs().max()) < 1e-4
     assert int(rec.contacts.count.max()) > 16
     loss = (rec.p[:, 1:, 1:] ** 2).sum() * 1e-4
     loss.backward()
-    for t in (Mdiag.grad, v0.grad):
+    for t in (Mdiag.grad, v0.grad, p0.grad):                   # (p0: through the contact frames of 20 bodies - lcp_contact_frame_backward_f64)
         assert t is not None and bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0
 
 
