@@ -68,7 +68,9 @@ extern "C" {
 #define LCP_IO_F64 0x400
 
 #define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
-#define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan  */
+#define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan (the generic kernels keep the matrices in the
+                               * workspace when 160 KB of LDS do not hold them: e.g. 32 bodies x 128 contacts in fp64 plan; the limit
+                               * is the vectors, ~(8 nz + 15 nineq + 9 neq) numbers in LDS)                                   */
 #define LCP_E_LAUNCH   (-3)   /* hipLaunchKernel reported an error                     */
 
 /* per-scene status bits written to `status[B]` */
