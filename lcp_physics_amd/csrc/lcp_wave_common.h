@@ -60,6 +60,13 @@ __device__ __forceinline__ void store4(float* dst, float a, float b, float c, fl
 __device__ __forceinline__ void store4(double* dst, double a, double b, double c, double d) {
   *reinterpret_cast<double2*>(dst) = make_double2(a, b); *reinterpret_cast<double2*>(dst + 2) = make_double2(c, d);
 }
+// the same as a streaming store (no reuse: gradients written once and read by another kernel) - A/B in lcp_bwd_quad: LCP_Q_NT_STORES
+typedef float lcp_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_nt(float* dst, float a, float b, float c, float d) {
+  lcp_f4v v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<lcp_f4v*>(dst));
+}
+__device__ __forceinline__ void store4_nt(double* dst, double a, double b, double c, double d) { store4(dst, a, b, c, d); }
 __device__ __forceinline__ void store2(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 __device__ __forceinline__ void store2(double* dst, double a, double b) { *reinterpret_cast<double2*>(dst) = make_double2(a, b); }
 
