@@ -5,8 +5,8 @@ equality rows pin the floor, `ALG = 1` behind it for any other equality rows) fo
 `bench.py --config 4` times the one-wave-per-scene body-space kernel (`lcp_primal_kernel<30, ..., PIN>`, `LCP_HINT_PINNED`) and its
 backward `lcp_step_backward_f32` on the 4096 x 64-contact piles of BASELINE configs[4].
 These tests run exactly those pairs at BASELINE configs[1] (1024 x 8 contacts), configs[2] (4096 x 16), one 4096-scene shard of
-configs[3] (rank 5 of 8: the seed bench.py gives that rank) - EVERY scene of the batch - and configs[4] (4096 x 64: 512 scenes
-sampled over the batch; the fp64 oracle factors 256 x 256 systems there) against the fp64 oracle on identical inputs
+configs[3] (rank 5 of 8: the seed bench.py gives that rank) and configs[4] (4096 x 64; the fp64 oracle factors 256 x 256 systems
+there: ~35 s) - EVERY scene of each batch - against the fp64 oracle on identical inputs
 (pdipm.py:49-186, lcp.py:37-64):
 
   * SURVEY 8d err_x <= 1e-4 on every compared scene;
@@ -47,7 +47,7 @@ CASES = [
     ("configs3_shard5_4096x16", "stack", 4096, 4, 1236 + 5000, "pinned", 4096, STRICT),
     ("configs2_4096x16_general_rows", "stack", 4096, 4, 1236, "scaled", 4096, STRICT),    # A = 2 [I 0]: the same constraint, not the pinned form -> ALG = 1
     ("configs1_1024x8_general_rows", "stack", 1024, 2, 1236, "coupled", 1024, CONVERGED), # a row with a general entry -> ALG = 1
-    ("configs4_4096x64_pile", "pile", 4096, 10, 5, "pinned", 512, STRICT),                # lcp_primal_kernel<30, ..., PIN> + lcp_step_backward_f32
+    ("configs4_4096x64_pile", "pile", 4096, 10, 5, "pinned", 4096, STRICT),               # lcp_primal_kernel<30, ..., PIN> + lcp_step_backward_f32; every scene since the end of round 4 (the oracle's 256 x 256 systems: ~35 s on the GPU box's host)
 ]
 
 
