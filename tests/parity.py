@@ -181,7 +181,7 @@ def err_physical(pg, pg_ref, phys, floor, keys=None):
 # bench.py's `parity` object print the same fields)
 # ----------------------------------------------------------------------------
 def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4), grads=None, phys=None, dt=None,
-                    phys_grads=None):
+                    phys_grads=None, input_stability=False):
     """`lcp64`: the LCP the kernel solved (fp64 copies of the fp32 data the HIP assembly produced: identical inputs),
     `x, z, s, iters`: what the kernel returned for those scenes, `dp` (optional): its dl/dp for the cotangent `cot`.
     `grads` (optional): the kernel's dense gradients, dict over "QpGhAbF" (lcp.py:52-61); `phys` + `dt`: the scenes' physical
@@ -205,7 +205,12 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
                                        fields compare); bwd_kkt_resid_at_oracle_iterate_max: the same vectors in the system at the
                                        ORACLE's iterate - informative only: where a solve converged to rounding s_i / z_i is a ratio of two
                                        1e-17 numbers and the two systems are different matrices (configs[1]: O(1))
-      bwd_err_phys_max                 `err_physical` over Mdiag, v, f (the parameters that enter through Q and p)"""
+      bwd_err_phys_max                 `err_physical` over Mdiag, v, f (the parameters that enter through Q and p)
+    `input_stability` (needs `phys`, `dt`): the backward fields are taken over the well-posed scenes whose ORACLE answer is itself stable
+    under fp32 rounding of its inputs - the oracle is run a second time on its own fp64 assembly of the physical inputs (the dense
+    tensors in `lcp64` are fp32 numbers) and a scene whose oracle dl/dp moves by more than the tolerance between the two is counted in
+    `bwd_input_sensitive_scenes` instead (`bwd_input_sensitivity_max`: the largest such move).  One scene of the 32768 of BASELINE
+    configs[3] is (shard 4, scene 146: its oracle moves by 5e-6 in x and 1e-3 in dl/dp - profiles/r04_config3_all_shards_parity.json)."""
     Q, p, G, h, A, b, F = lcp64
     ref = oracle.lcp_forward(*lcp64)
     n = Q.shape[0]
@@ -235,6 +240,18 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
         gref = oracle.lcp_backward(ref, *lcp64, c64)
         ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
+        if input_stability:
+            ph64 = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
+            lcp_o = oracle.assemble_lcp(ph64["Mdiag"], ph64["v"], ph64["f"], dt, ph64["c_n"], ph64["c_p1"], ph64["c_p2"], ph64["c_i1"], ph64["c_i2"],
+                                        ph64["rest"], ph64["fric"], ph64.get("Je"))
+            ref_o = oracle.lcp_forward(*lcp_o)
+            g_o = oracle.lcp_backward(ref_o, *lcp_o, c64)
+            sens = err_grads({"p": g_o["dp"]}, {"p": gref["dp"]}, fl)["p"]
+            stable = sens <= out["tolerance"]
+            out["bwd_input_sensitive_scenes"] = int((ok & ~stable).sum())
+            out["bwd_input_sensitivity_max"] = float(sens[ok].max()) if bool(ok.any()) else 0.0
+            out["fwd_input_sensitivity_err_x_max"] = float(err_x(ref_o.x, ref.x, Q, p).max())
+            ok = ok & stable
         eg = err_grads({"p": dp.double()}, {"p": gref["dp"]}, fl)["p"]
         if bool(ok.any()):           # (callers gate bwd_well_posed_frac; without a well-posed scene the bwd_err_* keys are ABSENT and a gate on them fails loudly)
             out.update({"bwd_err_dp_max": float(eg[ok].max()), "bwd_err_dp_median": float(eg[ok].median())})

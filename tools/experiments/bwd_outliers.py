@@ -72,3 +72,32 @@ for k in top.tolist():
 for thr in (1e-6, 1e-5, 1e-4, 1e-3):
     sel = ok & (margin > thr)
     print("margin > %.0e: %4d scenes  dp max %.2e  phys max %.2e" % (thr, int(sel.sum()), float(errs["p"][sel].max()), float(epall[sel].max())))
+# how much the ORACLE moves on the same scenes when only its own arithmetic changes (LU without pivoting instead of with: pdipm.py
+# factors with pivoting; the same equations): the scene's sensitivity, against which the kernel's distance is to be read
+sub = [None if t is None else t[top] for t in lcp64]
+ref_np = O.lcp_forward(*sub, pivot=False)
+g_np = O.lcp_backward(ref_np, *sub, c64[top])
+for i, k in enumerate(top.tolist()):
+    ex_k = float(parity.err_x(x.double().cpu()[k:k + 1], ref.x[k:k + 1], Q[k:k + 1], p[k:k + 1]))
+    ex_o = float(parity.err_x(ref_np.x[i:i + 1], ref.x[k:k + 1], Q[k:k + 1], p[k:k + 1]))
+    dp_o = float(parity.err_grads({"p": g_np["dp"][i:i + 1]}, {"p": gref["dp"][k:k + 1]}, {kk: v[k:k + 1] for kk, v in fl.items()})["p"])
+    print("scene %5d  err_x kernel vs oracle %.2e | oracle (no pivoting) vs oracle %.2e   dp: kernel %.2e | oracle variant %.2e   iters %d / %d / %d" % (
+        k, ex_k, ex_o, float(errs["p"][k]), dp_o, int(iters[k]), int(ref.iters[k]), int(ref_np.iters[i])))
+# ... and when the oracle's INPUTS change by fp32 rounding: the dense tensors above come from lcp_assemble_contacts_f32 (fp32 entries), the
+# fused kernel assembles the same physical inputs in fp64 - the oracle on ITS OWN fp64 assembly of those inputs is the like-for-like reference
+sct = sc.slice(0, B)
+args64 = [a.double() if (isinstance(a, torch.Tensor) and a.is_floating_point()) else a for a in sct.assembly_args()]
+sel = lambda a: a[top] if isinstance(a, torch.Tensor) else a
+lcpo = [None if t is None else t for t in O.assemble_lcp(*[sel(a) for a in args64])]
+ref_o = O.lcp_forward(*lcpo)
+g_o = O.lcp_backward(ref_o, *lcpo, c64[top])
+for i, k in enumerate(top.tolist()):
+    Qo, po = lcpo[0][i:i + 1], lcpo[1][i:i + 1]
+    ex_ko = float(parity.err_x(x.double().cpu()[k:k + 1], ref_o.x[i:i + 1], Qo, po))
+    ex_oo = float(parity.err_x(ref.x[k:k + 1], ref_o.x[i:i + 1], Qo, po))
+    flo = {kk: v[k:k + 1] for kk, v in fl.items()}
+    dp_ko = float(parity.err_grads({"p": g64["p"][k:k + 1]}, {"p": g_o["dp"][i:i + 1]}, flo)["p"])
+    dp_oo = float(parity.err_grads({"p": gref["dp"][k:k + 1]}, {"p": g_o["dp"][i:i + 1]}, flo)["p"])
+    relz_ko = float(parity._n(zk[k:k + 1] - ref_o.z[i:i + 1]) / parity._n(ref_o.z[i:i + 1]))
+    print("scene %5d  against the oracle on its own fp64 assembly: err_x kernel %.2e | oracle on the fp32 tensors %.2e   dp: kernel %.2e | oracle on the fp32 tensors %.2e   rel|z - z_ref| kernel %.1e" % (
+        k, ex_ko, ex_oo, dp_ko, dp_oo, relz_ko))
