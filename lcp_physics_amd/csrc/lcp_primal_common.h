@@ -17,6 +17,9 @@
 #ifndef LCP_PRIMAL_GRIDLU_V2
 #define LCP_PRIMAL_GRIDLU_V2 2 // form of the lane-grid LU - 2: fused multiply-adds, multipliers through LDS, constant lane masks, software-pipelined (round 4); 1: the same without the pipelining; 0: round 3's form (v_mov_b64_dpp + v_fma pairs, v_permlane swaps) (A/B)
 #endif
+#ifndef LCP_PRIMAL_UNROLL_PASS
+#define LCP_PRIMAL_UNROLL_PASS 1   // the two KKT solves of an iteration as two copies of the code instead of a two-trip loop (0: the loop - A/B: config 5 forward 0.317 -> 0.313 ms, 239 -> 221 registers; the four-scenes kernels: LCP_Q_UNROLL_PASS)
+#endif
 #ifndef LCP_PRIMAL_GRIDLU_XROW
 #define LCP_PRIMAL_GRIDLU_XROW 0   // lane-grid LU (pipelined form): a pivot's multipliers reach the other DPP rows by lane swaps (1) instead of through LDS (0) (A/B)
 #endif
