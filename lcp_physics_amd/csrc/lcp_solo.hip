@@ -22,6 +22,10 @@
 // Contact-list inputs, fp32 I/O, fp64 arithmetic, nz <= 16, <= 16 contacts, neq <= 4.
 #include "lcp_quad_prims.h"
 
+#ifndef LCP_SOLO_UNROLL_PASS
+#define LCP_SOLO_UNROLL_PASS 1   // the two KKT solves of an iteration as two copies of the code instead of a two-trip loop (0: the loop, A/B)
+#endif
+
 namespace lcp {
 namespace solo {
 
@@ -518,8 +522,14 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     if (it >= 0 && it == max_iter - 1) break;                             // (the iterate the last pass would produce is never evaluated)
     TC ax = 0, ay = 0, as_ = 0, az = 0;
     const int npass = (it < 0) ? 1 : 2;
+#if LCP_SOLO_UNROLL_PASS
+    // (the two solves of an iteration as two copies of the code, `pass` a compile-time constant - as LCP_Q_UNROLL_PASS in lcp_quad_kernels.inc)
+    auto one_pass = [&](auto PASS_) LCP_INL {
+      constexpr int pass = PASS_;
+#else
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
+#endif
       TC ox, oy, os, oz;
       solve(dinv, rx, rs, rz, ry, ox, os, oz, oy);
       if (it < 0) {
@@ -546,7 +556,13 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         x += alpha * cx; y += alpha * cy;                                     // (:171-174)
         if (vc) { s += alpha * cs; z += alpha * cz; }
       }
+#if LCP_SOLO_UNROLL_PASS
+    };
+    one_pass(std::integral_constant<int, 0>{});
+    if (npass > 1) one_pass(std::integral_constant<int, 1>{});
+#else
     }
+#endif
     if (done) break;
   }
 
