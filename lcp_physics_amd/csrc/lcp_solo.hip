@@ -22,6 +22,9 @@
 // Contact-list inputs, fp32 I/O, fp64 arithmetic, nz <= 16, <= 16 contacts, neq <= 4.
 #include "lcp_quad_prims.h"
 
+#ifndef LCP_SOLO_PEEL_INIT
+#define LCP_SOLO_PEEL_INIT 1     // the initialisation pass (it = -1) as its own copy of the loop body (0: one loop, A/B)
+#endif
 #ifndef LCP_SOLO_UNROLL_PASS
 #define LCP_SOLO_UNROLL_PASS 1   // the two KKT solves of an iteration as two copies of the code instead of a two-trip loop (0: the loop, A/B)
 #endif
@@ -484,8 +487,17 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     return kl ? nan_of<TC>() : l;
   };
 
+#if LCP_SOLO_PEEL_INIT
+  // (the initialisation pass - it = -1 - as its own copy of the loop body: LCP_Q_PEEL_INIT in lcp_quad_kernels.inc)
+  auto iteration = [&](auto INIT_, const int it) LCP_INL -> bool {
+    constexpr bool INIT = decltype(INIT_)::value;
+    __builtin_assume(INIT == (it < 0));
+#define LCP_SOLO_BREAK return false
+#else
 #pragma unroll 1
   for (int it = -1; it < max_iter; ++it) {
+#define LCP_SOLO_BREAK break
+#endif
     TC rx, ry, rs, rz, mu = 0, resid = 0, szsum = 0;
     if (it < 0) {                                                          // init: (p, 0, -h, -b), d = 1 (:57-63); b = 0 from a contact list
       rx = p; ry = 0; rs = 0; rz = -hn; dinv = 1;
@@ -518,8 +530,8 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
       }
     }
-    if (done) break;
-    if (it >= 0 && it == max_iter - 1) break;                             // (the iterate the last pass would produce is never evaluated)
+    if (done) LCP_SOLO_BREAK;
+    if (it >= 0 && it == max_iter - 1) LCP_SOLO_BREAK;                             // (the iterate the last pass would produce is never evaluated)
     TC ax = 0, ay = 0, as_ = 0, az = 0;
     const int npass = (it < 0) ? 1 : 2;
 #if LCP_SOLO_UNROLL_PASS
@@ -563,8 +575,18 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
 #else
     }
 #endif
-    if (done) break;
+    if (done) LCP_SOLO_BREAK;
+#if LCP_SOLO_PEEL_INIT
+    return true;
+  };
+  if (iteration(std::true_type{}, -1)) {
+#pragma unroll 1
+    for (int it = 0; it < max_iter; ++it) { if (!iteration(std::false_type{}, it)) break; }
   }
+#else
+  }
+#endif
+#undef LCP_SOLO_BREAK
 
   // ---- outputs: natural m-space order [normal | friction pairs | cone]; the best iterate also goes to the workspace in fp64
   const int oi = c0 ? l16 : (c3 ? 3 * nc + l16 : nc + 2 * l16 + (comp - 1));
