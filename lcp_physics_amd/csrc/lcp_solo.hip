@@ -22,6 +22,9 @@
 // Contact-list inputs, fp32 I/O, fp64 arithmetic, nz <= 16, <= 16 contacts, neq <= 4.
 #include "lcp_quad_prims.h"
 
+// register-resident Jacobian entries are read through an opaque statement (their conversions to fp64 must not be hoisted out of the PDIPM
+// loop) - in place, not on a by-value copy, which cost a v_mov_b32 per use (LCP_Q_LAUNDER_IN_PLACE in lcp_quad_kernels.inc)
+#define LCP_SOLO_OPAQUE(x) asm volatile("" : "+v"(x))
 #ifndef LCP_SOLO_PEEL_INIT
 #define LCP_SOLO_PEEL_INIT 1     // the initialisation pass (it = -1) as its own copy of the loop body (0: one loop, A/B)
 #endif
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   // J v for the lane's (component, contact)
   auto Gv = [&](TC v) -> TC {
     TC a0 = 0, a1 = 0, cf[16];
-    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(Grow[J]); else cf[J] = Grow[J]; });
+    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) { LCP_SOLO_OPAQUE(Grow[J]); cf[J] = (TC)Grow[J]; } else cf[J] = Grow[J]; });
     if constexpr (TRIM) dot_dpp<CLO, NCOLS>(a0, a1, v, cf);             // (v is zero on the pinned lanes, absent beyond nz)
     else dot16_dpp(a0, a1, v, cf);
     return a0 + a1;
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   // J^T w: every row sums its component over the contacts, then the rows are added (result replicated)
   auto Gtw = [&](TC w) -> TC {
     TC a0 = 0, a1 = 0, cf[16];
-    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) cf[J] = (TC)launder(GTc[J]); else cf[J] = GTc[J]; });
+    static_for<16>([&](auto J) LCP_INL { if constexpr (LCP_SOLO_OCC >= 2) { LCP_SOLO_OPAQUE(GTc[J]); cf[J] = (TC)GTc[J]; } else cf[J] = GTc[J]; });
     if constexpr (NCF > 0) dot_dpp<0, KHI>(a0, a1, w, cf);
     else dot16_dpp(a0, a1, w, cf);
     return rows_sum(a0 + a1);
@@ -381,7 +384,8 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const TC b11 = vc ? kap * fma(i1 + i2, D.g, (TC)4 * (i1 * i2)) : (TC)0;
     TC p0[4], p1[4], x4[4];
     static_for<NS>([&](auto JJ) LCP_INL {
-      const TC jc_ = (TC)launder(jcq[JJ]), jt_ = (TC)launder(jtq[JJ]);
+      LCP_SOLO_OPAQUE(jcq[JJ]); LCP_SOLO_OPAQUE(jtq[JJ]);
+      const TC jc_ = (TC)jcq[JJ], jt_ = (TC)jtq[JJ];
       p0[JJ] = b00 * jc_; p1[JJ] = fma(b10, jc_, b11 * jt_);
       x4[JJ] = (ll == colof(JJ)) ? ((ll < nzs) ? qd : (TC)1) : (TC)0;
     });
