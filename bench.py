@@ -110,11 +110,17 @@ def parse(argv=None):
     a.batch = a.batch or 4096
     if a.pile:
         a.nbox, a.pts = 10, 4
-        if a.mode != "fused":
-            raise SystemExit("bench.py: --pile runs the contact-list entry points (--mode fused)")
-        if a.bwd == "dense":
-            raise SystemExit("bench.py: the pile's backward is lcp_step_backward_f32 (--bwd physical)")
-        a.bwd = "physical"
+        if a.mode == "fused":
+            if a.bwd == "dense":
+                raise SystemExit("bench.py: the backward of the pile's contact-list step is lcp_step_backward_f32 (--bwd physical); "
+                                 "--mode dense times the seven dense gradients")
+            a.bwd = "physical"
+        else:
+            # the dense LCPFunction boundary at nineq 256: lcp_pdipm_forward_f32 on 302 KB of (Q, p, G, h, A, b, F) per scene and the
+            # seven dense gradients of lcp_pdipm_backward_f32 (another 302 KB per scene)
+            if a.bwd == "physical":
+                raise SystemExit("bench.py: --bwd physical needs --mode fused")
+            a.bwd = "dense"
     a.nbox = a.nbox or 4
     a.bwd = a.bwd or "dense"
     return a
@@ -282,7 +288,7 @@ def cpu_reference_quote(nc=16):
 
 def _quoted(name, key):
     """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             j = json.load(open(path)).get(key)
@@ -324,7 +330,7 @@ class HipWorkload:
         self.cot = self.cot_cpu.to(dev)
         self.cot_v = (-self.cot).reshape(B, self.nb, 3).contiguous()          # d(loss)/d(v_new) = -d(loss)/dx
         self.lcp = self.sol = self.grads = self.step_sol = self.pgrads = None
-        if not self.pile:
+        if not self.pile or args.mode == "dense":
             # dense (Q,p,G,h,A,b,F) in HBM, built by the HIP assembly kernel (the dense backward reads G and A; --mode dense solves it)
             self.lcp = assemble_contacts(self.sc)
             self.sol = lcp_solve(*self.lcp, compute=args.compute, path="big" if args.contact_space else "auto")
@@ -512,21 +518,24 @@ class HipWorkload:
         # the contact-list entry points run the body-space variant of lcp_fwd_quad (nz <= 16, fp64 arithmetic; the stack scenes pin
         # their floor: ALG = 2), the one-wave-per-scene lcp_primal_kernel for the piles, the dense boundary the contact-space one
         body_space = a.compute == "f64" and nz <= 16 and not (a.mode == "dense" and a.contact_space)
-        primal = self.pile and a.compute == "f64"
+        primal = self.pile and a.compute == "f64" and not (a.mode == "dense" and a.contact_space)
+        dense_pile = self.pile and a.mode == "dense"      # the dense boundary at nineq 256: bound by the 302 KB per scene it reads / writes
         model = (flops.flops_forward_executed_primal if primal else
                  flops.flops_forward_executed_body_space if body_space else flops.flops_forward_executed)
         fl_exec = float(sum(model(nz, nc, e, it) for it in it_list))
         fl_nec = float(sum(flops.flops_forward_executed_primal(nz, nc, e, it, True) for it in it_list)) if (body_space or primal) else None
         peak = PEAK_TFLOPS[a.compute]
         alg_bytes = (flops.bytes_fused_step(nb, nc) if a.mode == "fused" else flops.bytes_forward(nz, m, e)) * B
-        key = "%s_B%d_nc%d_%s" % (a.mode, B, nc, a.compute)
+        key = "%s%s_B%d_nc%d_%s" % (a.mode, "_cs" if (a.mode == "dense" and a.contact_space) else "", B, nc, a.compute)
         # HBM traffic and issue counters: measured separately with rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in their own passes;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) and committed under profiles/; bench.py quotes the file that matches.
         tj = _quoted("traffic", key)
         traffic = (2 * tj["fetch_kb"] + tj["write_kb"]) * 1024.0 if tj else None
         cj = _quoted("counters", key)
         sized = body_space and (nz, e) in flops.SIZED_SHAPES
-        rj = _quoted("kernel_resources", "lcp_primal_kernel_30_pinned_fwd" if primal else
+        rj = _quoted("kernel_resources", "lcp_big_kernel_64_dense_fwd" if (dense_pile and not primal) else
+                     "lcp_primal_kernel_dense_fwd" if dense_pile else
+                     "lcp_primal_kernel_30_pinned_fwd" if primal else
                      "lcp_fwd_quad_f64_dense_contact_space" if (a.mode == "dense" and a.contact_space) else
                      "lcp_fwd_solo_9_3_8" if (body_space and B <= 1024 and (nz, e, nc) == (9, 3, 8)) else
                      "lcp_fwd_quad_f64_fused_two_waves" if (sized and B > 4096) else
@@ -537,7 +546,16 @@ class HipWorkload:
         what = "forward only" if a.fwd_only else "forward + backward (implicit diff)"
         st = status.cpu()
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
-        if primal:
+        if dense_pile and not primal:
+            kname = ("lcp_classify_big + lcp_big_kernel<64, false, DENSE> (LCP_PATH_CONTACT_SPACE: the reference's T of pdipm.py:414-454 reduced to "
+                     "2 nc = 128 rows, one 256-thread workgroup per scene, blocked LU on v_mfma_f64_16x16x4_f64, factors in LDS)")
+            emodel = "flops.flops_forward_executed: the reduced 2 nc contact-space system, dense arithmetic"
+        elif dense_pile:
+            kname = ("lcp_classify_big + lcp_primal_kernel<..., DENSE> (one wavefront per scene, body space: rows of G read from the dense "
+                     "tensors; the event-timed call also holds the lcp_big_kernel / generic launches that find no scene)")
+            emodel = ("flops.flops_forward_executed_primal(nz, nc, neq, iters, pinned=True): per iteration the SPARSE formation (6 x 6 block per "
+                      "contact) + LU of nz - neq rows + 2 KKT solves + residuals + step lengths")
+        elif primal:
             kname = ("lcp_primal_kernel<30, false, false, 4, PIN = 3> (one wavefront per scene, body space: the 30 free coordinates' system; "
                      "fused assembly + integrate; LCP_HINT_PINNED)")
             emodel = ("flops.flops_forward_executed_primal(nz, nc, neq, iters, pinned=True): per iteration the SPARSE formation (6 x 6 block per "
@@ -580,7 +598,23 @@ class HipWorkload:
                                     % (m, (nz - e) if (body_space or primal) else 2 * nc),
                 "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "event_timed_steps": len(samples),
                 "event_timing": "HIP events on the launch stream around eager launches right after the timed region"}
-        if primal:
+        if dense_pile:
+            # 302 KB of dense tensors in per scene against ~0.6 MFLOP executed: the forward CALL (classification included) is priced
+            # against HBM - algorithmic bytes (bytes_in + bytes_out of the dense boundary) over the event-timed call
+            valu = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "flops", "executed_flops_per_launch", "executed_model",
+                                         "frac_necessary", "necessary_flops_per_launch", "frac_algorithmic", "algorithmic_flops_per_launch")}
+            valu["bound"] = roof["bound"]
+            gbs = alg_bytes / (fwd_ms * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "bytes": "algorithmic (SURVEY 8d: the dense tensors in, x / z / s / y out)",
+                         "achieved_measured_traffic": (traffic / (fwd_ms * 1e-3) / 1e9) if traffic else None,
+                         "valu": valu})
+            for k in ("flops", "executed_flops_per_launch", "executed_model", "frac_necessary", "necessary_flops_per_launch", "necessary_model",
+                      "frac_algorithmic", "algorithmic_flops_per_launch", "note_algorithmic"):
+                roof.pop(k, None)
+            if cj and cj.get("mfma_f64_ops") is not None:
+                roof["mfma_f64_ops_per_launch"] = cj["mfma_f64_ops"]
+        if primal and not dense_pile:
             ph = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_config5_primal_phases.txt")), reverse=True)
             if ph:
                 roof["phases_source"] = os.path.relpath(ph[0], ROOT) + " (in-kernel cycle counters per phase: make primalprof)"
@@ -607,13 +641,15 @@ class HipWorkload:
             if dense_bwd:
                 used = btraffic if btraffic else balg
                 roof["bwd"] = {"bound": "hbm",
-                               "kernel": "lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
+                               "kernel": ("lcp_big_kernel<64, true, DENSE> / lcp_primal_kernel<..., BWD, DENSE> (lcp.py:37-64 at nineq 256: the seven dense "
+                                          "gradients, 302 KB per scene)") if dense_pile else
+                                         "lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
                                          % ("true" if body_space else "false"),
                                "achieved": used / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": used / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "bytes": "measured traffic" if btraffic else "algorithmic",
                                "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
-                               "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if body_space else None}
+                               "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if (body_space or dense_pile) else None}
             else:
                 # the physical backward moves ~1 KB per scene: it is bound by its one factorisation + 1 + 2 KKT solves (fp64 VALU)
                 bfl = (flops.flops_forward_executed_primal(nz, nc, e, 0, True) + 2 * (nc * 102 + 2 * (nz - e) ** 2) if primal

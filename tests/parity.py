@@ -181,7 +181,7 @@ def err_physical(pg, pg_ref, phys, floor, keys=None):
 # bench.py's `parity` object print the same fields)
 # ----------------------------------------------------------------------------
 def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4), grads=None, phys=None, dt=None,
-                    phys_grads=None, input_stability=False):
+                    phys_grads=None, input_stability=False, all_grads=False, cache=None):
     """`lcp64`: the LCP the kernel solved (fp64 copies of the fp32 data the HIP assembly produced: identical inputs),
     `x, z, s, iters`: what the kernel returned for those scenes, `dp` (optional): its dl/dp for the cotangent `cot`.
     `grads` (optional): the kernel's dense gradients, dict over "QpGhAbF" (lcp.py:52-61); `phys` + `dt`: the scenes' physical
@@ -210,9 +210,22 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
     under fp32 rounding of its inputs - the oracle is run a second time on its own fp64 assembly of the physical inputs (the dense
     tensors in `lcp64` are fp32 numbers) and a scene whose oracle dl/dp moves by more than the tolerance between the two is counted in
     `bwd_input_sensitive_scenes` instead (`bwd_input_sensitivity_max`: the largest such move).  One scene of the 32768 of BASELINE
-    configs[3] is (shard 4, scene 146: its oracle moves by 5e-6 in x and 1e-3 in dl/dp - profiles/r04_config3_all_shards_parity.json)."""
+    configs[3] is (shard 4, scene 146: its oracle moves by 5e-6 in x and 1e-3 in dl/dp - profiles/r04_config3_all_shards_parity.json).
+    On EVERY scene, well-posed or not (round 5): `bwd_nonfinite_scenes` - scenes with a NaN / inf anywhere in the gradients the kernel
+    returned - and, with dense gradients, `bwd_kkt_resid_all_max`: the residual of (dx, dlam, dnu) = (dp, -dh, -db) in lcp.py:47-50's system
+    at the iterate the kernel returned, over all scenes (`bwd_kkt_resid_all_scenes_over_1e-6`: how many exceed 1e-6).  That system is the
+    kernel's own - no oracle solution enters -, so it holds the scenes the filters above drop to "the kernel solved what lcp.py:44-50 poses".
+    `all_grads`: dG, dh, dF are compared too (`bwd_err_dG_max` ...) and the physical gradients over ALL of PHYS_KEYS (`bwd_err_phys_all_max`):
+    meaningful where the multipliers are unique (two points per interface, the reference's own convention - not the 4-point shapes).
+    With BOTH `grads` and `phys_grads` the physical comparison is reported for each source (`bwd_err_phys_max` = the dense gradients
+    contracted through the assembly, `bwd_err_phys_direct_max` = lcp_step_backward_f32's own outputs).
+    `cache` (a dict the caller keeps): the oracle's forward / backward of these LCPs is stored there and re-used by the next call with
+    the same dict (several entry points solving the same scenes)."""
     Q, p, G, h, A, b, F = lcp64
-    ref = oracle.lcp_forward(*lcp64)
+    cache = {} if cache is None else cache
+    if "ref" not in cache:
+        cache["ref"] = oracle.lcp_forward(*lcp64)
+    ref = cache["ref"]
     n = Q.shape[0]
     ex = err_x(x.double(), ref.x, Q, p)
     out = {"scenes": int(n), "tolerance": 1e-4, "fwd_err_x_max": float(ex.max()), "fwd_err_x_median": float(ex.median())}
@@ -237,15 +250,33 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
         dp = phys_grads["f"].double().reshape(n, -1) / dt              # d(loss)/df = dt dl/dp
     if dp is not None:
         c64 = cot.double()
-        gref = oracle.lcp_backward(ref, *lcp64, c64)
+        if "gref" not in cache:
+            cache["gref"] = oracle.lcp_backward(ref, *lcp64, c64)
+        gref = cache["gref"]
+        # every scene, before any filter: finite gradients, and the kernel's own backward system solved
+        fin = torch.ones(n, dtype=torch.bool)
+        for gsrc in (grads, phys_grads):
+            for t in (gsrc or {}).values():
+                if t is not None:
+                    fin &= torch.isfinite(t.reshape(n, -1).double()).all(dim=1)
+        out["bwd_nonfinite_scenes"] = int((~fin).sum())
+        if grads is not None and grads.get("h") is not None:
+            dnu_k = None if (A is None or grads.get("b") is None) else -grads["b"].double()
+            res_all = kkt_backward_residual(Q, G, A, F, z, s, c64, grads["p"].double(), -grads["h"].double(), dnu_k)
+            worst = torch.stack([torch.nan_to_num(v, nan=float("inf")) for v in res_all.values()]).max(dim=0)[0]
+            out["bwd_kkt_resid_all_max"] = float(worst.max())
+            out["bwd_kkt_resid_all_scenes_over_1e-6"] = int((worst > 1e-6).sum())
+            out["bwd_kkt_resid_all_median"] = float(worst.median())
         ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
         if input_stability:
             ph64 = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
-            lcp_o = oracle.assemble_lcp(ph64["Mdiag"], ph64["v"], ph64["f"], dt, ph64["c_n"], ph64["c_p1"], ph64["c_p2"], ph64["c_i1"], ph64["c_i2"],
-                                        ph64["rest"], ph64["fric"], ph64.get("Je"))
-            ref_o = oracle.lcp_forward(*lcp_o)
-            g_o = oracle.lcp_backward(ref_o, *lcp_o, c64)
+            if "ref_o" not in cache:
+                lcp_o = oracle.assemble_lcp(ph64["Mdiag"], ph64["v"], ph64["f"], dt, ph64["c_n"], ph64["c_p1"], ph64["c_p2"], ph64["c_i1"], ph64["c_i2"],
+                                            ph64["rest"], ph64["fric"], ph64.get("Je"))
+                cache["ref_o"] = oracle.lcp_forward(*lcp_o)
+                cache["g_o"] = oracle.lcp_backward(cache["ref_o"], *lcp_o, c64)
+            ref_o, g_o = cache["ref_o"], cache["g_o"]
             sens = err_grads({"p": g_o["dp"]}, {"p": gref["dp"]}, fl)["p"]
             stable = sens <= out["tolerance"]
             out["bwd_input_sensitive_scenes"] = int((ok & ~stable).sum())
@@ -260,7 +291,7 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
         gr = {k: gref["d" + k] for k in "QpGhAbF"}
         if grads is not None and bool(ok.any()):
             g64 = {k: (None if grads.get(k) is None else grads[k].double()) for k in "QpGhAbF"}
-            keys = [k for k in "QAb" if g64.get(k) is not None and gr[k] is not None]
+            keys = [k for k in ("QAbGhF" if all_grads else "QAb") if g64.get(k) is not None and gr[k] is not None]
             errs = err_grads({k: g64[k] for k in keys}, {k: gr[k] for k in keys}, fl)
             for k in keys:
                 out["bwd_err_d%s_max" % k] = float(errs[k][ok].max())
@@ -272,13 +303,22 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
             ph = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
             keys = ["Mdiag", "v", "f"]
             pg_ref = physical_grads(ph, dt, gr, oracle)
-            pg = ({k: phys_grads[k].double() for k in keys} if phys_grads is not None
-                  else physical_grads(ph, dt, {k: g64[k] for k in "QpGhF"}, oracle))
             scl = free_scales(Q, p, c64)
             floor = _n(c64) * torch.maximum(scl["x_free"], _n(ref.x))
-            ep = err_physical(pg, pg_ref, ph, floor, keys=keys)
-            out["bwd_err_phys_max"] = float(ep[ok].max())
-            out["bwd_err_phys_median"] = float(ep[ok].median())
-            out["bwd_phys_source"] = ("the kernel's own physical gradients (lcp_step_backward_f32)" if phys_grads is not None
-                                      else "the kernel's dense gradients contracted through the assembly (engines.py:31-32,50-74)")
+            sources = []
+            if grads is not None:
+                sources.append(("", physical_grads(ph, dt, {k: g64[k] for k in "QpGhF"}, oracle),
+                                "the kernel's dense gradients contracted through the assembly (engines.py:31-32,50-74)"))
+            if phys_grads is not None:
+                sources.append(("_direct" if grads is not None else "", {k: phys_grads[k].double() for k in PHYS_KEYS if k in phys_grads},
+                                "the kernel's own physical gradients (lcp_step_backward_f32)"))
+            for sfx, pg, what in sources:
+                ep = err_physical(pg, pg_ref, ph, floor, keys=keys)
+                out["bwd_err_phys%s_max" % sfx] = float(ep[ok].max())
+                out["bwd_err_phys%s_median" % sfx] = float(ep[ok].median())
+                out["bwd_phys%s_source" % sfx] = what
+                if all_grads:
+                    epa = err_physical(pg, pg_ref, ph, floor, keys=PHYS_KEYS)
+                    out["bwd_err_phys_all%s_max" % sfx] = float(epa[ok].max())
+                    out["bwd_err_phys_all%s_median" % sfx] = float(epa[ok].median())
     return out, ref

@@ -15,22 +15,35 @@ KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E",               
            "dense_B4096_nc16_f64_bwd": ["lcp_bwd_quadIfdLb1E", "lcp_bwd_wave_any"],
            # --config 4 (the piles): lcp_primal_kernel<30, fwd, PIN = 3> and its backward <32, bwd, PIN = 3>
            "fused_B4096_nc64_f64": "lcp_primal_kernelILi30ELb0ELb0ELi4ELi3E",
-           "fused_B4096_nc64_f64_bwd_physical": "lcp_primal_kernelILi32ELb1ELb0ELi4ELi3E"}
+           "fused_B4096_nc64_f64_bwd_physical": "lcp_primal_kernelILi32ELb1ELb0ELi4ELi3E",
+           # --config 4 --mode dense: classify + lcp_primal_kernel<40, fwd, DENSE> (36 rows: the dense boundary does not promise pinned rows) +
+           # the contact-space and generic launches that find no scene; --contact-space: lcp_big_kernel<64, fwd, DENSE> does the work.
+           # ("@part": only tables whose FILE name contains `part` - the two runs launch the same kernel names)
+           "dense_B4096_nc64_f64": ["lcp_primal_kernelILi40ELb0ELb1E", "lcp_classify_big", "lcp_big_kernelILi64ELb0ELb1E", "lcp_fwd_kernel", "@dense5."],
+           "dense_B4096_nc64_f64_bwd": ["lcp_primal_kernelILi40ELb1ELb1E", "lcp_big_kernelILi64ELb1ELb1E", "lcp_bwd_kernel", "@dense5."],
+           "dense_cs_B4096_nc64_f64": ["lcp_big_kernelILi64ELb0ELb1E", "lcp_classify_big", "lcp_fwd_kernel", "@dense5cs."],
+           "dense_cs_B4096_nc64_f64_bwd": ["lcp_big_kernelILi64ELb1ELb1E", "lcp_bwd_kernel", "@dense5cs."]}
 
 
 def main(paths, tag):
     rows = {}
     path = paths[0]
-    for line in (l for p_ in paths for l in open(p_)):
-        parts = line.split()
-        if len(parts) >= 5 and parts[0].startswith("_ZN"):
-            rows[(parts[0], parts[1])] = float(parts[-1])          # avg per launch (per counter instance)
+    for p_ in paths:
+        for line in open(p_):
+            parts = line.split()
+            if len(parts) >= 5 and parts[0].startswith("_ZN"):
+                rows[(os.path.basename(p_), parts[0], parts[1])] = float(parts[-1])          # avg per launch (per counter instance)
     traffic, counters = {}, {}
-    src = os.path.relpath(path, ROOT)
     for key, subs in KERNELS.items():
         subs = [subs] if isinstance(subs, str) else list(subs)
+        part = next((sb[1:] for sb in subs if sb.startswith("@")), None)   # restrict to the tables of one run
+        subs = [sb for sb in subs if not sb.startswith("@")]
         sub = subs[0]                                                   # the kernel the counters describe; traffic sums the whole call
-        get = lambda c, sb=sub: next((v for (k, cn), v in rows.items() if sb in k and cn == c), None)
+        files = sorted({f for (f, _, _) in rows if (part is None or part in f)})
+        if part is None:
+            files = [f for f in files if "dense5" not in f]
+        src = ", ".join("profiles/" + f for f in files)
+        get = lambda c, sb=sub: next((v for (f, k, cn), v in rows.items() if f in files and sb in k and cn == c), None)
         if get("FETCH_SIZE") is not None and get("WRITE_SIZE") is not None:
             tot = lambda c: sum(v for v in (get(c, sb) for sb in subs) if v is not None)
             traffic[key] = {"kernel": sub, "fetch_kb": tot("FETCH_SIZE"), "write_kb": tot("WRITE_SIZE"),
@@ -46,6 +59,8 @@ def main(paths, tag):
             if get("SQ_INSTS_VALU") is not None and get("SQ_WAVES"):
                 c["valu_insts_per_wave"] = get("SQ_INSTS_VALU") / get("SQ_WAVES")
             c["mfma_f64_ops"] = get("SQ_INSTS_VALU_MFMA_MOPS_F64")
+            if get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and get("SQ_BUSY_CYCLES"):
+                c["mfma_busy_frac"] = get("SQ_VALU_MFMA_BUSY_CYCLES") / get("SQ_BUSY_CYCLES")
             counters[key] = c
     json.dump(traffic, open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w"), indent=1)
     json.dump(counters, open(os.path.join(ROOT, "profiles", tag + "_counters.json"), "w"), indent=1)
