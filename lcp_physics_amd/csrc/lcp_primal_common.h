@@ -20,6 +20,9 @@
 #ifndef LCP_PRIMAL_PEEL_INIT
 #define LCP_PRIMAL_PEEL_INIT 0     // 1: the initialisation pass (it = -1) as its own copy of the loop body - what gave the four-scenes kernels 4 % (LCP_Q_PEEL_INIT) costs these kernels registers (221 -> 229; the 40-column instantiation spills 37 instead of 25): off
 #endif
+#ifndef LCP_PRIMAL_RCP_STEP
+#define LCP_PRIMAL_RCP_STEP 1      // step lengths, d = z / s and the corrector's rs / s through one reciprocal per z_i, s_i (LCP_Q_RCP_STEP in lcp_quad_kernels.inc; 0: IEEE quotients, A/B)
+#endif
 #ifndef LCP_PRIMAL_UNROLL_PASS
 #define LCP_PRIMAL_UNROLL_PASS 1   // the two KKT solves of an iteration as two copies of the code instead of a two-trip loop (0: the loop - A/B: config 5 forward 0.317 -> 0.313 ms, 239 -> 221 registers; the four-scenes kernels: LCP_Q_UNROLL_PASS)
 #endif

@@ -28,6 +28,9 @@
 #ifndef LCP_SOLO_PEEL_INIT
 #define LCP_SOLO_PEEL_INIT 1     // the initialisation pass (it = -1) as its own copy of the loop body (0: one loop, A/B)
 #endif
+#ifndef LCP_SOLO_RCP_STEP
+#define LCP_SOLO_RCP_STEP 1      // step lengths, d = z / s, rs / s through one reciprocal per z_i, s_i (LCP_Q_RCP_STEP; 0: IEEE quotients, A/B)
+#endif
 #ifndef LCP_SOLO_UNROLL_PASS
 #define LCP_SOLO_UNROLL_PASS 1   // the two KKT solves of an iteration as two copies of the code instead of a two-trip loop (0: the loop, A/B)
 #endif
@@ -491,6 +494,16 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     return kl ? nan_of<TC>() : l;
   };
 
+  // get_step through the reciprocals of the iterate (LCP_SOLO_RCP_STEP; step_pair_rcp of lcp_quad_kernels.inc for one row per lane):
+  // alpha = -1 / min_i(dv_i / v_i) where both vectors have a decreasing entry and no t_i is zero or NaN, step_pair otherwise
+  auto step_pair_rcp = [&](TC zv, TC rzv, TC dz, TC sv, TC rsv, TC ds) -> TC {
+    const TC tz = dz * rzv, ts = ds * rsv;
+    const bool bad = __builtin_amdgcn_class(tz * ts, 0xF3);                // NaN, +-0, +-denormal
+    if (__builtin_expect(!__any(vc && bad) && __any(vc && tz < (TC)0) && __any(vc && ts < (TC)0), 1))
+      return -fast_rcp(wave_fmin(vc ? fmin_(tz, ts) : inf_of<TC>()));
+    return step_pair(zv, dz, sv, ds);
+  };
+
 #if LCP_SOLO_PEEL_INIT
   // (the initialisation pass - it = -1 - as its own copy of the loop body: LCP_Q_PEEL_INIT in lcp_quad_kernels.inc)
   auto iteration = [&](auto INIT_, const int it) LCP_INL -> bool {
@@ -520,7 +533,11 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       szsum = sz;
       mu = sz / mf; mu = mu < 0 ? -mu : mu;                                // (:91)
       resid = sqrt(n_rz) + sqrt(n_ry) + sqrt(n_rx) + mf * mu;              // (:92-96)
+#if LCP_SOLO_RCP_STEP
+      dinv = vc ? s * fast_rcp(z) : (TC)1;
+#else
       dinv = vc ? s / z : (TC)1;                                           // 1 / d, d = z / s (:98)
+#endif
     }
     const bool singular = factor(dinv);                                    // (:99-100)
     if (it < 0 && singular && e > 0) status |= LCP_ST_SINGULAR_S11;
@@ -560,15 +577,29 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         if (ncs == 0) { bx = x; by = y; done = true; }                        // engines.py:36-50: x = P^-1 u, no LCP
       } else if (pass == 0) {
         ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
+#if LCP_SOLO_RCP_STEP
+        const TC irs = fast_rcp(s), irz = dinv * irs;                         // (1 / s_i: the step length and the corrector's rs / s; 1 / z_i = (s_i / z_i) (1 / s_i))
+        const TC alpha = pmin(step_pair_rcp(z, irz, az, s, irs, as_), (TC)1);
+#else
         const TC alpha = pmin(step_pair(z, az, s, as_), (TC)1);              // (:142-144)
+#endif
         const TC t3 = wave_sum(vc ? (s + alpha * as_) * (z + alpha * az) : (TC)0);
         const TC r3 = t3 / szsum, sig = r3 * r3 * r3;                         // (:146-150)
         const TC ms = -mu * sig;
         rx = 0; ry = 0; rz = 0;
+#if LCP_SOLO_RCP_STEP
+        rs = vc ? (ms + as_ * az) * irs : (TC)0;
+#else
         rs = vc ? (ms + as_ * az) / s : (TC)0;                                // (:153)
+#endif
       } else {
         const TC cx = ox + ax, cy = oy + ay, cs = os + as_, cz = oz + az;     // (:160-163)
+#if LCP_SOLO_RCP_STEP
+        const TC irs = fast_rcp(s), irz = dinv * irs;
+        const TC alpha = pmin((TC)0.999 * step_pair_rcp(z, irz, cz, s, irs, cs), (TC)1);
+#else
         const TC alpha = pmin((TC)0.999 * step_pair(z, cz, s, cs), (TC)1);   // (:164-166)
+#endif
         x += alpha * cx; y += alpha * cy;                                     // (:171-174)
         if (vc) { s += alpha * cs; z += alpha * cz; }
       }

@@ -29,6 +29,8 @@ CASES = {
     "configs2_4096x16_dense": (dict(kind="stack", B=4096, nbox=4, seed=1236, entry="dense"), 4096),
     "configs2_4096x8_two_points": (dict(kind="stack", B=4096, nbox=4, seed=1236, pts=2, both_backwards=True), 4096),
     "configs1_1024x4_two_points": (dict(kind="stack", B=1024, nbox=2, seed=1236, pts=2, both_backwards=True), 1024),
+    "configs2_4096x4_one_point": (dict(kind="stack", B=4096, nbox=4, seed=1236, pts=1, both_backwards=True), 4096),
+    "configs4_4096x64_pile": (dict(kind="pile", B=4096, nbox=10, seed=5), 4096),
     "configs4_4096x64_pile_dense": (dict(kind="pile", B=4096, nbox=10, seed=5, entry="dense"), 1024),
     "configs4_4096x64_pile_dense_contact_space": (dict(kind="pile", B=4096, nbox=10, seed=5, entry="dense", path="big"), 1024),
 }
