@@ -27,6 +27,20 @@ template <typename T> __device__ __forceinline__ T pmax(T a, T b) {
   return (a != a || b != b) ? nan_of<T>() : (a > b ? a : b);
 }
 
+// get_step (pdipm.py:182-186) from t_i = dv_i (1 / v_i) instead of the quotients a_i = -v_i / dv_i = -1 / t_i - the EXACT form, every case
+// (tests/test_step_length_model.py holds the same algebra against the oracle's get_step on adversarial vectors):
+//   an entry the fill replaces (dv_i > 0) has t_i > 0; the fill max(1, a.max()) is never below an entry it does not replace, so with a
+//   decreasing entry (t_i < 0) the result is -1 / min_i t_i; an exact +0 among the dv_i is a_i = -inf (the reference's solve then dies on
+//   NaN iterates), -0 is a_i = +inf; without a decreasing entry the result is the fill itself: 1, or +inf beside a -0; NaN propagates.
+// step_flags: the five facts about one t_i; OR them over the vector (and the scene), take the NaN-ignoring minimum of the t_i beside them.
+__device__ __forceinline__ uint32_t step_flags(double t) {
+  return (__builtin_amdgcn_class(t, 0x3) ? 1u : 0u) | (__builtin_amdgcn_class(t, 0x40) ? 2u : 0u) | (__builtin_amdgcn_class(t, 0x20) ? 4u : 0u) |
+         ((t < 0.0) ? 8u : 0u) | ((t > 0.0) ? 16u : 0u);
+}
+__device__ __forceinline__ double step_from_flags(uint32_t f, double tmin) {
+  return (f & 1u) ? nan_of<double>() : ((f & 2u) ? -inf_of<double>() : ((f & 8u) ? -1.0 / tmin : ((f & 16u) ? ((f & 4u) ? inf_of<double>() : 1.0) : inf_of<double>())));
+}
+
 struct OpSum { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
 struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return pmin(a, b); } };
 struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return pmax(a, b); } };

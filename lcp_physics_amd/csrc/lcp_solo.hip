@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     os = vc ? (-rs - oz) * di : (TC)0;                                     // :347,350
   };
 
+#if !LCP_SOLO_RCP_STEP
   // get_step for (z, dz), (s, ds) of the scene (pdipm.py:182-186): min(step(z, dz), step(s, ds)), NaN semantics as step_pair_q
   auto step_pair = [&](TC zv, TC dz, TC sv, TC ds) -> TC {
     const TC ninf = -inf_of<TC>(), pinf = inf_of<TC>();
@@ -494,16 +495,22 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     return kl ? nan_of<TC>() : l;
   };
 
+#else
   // get_step through the reciprocals of the iterate (LCP_SOLO_RCP_STEP; step_pair_rcp of lcp_quad_kernels.inc for one row per lane):
-  // alpha = -1 / min_i(dv_i / v_i) where both vectors have a decreasing entry and no t_i is zero or NaN, step_pair otherwise
-  auto step_pair_rcp = [&](TC zv, TC rzv, TC dz, TC sv, TC rsv, TC ds) -> TC {
+  // alpha = -1 / min_i(dv_i / v_i) where both vectors have a decreasing entry and no t_i is zero, NaN or infinite; the exact form of
+  // lcp_device.h (step_flags / step_from_flags) otherwise
+  auto step_pair_rcp = [&](TC rzv, TC dz, TC rsv, TC ds) -> TC {
     const TC tz = dz * rzv, ts = ds * rsv;
-    const bool bad = __builtin_amdgcn_class(tz * ts, 0xF3);                // NaN, +-0, +-denormal
+    const bool bad = __builtin_amdgcn_class(tz * ts, 0x2F7);               // NaN, +-inf, +-0, +-denormal
     if (__builtin_expect(!__any(vc && bad) && __any(vc && tz < (TC)0) && __any(vc && ts < (TC)0), 1))
       return -fast_rcp(wave_fmin(vc ? fmin_(tz, ts) : inf_of<TC>()));
-    return step_pair(zv, dz, sv, ds);
+    const uint32_t g = wave_or(vc ? (step_flags(tz) | (step_flags(ts) << 8)) : 0u);
+    TC mz = vc ? tz : inf_of<TC>(), ms = vc ? ts : inf_of<TC>();
+    mz = wave_fmin(mz); ms = wave_fmin(ms);
+    return pmin(step_from_flags(g & 0xffu, mz), step_from_flags(g >> 8, ms));
   };
 
+#endif
 #if LCP_SOLO_PEEL_INIT
   // (the initialisation pass - it = -1 - as its own copy of the loop body: LCP_Q_PEEL_INIT in lcp_quad_kernels.inc)
   auto iteration = [&](auto INIT_, const int it) LCP_INL -> bool {
@@ -579,7 +586,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         ax = ox; ay = oy; as_ = os; az = oz;                                  // affine direction (:138-139)
 #if LCP_SOLO_RCP_STEP
         const TC irs = fast_rcp(s), irz = dinv * irs;                         // (1 / s_i: the step length and the corrector's rs / s; 1 / z_i = (s_i / z_i) (1 / s_i))
-        const TC alpha = pmin(step_pair_rcp(z, irz, az, s, irs, as_), (TC)1);
+        const TC alpha = pmin(step_pair_rcp(irz, az, irs, as_), (TC)1);
 #else
         const TC alpha = pmin(step_pair(z, az, s, as_), (TC)1);              // (:142-144)
 #endif
@@ -596,7 +603,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         const TC cx = ox + ax, cy = oy + ay, cs = os + as_, cz = oz + az;     // (:160-163)
 #if LCP_SOLO_RCP_STEP
         const TC irs = fast_rcp(s), irz = dinv * irs;
-        const TC alpha = pmin((TC)0.999 * step_pair_rcp(z, irz, cz, s, irs, cs), (TC)1);
+        const TC alpha = pmin((TC)0.999 * step_pair_rcp(irz, cz, irs, cs), (TC)1);
 #else
         const TC alpha = pmin((TC)0.999 * step_pair(z, cz, s, cs), (TC)1);   // (:164-166)
 #endif

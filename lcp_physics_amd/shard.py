@@ -2,8 +2,8 @@
 
 Scenes never read each other, so the batch shards embarrassingly: one process per GPU, rank r of
 N owns a contiguous slice of the scene indices, and there is NO collective on the solve path.
-`torch.distributed` (RCCL on GPUs, gloo in the CPU tests) is only used for the barrier and the
-max-over-ranks timing reduction of the benchmark, and for an optional result gather.
+`torch.distributed` is only used for the barrier and the max-over-ranks timing reduction of the benchmark, and for an
+optional result gather: RCCL on GPUs when it comes up on every rank, gloo otherwise and in the CPU tests (`control_plane()`).
 """
 import os
 import socket
@@ -59,14 +59,64 @@ def launch_ranks(n, script, argv, share_devices=False, device_count=None, timeou
     return subprocess.call(cmd, env=env, timeout=timeout)
 
 
+# The control plane of a multi-rank run.  There is no collective on the solve path, so nothing about a run's RESULT depends on which
+# library carries the barriers and the three timing scalars: gloo (TCP on 127.0.0.1) is brought up first and always works; RCCL
+# ("nccl" on ROCm) is then TRIED - communicator + a one-element all_reduce under a blocking-wait timeout - and used for the barriers /
+# reductions only if every rank succeeded (agreed over gloo).  A node where RCCL cannot come up (IPC mode, a missing xGMI link, two ranks
+# on one device) still produces its line, with `control_plane()` saying why.
+_CTRL = {"group": None, "backend": None, "note": None}
+
+
+def control_plane():
+    """What carries the barriers / timing reductions of this run, for the benchmark line: e.g. "rccl", "gloo (rccl init failed: ...)"."""
+    if not dist.is_initialized():
+        return "single process"
+    if _CTRL["backend"] == "nccl":
+        return "rccl"
+    return "gloo" + ((" (%s)" % _CTRL["note"]) if _CTRL["note"] else "")
+
+
+def _try_rccl(local_rank, world, timeout_s):
+    """Collective over the default (gloo) group.  Returns (ok on EVERY rank, note)."""
+    import datetime
+    ok, note, group = 1.0, None, None
+    try:
+        n = torch.cuda.device_count()
+        dev = torch.device("cuda", local_rank % max(n, 1))
+        torch.cuda.set_device(dev)
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize(dev)
+        if int(round(float(t.item()))) != world:
+            raise RuntimeError("all_reduce returned %r for %d ranks" % (float(t.item()), world))
+    except Exception as ex:                                   # noqa: BLE001 - any failure of the optional transport means "use gloo"
+        ok, note = 0.0, "rccl init failed: %s" % (str(ex).strip().splitlines() or [type(ex).__name__])[0][:160]
+    flag = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # (default group: gloo)
+    if float(flag.item()) < 0.5:
+        return False, note or "rccl init failed on another rank", None
+    return True, None, group
+
+
 def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process).  `backend=None`: gloo as the
+    control plane, then RCCL if it comes up on every rank (see `_CTRL` above); "gloo": gloo only (the CPU tests, shared devices)."""
     rank, local_rank, world = env_rank()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        want_rccl = backend in (None, "nccl") and torch.cuda.is_available()
+        if want_rccl:
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")      # a collective that cannot complete raises after the timeout instead of hanging
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        _CTRL.update(group=None, backend="gloo", note=None)
+        if want_rccl:
+            ok, note, group = _try_rccl(local_rank, world, int(os.environ.get("LCP_RCCL_TIMEOUT_S", "60")))
+            if ok:
+                _CTRL.update(group=group, backend="nccl", note=None)
+            else:
+                _CTRL.update(note=note)
     return rank, local_rank, world
 
 
@@ -84,14 +134,14 @@ def rank_device(local_rank, share_devices=False):
 
 def reduce_device(device):
     """Where the small timing reductions live: on the GPU under RCCL, on the host under gloo."""
-    if dist.is_initialized() and dist.get_backend() == "gloo":
+    if dist.is_initialized() and _CTRL["backend"] != "nccl":
         return "cpu"
     return device
 
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(group=_CTRL["group"])
 
 
 def max_over_ranks(value, device="cpu"):
@@ -99,7 +149,7 @@ def max_over_ranks(value, device="cpu"):
     if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTRL["group"])
     return float(t.item())
 
 
@@ -107,7 +157,7 @@ def sum_over_ranks(value, device="cpu"):
     if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_CTRL["group"])
     return float(t.item())
 
 
@@ -122,5 +172,11 @@ def gather_scenes(local, total, device=None):
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad)
+    on_gpu = pad.is_cuda
+    if on_gpu and _CTRL["backend"] != "nccl":                   # gloo moves host memory
+        pad = pad.cpu()
+        outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=_CTRL["group"] if pad.is_cuda else None)
+    if on_gpu and not pad.is_cuda:
+        outs = [o.to(local.device) for o in outs]
     return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(outs, sizes)], 0)

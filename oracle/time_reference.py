@@ -22,25 +22,22 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import pdipm_oracle as O, ref_shim  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--dtype", default="float64", choices=["float32", "float64"])
-    ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--pile", action="store_true", help="BASELINE configs[4]: the ten-box piles (64 contacts, nineq 256)")
-    ap.add_argument("--machine", default="build container (not the GPU box)")
-    args = ap.parse_args()
+def time_reference(batch=256, dtype="float64", reps=2, pile=False, threads=None, machine="build container (not the GPU box)"):
+    """One timing of the unmodified reference on the first `batch` scenes of the workload; `threads`: torch intra-op threads
+    (None: the process default).  Returns the record `profiles/r*_reference_cpu_timing.json` keeps."""
     from lcp_physics_amd import scenes
     ref_shim.load_reference()
-    dt = getattr(torch, args.dtype)
-    # (torch.set_num_threads breaks MKL's batched 256 x 256 getrf - see bench.py cpu_baseline: the process keeps its default threads)
+    dt = getattr(torch, dtype)
+    # (torch.set_num_threads breaks MKL's batched 256 x 256 getrf - see bench.py cpu_baseline: the piles keep the process default)
+    if threads is not None and not pile:
+        torch.set_num_threads(int(threads))
     threads = torch.get_num_threads()
-    sc = (scenes.make_pile_scenes(B=args.batch, seed=5, dtype=torch.float32) if args.pile else
-          scenes.make_stack_scenes(B=args.batch, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32))
+    sc = (scenes.make_pile_scenes(B=batch, seed=5, dtype=torch.float32) if pile else
+          scenes.make_stack_scenes(B=batch, nbox=4, pts_per_interface=4, seed=1236, dtype=torch.float32))
     lcp = [None if t is None else t.to(dt) for t in O.assemble_lcp(*sc.assembly_args())]
-    cot = torch.randn(args.batch, lcp[0].shape[1], generator=torch.Generator().manual_seed(4321), dtype=dt)
+    cot = torch.randn(batch, lcp[0].shape[1], generator=torch.Generator().manual_seed(4321), dtype=dt)
     best = None
-    for _ in range(args.reps):
+    for _ in range(reps):
         ins = [t.clone().requires_grad_(True) for t in lcp]
         t0 = time.perf_counter()
         x = ref_shim.RefLCPFunction(max_iter=10)(*ins)
@@ -49,13 +46,30 @@ def main():
         t2 = time.perf_counter()
         if best is None or t2 - t0 < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
-    out = {"what": "unmodified reference pdipm (through oracle/ref_shim.py), fwd+bwd, batched call",
-           "workload": ("first %d scenes of the configs[4] workload (ten-box pile, 64 contacts, nineq 256)" if args.pile else
-                        "first %d scenes of the headline workload (4-box stack, 16 contacts, nineq 64)") % args.batch,
-           "nc": sc.nc, "batch": args.batch,
-           "dtype": args.dtype, "cpu_threads": threads, "host_cores": os.cpu_count(), "value": args.batch / best[0], "unit": "sim steps/s",
-           "fwd_s": best[1], "bwd_s": best[2], "machine": args.machine}
-    print(json.dumps(out))
+    return {"what": "unmodified reference pdipm (through oracle/ref_shim.py), fwd+bwd, batched call",
+            "workload": ("first %d scenes of the configs[4] workload (ten-box pile, 64 contacts, nineq 256)" if pile else
+                         "first %d scenes of the headline workload (4-box stack, 16 contacts, nineq 64)") % batch,
+            "nc": sc.nc, "batch": batch,
+            "dtype": dtype, "cpu_threads": threads, "host_cores": os.cpu_count(), "value": batch / best[0], "unit": "sim steps/s",
+            "fwd_s": best[1], "bwd_s": best[2], "machine": machine}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dtype", default="float64", choices=["float32", "float64"])
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--pile", action="store_true", help="BASELINE configs[4]: the ten-box piles (64 contacts, nineq 256)")
+    ap.add_argument("--threads", default=None, help="torch intra-op threads; a comma-separated list sweeps them (one JSON line each, then the best)")
+    ap.add_argument("--machine", default="build container (not the GPU box)")
+    args = ap.parse_args()
+    sweep = [None] if args.threads is None else [int(t) for t in args.threads.split(",")]
+    runs = [time_reference(args.batch, args.dtype, args.reps, args.pile, t, args.machine) for t in sweep]
+    for r in runs:
+        print(json.dumps(r), flush=True)
+    if len(runs) > 1:
+        best = max(runs, key=lambda r: r["value"])
+        print(json.dumps(dict(best, best_of_thread_sweep=[r["cpu_threads"] for r in runs])), flush=True)
 
 
 if __name__ == "__main__":

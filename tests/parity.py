@@ -215,8 +215,11 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
     returned - and, with dense gradients, `bwd_kkt_resid_all_max`: the residual of (dx, dlam, dnu) = (dp, -dh, -db) in lcp.py:47-50's system
     at the iterate the kernel returned, over all scenes (`bwd_kkt_resid_all_scenes_over_1e-6`: how many exceed 1e-6).  That system is the
     kernel's own - no oracle solution enters -, so it holds the scenes the filters above drop to "the kernel solved what lcp.py:44-50 poses".
-    `all_grads`: dG, dh, dF are compared too (`bwd_err_dG_max` ...) and the physical gradients over ALL of PHYS_KEYS (`bwd_err_phys_all_max`):
-    meaningful where the multipliers are unique (two points per interface, the reference's own convention - not the 4-point shapes).
+    `all_grads`: dG, dh, dF are compared too (`bwd_err_dG_max` ...: informative, see the note at `bwd_err_dlam_determined_max` in the code)
+    and the physical gradients over ALL of PHYS_KEYS (`bwd_err_phys_all_max`): meaningful where the multipliers are unique - ONE point per
+    interface; the reference's own two points per interface are already redundant in the tangential direction (both lie on the line their
+    friction directions span: measured, the split of the friction gradient between the two points of an interface differs O(1)
+    between any two solves while its sum agrees).
     With BOTH `grads` and `phys_grads` the physical comparison is reported for each source (`bwd_err_phys_max` = the dense gradients
     contracted through the assembly, `bwd_err_phys_direct_max` = lcp_step_backward_f32's own outputs).
     `cache` (a dict the caller keeps): the oracle's forward / backward of these LCPs is stored there and re-used by the next call with
@@ -295,6 +298,25 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
             errs = err_grads({k: g64[k] for k in keys}, {k: gr[k] for k in keys}, fl)
             for k in keys:
                 out["bwd_err_d%s_max" % k] = float(errs[k][ok].max())
+            if all_grads:
+                # dG, dh, dF are functions of dlam = -dh, and of dlam only a part is DETERMINED on a contact LCP: a sticking contact has both
+                # friction multipliers active, (dlam_f1 - dlam_f2) enters G^T dlam and the limiting system fixes nothing else about the pair
+                # (measured, one point per interface: the sum differs by up to 1e3 between kernel and oracle where the difference agrees to
+                # 1e-7).  Compared: (dlam_n, dlam_f1 - dlam_f2, dlam_gamma) on every well-posed scene, the rows of dG they determine, and the
+                # full dh / dG / dF on the scenes WITHOUT a sticking contact (z_gamma > s_gamma on every contact), which are counted.
+                nc_ = G.shape[1] // 4
+                det = lambda dl: torch.cat([dl[:, :nc_], dl[:, nc_:3 * nc_:2] - dl[:, nc_ + 1:3 * nc_:2], dl[:, 3 * nc_:]], 1)
+                dlk, dlo = -g64["h"], -gr["h"]
+                e_det = _n(det(dlk) - det(dlo)) / torch.maximum(_n(det(dlo)), fl["h"]).clamp_min(1e-300)
+                out["bwd_err_dlam_determined_max"] = float(e_det[ok].max())
+                detG = lambda dG_: torch.cat([dG_[:, :nc_], dG_[:, nc_:3 * nc_:2] - dG_[:, nc_ + 1:3 * nc_:2], dG_[:, 3 * nc_:]], 1)
+                e_dG = _n(detG(g64["G"]) - detG(gr["G"])) / torch.maximum(_n(detG(gr["G"])), fl["G"]).clamp_min(1e-300)
+                out["bwd_err_dG_determined_max"] = float(e_dG[ok].max())
+                slide = ok & ~(ref.z[:, 3 * nc_:] < ref.s[:, 3 * nc_:]).any(dim=1)
+                out["bwd_scenes_without_sticking_contact"] = int(slide.sum())
+                if bool(slide.any()):
+                    for k in "hGF":
+                        out["bwd_err_d%s_no_sticking_max" % k] = float(errs[k][slide].max())
             dnu = None if (A is None or g64.get("b") is None) else -g64["b"]
             for name, zz, ss in (("bwd_kkt_resid_max", z, s), ("bwd_kkt_resid_at_oracle_iterate_max", ref.z, ref.s)):
                 res = kkt_backward_residual(Q, G, A, F, zz, ss, c64, g64["p"], -g64["h"], dnu)

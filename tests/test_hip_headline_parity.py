@@ -185,6 +185,32 @@ def test_timed_kernel_against_oracle_at_metric_sizes(label, kind, B, nbox, seed,
     check_gates(rep, gates, dense_grads=not pile, sample=sample)
 
 
+def test_every_gradient_on_the_nonredundant_metric_shape():
+    """The metric's stack with ONE contact point per interface (4096 x 4 contacts, nz 15): the only variant of the shape whose
+    multipliers are unique, so that EVERY gradient lcp.py:52-61 / the engine assembly defines can be held against the oracle - with four
+    points per interface (BASELINE's count) the normal multipliers are redundant, with the reference's own two the tangential ones are.
+    Both backward kernels run (`both_backwards`): the seven dense gradients of lcp_pdipm_backward_f32 and lcp_step_backward_f32's
+    physical ones.  Compared at B = 4096, every scene well posed:
+      * dp, dQ, dA, db and all EIGHT physical gradients - Mdiag, v, f AND c_n, c_p1, c_p2, rest, fric - from both kernels;
+      * of dh / dG the part the KKT system determines: (dlam_n, dlam_f1 - dlam_f2, dlam_gamma) - a sticking contact leaves the sum of its
+        friction pair to rounding, in the reference as here;
+      * dh, dG, dF in full on the scenes without a sticking contact (counted).
+    These solves converge to rounding inside ten iterations, like configs[1]: iteration counts may differ (CONVERGED-style gates)."""
+    K = run_kernels("stack", 4096, 4, 1236, "pinned", entry="fused", pts=1, both_backwards=True)
+    rep, _ = report(K, None, all_grads=True, input_stability=True)
+    print("\nheadline parity configs2_4096x4_one_point: %s" % json.dumps(rep))
+    assert rep["status_nonzero"] == 0 and rep["fwd_err_x_max"] <= 1e-4, rep
+    assert rep["index_set_mismatches_floor_0.0001"] == 0 and rep["index_set_mismatches_unmasked"] <= 0.01 * rep["index_set_rows_total"], rep
+    assert rep["bwd_nonfinite_scenes"] == 0 and rep["bwd_kkt_resid_all_max"] <= 1e-6, rep
+    assert rep["bwd_well_posed_frac"] >= 0.95, rep
+    for k in ("bwd_err_dp_max", "bwd_err_dQ_max", "bwd_err_dA_max", "bwd_err_db_max", "bwd_err_phys_max", "bwd_err_phys_all_max",
+              "bwd_err_phys_direct_max", "bwd_err_phys_all_direct_max", "bwd_err_dlam_determined_max", "bwd_err_dG_determined_max"):
+        assert rep[k] <= 1e-4, (k, rep)
+    assert rep["bwd_scenes_without_sticking_contact"] >= 1, rep
+    for k in "hGF":
+        assert rep["bwd_err_d%s_no_sticking_max" % k] <= 1e-4, (k, rep)
+
+
 DENSE_CASES = [
     ("configs1_1024x8_dense", "stack", 1024, 2, 1236, "pinned", 1024, CONVERGED),
     ("configs2_4096x16_dense", "stack", 4096, 4, 1236, "pinned", 4096, STRICT),
