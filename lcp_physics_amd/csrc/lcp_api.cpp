@@ -159,9 +159,10 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
   if (bigd) {
     const size_t per_scene = per_scene_all;
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
-    // classes per scene: 3 = contact structure, at most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure
-    // (lcp_big.hip); 0 = anything else (the generic kernels)
-    const int primal_ok = (path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? 1 : 0;
+    // classes per scene: 4 = as 3 with equality rows that pin the leading coordinates (lcp_primal_pin.hip); 3 = contact structure, at
+    // most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure (lcp_big.hip); 0 = anything else (the generic kernels)
+    // (bit 1: the pinned form's sizes - lcp_classify_big then also looks at A and b and marks the scenes whose rows pin the leading coordinates 4)
+    const int primal_ok = (path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? (1 | (lcp::primal_pin_supported(nz, e) ? 2 : 0)) : 0;
     int rc = lcp::big_dense_forward(P, cls, per_scene, primal_ok, stream);
     if (rc) return rc;
     if (primal_ok) { rc = lcp::primal_dense_forward(P, cls, per_scene, stream); if (rc) return rc; }

@@ -1134,41 +1134,109 @@ namespace big {
 // One workgroup per scene: is the dense LCP the mixed contact LCP of engines.py:50-74 with a diagonal Q ?
 //   G = [Jc; Jf; 0] with Jf rows in (+jt, -jt) pairs, F = [[0, 0, 0], [0, 0, E], [mu, -E^T, 0]], h = [h_n; 0; 0], Q diagonal.
 // cls[scene] = 2 if so (lcp_big_kernel<.., DENSE> serves it), else 0 (the generic kernels do).
-// ... and 3 if, in addition, `primal_ok` (the sizes fit lcp_primal.hip) and no contact's rows touch more than two bodies (columns in
-// body triples): the body-space kernel takes those.
-__global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e, int primal_ok) {
+// ... 3 if, in addition, `primal_ok` (the sizes fit lcp_primal.hip) and no contact's rows touch more than two bodies (columns in
+// body triples): the body-space kernel takes those; 4 if, on top of that, `pin_ok` (the sizes of lcp_primal_pin.hip) and the equality
+// rows pin the leading coordinates - A = [I 0], b = 0, the TotalConstraint on the floor of the reference's worlds - : its pinned form.
+// Round 5: this pass is the ONLY one that reads the scene's dense tensors in full (F: 16-byte loads, eight in flight per lane); what the
+// body-space kernels need of them - per contact the six entries of its Jc / Jt rows on its two bodies, the bodies' first columns, mu and
+// h_n - it leaves in the scene's workspace block (`DENSE_EXTRACT_OFF`, component-major: 16 x ncap floats), so that the solver neither
+// scans the 33 KB of G again nor gathers the diagonal of F from 64 cache lines.
+#ifndef LCP_CLS_UNROLL
+#define LCP_CLS_UNROLL 8      // 16-byte loads of F in flight per lane
+#endif
+#ifndef LCP_CLS_NT
+#define LCP_CLS_NT 1          // F read with non-temporal loads: it is read once (A/B round 5: 0.668 -> 0.653 ms forward call; 8 or 16 loads in flight: no difference)
+#endif
+__global__ void __launch_bounds__(256) lcp_classify_big(DenseIO DN, int e, int primal_ok, int pin_ok, unsigned char* ws) {
   const int scene = blockIdx.x, tid = threadIdx.x, nz = DN.nz, m = DN.m, nc = m >> 2;
   const float* G = DN.G + (size_t)scene * m * nz;
   const float* F = DN.F + (size_t)scene * m * m;
   const float* Q = DN.Q + (size_t)scene * nz * nz;
   const float* h = DN.h + (size_t)scene * m;
   int good = 1;                                                            // (accumulated with &: no short-circuit between loads)
+  // F, four consecutive columns of one row per load (m is a multiple of four: a float4 never straddles a row)
+  {
+    const float4* F4 = reinterpret_cast<const float4*>(F);
+    const int q4 = m >> 2, total = m * q4;
+    for (int i0 = tid; i0 < total; i0 += 256 * LCP_CLS_UNROLL) {
+      float4 v[LCP_CLS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < LCP_CLS_UNROLL; ++u) {
+        const int i = i0 + 256 * u;
+#if LCP_CLS_NT
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        if (i < total) { const v4f w = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(F4 + i)); v[u] = make_float4(w.x, w.y, w.z, w.w); }
+        else v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+        v[u] = (i < total) ? F4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < LCP_CLS_UNROLL; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < total) {
+          const int r = i / q4, j0 = 4 * (i - r * q4);
+          const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t;
+            float want = 0.0f;
+            if (r >= nc && r < 3 * nc) want = (j == 3 * nc + ((r - nc) >> 1)) ? 1.0f : 0.0f;
+            else if (r >= 3 * nc) { const int cg = r - 3 * nc; if (j == cg) want = e4[t]; else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = -1.0f; }
+            good &= (e4[t] == want) ? 1 : 0;
+          }
+        }
+      }
+    }
+  }
   for (int i = tid; i < nc * nz; i += 256) { const int c = i / nz, k = i - c * nz; good &= (G[(size_t)(nc + 2 * c + 1) * nz + k] == -G[(size_t)(nc + 2 * c) * nz + k]) ? 1 : 0; }
   for (int i = tid; i < nc * nz; i += 256) good &= (G[(size_t)3 * nc * nz + i] == 0.0f) ? 1 : 0;
   for (int i = nc + tid; i < m; i += 256) good &= (h[i] == 0.0f) ? 1 : 0;
   for (int i = tid; i < nz * nz; i += 256) { const int r = i / nz, c = i - r * nz; good &= (r == c || Q[i] == 0.0f) ? 1 : 0; }
-  for (int i = tid; i < m * m; i += 256) {
-    const int r = i / m, j = i - r * m;
-    const float v = F[i];
-    float want = 0.0f;
-    if (r >= nc && r < 3 * nc) want = (j == 3 * nc + ((r - nc) >> 1)) ? 1.0f : 0.0f;
-    else if (r >= 3 * nc) { const int cg = r - 3 * nc; if (j == cg) want = v; else if (j == nc + 2 * cg || j == nc + 2 * cg + 1) want = -1.0f; }
-    good &= (v == want) ? 1 : 0;
-  }
+  // the per-contact records (and "at most two bodies"): four lanes per contact scan the bodies of its two rows, the contact's lane
+  // writes the record
+  __shared__ int sbf[64], sbl[64], sbn[64];
+  if (tid < 64) { sbf[tid] = 1 << 30; sbl[tid] = -1; sbn[tid] = 0; }
+  __syncthreads();
   int two = 1;
-  if (primal_ok && tid < nc) {
-    const float* gc = G + (size_t)tid * nz; const float* gt = G + (size_t)(nc + 2 * tid) * nz;
-    int blocks = 0;
-    for (int bq = 0; bq < nz / 3; ++bq) {
-      const bool nzb = (gc[3 * bq] != 0.0f) || (gc[3 * bq + 1] != 0.0f) || (gc[3 * bq + 2] != 0.0f) ||
-                       (gt[3 * bq] != 0.0f) || (gt[3 * bq + 1] != 0.0f) || (gt[3 * bq + 2] != 0.0f);
-      blocks += nzb ? 1 : 0;
+  if (primal_ok) {
+    const int c = tid >> 2, part = tid & 3, nbod = nz / 3;
+    if (c < nc) {
+      const float* gc = G + (size_t)c * nz; const float* gt = G + (size_t)(nc + 2 * c) * nz;
+      for (int bq = part; bq < nbod; bq += 4) {
+        const bool nzb = (gc[3 * bq] != 0.0f) || (gc[3 * bq + 1] != 0.0f) || (gc[3 * bq + 2] != 0.0f) ||
+                         (gt[3 * bq] != 0.0f) || (gt[3 * bq + 1] != 0.0f) || (gt[3 * bq + 2] != 0.0f);
+        if (nzb) { atomicMin(&sbf[c], bq); atomicMax(&sbl[c], bq); atomicAdd(&sbn[c], 1); }
+      }
     }
-    two = blocks <= 2 ? 1 : 0;
+    __syncthreads();
+    if (tid < nc) {
+      const float* gc = G + (size_t)tid * nz; const float* gt = G + (size_t)(nc + 2 * tid) * nz;
+      two = sbn[tid] <= 2 ? 1 : 0;
+      int bf = sbf[tid], bl = sbl[tid];
+      if (bl < 0) { bf = 0; bl = 0; }
+      float* rec = reinterpret_cast<float*>(ws + (size_t)scene * DN.ws_scene + DENSE_EXTRACT_OFF);
+      const int c0 = 3 * bf, c1 = 3 * bl;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        rec[q * nc + tid] = gc[c0 + q]; rec[(6 + q) * nc + tid] = gt[c0 + q];
+        rec[(3 + q) * nc + tid] = (bl != bf) ? gc[c1 + q] : 0.0f; rec[(9 + q) * nc + tid] = (bl != bf) ? gt[c1 + q] : 0.0f;
+      }
+      rec[12 * nc + tid] = __int_as_float(c0); rec[13 * nc + tid] = __int_as_float(c1);
+      rec[14 * nc + tid] = F[(size_t)(3 * nc + tid) * m + tid];             // mu_c (engines.py:71)
+      rec[15 * nc + tid] = h[tid];                                          // h_n (:74)
+    }
+  }
+  int pinned = 1;
+  if (pin_ok) {
+    const float* A = DN.A + (size_t)scene * e * nz;
+    for (int i = tid; i < e * nz; i += 256) { const int a = i / nz, k = i - a * nz; pinned &= (A[i] == ((k == a) ? 1.0f : 0.0f)) ? 1 : 0; }
+    if (tid < e) pinned &= (DN.b[(size_t)scene * e + tid] == 0.0f) ? 1 : 0;
   }
   const int all = __syncthreads_and(good);
   const int sparse = __syncthreads_and(two);
-  if (tid == 0) DN.cls[scene] = all ? ((primal_ok && sparse) ? 3 : 2) : 0;
+  const int pin = __syncthreads_and(pinned);
+  if (tid == 0) DN.cls[scene] = all ? ((primal_ok && sparse) ? ((pin_ok && pin) ? 4 : 3) : 2) : 0;
 }
 }  // namespace big
 
@@ -1184,7 +1252,7 @@ int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int prima
   dense_io(DN, P.nz, P.m, cls, ws_scene);
   DN.Q = (const float*)P.Q; DN.p = (const float*)P.p; DN.G = (const float*)P.G; DN.h = (const float*)P.h;
   DN.A = (const float*)P.A; DN.b = (const float*)P.b; DN.F = (const float*)P.F;
-  hipLaunchKernelGGL(big::lcp_classify_big, dim3(P.B), dim3(256), 0, (hipStream_t)stream, DN, P.e, primal_ok);
+  hipLaunchKernelGGL(big::lcp_classify_big, dim3(P.B), dim3(256), 0, (hipStream_t)stream, DN, P.e, primal_ok & 1, (primal_ok >> 1) & 1, (unsigned char*)P.ws);
   StepArgs SP = {};
   SP.B = P.B; SP.nb = (P.nz + 2) / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
   SP.eps = P.eps; SP.max_iter = P.max_iter; SP.lim = P.lim;

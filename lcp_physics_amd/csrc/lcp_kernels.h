@@ -48,6 +48,10 @@ struct BwdArgs {
 };
 
 // dense (Q, p, G, h, A, b, F) boundary of lcp_big.hip: LCPFunction sizes beyond the wave-per-scene kernels (nineq <= 256)
+// where lcp_classify_big leaves the per-contact records of a contact-structured dense scene for the body-space kernels (bytes into the
+// scene's workspace block; behind lcp_primal's 6.3 KB iterate block, 4 KB long at 64 contacts - the block is at least 32 KB at these sizes)
+constexpr size_t DENSE_EXTRACT_OFF = 8192;
+
 struct DenseIO {
   int nz, m;
   int32_t* tag;                                     // workspace trailer word (see FwdArgs::tag)
@@ -131,10 +135,11 @@ int primal_step(const StepArgs& P, void* stream, bool pinned = false);      // p
 int primal_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream, bool pinned = false);
 bool primal_pin_supported(int nz, int e);             // lcp_primal_pin.hip: nz - neq pivots when the equality rows pin the leading coordinates
 int primal_pin_launch(const StepArgs& P, const StepBwdArgs& G, int backward, void* stream);
+int primal_pin_dense_launch(const StepArgs& P, const DenseIO& DN, int backward, void* stream);   // dense boundary, scenes of class 4
 int primal_chain_launch(const StepArgs& P, const StepBwdArgs& G, int backward, void* stream);   // lcp_primal_chain.hip: 5 .. 24 equality rows
 int primal_post_stab_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);   // lcp.py:37-64 on that LCP, contracted through engines.py:84-112
 int primal_post_stab(const StepArgs& P, void* stream);                                         // engines.py:80-116 in body space
-int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);      // scenes of class 3
+int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);      // scenes of class 3 (and 4: the pinned form)
 int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
 
 // four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
@@ -159,7 +164,7 @@ int big_step(const StepArgs& P, void* stream);
 int big_step_backward(const StepArgs& P, const StepBwdArgs& G, void* stream);
 // dense boundary (lcp_pdipm_forward_f32 / _backward_f32) for 16 < nineq / 4 <= 64 contacts: classification, then the same kernel
 bool big_dense_supported(int nz, int m, int e);
-int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int primal_ok, void* stream);   // (classifies: 0 / 2 / 3)
+int big_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, int primal_ok, void* stream);   // (classifies: 0 / 2 / 3 / 4; primal_ok: bit 0 = lcp_primal sizes, bit 1 = pinned sizes)
 int big_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream);
 
 // narrow-phase contact generation + position update - lcp_contacts.hip

@@ -84,6 +84,7 @@ int primal_dense_forward(const FwdArgs& P, int32_t* cls, size_t ws_scene, void* 
   SP.v_new = P.x; SP.z = P.z; SP.s = P.s; SP.y = P.y; SP.iters = P.iters; SP.status = P.status;
   SP.tag = P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
+  if (primal_pin_supported(P.nz, P.e)) { const int rc = primal_pin_dense_launch(SP, DN, 0, stream); if (rc) return rc; }   // class 4: the pinned form
   return primal_dispatch<false, true>(SP, Gd, stream, DN);
 }
 int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void* stream) {
@@ -95,6 +96,7 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
   SP.B = P.B; SP.nb = P.nz / 3; SP.nc = P.m / 4; SP.e = P.e; SP.ws = P.ws;
   SP.tag = (int32_t*)P.tag; SP.tag_value = P.tag_value;
   StepBwdArgs Gd = {};
+  if (primal_pin_supported(P.nz, P.e)) { const int rc = primal_pin_dense_launch(SP, DN, 1, stream); if (rc) return rc; }
   return primal_dispatch<true, true>(SP, Gd, stream, DN);
 }
 

@@ -52,7 +52,7 @@ def assemble_contacts(sc):
     Q, p, G, h, F = new(B, nz, nz), new(B, nz), new(B, m, nz), new(B, m), new(B, m, m)
     A, b = (new(B, e, nz), new(B, e)) if e else (None, None)
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_assemble_contacts_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest),
                                            P(sc.fric), P(sc.c_n), P(sc.c_p1), P(sc.c_p2), P(sc.c_i1),
                                            P(sc.c_i2), P(sc.Je) if e else None, float(sc.dt),
@@ -180,7 +180,7 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None, want_Je=False
     if want_Je and e and "Je" not in grads:
         grads["Je"] = torch.empty(B, e, 3 * nb, dtype=torch.float32, device=dev)
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_step_backward_je_f32(B, nb, nc, e, P(sc.Mdiag), P(sc.v), P(sc.f), P(sc.rest), P(sc.fric), P(sc.c_n),
                                           P(sc.c_p1), P(sc.c_p2), P(sc.c_i1), P(sc.c_i2), P(sc.Je) if e else None,
                                           float(sc.dt), P(dl_dv), _word(out, compute),
@@ -303,7 +303,7 @@ def solve_dynamics(B, nb, maxc, e, count, Mdiag, v, f, rest, fric, cb, Je, dt, e
                "status": torch.empty(B, dtype=torch.int32, device=dev)}
     out["ws"] = ws
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_solve_dynamics_f32(B, nb, maxc, e, P(count), P(Mdiag), P(v), P(f), P(rest), P(fric),
                                         P(cb.c_n), P(cb.c_p1), P(cb.c_p2), P(cb.c_i1), P(cb.c_i2),
                                         P(Je) if e else None, float(dt), float(eps), int(max_iter),
@@ -331,7 +331,7 @@ def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt,
     if want_Je and e and "Je" not in grads:
         grads["Je"] = torch.empty(B, e, 3 * nb, dtype=torch.float32, device=dev)
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_step_backward_je_f32(B, nb, maxc, e, P(Mdiag), P(v), P(f), P(rest), P(fric), P(cb.c_n), P(cb.c_p1),
                                           P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(dt), P(dl_dv),
                                           _word(out, compute),
@@ -512,7 +512,7 @@ def post_stabilization(B, nb, maxc, e, count, Mdiag, v, rest, cb, Je, p=None, dt
         if t is not None:
             _lib.require_gpu_tensor(t, name, torch.float64)
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_post_stabilization_f32(B, nb, maxc, e, P(count), P(Mdiag), P(v), P(rest), P(cb.c_n), P(cb.c_p1),
                                             P(cb.c_p2), P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, float(eps),
                                             int(max_iter), int(not_improved_lim), comp, P(p), P(dt_scene), float(dt),
@@ -536,7 +536,7 @@ def post_stabilization_backward(B, nb, maxc, e, Mdiag, v, rest, cb, Je, dl_ddp, 
     if want_Je and e:
         grads["Je"] = new(B, e, 3 * nb)
     P = _lib.ptr
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.lcp_post_stabilization_backward_f32(B, nb, maxc, e, P(Mdiag), P(v), P(rest), P(cb.c_n), P(cb.c_p1), P(cb.c_p2),
                                                      P(cb.c_i1), P(cb.c_i2), P(Je) if e else None, P(dl_ddp), _word(out, compute),
                                                      P(grads["Mdiag"]), P(grads["v"]), P(grads["rest"]), P(grads["c_n"]),

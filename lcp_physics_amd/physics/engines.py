@@ -42,38 +42,63 @@ def _gpu():
 
 class _Lifted:
     """What `Engine.solve_dynamics` reads from the reference's `World` (`world.py:124-234`), as float32 GPU tensors with a
-    leading batch axis of one.  Built with differentiable torch ops only (stack / reshape / `.to`), so gradients that
-    arrive at these tensors flow on to the world's own leaves."""
+    leading batch axis of one.  Built with differentiable torch ops only (cat / reshape / `.to` / slices), so gradients that
+    arrive at these tensors flow on to the world's own leaves.
+
+    The reference calls its engine once per `World.step()` with a batch of ONE scene, so what a step costs here is host work, not the
+    35 us of the kernel: everything the kernel reads travels in TWO transfers - the floats packed into one tensor on the host (one
+    `torch.cat`, one copy, views on the device), the contact indices and the count in one int32 tensor - instead of a dozen small
+    copies (round 4: 3.5 ms per step on ball + floor against the reference engine's 0.40; profiles/r05_reference_world_plugin.json)."""
 
     def __init__(self, world, forces=True):
         dev = _gpu()
         bodies = world.bodies
         nb = len(bodies)
-        up = lambda t, *shape: t.reshape(1, *shape).to(device=dev, dtype=torch.float32).contiguous()
+        nz = 3 * nb
         self.nb, self.dev = nb, dev
-        self.v = up(world.get_v(), nb, 3)
-        self.Mdiag = up(torch.diagonal(world.M()), nb, 3)
-        self.rest = up(torch.stack([b.restitution.reshape(()) for b in bodies]), nb)
-        self.fric = up(torch.stack([b.fric_coeff.reshape(()) for b in bodies]), nb)
-        self.f = up(world.apply_forces(world.t), nb, 3) if forces else None
         Je = world.Je()
         self.e = Je.size(0) if (Je.ndimension() > 1 and Je.numel() > 0) else 0
-        self.Je = up(Je, self.e, 3 * nb) if self.e else None                 # (its gradient flows on to the joints' anchors)
         contacts = world.contacts or []
         self.nc = len(contacts)
-        cap = max(1, self.nc)
+        cap = self.cap = max(1, self.nc)
+        flat = lambda t: t.reshape(-1)
+        parts = [flat(world.get_v()), flat(torch.diagonal(world.M())),
+                 torch.stack([b.restitution.reshape(()) for b in bodies]), torch.stack([b.fric_coeff.reshape(()) for b in bodies])]
+        sizes = [nz, nz, nb, nb]
+        if forces:
+            parts.append(flat(world.apply_forces(world.t)))
+            sizes.append(nz)
+        if self.e:
+            parts.append(flat(Je))                                         # (its gradient flows on to the joints' anchors)
+            sizes.append(self.e * nz)
         if contacts:
-            col = lambda k: up(torch.stack([c[0][k].reshape(2) for c in contacts]), cap, 2)
-            self.c_n, self.c_p1, self.c_p2 = col(0), col(1), col(2)
-            ids = lambda k: torch.tensor([[int(c[k]) for c in contacts]], dtype=torch.int32, device=dev)
-            self.c_i1, self.c_i2 = ids(1), ids(2)
+            for k in range(3):                                             # normal, p1, p2 of ((normal, p1, p2, penetration), i1, i2)
+                parts.append(torch.stack([c[0][k].reshape(2) for c in contacts]).reshape(-1))
+                sizes.append(2 * cap)
+        dtype0 = parts[0].dtype
+        host = torch.cat([q if q.dtype == dtype0 else q.to(dtype0) for q in parts])
+        devf = host.to(device=dev, dtype=torch.float32)                    # ONE copy (differentiable: the gradient comes back the same way)
+        cut = list(torch.split(devf, sizes))
+        self.v, self.Mdiag = cut[0].reshape(1, nb, 3), cut[1].reshape(1, nb, 3)
+        self.rest, self.fric = cut[2].reshape(1, nb), cut[3].reshape(1, nb)
+        i = 4
+        self.f = None
+        if forces:
+            self.f = cut[i].reshape(1, nb, 3)
+            i += 1
+        self.Je = None
+        if self.e:
+            self.Je = cut[i].reshape(1, self.e, nz)
+            i += 1
+        if contacts:
+            self.c_n, self.c_p1, self.c_p2 = (cut[i + k].reshape(1, cap, 2) for k in range(3))
+            ints = [int(c[1]) for c in contacts] + [int(c[2]) for c in contacts] + [self.nc]
         else:                                       # engines.py:35-49: the no-contact branch, a list of capacity one, count 0
-            z2 = lambda: torch.zeros(1, cap, 2, dtype=torch.float32, device=dev)
-            self.c_n, self.c_p1, self.c_p2 = z2(), z2(), z2()
-            self.c_i1 = torch.zeros(1, cap, dtype=torch.int32, device=dev)
-            self.c_i2 = torch.zeros(1, cap, dtype=torch.int32, device=dev)
-        self.cap = cap
-        self.count = torch.full((1,), self.nc, dtype=torch.int32, device=dev)
+            z = torch.zeros(3, 1, cap, 2, dtype=torch.float32, device=dev)
+            self.c_n, self.c_p1, self.c_p2 = z[0], z[1], z[2]
+            ints = [0, 0, 0]
+        devi = torch.tensor(ints, dtype=torch.int32).to(dev)               # the second (and last) copy
+        self.c_i1, self.c_i2, self.count = devi[:cap].reshape(1, cap), devi[cap:2 * cap].reshape(1, cap), devi[2 * cap:]
 
 
 class HipPdipmEngine(Engine):

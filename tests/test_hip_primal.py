@@ -193,7 +193,7 @@ def test_backward_matches_the_contact_space_backward(kind):
 
 def test_dense_boundary_routes_every_scene_to_its_kernel():
     """`lcp_pdipm_forward_f32 / _backward_f32` at config-5 sizes: one call serves contact-structured scenes whose rows touch two
-    bodies (class 3: lcp_primal.hip), contact-structured scenes that do not (class 2: lcp_big.hip - here a normal row with an entry
+    bodies (class 3: lcp_primal.hip; class 4, its pinned form, where A = [I 0] and b = 0), contact-structured scenes that do not (class 2: lcp_big.hip - here a normal row with an entry
     on a third body) and general LCPs (class 0: the generic kernels - here a perturbed F).  The classes the device wrote are read
     back from the tail of the workspace; answers and gradients against the generic kernels forced on every scene."""
     from lcp_physics_amd import _lib, scenes
@@ -205,6 +205,7 @@ def test_dense_boundary_routes_every_scene_to_its_kernel():
     lcp[2][2, 5, 3 * 9 + 1] = 0.125                       # scene 2: contact 5 (bodies 0 and 2) also pushes on body 9
     lcp[2][7, 40, 3 * 1 + 2] = -0.25                      # scene 7: likewise
     lcp[6][4, 5, 7] = 0.25                                # scene 4: F is not the contact F any more
+    lcp[4][9] = lcp[4][9] * 2.0                           # scene 9: A = 2 [I 0] - the same constraint, but not rows that PIN the coordinates
     g = [None if t is None else t.to(DEV).contiguous() for t in lcp]
     cot = torch.randn(B, nz, generator=torch.Generator().manual_seed(2), dtype=torch.float32).to(DEV)
 
@@ -221,9 +222,10 @@ def test_dense_boundary_routes_every_scene_to_its_kernel():
     sol, grads = run("auto")
     per_scene = (_lib.workspace_bytes(B, nz, m, 3, _lib.COMPUTE_F64) - ((B * 4 + 255) & ~255) - 256) // B
     cls = sol.ws[B * per_scene: B * per_scene + 4 * B].view(torch.int32).cpu().tolist()
-    want = [3] * B
+    want = [4] * B                                        # (class 4, round 5: class 3 whose equality rows pin the leading coordinates - lcp_primal_pin.hip)
     want[2] = want[7] = 2
     want[4] = 0
+    want[9] = 3
     assert cls == want, cls
     solg, gg = run("generic")
     solb, gb = run("big")                                  # (contact-space kernel on the classes 2 AND 3)

@@ -16,11 +16,11 @@ KERNELS = {"fused_B4096_nc16_f64": "lcp_fwd_quadIfdLb1ELi1ELi2E",               
            # --config 4 (the piles): lcp_primal_kernel<30, fwd, PIN = 3> and its backward <32, bwd, PIN = 3>
            "fused_B4096_nc64_f64": "lcp_primal_kernelILi30ELb0ELb0ELi4ELi3E",
            "fused_B4096_nc64_f64_bwd_physical": "lcp_primal_kernelILi32ELb1ELb0ELi4ELi3E",
-           # --config 4 --mode dense: classify + lcp_primal_kernel<40, fwd, DENSE> (36 rows: the dense boundary does not promise pinned rows) +
-           # the contact-space and generic launches that find no scene; --contact-space: lcp_big_kernel<64, fwd, DENSE> does the work.
+           # --config 4 --mode dense: classify (+ extract) + lcp_primal_kernel<30, fwd, DENSE, PIN> (the scenes whose rows pin the floor: class 4) +
+           # the general body-space, contact-space and generic launches that find no scene; --contact-space: lcp_big_kernel<64, fwd, DENSE> does the work.
            # ("@part": only tables whose FILE name contains `part` - the two runs launch the same kernel names)
-           "dense_B4096_nc64_f64": ["lcp_primal_kernelILi40ELb0ELb1E", "lcp_classify_big", "lcp_big_kernelILi64ELb0ELb1E", "lcp_fwd_kernel", "@dense5."],
-           "dense_B4096_nc64_f64_bwd": ["lcp_primal_kernelILi40ELb1ELb1E", "lcp_big_kernelILi64ELb1ELb1E", "lcp_bwd_kernel", "@dense5."],
+           "dense_B4096_nc64_f64": ["lcp_primal_kernelILi30ELb0ELb1ELi4ELi3E", "lcp_classify_big", "lcp_primal_kernelILi40ELb0ELb1E", "lcp_big_kernelILi64ELb0ELb1E", "lcp_fwd_kernel", "@dense5."],
+           "dense_B4096_nc64_f64_bwd": ["lcp_primal_kernelILi32ELb1ELb1ELi4ELi3E", "lcp_primal_kernelILi40ELb1ELb1E", "lcp_big_kernelILi64ELb1ELb1E", "lcp_bwd_kernel", "@dense5."],
            "dense_cs_B4096_nc64_f64": ["lcp_big_kernelILi64ELb0ELb1E", "lcp_classify_big", "lcp_fwd_kernel", "@dense5cs."],
            "dense_cs_B4096_nc64_f64_bwd": ["lcp_big_kernelILi64ELb1ELb1E", "lcp_bwd_kernel", "@dense5cs."]}
 

@@ -3,7 +3,7 @@
 # For ONE gpurun call a read-only copy of the reference's python package is staged in untracked scratch (oracle/_ref/stage:
 # git-ignored, so it can never be committed; it travels to the GPU box with the snapshot like a built .so), the measurement runs
 # there, and the copy is removed again whatever happens.  Nothing of the product imports it (LCP_REFERENCE_ROOT is read by
-# oracle/ref_shim.py only).  Outputs: gpurun_out/r04_reference_world_plugin.json, gpurun_out/r04_reference_cpu_timing_*.json.
+# oracle/ref_shim.py only).  Outputs: gpurun_out/<TAG>_reference_world_plugin.json, gpurun_out/<TAG>_reference_cpu_timing_*.jsonl, gpurun_out/<TAG>_bench_fused_with_reference.json.
 set -e
 cd "$(dirname "$0")/.."
 STAGE=oracle/_ref/stage
