@@ -232,6 +232,7 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
       P.skip_tag = TAG_STEP_GENERIC;
       int rc = lcp::wave64_backward(P, compute, false, stream, 0);
       if (rc) return rc;
+      if (!pl.ok) return 0;                                                   // (no generic plan at these sizes: the generic step cannot have run either)
       P.tag_value = TAG_STEP_GENERIC; P.skip_tag = TAG_STEP_WAVE64;
       return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);
     }

@@ -8,6 +8,23 @@
 #include "lcp_device.h"
 
 namespace lcp {
+
+// Scenes a launch of the four-scenes-per-wavefront kernels may hold while every wavefront still has a SIMD of its own: 4 scenes x 4 SIMDs
+// per compute unit of the device that is CURRENT on the calling thread (the launch goes to it).  Read from the device - 1024 SIMDs =
+// 4096 scenes on an MI355X - and kept per host thread and device ordinal (no process-global state; the attribute never changes).
+inline int one_wave_per_simd_scenes() {
+  thread_local int cached_dev = -1, cached = 4096;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 4096;
+  if (dev != cached_dev) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cached = 16 * cus;
+    else cached = 4096;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 namespace w64 {
 
 constexpr int MP = 64;    // padded nineq (lanes)

@@ -169,6 +169,8 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None, want_Je=False
     returned (its workspace is read); the scene must not have changed in between.  `want_Je`: also "Je" [B,e,3nb], the
     gradient of the joint Jacobian (`lcp.py:57`, dA = dnu x^T + nu dx^T)."""
     lib = _lib.load()
+    from .dense_step import require_fused_record
+    require_fused_record(out, "fused_step_backward")
     e = _check_scene(sc)
     B, nb, nc = sc.B, sc.nb, sc.nc
     dev = sc.v.device
@@ -195,6 +197,8 @@ def fused_step_backward(sc, out, dl_dv, compute="f64", grads=None, want_Je=False
 def solution_of_step(sc, out, G, A, compute="f64"):
     """Wrap a fused step's workspace as an `LCPSolution` so `lcp.lcp_backward` can follow
     (G, A from `assemble_contacts`)."""
+    from .dense_step import require_fused_record
+    require_fused_record(out, "solution_of_step")
     sol = LCPSolution()
     B, nb, nc = sc.B, sc.nb, sc.nc
     e = A.shape[1] if A is not None else 0
@@ -322,6 +326,8 @@ def solve_dynamics_backward(B, nb, maxc, e, Mdiag, v, f, rest, fric, cb, Je, dt,
     Returns dict(Mdiag, v, f [B,nb,3], rest, fric [B,nb], c_n, c_p1, c_p2 [B,maxc,2]) and, with `want_Je`, Je [B,e,3nb] - the
     gradient of the joint Jacobian (`lcp.py:57` with A = Je), which worlds with pose-dependent joints propagate on."""
     lib = _lib.load()
+    from .dense_step import require_fused_record
+    require_fused_record(out, "solve_dynamics_backward")
     dev = v.device
     dl_dv = _lib.require_gpu_tensor(dl_dv.to(torch.float32).contiguous(), "dl_dv", torch.float32)
     if grads is None:

@@ -94,6 +94,21 @@ def _groups(count, maxc, B, dev):
     return [(int(c), (cnt == int(c)).nonzero().flatten()) for c in host.unique().tolist()], count > maxc
 
 
+_WARNED = set()
+
+
+def _warn_once(kind, nb, maxc, e):
+    """The switch to this route used to be silent: said once per (entry, size) and process."""
+    key = (kind, nb, maxc, e)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn("lcp_physics_amd: a recorded %s step of %d bodies / %d contacts / %d joint rows is beyond the fused backward kernels "
+                      "(3 nb + neq <= 56, 64 contacts): it goes through the dense LCPFunction boundary (physics/dense_step.py - the reference's "
+                      "own route: correct and differentiable, not fast; one host synchronisation per step for the contact counts)"
+                      % (kind, nb, maxc, e), RuntimeWarning, stacklevel=4)
+
+
 def _run(kind, phys, lists, count, Je, dt, opts):
     """Shared driver: phys = per-body tensors, lists = (c_n, c_p1, c_p2, c_i1, c_i2).  Returns (x [B,nb,3] float32, record)."""
     c_n = lists[0]
@@ -108,7 +123,8 @@ def _run(kind, phys, lists, count, Je, dt, opts):
     rec = {"z": torch.zeros(B, nrows, dtype=torch.float32, device=dev), "s": torch.zeros(B, nrows, dtype=torch.float32, device=dev),
            "y": torch.zeros(B, e, dtype=torch.float32, device=dev) if e else None,
            "iters": torch.zeros(B, dtype=torch.int32, device=dev), "status": torch.zeros(B, dtype=torch.int32, device=dev),
-           "ws": None, "dense_boundary": True}
+           "ws": None, "compute": None, "dense_boundary": True}      # (no fused workspace: `require_fused_record` below is what the helpers that need one call)
+    _warn_once(kind, nb, maxc, e)
     groups, truncated = _groups(count, maxc, B, dev)
     x_all = None
     for nc, sel in groups:
@@ -152,6 +168,14 @@ def _run(kind, phys, lists, count, Je, dt, opts):
     if truncated is not None:
         rec["status"] |= truncated.to(torch.int32) * _lib.ST_TRUNCATED
     return x_all, rec
+
+
+def require_fused_record(out, what):
+    """Helpers that read a fused step's workspace (`solution_of_step`, `fused_step_backward`, `solve_dynamics_backward`, reuse of
+    `out["ws"]`) call this first: a record left by the dense-boundary route has none, and says so instead of dereferencing None."""
+    if out is not None and out.get("dense_boundary"):
+        raise RuntimeError("%s needs the workspace of a fused step; this record was left by the dense-boundary route "
+                           "(physics/dense_step.py: sizes beyond the fused kernels) - differentiate through the returned tensor instead" % what)
 
 
 def solve_dynamics_dense(Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts):

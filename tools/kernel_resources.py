@@ -5,7 +5,7 @@ import json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
-FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_quad_n15e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n9e3.hip": ["-fno-slp-vectorize"],
+FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_quad_n15e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n9e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n12e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n6e3.hip": ["-fno-slp-vectorize"],
          "lcp_solo.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_primal_pin.hip": [], "lcp_primal_chain.hip": [], "lcp_primal_poststab.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
 KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
         "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_static_bytes",
@@ -52,6 +52,10 @@ def main():
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
         "lcp_primal_kernel_30_pinned_fwd": pick("lcp_primal_kernel<30, false, false, 4, 3>"),   # BASELINE config 5 under LCP_HINT_PINNED
         "lcp_primal_kernel_32_pinned_bwd": pick("lcp_primal_kernel<32, true, false, 4, 3>"),
+        "lcp_primal_kernel_dense_fwd": pick("lcp_primal_kernel<30, false, true, 4, 3>"),        # configs[4] through the dense boundary: the pinned form reading lcp_classify_big's records
+        "lcp_primal_kernel_dense_bwd": pick("lcp_primal_kernel<32, true, true, 4, 3>"),
+        "lcp_big_kernel_64_dense_fwd": pick("lcp_big_kernel<64, false, true>"),                 # ... with LCP_PATH_CONTACT_SPACE
+        "lcp_classify_big": pick("lcp_classify_big"),
         "lcp_primal_kernel_40_fwd": pick("lcp_primal_kernel<40, false, false, 4, 0>"),           # the general form (36 x 36 on config 5)
         "lcp_primal_kernel_40_bwd": pick("lcp_primal_kernel<40, true, false, 4, 0>"),
         "all_kernels": nice,
