@@ -430,9 +430,11 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   P.pos64 = p; P.dt_scene = dt_scene; P.p_out64 = p_out;
   // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
   P.ws = ws;                                                                // (lcp_primal.hip leaves the best iterate there for the backward)
-  const bool body = path == 0 && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e);
+  // (LCP_PATH_PRIMAL: the one-wave-per-scene kernel at every size - the A/B partner of the four-scenes-per-wave form of round 5)
+  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e);
   P.tag = trailer_of(ws, B, scene_bytes(nz, m, e, compute, 0));
   P.tag_value = body ? TAG_POSTSTAB_PRIMAL : TAG_POSTSTAB_GENERIC;
+  if (body && path == 0 && lcp::quad_post_supported(nz, m, e)) return lcp::quad_post_stab(P, stream);   // (same workspace layout, same tag: one backward)
   if (body) return lcp::primal_post_stab(P, stream);
   const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
   lcp::Plan pl = lcp::make_plan(nz, m, e, cs);
@@ -447,7 +449,7 @@ int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute) {
   int path;
   compute = split_compute(compute, &generic, &path);
   // (the routing test of lcp_post_stabilization_backward_f32 below)
-  return (compute == LCP_COMPUTE_F64 && path == 0 && lcp::primal_supported(3 * nb, 4 * maxc, e)) ? 1 : 0;
+  return (compute == LCP_COMPUTE_F64 && (path == 0 || path == 4) && lcp::primal_supported(3 * nb, 4 * maxc, e)) ? 1 : 0;
 }
 
 int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const float* Mdiag, const float* v,
@@ -464,7 +466,7 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const fl
   if (rc) return rc;
   if (!dl_ddp || !ws) return LCP_E_BADARG;
   // only the body-space kernel keeps the iterate this backward reads (the same routing test as the forward)
-  if (path != 0 || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
+  if ((path != 0 && path != 4) || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
   P.ws = ws;
   P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * maxc, e, compute, 0));
   P.tag_value = TAG_POSTSTAB_PRIMAL;

@@ -145,6 +145,8 @@ int primal_dense_backward(const BwdArgs& P, int32_t* cls, size_t ws_scene, void*
 // four-scenes-per-wave contact-structured path (nc <= 16, neq <= 4, diagonal Q; nz <= 16, or nz <= 32 from a contact
 // list) - lcp_quad.hip
 // `accept`: classification flag value (workspace meta[0]) the launch serves
+bool quad_post_supported(int nz, int m, int e);        // post-stabilisation on this mapping (m = 4 maxc as everywhere; the LCP has maxc rows)
+int quad_post_stab(const StepArgs& P, void* stream);
 bool quad_supported(int nz, int m, int e);
 bool quad_step_supported(int nz, int m, int e);   // contact-list entry points: nz <= 32
 int quad_forward(const FwdArgs& P, int compute, int accept, void* stream, int io_f64 = 0, int body_space = 0);   // body_space: the dense boundary on the body-space kernels (fp32 tensors, fp64 arithmetic)

@@ -4,6 +4,8 @@
 
 namespace lcp {
 namespace primal {
+// (lcp_quad_kernels.inc's post-stabilisation forward writes this layout by its own constants: POST_WS_IT / _ZO / _TOTAL)
+static_assert(WsLayout::IT == 64 && ZO == 88 && WsLayout::TOTAL == 792 && LX == 64, "workspace layout shared with lcp_fwd_quad<..., POST>");
 
 // ---------------------------------------------------------------- post-stabilisation (engines.py:80-116; world.py:109-117)
 // The frictionless LCP of PdipmEngine.post_stabilization - Q = M, p = 0, G = Jc, h = gc = Jc v + Jc v * -restitutions, A = Je,

@@ -163,6 +163,22 @@ int quad_step(const StepArgs& SP, int compute, void* stream, int body_space, int
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
+// PdipmEngine.post_stabilization (engines.py:80-116) on the four-scenes-per-wavefront mapping (round 5): nz <= 16, <= 16 contacts, <= 4 joint
+// rows, fp64 arithmetic.  The pinned body-space kernel first (equality rows [I 0] with Je v = 0: the fixed floor of the reference's worlds),
+// the general body-space kernel behind it for the waves that one marked.  The best iterate is left in lcp_poststab_primal_kernel's
+// workspace layout: lcp_post_stabilization_backward_f32 (one wave per scene) serves both forwards.
+bool quad_post_supported(int nz, int m, int e) { return nz <= 16 && (m % 4) == 0 && m / 4 <= 16 && e <= q16::EQ; }
+int quad_post_stab(const StepArgs& SP, void* stream) {
+  FwdArgs P = {};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((SP.B + 3) / 4), blk(64);
+  const int lb = (int)q16_lds<double>(LCP_Q_LDSW != 0, 1, false);
+  const size_t lbytes = 4 * lb + 20 * 64 * sizeof(double);                   // (+ the parked best iterate and affine direction)
+  hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 2, 0, 0, 0, false, true>), grid, blk, lbytes, st, P, SP, lb, 2);
+  hipLaunchKernelGGL((q16::lcp_fwd_quad<float, double, true, 1, 1, 0, 0, 0, false, true>), grid, blk, 4 * lb, st, P, SP, lb, 3);   // whatever that one left
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64, int body, bool pinned) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
