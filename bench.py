@@ -94,6 +94,7 @@ def parse(argv=None):
                     help="seconds of untimed launches while the workload is built, before the W warm-up steps: the first ~0.2 s of "
                          "launches on a fresh process run at ramping clocks, which a 2 ms timed region (--steps 20) would otherwise measure")
     ap.add_argument("--event-samples", type=int, default=128, help="eager launches bracketed by HIP events for roofline.kernel_ms")
+    ap.add_argument("--event-group", type=int, default=8, help="launches of one kind between two event records (1: every launch bracketed by itself)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline")
@@ -217,8 +218,9 @@ def run_rank(args, make_work, device=None):
         # `fwd_ms` / `bwd_ms` are therefore slightly conservative, never optimistic
         roof["kernel_ms_sum"] = float(roof["fwd_ms"]) + float(roof.get("bwd_ms") or 0.0)
         roof["kernel_ms_sum_over_step_ms"] = roof["kernel_ms_sum"] / (wall / args.steps * 1e3)
-        roof["kernel_ms_note"] = ("fwd_ms + bwd_ms (HIP events around single launches, after the timed region) vs ms_per_step (wall clock over K "
-                                  "un-instrumented steps): the event records cost the stream 1-2 us per step, so achieved / frac are conservative")
+        roof["kernel_ms_note"] = ("fwd_ms + bwd_ms (HIP events around groups of launches, after the timed region) vs ms_per_step (wall clock over K "
+                                  "un-instrumented steps of forward + backward): what is left above 1 is the event records' share and the "
+                                  "difference between back-to-back launches of one kernel and the alternating pair; achieved / frac are conservative")
     mine = torch.tensor([[float(rank), float(dev_index), own_wall / args.steps * 1e3, float(roof.get("fwd_ms") or 0.0),
                           float(roof.get("bwd_ms") or 0.0)]], dtype=torch.float64, device=rdev)
     allr = shard.gather_scenes(mine, world, device=rdev) if world > 1 else mine
@@ -435,19 +437,24 @@ class HipWorkload:
             self.eager_step()
 
     def sample_kernels(self, n):
-        """HIP events on the launch stream around `n` eager forward / backward launches (the first one is dropped: the queue is
-        empty when it arrives, and the gap between its event record and the launch would be booked as kernel time)."""
-        n = max(2, n)
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        """HIP events on the launch stream around eager launches, `n` of each kind: G forwards back to back between two events, then G
+        backwards between two events (G = --event-group, default 8) - an event record costs the stream 1-2 us, which bracketing every
+        single launch (rounds 1-4) booked as kernel time: 6-8 % of a 50 us kernel (`kernel_ms_sum_over_step_ms` was 1.06-1.08).  The first
+        group is dropped: the queue is empty when it arrives."""
+        g = max(1, int(self.args.event_group))
+        groups = max(2, (max(2, n) + g - 1) // g + 1)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(groups)]
         torch.cuda.synchronize()
         for ev in evs:
             ev[0].record()
-            self.forward()
+            for _ in range(g):
+                self.forward()
             ev[1].record()
-            self.backward()
+            for _ in range(g):
+                self.backward()
             ev[2].record()
         torch.cuda.synchronize()
-        return [(ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])) for ev in evs[1:]]
+        return [(ev[0].elapsed_time(ev[1]) / g, ev[1].elapsed_time(ev[2]) / g) for ev in evs[1:]]
 
     def _time(self, fn, sync):
         a = self.args
@@ -631,8 +638,9 @@ class HipWorkload:
                 "note_algorithmic": "SURVEY 8d counts the reference's dense formulation (LU of nineq = %d rows per iteration); the kernel "
                                     "factors %d rows: a fraction above 1 is the algorithmic saving, not an efficiency"
                                     % (m, (nz - e) if (body_space or primal) else 2 * nc),
-                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "event_timed_steps": len(samples),
-                "event_timing": "HIP events on the launch stream around eager launches right after the timed region"}
+                "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "event_timed_steps": len(samples) * max(1, int(a.event_group)),
+                "event_timing": "HIP events on the launch stream around groups of %d eager launches of one kind, right after the timed region"
+                                % max(1, int(a.event_group))}
         if dense_pile:
             # 302 KB of dense tensors in per scene against ~0.6 MFLOP executed: the forward CALL (classification included) is priced
             # against HBM - algorithmic bytes (bytes_in + bytes_out of the dense boundary) over the event-timed call

@@ -365,6 +365,65 @@ def test_post_stabilization_body_space_matches_the_generic_kernel_and_the_oracle
         assert e <= 2e-3, (k, n, e)                           # (the bound of the trajectory test: this LCP is ill-conditioned at rest)
 
 
+@pytest.mark.parametrize("nbox,pts,rows", [(4, 4, "pinned"), (2, 4, "pinned"), (4, 2, "moving_floor"), (3, 4, "scaled")])
+def test_post_stabilization_four_scenes_per_wave_matches_one_wave_per_scene(nbox, pts, rows):
+    """Round 5: at nz <= 16, <= 16 contacts `lcp_post_stabilization_f32` runs `lcp_fwd_quad<..., POST>` (four scenes per wavefront; the
+    pinned body-space kernel, the general one behind it) where it ran `lcp_poststab_primal_kernel` (one wavefront per scene:
+    LCP_PATH_PRIMAL keeps it).  Same LCP (engines.py:80-116), same correction move, and the SAME workspace layout: the one backward kernel
+    (`lcp_post_stabilization_backward_f32`) follows either forward.  `moving_floor`: the pinned body has a velocity, so b = Je v is not zero
+    and no wave qualifies for the pinned kernel; `scaled`: A = 2 [I 0] - not rows that pin."""
+    from lcp_physics_amd import _lib, scenes
+    from lcp_physics_amd.physics.batched_world import post_stabilization, post_stabilization_backward
+    from lcp_physics_amd.physics.contacts import ContactBuffers
+    B = 203                                                   # (a last wavefront with three live scenes)
+    sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=500 + nbox + pts, dtype=torch.float32)
+    sc.v = sc.v + 0.3 * torch.randn(sc.v.shape, generator=torch.Generator().manual_seed(1))
+    if rows == "moving_floor":
+        sc.v[:, 0] = 0.05 * torch.randn(B, 3, generator=torch.Generator().manual_seed(5))
+    elif rows == "scaled":
+        sc.Je = sc.Je * 2.0
+    else:
+        sc.v[:, 0] = 0.0
+    scg = sc.to(device=DEV)
+    cb = ContactBuffers(B, sc.nb, sc.nc, DEV)
+    cb.c_n, cb.c_p1, cb.c_p2, cb.c_i1, cb.c_i2 = scg.c_n, scg.c_p1, scg.c_p2, scg.c_i1, scg.c_i2
+    count = torch.randint(0, sc.nc + 1, (B,), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    count[:64] = sc.nc
+    p = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(DEV)
+    dts = (0.01 + 0.02 * torch.rand(B, generator=torch.Generator().manual_seed(4), dtype=torch.float64)).to(DEV)
+    cot = torch.randn(B, sc.nb, 3, generator=torch.Generator().manual_seed(6), dtype=torch.float32).to(DEV)
+    res = {}
+    for path in ("auto", "primal"):
+        _lib.set_path(path)
+        try:
+            po = torch.empty_like(p)
+            out = post_stabilization(B, sc.nb, sc.nc, 3, count.to(DEV), scg.Mdiag, scg.v, scg.rest, cb, scg.Je, p=p, dt_scene=dts, p_out=po)
+            g = post_stabilization_backward(B, sc.nb, sc.nc, 3, scg.Mdiag, scg.v, scg.rest, cb, scg.Je, cot, out, want_Je=True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_path("auto")
+        res[path] = (out["dp"].double().cpu(), po.cpu(), out["iters"].cpu(), out["status"].cpu(), {k: v.double().cpu() for k, v in g.items()})
+    a, b = res["auto"], res["primal"]
+    scale = b[0].abs().reshape(B, -1).max(dim=1)[0].clamp_min(1.0)
+    err = (a[0] - b[0]).abs().reshape(B, -1).max(dim=1)[0] / scale
+    assert float(err.max()) <= 1e-6, float(err.max())
+    assert float((a[1] - b[1]).abs().max()) <= 1e-7                       # the moved poses (fp64)
+    assert int(((a[3] | b[3]) & 8).sum()) == 0                            # no NaN status either way
+    # (solves of a few contacts converge to rounding inside the ten iterations, the exit tests of pdipm.py:133 then compare rounding noise:
+    #  the two eliminations can leave such a solve a few passes apart - dp above is unaffected)
+    assert int((a[2] - b[2]).abs().max()) <= 4
+    # the backward read either forward's workspace: gradients agree where the two forwards kept the same iterate
+    same = (a[2] == b[2])
+    assert int(same.sum()) >= int(0.6 * B)
+    for k in ("Mdiag", "v", "rest", "Je"):
+        if k not in a[4]:
+            continue
+        ga, gb = a[4][k].reshape(B, -1)[same], b[4][k].reshape(B, -1)[same]
+        den = gb.abs().max(dim=1)[0].clamp_min(1e-6 * float(gb.abs().max()))
+        assert bool(torch.isfinite(ga).all()), k
+        assert float(((ga - gb).abs().max(dim=1)[0] / den).max()) <= 1e-3, (k, float(((ga - gb).abs().max(dim=1)[0] / den).max()))
+
+
 def _with_joint_rows(sc, e_target):
     """Stack scenes with more joints: next to the TotalConstraint on the floor (3 rows) the top box is welded to the world (3),
     then X / Rot / Y constraints on the boxes in between, until `e_target` rows (constraints.py:95-217: rows of the identity) -
