@@ -37,18 +37,19 @@ def main():
     pick = lambda sub: next((dict(v, kernel=k) for k, v in nice.items() if sub in k), None)
     out = {
         # the keys bench.py quotes in its roofline object
-        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 2, 15, 3, 16, true>"),   # the headline (<= 4096 scenes): sizes at compile time, Jc / Jt columns in registers
-        "lcp_fwd_quad_f64_fused_two_waves": pick("lcp_fwd_quad<float, double, true, 1, 2, 15, 3, 16, false>"),   # > 4096 scenes: the lean form, two waves per SIMD
-        "lcp_fwd_quad_f64_fused_runtime_sizes": pick("lcp_fwd_quad<float, double, true, 1, 2, 0, 0, 0, false>"),
+        "lcp_fwd_quad_f64_fused": pick("lcp_fwd_quad<float, double, true, 1, 2, 15, 3, 16, true, false>"),   # the headline (<= 4096 scenes): sizes at compile time, Jc / Jt columns in registers
+        "lcp_fwd_quad_f64_fused_two_waves": pick("lcp_fwd_quad<float, double, true, 1, 2, 15, 3, 16, false, false>"),   # > 4096 scenes: the lean form, two waves per SIMD
+        "lcp_fwd_quad_f64_fused_runtime_sizes": pick("lcp_fwd_quad<float, double, true, 1, 2, 0, 0, 0, false, false>"),
+        "lcp_fwd_quad_f64_post_stab": pick("lcp_fwd_quad<float, double, true, 1, 2, 0, 0, 0, false, true>"),   # post-stabilisation on the four-scenes mapping (round 5)
         "lcp_bwd_quad_f64_body": pick("lcp_bwd_quad<float, double, true, 15, 3, true>"),
         "lcp_bwd_step_quad_f64_body": pick("lcp_bwd_step_quad<float, double, 1, true, 15, 3, true>"),
         "lcp_fwd_solo_9_3_8": pick("lcp_fwd_solo<9, 3, 8>"),
-        "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1, 0, 0, 0, false>"),
-        "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0, 0, 0, 0, false>"),
-        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 2, 15, 3, 16, true>"),   # the dense boundary, body space (round 4): the same kernel reading rows of G
-        "lcp_fwd_quad_f64_dense_contact_space": pick("lcp_fwd_quad<float, double, false, 1, 0, 0, 0, 0, false>"),   # LCP_PATH_CONTACT_SPACE
-        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0, 0, 0, 0, false>"),
-        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0, 0, 0, 0, false>"),
+        "lcp_fwd_quad_f64_fused_general_equality_rows": pick("lcp_fwd_quad<float, double, true, 1, 1, 0, 0, 0, false, false>"),
+        "lcp_fwd_quad_f64_fused_contact_space": pick("lcp_fwd_quad<float, double, true, 1, 0, 0, 0, 0, false, false>"),
+        "lcp_fwd_quad_f64_dense": pick("lcp_fwd_quad<float, double, false, 1, 2, 15, 3, 16, true, false>"),   # the dense boundary, body space (round 4): the same kernel reading rows of G
+        "lcp_fwd_quad_f64_dense_contact_space": pick("lcp_fwd_quad<float, double, false, 1, 0, 0, 0, 0, false, false>"),   # LCP_PATH_CONTACT_SPACE
+        "lcp_fwd_quad_f32_fused": pick("lcp_fwd_quad<float, float, true, 1, 0, 0, 0, 0, false, false>"),
+        "lcp_fwd_quad_f32_dense": pick("lcp_fwd_quad<float, float, false, 1, 0, 0, 0, 0, false, false>"),
         "lcp_big_kernel_64_fwd": pick("lcp_big_kernel<64, false, false>"),
         "lcp_primal_kernel_30_pinned_fwd": pick("lcp_primal_kernel<30, false, false, 4, 3>"),   # BASELINE config 5 under LCP_HINT_PINNED
         "lcp_primal_kernel_32_pinned_bwd": pick("lcp_primal_kernel<32, true, false, 4, 3>"),

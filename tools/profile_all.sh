@@ -2,7 +2,7 @@
 # Collect the round's profiles on the GPU box: kernel trace + stats, then PMC counters in separate passes
 # (never combined with tracing domains).  Outputs land in gpurun_out/prof_<tag>/ ; summaries are made by
 # tools/rocprof_summary.py and tools/pmc_summary.py and copied into profiles/ by hand.
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

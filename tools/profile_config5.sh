@@ -2,7 +2,7 @@
 # BASELINE config 5 (4096 scenes x 64 contacts) on the GPU box: rocprofv3 kernel trace + stats, PMC counters in their own
 # passes (never combined with tracing domains), and - when tools/liblcp_primalprof.so exists - the in-kernel phase profile.
 # Summaries land in gpurun_out/prof_<tag>_config5.*; copy them into profiles/ by hand.
-TAG=${1:-r02}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
