@@ -686,7 +686,7 @@ class HipWorkload:
                 roof["bwd"] = {"bound": "hbm",
                                "kernel": ("lcp_big_kernel<64, true, DENSE> / lcp_primal_kernel<..., BWD, DENSE> (lcp.py:37-64 at nineq 256: the seven dense "
                                           "gradients, 302 KB per scene)") if dense_pile else
-                                         "lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 2 KKT solves, the seven dense gradients)"
+                                         "lcp_bwd_quad<float,double,%s> (lcp.py:37-64: one factorisation, 1 + 1 KKT solves, the seven dense gradients)"
                                          % ("true" if body_space else "false"),
                                "achieved": used / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": used / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -694,14 +694,14 @@ class HipWorkload:
                                "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
                                "executed_flops_per_launch": flops.flops_backward_executed_body_space(nz, nc, e) * B if (body_space or dense_pile) else None}
             else:
-                # the physical backward moves ~1 KB per scene: it is bound by its one factorisation + 1 + 2 KKT solves (fp64 VALU)
+                # the physical backward moves ~1 KB per scene: it is bound by its one factorisation + 1 + 1 KKT solves (fp64 VALU)
                 bfl = (flops.flops_forward_executed_primal(nz, nc, e, 0, True) + 2 * (nc * 102 + 2 * (nz - e) ** 2) if primal
                        else flops.flops_backward_executed_body_space(nz, nc, e) - (2 * nz * nz + 3 * m * nz + m * m + 3 * e * nz)) * B
                 roof["bwd"] = {"bound": "valu_fp64",
                                "kernel": ("lcp_primal_kernel<30, true, ...> behind lcp_step_backward_f32" if primal else "lcp_bwd_step_quad")
                                          + " (lcp.py:37-64 contracted through the assembly: gradients w.r.t. the physical inputs)",
                                "achieved": tf(bfl, bwd_ms), "peak": peak, "unit": "TFLOP/s", "frac": tf(bfl, bwd_ms) / peak,
-                               "flops": "executed (one formation + LU at the best iterate, 1 + 2 KKT solves)",
+                               "flops": "executed (one formation + LU at the best iterate, 1 + 1 KKT solves)",
                                "traffic": btraffic, "algorithmic_bytes_per_launch": balg, "kernel_ms": bwd_ms,
                                "executed_flops_per_launch": bfl}
             if btj:

@@ -70,8 +70,8 @@ def flops_forward_executed_primal(nz, nc, e, it, pinned=True):
     return Fk + S + it * I
 
 
-def flops_backward_executed_body_space(nz, nc, e, refine=2, pinned=True):
-    """The body-space backward solve (lcp_quad.hip bwd_solve_body): one formation + LU, 1 + `refine` KKT solves and the residual
+def flops_backward_executed_body_space(nz, nc, e, refine=1, pinned=True):
+    """The body-space backward solve (lcp_quad.hip bwd_solve_body): one formation + LU, 1 + `refine` KKT solves (LCP_Q_BWD_REFINE = 1 since round 5; the one-wave-per-scene kernels always took one) and the residual
     products of the refinement steps; the outer products of lcp.py:52-61 are counted with the dense gradient sizes."""
     n = (nz - e) if pinned else (nz + e)
     m = 4 * nc

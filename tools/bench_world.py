@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--box", type=float, default=40.0)
     ap.add_argument("--graph", action="store_true", help="time ContactWorld.run(steps, graph=True): HIP graph replay")
     ap.add_argument("--post-stab", action="store_true", help="with post-stabilisation (world.py:109-121; off by default as in the reference)")
+    ap.add_argument("--no-strict", action="store_true", help="World(strict_no_pen=False): the retry loop of world.py:88-101 stops at dt / 4")
     args = ap.parse_args()
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics import batched_world as bw
@@ -32,7 +33,8 @@ def main():
     w = scenes.make_drop_world(args.batch, nbox=args.nbox, box=args.box)
     geom = ct.GeometryBatch.from_shapes(w["shapes"], args.batch).to(dev)
     g = lambda k: w[k].to(dev)
-    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc, post_stab=args.post_stab)
+    world = bw.ContactWorld(geom, g("p"), g("v"), g("Mdiag"), g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc, post_stab=args.post_stab,
+                            strict_no_penetration=not args.no_strict)
     for _ in range(args.settle):
         world.step()
     world.check_capacity()
@@ -75,7 +77,8 @@ def main():
     solve_ms = None if args.graph else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     move_ms = None if args.graph else sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     out = {"metric": "sim steps/s with contact detection (ContactWorld.step)", "value": args.batch * args.steps / wall,
-           "unit": "sim steps/s", "batch": args.batch, "steps": args.steps, "hip_graph": bool(args.graph), "ms_per_step": wall / args.steps * 1e3,
+           "unit": "sim steps/s", "batch": args.batch, "steps": args.steps, "hip_graph": bool(args.graph), "post_stab": bool(args.post_stab),
+           "strict_no_penetration": not args.no_strict, "ms_per_step": wall / args.steps * 1e3,
            "solve_dynamics_ms": solve_ms, "move_find_contacts_ms": move_ms,
            "mean_contacts_start": float(counts0.mean()), "mean_contacts_end": float(world.contacts.count.float().mean()),
            "max_contacts": int(world.contacts.count.max()), "mean_trials_last_step": float(world.contacts.trials.float().mean()),

@@ -18,9 +18,11 @@ PY
 [ -n "$ONLY_PLUGIN" ] && exit 0                  # (the world comparison alone; the reference timings below take a few minutes)
 M="GPU box host ($(nproc) cores, same box as the bench)"
 # thread sweep of the unmodified reference on the headline workload: the best thread count is what bench.py quotes
+if [ -z "$SKIP_SWEEP" ]; then                    # (SKIP_SWEEP=1: keep the committed sweep, refresh the world comparison and the in-run line only)
 timeout 900 python oracle/time_reference.py --batch 1024 --dtype float64 --reps 1 --threads 1,4,8,16,32,64,128 --machine "$M" > $O/${TAG}_reference_cpu_timing_f64_sweep.jsonl 2>/dev/null; cut -c1-20,180-330 $O/${TAG}_reference_cpu_timing_f64_sweep.jsonl
 timeout 600 python oracle/time_reference.py --batch 1024 --dtype float32 --reps 1 --threads 8,16 --machine "$M" > $O/${TAG}_reference_cpu_timing_f32_sweep.jsonl 2>/dev/null; cut -c1-20,180-330 $O/${TAG}_reference_cpu_timing_f32_sweep.jsonl
 timeout 600 python oracle/time_reference.py --batch 128 --dtype float64 --reps 1 --pile --machine "$M" > $O/${TAG}_reference_cpu_timing_pile.jsonl 2>/dev/null; cut -c1-20,180-330 $O/${TAG}_reference_cpu_timing_pile.jsonl
+fi
 # the bench line WITH the reference timed inside the run (cpu_reference.measured_in_this_run = true)
 timeout 600 python bench.py > $O/${TAG}_bench_fused_with_reference.json 2> $O/${TAG}_bench_fused_with_reference.err; python -c "
 import json; j = json.loads(open('$O/${TAG}_bench_fused_with_reference.json').read().strip().splitlines()[-1]); print(j['value'], j['cpu_reference'])"
