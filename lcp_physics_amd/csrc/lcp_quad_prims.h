@@ -81,6 +81,8 @@ template <> __device__ __forceinline__ bool key_is_nan<float>(uint32_t k) { retu
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fabs_(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float fabs_(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ uint32_t row_umax(uint32_t k) {

@@ -176,6 +176,39 @@ def err_physical(pg, pg_ref, phys, floor, keys=None):
     return num.sqrt() / torch.maximum(den.sqrt(), floor).clamp_min(1e-300)
 
 
+def own_iterate_backward(oracle, lcp64, ref, cot, x, z, s, grads, fl, wobble=1e-7, moved_tol=1e-5, seed=11):
+    """The kernel's backward against the ORACLE'S BACKWARD EVALUATED AT THE KERNEL'S OWN ITERATE - the same linear system (lcp.py:44-50), two
+    solvers - on every scene where that system determines its solution.  Round 5 (a gate that does not depend on which
+    iterate either side kept, and does not select on the outcome): the conditioning test uses the oracle alone - the system at (z, s) is
+    well posed by the oracle's own residual (`backward_well_posed`) and its dl/dp, dQ, db move by less than `moved_tol` when (z, s) are
+    moved by a relative `wobble`.  A residual alone cannot see a solve that divided by rounding noise (multipliers of 1e15 satisfy the
+    system to 1e-16 of their own size: tools/experiments/fp64_io_backward_diag.py).  Compared: dl/dp, dQ, db (dA needs the kernel's nu,
+    which the metric's entry points do not return).  Fields: bwd_own_iterate_determined_scenes, bwd_own_iterate_err_max / _median."""
+    import copy
+    Q, p, G, h, A, b, F = lcp64
+
+    def at_iterate(zz, ss):
+        at = copy.copy(ref)
+        at.x, at.z, at.s = x, zz, ss                      # (y: the oracle's - only dA reads it)
+        g = oracle.lcp_backward(at, *lcp64, cot)
+        return g, backward_well_posed(Q, G, A, F, at, cot, g)
+
+    keys = [k for k in ("p", "Q", "b") if grads.get(k) is not None]
+    g1, ok1 = at_iterate(z, s)
+    gen = torch.Generator().manual_seed(seed)
+    wob = lambda t: t * (1 + wobble * torch.randn(t.shape, generator=gen, dtype=torch.float64))
+    g2, ok2 = at_iterate(wob(z), wob(s))
+    moved = err_grads({k: g2["d" + k] for k in keys}, {k: g1["d" + k] for k in keys}, fl)
+    det = ok1 & ok2 & (torch.stack(list(moved.values())).max(dim=0)[0] < moved_tol)
+    errs = err_grads({k: grads[k].double() for k in keys}, {k: g1["d" + k] for k in keys}, fl)
+    worst = torch.stack(list(errs.values())).max(dim=0)[0]
+    out = {"bwd_own_iterate_determined_scenes": int(det.sum()), "bwd_own_iterate_compared": "d" + ", d".join(keys)}
+    if bool(det.any()):
+        out["bwd_own_iterate_err_max"] = float(worst[det].max())
+        out["bwd_own_iterate_err_median"] = float(worst[det].median())
+    return out
+
+
 # ----------------------------------------------------------------------------
 # one report for "the kernel the metric times against the oracle" (tests/test_hip_headline_parity.py and
 # bench.py's `parity` object print the same fields)
@@ -272,6 +305,8 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
             out["bwd_kkt_resid_all_median"] = float(worst.median())
         ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
+        if grads is not None:
+            out.update(own_iterate_backward(oracle, lcp64, ref, c64, x.double(), z, s, grads, fl))
         if input_stability:
             ph64 = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
             if "ref_o" not in cache:
