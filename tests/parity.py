@@ -305,8 +305,8 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
             out["bwd_kkt_resid_all_median"] = float(worst.median())
         ok = backward_well_posed(Q, G, A, F, ref, c64, gref)
         fl = grad_floors(Q, p, c64, ref.x, ref.z, ref.y)
-        if grads is not None:
-            out.update(own_iterate_backward(oracle, lcp64, ref, c64, x.double(), z, s, grads, fl))
+        # (with the physical gradients alone - lcp_step_backward_f32 - dl/dp = d(loss)/df / dt is what there is to compare)
+        out.update(own_iterate_backward(oracle, lcp64, ref, c64, x.double(), z, s, grads if grads is not None else {"p": dp.double()}, fl))
         if input_stability:
             ph64 = {k: (v.double() if (v is not None and v.is_floating_point()) else v) for k, v in phys.items()}
             if "ref_o" not in cache:

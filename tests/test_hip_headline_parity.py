@@ -157,10 +157,11 @@ def check_gates(rep, gates, dense_grads, sample):
     assert rep["bwd_nonfinite_scenes"] == 0, rep
     if dense_grads:
         assert rep["bwd_kkt_resid_all_max"] <= gates["kkt_max"], rep
-        # ... and against the ORACLE'S backward evaluated at the KERNEL'S iterate (the same system, two solvers), on every scene where the
-        # oracle alone says that system determines its solution - a gate that does not depend on which iterate either side kept
-        assert rep["bwd_own_iterate_determined_scenes"] >= gates["well_posed_min"] * rep["scenes"], rep
-        assert rep["bwd_own_iterate_err_max"] <= 1e-4, rep           # (the tolerance of every other backward gate: the kernel hands over fp32 z, s - 6e-8 relative - and one scene of configs[3] shard 4 amplifies that 400 x)
+    # ... and against the ORACLE'S backward evaluated at the KERNEL'S iterate (the same system, two solvers), on every scene where the
+    # oracle alone says that system determines its solution - a gate that does not depend on which iterate either side kept
+    # (dl/dp, dQ, db of the dense gradients; dl/dp = d(loss)/df / dt where the kernel returns the physical ones: the piles)
+    assert rep["bwd_own_iterate_determined_scenes"] >= gates["well_posed_min"] * rep["scenes"], rep
+    assert rep["bwd_own_iterate_err_max"] <= 1e-4, rep               # (the tolerance of every other backward gate: the kernel hands over fp32 z, s - 6e-8 relative - and one scene of configs[3] shard 4 amplifies that 400 x)
     assert rep["bwd_well_posed_frac"] >= gates["well_posed_min"], rep
     # (`bwd_input_sensitive_scenes`: scenes whose ORACLE dl/dp moves by more than the tolerance under fp32 rounding of its own inputs - about
     #  3 % of a stack batch, among them the one scene of configs[3] where the kernel is 1e-3 from the oracle and the oracle 1e-3 from itself;
