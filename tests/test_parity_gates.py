@@ -1,0 +1,72 @@
+"""CPU: the comparison helpers of tests/parity.py checked on the oracle itself - a gate that cannot fail is no gate.
+
+`own_iterate_backward` (round 5): the kernel's backward against the oracle's backward evaluated at the kernel's own iterate.  Fed with the
+oracle's own gradients it must report zero error on the scenes it calls determined; fed with a gradient that solves the system only up to
+a null-space blow-up (what the contact-space kernel returned on one converged scene before round 5: multipliers of 1e15, dx off by per
+cent, residual 1e-16 of their size) it must report the error although `kkt_backward_residual` - the gate round 5 started with - does not."""
+import copy
+
+import torch
+
+from lcp_physics_amd import scenes
+from oracle import pdipm_oracle as O
+from tests import parity
+
+
+def _case(B=24, seed=4242):
+    sc = scenes.make_stack_scenes(B=B, nbox=4, pts_per_interface=4, seed=seed, dtype=torch.float64)
+    lcp = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    ref = O.lcp_forward(*lcp)
+    cot = torch.randn(B, lcp[0].shape[1], generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    g = O.lcp_backward(ref, *lcp, cot)
+    fl = parity.grad_floors(lcp[0], lcp[1], cot, ref.x, ref.z, ref.y)
+    return lcp, ref, cot, g, fl
+
+
+def test_own_iterate_gate_is_silent_on_the_oracle_itself():
+    lcp, ref, cot, g, fl = _case()
+    rep = parity.own_iterate_backward(O, lcp, ref, cot, ref.x, ref.z, ref.s, {k: g["d" + k] for k in "pQb"}, fl)
+    assert rep["bwd_own_iterate_determined_scenes"] >= 16, rep
+    assert rep["bwd_own_iterate_err_max"] <= 1e-12, rep
+
+
+def test_own_iterate_gate_sees_what_the_residual_gate_cannot():
+    lcp, ref, cot, g, fl = _case()
+    Q, p, G, h, A, b, F = lcp
+    B, m, nz = G.shape
+    nc = m // 4
+    # a direction the converged system does not see: on a STICKING contact (cone row inactive: z_g << s_g; both friction multipliers
+    # active: s_f << z_f) dlam_f1 = dlam_f2 = t leaves G^T dlam alone (world.py:191-192: rows +jt, -jt), the cone row takes it with
+    # dlam_g = 2 t z_g / s_g, and the friction rows see (s_f / z_f) t - nothing, relative to t.  A huge t hides a wrong dx behind
+    # the block norms of the residual.
+    z, s_ = ref.z, ref.s
+    c = torch.arange(nc)
+    f1, f2, gm = nc + 2 * c, nc + 2 * c + 1, 3 * nc + c
+    stick = (z[:, gm] / s_[:, gm] < 1e-8) & (s_[:, f1] / z[:, f1] < 1e-8) & (s_[:, f2] / z[:, f2] < 1e-8)
+    has = stick.any(dim=1)
+    assert int(has.sum()) >= 8, int(has.sum())
+    t = 1e12 * stick.double()
+    bad = {k: g["d" + k].clone() for k in "pQb"}
+    dlam = -g["dh"].clone()
+    dlam[:, f1] += t
+    dlam[:, f2] += t
+    dlam[:, gm] += 2 * t * z[:, gm] / s_[:, gm]
+    free = torch.ones(nz, dtype=torch.float64)
+    free[:3] = 0                                                                  # (A = [I 0] pins the floor: A dx = 0 stays true)
+    bad["p"] = bad["p"] + has.double().unsqueeze(1) * 0.05 * parity._n(g["dp"]).unsqueeze(1) * free / nz ** 0.5
+    res = parity.kkt_backward_residual(Q, G, A, F, ref.z, ref.s, cot, bad["p"], dlam, -g["db"])
+    assert float(torch.stack(list(res.values()))[:, has].max()) < 1e-6           # the residual gate passes it ...
+    rep = parity.own_iterate_backward(O, lcp, ref, cot, ref.x, ref.z, ref.s, bad, fl)
+    assert rep["bwd_own_iterate_err_max"] > 1e-3, rep                            # ... the own-iterate gate does not
+
+
+def test_own_iterate_gate_does_not_count_a_scene_the_oracle_cannot_determine():
+    lcp, ref, cot, g, fl = _case()
+    # make one scene's system singular to working precision: a contact pair with z_i ~ s_i ~ 1e-17 (what an over-converged solve leaves)
+    at = copy.copy(ref)
+    at.z, at.s = ref.z.clone(), ref.s.clone()
+    at.z[0, :4], at.s[0, :4] = 1e-17, 1e-17
+    full = parity.own_iterate_backward(O, lcp, ref, cot, ref.x, ref.z, ref.s, {k: g["d" + k] for k in "pQb"}, fl)
+    g_at = O.lcp_backward(at, *lcp, cot)
+    rep = parity.own_iterate_backward(O, lcp, ref, cot, ref.x, at.z, at.s, {k: g_at["d" + k] for k in "pQb"}, fl)
+    assert rep["bwd_own_iterate_determined_scenes"] <= full["bwd_own_iterate_determined_scenes"], (rep, full)
