@@ -228,9 +228,10 @@ __device__ int prefactor(Scene<TC>& S, const FT& F) {
 }
 
 // factor_kkt (pdipm.py:414-454): T = R + diag(1/d) = R + diag(s/z); LU in place.
-// Returns true when an exact zero pivot was met (the reference's `except` path, :99-102).
+// Returns non-zero when an exact zero pivot was met (bit 0: the reference's `except` path, :99-102) or - backward only, `tiny` > 0 - a
+// pivot below `tiny` (bit 1: what is left of it is rounding noise; see lcp_bwd_kernel).
 template <typename TC, bool PIVOT>
-__device__ bool factor_T(Scene<TC>& S, const TC* dinv) {
+__device__ int factor_T(Scene<TC>& S, const TC* dinv, TC tiny = (TC)0) {
   const int m = S.m, ld = S.ldT, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   for (int idx = tid; idx < m * m; idx += NT) {
@@ -270,7 +271,8 @@ __device__ bool factor_T(Scene<TC>& S, const TC* dinv) {
       __syncthreads();
     }
     const TC piv = S.T[(size_t)k * ld + k];
-    if (piv == (TC)0 && tid == 0) *S.flag = 1;
+    if (piv == (TC)0 && tid == 0) *S.flag |= 1;
+    if (tiny > (TC)0 && !((piv < 0 ? -piv : piv) >= tiny) && tid == 0) *S.flag |= 2;
     const TC pinv = (TC)1 / piv;
     for (int i = k + 1 + w; i < m; i += NW) {
       const TC lik = S.T[(size_t)i * ld + k] * pinv;
@@ -279,7 +281,7 @@ __device__ bool factor_T(Scene<TC>& S, const TC* dinv) {
     }
     __syncthreads();
   }
-  return *S.flag != 0;
+  return *S.flag;
 }
 
 // In-place solve T w = rhs with the LU above; rhs / result in S.hz.
@@ -798,8 +800,28 @@ __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
     const TC dd = zz / ss;                                                 // lcp.py:44
     S.d[i] = dd; S.rs[i] = (TC)1 / dd;
   }
+  // (round 5) A solve that converged to rounding leaves s / z ~ 1e-16 on its active rows, lost against an R that redundant contact
+  // points make singular (two sticking points on one interface have identical tangential rows): the elimination then divides by
+  // rounding noise - pivoting or not - and returns multipliers of 1e15 whose cancellation leaves dx off by O(1) with a residual of
+  // 1e-16 of their size (one scene of 1024 on fp64 two-point stacks: profiles/r05_own_iterate_probe.txt; the reference's own solve has
+  // the same exposure).  A pivot below 1e-13 of R's largest diagonal entry, or an exact zero, repeats the factorisation with s / z
+  // floored at 1e-12 x the row's diagonal of R, as the four-scenes-per-wave contact-space backward does (factor_bwd_q).
+  if (tid == 0) {
+    TC mx = 0;
+    for (int i = 0; i < m; ++i) { TC a = S.R[(size_t)i * m + i]; a = a < 0 ? -a : a; mx = a > mx ? a : mx; }
+    S.cs[0] = mx;                                                          // (cs is written by solve_kkt below; free until then)
+  }
   __syncthreads();
-  factor_T<TC, PIVOT>(S, S.rs);                                           // lcp.py:46
+  const TC rmax = S.cs[0];
+  __syncthreads();
+  if (factor_T<TC, PIVOT>(S, S.rs, (TC)1e-13 * rmax)) {                    // lcp.py:46
+    for (int i = tid; i < m; i += NT) {
+      const TC f = (TC)1e-12 * S.R[(size_t)i * m + i];
+      if (S.rs[i] < f) { S.rs[i] = f; S.d[i] = (TC)1 / f; }
+    }
+    __syncthreads();
+    factor_T<TC, PIVOT>(S, S.rs);
+  }
   solve_kkt<TC, PIVOT>(S, S.rx, (const TC*)nullptr, (const TC*)nullptr, (const TC*)nullptr,
                        S.cx, S.cs, S.cz, S.cy);                           // lcp.py:47-50
   // outer products (lcp.py:52-61); dx = cx, dlam = cz, dnu = cy
