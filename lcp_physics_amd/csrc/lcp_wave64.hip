@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void bwd_wave_body(const BwdArgs& P, int lds_per_wave
   const TC y = (ae < e) ? W.y[ae] : (TC)0;
   TC g = (jx < nz) ? (TC)((const TI*)P.dl_dx)[(size_t)scene * nz + jx] : (TC)0;
   if (P.tag && *P.tag != P.tag_value) g = nan_of<TC>();            // (another family's workspace: NaN gradients instead of a misread)
-  const TC d = vm ? z / s : (TC)1;                                           // lcp.py:44
+  TC d = vm ? z / s : (TC)1;                                                 // lcp.py:44
   TC t[MP];
   int mystep, porder;
   TC udinv;
@@ -1181,7 +1181,30 @@ __device__ __forceinline__ void bwd_wave_body(const BwdArgs& P, int lds_per_wave
   Red<TC> RD;
   RD.init(m >> 2, lane, m);
   if (STRUCT && RD.isu) RD.mu = W.meta[1 + RD.cu];
-  factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, vm ? (TC)1 / d : (TC)1, mystep, porder, udinv);   // lcp.py:46
+  TC dinv = vm ? (TC)1 / d : (TC)1;
+  const bool sing = factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, dinv, mystep, porder, udinv);   // lcp.py:46
+  {
+    // (round 5) At an iterate that converged to rounding s / z ~ 1e-16 is lost against an R that redundant contact points make singular
+    // and the elimination divides by rounding noise: multipliers of 1e15 .. 1e32, a dx that is their cancellation error (measured on
+    // fp64 stacks with a non-diagonal Q: profiles/r05_own_iterate_probe.txt).  A pivot below 1e-13 of the largest diagonal entry of the
+    // (reduced) R, or an exact zero, repeats the factorisation with s / z floored at 1e-12 x the row's own diagonal entry - as
+    // factor_bwd_q (lcp_quad_kernels.inc) and lcp_bwd_kernel (lcp_generic.hip) do.
+    auto rdiag = [&](int i) { const TC v = W.R2[(((size_t)(i >> 1)) * MP + i) * 2 + (i & 1)]; return v < 0 ? -v : v; };
+    const int nrows = STRUCT ? RD.nr : m;
+    TC scale = (lane < nrows) ? rdiag(lane) : (TC)0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const TC o = shfl_xor_t(scale, off); scale = o > scale ? o : scale; }
+    const TC piv = (TC)1 / udinv, apiv = piv < 0 ? -piv : piv;
+    const bool tiny = (lane < nrows) && !(apiv >= (TC)1e-13 * scale);
+    if (__any(tiny || sing)) {
+      const int nc = m >> 2;
+      int idx = lane;                                                        // general scene: system row = m-space row
+      bool fl = vm;
+      if (STRUCT) { if (lane < nc) idx = lane; else if (lane < 3 * nc) idx = nc + ((lane - nc) >> 1); else fl = false; }   // (cone rows: no diagonal in R)
+      if (fl) { const TC f = (TC)1e-12 * rdiag(idx); if (dinv < f) { dinv = f; d = (TC)1 / f; } }
+      factor<TI, TC, PIVOT, STRUCT>(t, O, W, RD, structured, dinv, mystep, porder, udinv);
+    }
+  }
   TC dx, ds, dlam, dnu;
   solve_kkt<TI, TC, PIVOT, STRUCT>(O, t, mystep, porder, udinv, RD, structured, d, g, (TC)0, (TC)0, (TC)0,
                                   dx, ds, dlam, dnu);                                                    // lcp.py:47-50

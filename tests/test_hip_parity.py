@@ -705,19 +705,27 @@ def test_fp64_io_takes_the_fast_kernels_and_agrees_with_the_generic_ones(kernel_
         assert fast < 0.25 * slow, (fast, slow)
 
 
-@pytest.mark.parametrize("nbox,pts,dtype", [(3, 2, torch.float64), (4, 4, torch.float64), (2, 2, torch.float64), (4, 2, torch.float32)])
-def test_backward_on_converged_solves_agrees_with_the_oracle_at_the_kernels_own_iterate(kernel_path, nbox, pts, dtype):
+@pytest.mark.parametrize("nbox,pts,dtype,dense_q", [(3, 2, torch.float64, False), (4, 4, torch.float64, False), (2, 2, torch.float64, False),
+                                                     (4, 2, torch.float32, False), (4, 4, torch.float64, True), (2, 4, torch.float64, True)])
+def test_backward_on_converged_solves_agrees_with_the_oracle_at_the_kernels_own_iterate(kernel_path, nbox, pts, dtype, dense_q):
     """Small stacks converge to rounding inside the ten iterations: `s / z` of the active rows is 1e-13 .. 1e-17 and the backward matrix
     of lcp.py:44-46 is singular to working precision wherever contact points are redundant.  Whatever iterate the kernel kept, its
     backward must agree with the oracle's backward evaluated AT THAT ITERATE (`parity.own_iterate_backward`) on every scene where
     the oracle alone says the system determines its solution - 1024 scenes per shape, every kernel family that serves the size.
-    Before round 5 the contact-space kernels (one scene of 64 at 4 x 4 points, fp64 tensors: dx off by 7 %) and the generic kernels
-    (one of 1024 at 3 x 2 points: off by 2.7) divided by a pivot that was rounding noise (profiles/r05_own_iterate_probe.txt)."""
+    `dense_q`: a non-diagonal SPD Q - contact structure without the diagonal Q the four-scenes-per-wave kernels want: lcp_*_wave_any.
+    Before round 5 the contact-space kernels (one scene of 64 at 4 x 4 points, fp64 tensors: dx off by 7 %), the generic kernels
+    (one of 1024 at 3 x 2 points: off by 2.7) and the wave-per-scene kernels (dense Q, 4 x 4 points: multipliers of 1e32) divided
+    by a pivot that was rounding noise (profiles/r05_own_iterate_probe.txt); each now repeats such a factorisation with s / z floored."""
     from lcp_physics_amd import scenes
     from lcp_physics_amd.lcp import lcp_backward
     B = 1024
     sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=4242, dtype=dtype)
-    lcp = O.assemble_lcp(*sc.assembly_args())
+    lcp = list(O.assemble_lcp(*sc.assembly_args()))
+    if dense_q:
+        Q = lcp[0]
+        E = torch.randn(Q.shape, generator=torch.Generator().manual_seed(5), dtype=Q.dtype) * 0.02
+        dq = torch.diagonal(Q, dim1=1, dim2=2).sqrt()
+        lcp[0] = Q + (E + E.transpose(1, 2)) * dq.unsqueeze(2) * dq.unsqueeze(1)
     lcp64 = [None if t is None else t.double() for t in lcp]
     ref = O.lcp_forward(*lcp64)
     sol = _solve(lcp, dtype)
@@ -727,7 +735,7 @@ def test_backward_on_converged_solves_agrees_with_the_oracle_at_the_kernels_own_
     assert all(bool(torch.isfinite(g).all()) for g in g64.values() if g is not None)
     fl = parity.grad_floors(lcp64[0], lcp64[1], cot, ref.x, ref.z, ref.y)
     rep = parity.own_iterate_backward(O, lcp64, ref, cot, sol.x.double().cpu(), sol.z.double().cpu(), sol.s.double().cpu(), g64, fl)
-    print(kernel_path, nbox, pts, dtype, rep)
+    print(kernel_path, nbox, pts, dtype, dense_q, rep)
     assert rep["bwd_own_iterate_determined_scenes"] >= 0.5 * B, rep      # (642 .. 1010 of 1024: the body-space loop runs a step further into convergence on fp32 data)
     assert rep["bwd_own_iterate_err_max"] <= (1e-7 if dtype == torch.float64 else 1e-5), rep
 

@@ -13,6 +13,13 @@ nbox, pts, B, dtype = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), geta
 dev = torch.device("cuda")
 sc = scenes.make_stack_scenes(B=B, nbox=nbox, pts_per_interface=pts, seed=4242, dtype=dtype)
 lcp = O.assemble_lcp(*sc.assembly_args())
+if os.environ.get("LCP_DIAG_DENSEQ"):        # a non-diagonal SPD Q: contact structure without the diagonal Q the quad kernels want -> lcp_*_wave_any
+    Q = lcp[0]
+    gq = torch.Generator().manual_seed(5)
+    E = torch.randn(Q.shape, generator=gq, dtype=Q.dtype) * 0.02
+    d = torch.diagonal(Q, dim1=1, dim2=2).sqrt()
+    lcp = list(lcp)
+    lcp[0] = Q + (E + E.transpose(1, 2)) * d.unsqueeze(2) * d.unsqueeze(1)
 lcp64 = [None if t is None else t.double() for t in lcp]
 ref = O.lcp_forward(*lcp64)
 cot = torch.randn(B, lcp64[0].shape[1], generator=torch.Generator().manual_seed(3), dtype=torch.float64)
