@@ -378,4 +378,9 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
                     epa = err_physical(pg, pg_ref, ph, floor, keys=PHYS_KEYS)
                     out["bwd_err_phys_all%s_max" % sfx] = float(epa[ok].max())
                     out["bwd_err_phys_all%s_median" % sfx] = float(epa[ok].median())
+                    # the five parameters whose gradients are functions of (dx, dlam_n, dlam_f1 - dlam_f2, dlam_gamma) alone - determined
+                    # also where the SPLIT of a friction pair or between two points of an interface is not (restitution enters h's normal
+                    # rows, friction F's (gamma, n) entries: engines.py:61-74): Mdiag, v, f, rest, fric
+                    ep5 = err_physical(pg, pg_ref, ph, floor, keys=["Mdiag", "v", "f", "rest", "fric"])
+                    out["bwd_err_phys_five%s_max" % sfx] = float(ep5[ok].max())
     return out, ref
