@@ -47,10 +47,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // 1/x by v_rcp + Newton steps (the IEEE division sequence is ~12 dependent instructions and sat on the
 // critical path of every elimination step).  Two steps for fp64 (v_rcp_f64 is ~26 bits), one for fp32.
+#ifndef LCP_FAST_RCP_STEPS
+#define LCP_FAST_RCP_STEPS 2
+#endif
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
+#if LCP_FAST_RCP_STEPS >= 2
   r = fma(fma(-x, r, 1.0), r, r);
+#endif
   return r;
 }
 __device__ __forceinline__ float fast_rcp(float x) {
