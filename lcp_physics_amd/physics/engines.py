@@ -115,18 +115,36 @@ class HipPdipmEngine(Engine):
         self.max_iter = max_iter
         self.compute = compute
         self.last = None                              # z, s, y, iters, status of the latest solve (device tensors)
+        self._buffers = {}                            # (entry, nb, cap, e) -> outputs + workspace of the steps nothing differentiates
 
     def _options(self):
         return {"max_iter": self.max_iter, "eps": 1e-12, "not_improved_lim": 3, "compute": self.compute}
+
+    def _records(self, s):
+        """Does this step have to be a node of an autograd graph ?  Only if something it reads requires a gradient - a plain
+        simulation (`run_world`, utils.py; grad mode is on there, nothing requires grad) launches the kernel directly on buffers the
+        engine keeps: no autograd node, no allocation per step."""
+        return (self.differentiable and torch.is_grad_enabled() and
+                any(t is not None and t.requires_grad for t in (s.Mdiag, s.v, s.f, s.rest, s.fric, s.c_n, s.c_p1, s.c_p2, s.Je)))
 
     def solve_dynamics(self, world, dt):
         base = world.get_v()
         opts = self._options()
         with torch.set_grad_enabled(self.differentiable and torch.is_grad_enabled()):
             s = _Lifted(world)
-            new_v = SolveDynamicsFunction.apply(s.Mdiag, s.v, s.f, s.rest, s.fric, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2,
-                                                s.count, s.Je, float(dt), opts)
-            self.last = opts.get("last")
+            if self._records(s):
+                new_v = SolveDynamicsFunction.apply(s.Mdiag, s.v, s.f, s.rest, s.fric, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2,
+                                                    s.count, s.Je, float(dt), opts)
+                self.last = opts.get("last")
+            else:
+                key = ("dyn", s.nb, s.cap, s.e)
+                old = self._buffers.get(key)
+                with torch.no_grad():
+                    out = batched_world.solve_dynamics(1, s.nb, s.cap, s.e, s.count, s.Mdiag, s.v, s.f, s.rest, s.fric, s, s.Je, float(dt),
+                                                       eps=opts["eps"], not_improved_lim=opts["not_improved_lim"], max_iter=opts["max_iter"],
+                                                       compute=opts["compute"], ws=None if old is None else old["ws"], out=old)
+                self._buffers[key] = self.last = out
+                new_v = out["v_new"]
             return new_v.reshape(-1).to(device=base.device, dtype=base.dtype)
 
     def post_stabilization(self, world):
@@ -134,7 +152,17 @@ class HipPdipmEngine(Engine):
         opts = self._options()
         with torch.set_grad_enabled(self.differentiable and torch.is_grad_enabled()):
             s = _Lifted(world, forces=False)
-            dp = PostStabilizationFunction.apply(s.Mdiag, s.v, s.rest, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2, s.count, s.Je, opts)
+            if self._records(s):
+                dp = PostStabilizationFunction.apply(s.Mdiag, s.v, s.rest, s.c_n, s.c_p1, s.c_p2, s.c_i1, s.c_i2, s.count, s.Je, opts)
+            else:
+                key = ("post", s.nb, s.cap, s.e)
+                old = self._buffers.get(key)
+                with torch.no_grad():
+                    # (the solver's defaults, as PostStabilizationFunction and engines.py:114 `self.lcp_solver()` - not the dynamics solve's settings)
+                    out = batched_world.post_stabilization(1, s.nb, s.cap, s.e, s.count, s.Mdiag, s.v, s.rest, s, s.Je,
+                                                           compute=opts["compute"], ws=None if old is None else old["ws"], out=old)
+                self._buffers[key] = out
+                dp = out["dp"]
             return dp.reshape(-1).to(device=base.device, dtype=base.dtype)
 
 
