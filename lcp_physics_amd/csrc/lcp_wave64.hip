@@ -1295,17 +1295,17 @@ int wave64_forward(const FwdArgs& P, int compute, void* stream, int io_f64, int 
   // classify, then: quad kernel (structured + diagonal Q), wave64 structured kernel, general kernel -
   // every scene is picked up by exactly one of them.
   if (io_f64) {                                  // fp64 I/O (the reference's native dtype): same kernels, fp64 loads / stores
-    const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
+    const int lw = (int)w64_lds<double, double>();
     hipLaunchKernelGGL((w64::lcp_classify_wave<double, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream, 1); if (rc) return rc; }
     LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<double, double>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
   } else if (compute == LCP_COMPUTE_F64) {
-    const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
+    const int lw = (int)w64_lds<double>();
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, double>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream, 0, body_space); if (rc) return rc; }
     LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<float, double>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
   } else {
-    const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
+    const int lw = (int)w64_lds<float>();
     hipLaunchKernelGGL((w64::lcp_classify_wave<float, float>), dim3((P.B + 3) / 4), dim3(256), 0, st, P);
     if (quad) { int rc = quad_forward(P, compute, 2, stream); if (rc) return rc; }
     LCP_W64_LAUNCH((w64::lcp_fwd_wave_any<float, float>), w64_grid(P.B), lw, P, SP, lw, quad);      // (lw >= ls: the general body's LDS)
@@ -1335,13 +1335,13 @@ int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, 
   // (the class-2 scenes of a dense forward that ran in body space left no W: their backward factors in body space too)
   if (quad) { int rc = quad_backward(P, compute, 2, stream, io_f64, quad_dense_is_body_space(io_f64, compute, body_space) ? 1 : 0); if (rc || all_quad) return rc; }     // all_quad: LCP_HINT_ALL_CONTACT
   if (io_f64) {
-    const int lw = (int)w64_lds<double, double>(), ls = (int)w64_lds<double, double>(false);
+    const int lw = (int)w64_lds<double, double>();
     LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<double, double>), w64_grid(P.B), lw, P, lw, quad);
   } else if (compute == LCP_COMPUTE_F64) {
-    const int lw = (int)w64_lds<double>(), ls = (int)w64_lds<double>(false);
+    const int lw = (int)w64_lds<double>();
     LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<float, double>), w64_grid(P.B), lw, P, lw, quad);
   } else {
-    const int lw = (int)w64_lds<float>(), ls = (int)w64_lds<float>(false);
+    const int lw = (int)w64_lds<float>();
     LCP_W64_LAUNCH((w64::lcp_bwd_wave_any<float, float>), w64_grid(P.B), lw, P, lw, quad);
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
