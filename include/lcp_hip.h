@@ -120,7 +120,12 @@ int lcp_pdipm_forward_f64(int B, int nz, int m, int e,
  * not K^T (exact only for symmetric F); that formula is reproduced.
  *   in : G[B,m,nz] A[B,e,nz] dl_dx[B,nz]
  *   out: dQ[B,nz,nz] dp[B,nz] dG[B,m,nz] dh[B,m] dA[B,e,nz] db[B,e] dF[B,m,m]
- *        (any output pointer may be NULL to skip that gradient) */
+ *        (any output pointer may be NULL to skip that gradient)
+ * At an iterate that converged to rounding (d_i = lams_i / slacks_i of 1e16 and more) the matrix of lcp.py:46 is singular to working
+ * precision wherever contact points are redundant; an elimination that meets a pivot of rounding noise there (or an exact zero) is
+ * repeated with slacks_i / lams_i floored at 1e-12 x the row's diagonal of G Q^-1 G^T - the body-space kernels floor always and refine
+ * once - so that dl/dp, dQ, dA, db stay the gradients of the converged solution instead of the cancellation error of multipliers of
+ * 1e15 (the reference's own pivoted LU has that exposure; tests/parity.py::own_iterate_backward is the gate). */
 int lcp_pdipm_backward_f32(int B, int nz, int m, int e,
                            const float* G, const float* A, const float* dl_dx, int compute,
                            float* dQ, float* dp, float* dG, float* dh,
