@@ -70,3 +70,21 @@ def test_own_iterate_gate_does_not_count_a_scene_the_oracle_cannot_determine():
     g_at = O.lcp_backward(at, *lcp, cot)
     rep = parity.own_iterate_backward(O, lcp, ref, cot, ref.x, at.z, at.s, {k: g_at["d" + k] for k in "pQb"}, fl)
     assert rep["bwd_own_iterate_determined_scenes"] <= full["bwd_own_iterate_determined_scenes"], (rep, full)
+
+
+def test_headline_report_on_the_oracle_itself_has_every_gated_field_and_no_error():
+    """`headline_report` fed with the oracle's own iterate and gradients (what a perfect kernel would return): every field the GPU gates
+    read (tests/test_hip_headline_parity.py::check_gates) exists and sits at its ideal value - the report's code paths run on CPU."""
+    lcp, ref, cot, g, fl = _case(B=16)
+    sc = scenes.make_stack_scenes(B=16, nbox=4, pts_per_interface=4, seed=4242, dtype=torch.float64)
+    grads = {k: g["d" + k] for k in "QpGhAbF"}
+    rep, _ = parity.headline_report(O, lcp, ref.x, ref.z, ref.s, ref.iters, cot=cot, grads=grads, phys=sc.phys_dict(), dt=sc.dt,
+                                    input_stability=True, all_grads=True)
+    for k in ("fwd_err_x_max", "index_set_mismatches_unmasked", "index_set_mismatches_floor_0.0001", "index_set_masked_frac", "iters_max_abs_delta",
+              "bwd_nonfinite_scenes", "bwd_kkt_resid_all_max", "bwd_own_iterate_determined_scenes", "bwd_own_iterate_err_max",
+              "bwd_well_posed_frac", "bwd_err_dp_max", "bwd_err_phys_max", "bwd_err_dQ_max", "bwd_err_dA_max", "bwd_err_db_max", "bwd_kkt_resid_max",
+              "bwd_err_phys_all_max", "bwd_err_phys_five_max", "bwd_err_dlam_determined_max"):
+        assert k in rep, k
+    assert rep["fwd_err_x_max"] == 0.0 and rep["index_set_mismatches_unmasked"] == 0 and rep["iters_max_abs_delta"] == 0
+    assert rep["bwd_nonfinite_scenes"] == 0
+    assert rep["bwd_err_dp_max"] == 0.0 and rep["bwd_err_phys_max"] <= 1e-12 and rep["bwd_own_iterate_err_max"] <= 1e-12, rep
