@@ -2,12 +2,12 @@
 // chains of joints (two rows per revolute `Joint`, constraints.py:13-50 - the reference's chain demo, `testChain`, the ten links
 // of experiments/inference.py).  The rows of A live packed in LDS (e x nz floats), every equality lane sums its own row for A v.
 // A translation unit of its own so that the build compiles the instantiations in parallel.
-// The step lengths of THIS unit stay on the IEEE-quotient form (LCP_PRIMAL_RCP_STEP = 0).  Measured, round 5: with the reciprocal form the
-// 56-column instantiation (one wavefront per SIMD, 90 accumulator registers of spill traffic, no inline asm anywhere in it) returns wrong
-// velocities on five chain cases - while the same source with the fast branch disabled, or with a printf beside it, passes, and fast and
-// exact form print identical step lengths (tools/gpu_calls/r05_e.sh): a code-generation fragility of that one instantiation, not
-// arithmetic.  Chains are not where the divisions cost (five to twenty-four equality rows dominate their factorisation).
-#define LCP_PRIMAL_RCP_STEP 0
+// Round 5 kept THIS unit's step lengths on IEEE quotients because its 56-column instantiation returned wrong velocities with the
+// reciprocal form.  Round 6 found why (profiles/r06_chain_rootcause.txt): not the step lengths - the compiler had placed the VGPR -> AGPR
+// spill of rz.n (two v_accvgpr_write_b32) at the top of the join block of `if (lane >= NROW) t[..] = 0`, in front of the
+// `s_or_b64 exec, exec, s[0:1]` that re-enables lanes 0 .. 55: the spill saved lanes 56 .. 63 only and the first solve of every scene read
+// stale accumulator registers for -h.  The build now moves such spill code behind the restore (csrc/compile_unit.sh,
+// tools/isa_lint.py --fix) and the unit uses the reciprocal step lengths like every other (LCP_PRIMAL_RCP_STEP default 1).
 #include "lcp_primal_common.h"
 
 namespace lcp {
