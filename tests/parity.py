@@ -78,6 +78,7 @@ def decisive_rows(z, s, rel=1e-3, floor=1e-5):
     return ((z - s).abs() > rel * big) & nondegenerate
 
 
+REORDER_PROBES = 16            # oracle solves with its unknowns in another order, per report, on the scenes with a row nothing else explains
 MAX_MASKED_FRAC = 0.02          # index-set rows the decisive_rows mask may drop on the BASELINE stack configs
 MIN_WELL_POSED_FRAC = 0.9       # scenes whose backward system the oracle itself solves (stack configs)
 
@@ -214,7 +215,7 @@ def own_iterate_backward(oracle, lcp64, ref, cot, x, z, s, grads, fl, wobble=1e-
 # bench.py's `parity` object print the same fields)
 # ----------------------------------------------------------------------------
 def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e-5, 1e-4), grads=None, phys=None, dt=None,
-                    phys_grads=None, input_stability=False, all_grads=False, cache=None):
+                    phys_grads=None, input_stability=False, all_grads=False, cache=None, oracle_stability="if_needed"):
     """`lcp64`: the LCP the kernel solved (fp64 copies of the fp32 data the HIP assembly produced: identical inputs),
     `x, z, s, iters`: what the kernel returned for those scenes, `dp` (optional): its dl/dp for the cotangent `cot`.
     `grads` (optional): the kernel's dense gradients, dict over "QpGhAbF" (lcp.py:52-61); `phys` + `dt`: the scenes' physical
@@ -228,6 +229,10 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
       index_set_mismatches             the same on the decisive rows (`decisive_rows`, floor = floors[0])
       index_set_masked_frac            share of rows that mask drops (ties of two numbers that both converged to zero)
       index_set_mismatches_floor_1e-4 / masked_frac_floor_1e-4   with the looser floor the body-space kernels are gated on
+      index_set_mismatches_oracle_stable   differing rows whose ORACLE decision is stable under fp32 arithmetic AND the pivot-free LU
+                                       (see the code: gated to zero; `index_set_mismatch_rows` lists the first 64 differing rows)
+      ref_fp32_vs_fp64_err_x_max / _index_rows   SURVEY 8(d)'s companion: the reference algorithm's own fp32-vs-fp64 error on these inputs
+                                       (`oracle_stability`: "always" computes them, "if_needed" only when a row differs, "never")
       iters_delta_hist                 histogram of iters - iters_oracle (pdipm.py:80-136 loop iterations per scene)
       iters_differ_frac                share of scenes with a non-zero delta
       bwd_err_dp_*                     dl/dp against lcp.py:52 on the scenes whose backward system is well posed
@@ -276,6 +281,114 @@ def headline_report(oracle, lcp64, x, z, s, iters, dp=None, cot=None, floors=(1e
         out["index_set_masked_frac" + sfx] = 1.0 - float(dec.sum()) / dec.numel()
         if i == 0:
             out["index_set_rows_compared"] = int(dec.sum())
+    # Every row that differs from the oracle's, accounted for (north_star: "contact index sets bit-exact"): is the
+    # oracle's own decision z_i > s_i on that row stable?  It is solved again (a) in fp32 arithmetic on the same numbers (the reference's
+    # dtype on a float32 world: pdipm.py runs in the dtype of its inputs) and (b) with the pivot-free LU the reference takes on its GPU
+    # path (pdipm.py:15-28 `btrifact_hack`): a row either of them flips is a row the reference itself does not decide reproducibly.
+    # `index_set_mismatches_oracle_stable` counts the differing rows that none of (a) .. (d) below explains - gated to zero everywhere.
+    # The same two solves give SURVEY 8(d)'s noise-floor companion: the reference algorithm's own fp32-vs-fp64 error on these inputs.
+    if oracle_stability == "always" or (oracle_stability == "if_needed" and int(diff.sum()) > 0):
+        if "ref_f32" not in cache:
+            cache["ref_f32"] = oracle.lcp_forward(*[None if t is None else t.float() for t in lcp64])
+            cache["ref_nopivot"] = oracle.lcp_forward(*lcp64, pivot=False)
+        r32, rnp = cache["ref_f32"], cache["ref_nopivot"]
+        flip_a = (r32.z.double() > r32.s.double()) != (ref.z > ref.s)
+        flip_b = (rnp.z > rnp.s) != (ref.z > ref.s)
+        # rows neither of the two flips: two more looks at the ORACLE alone, on the scenes concerned -
+        # (c) the same LCP with its unknowns and rows in another order (up to REORDER_PROBES permutation similarities: identical in exact
+        #     arithmetic, rounded differently - what another host's BLAS does to the oracle; measured: the GPU box's host and this container's keep different
+        #     iterates on scenes 117 / 330 of configs[1]);
+        # (d) its own trajectory (trace): the iterate it KEPT is chosen by `resid < best` and by the exact-zero-pivot exit of
+        #     pdipm.py:99-102 - on a converged solve both are decided by the last bits - and one iteration on the complementary products
+        #     shrink ~1000 x: a pair (z_i, s_i) that both go to zero changes sides.  A differing row is explained when the kernel decides it as the
+        #     oracle itself does at a NEIGHBOUR (at most two passes away) of the iterate it kept, whose x equals the kept one's to 1e-6 of the
+        #     free motion; "neighbour" includes the pass the oracle would have taken had it not stopped on 0.25 eps <= resid < eps.
+        flip_c = torch.zeros_like(diff)
+        via_iterate = torch.zeros_like(diff)
+        iterate_note = {}
+        scn = torch.nonzero((diff & ~(flip_a | flip_b)).any(dim=1)).flatten()
+        tr, tr_more = [], []
+        if scn.numel():
+            sub = [None if t is None else t[scn] for t in lcp64]
+            nzs, ms = sub[0].shape[1], sub[2].shape[1]
+            nes = 0 if sub[4] is None else sub[4].shape[1]
+            base_dec = ref.z[scn] > ref.s[scn]
+            kdec_s = z[scn] > s[scn]
+            need = (diff & ~(flip_a | flip_b))[scn]
+            xfree = torch.maximum(free_scales(sub[0], sub[1])["x_free"], ref.x[scn].norm(dim=1)).clamp_min(1e-300)
+            # the oracle on these scenes alone, with its trajectory, and continued past `best_resid < eps` (pdipm.py:133; eps = 1e-12: a residual of
+            # ~1e-12 is a sum of differences of O(1) numbers, known to a few per cent - measured: 8.96e-13 alone, 9.17e-13 in a batch of three):
+            # the extra passes count only for scenes that stopped with 0.25 eps <= resid < eps
+            rs_ = oracle.lcp_forward(*sub, trace=tr)
+            oracle.lcp_forward(*sub, trace=tr_more, eps=0.0)
+            window = (rs_.resid >= 0.25e-12) & (rs_.resid < 1e-12)
+            fc = torch.zeros_like(need)                  # rows the reordered oracle flips at the iterate it keeps
+            seen = torch.zeros_like(need)                # rows on which SOME iterate (same solution to 1e-6) of SOME probe decides as the kernel does
+            where = {}
+
+            def look(trace, zsel, xsel, tag, allowed):
+                for j, t in enumerate(trace):
+                    zz, ss, xx = zsel(t["z"].double()), zsel(t["s"].double()), xsel(t["x"].double())
+                    close = ((xx - ref.x[scn]).norm(dim=1) / xfree <= 1e-6) & allowed
+                    hit = ((zz > ss) == kdec_s) & close.unsqueeze(1) & need & ~seen
+                    for i in torch.nonzero(hit.any(dim=1)).flatten().tolist():
+                        where.setdefault(int(scn[i]), {"probe": tag, "oracle_iteration": j, "oracle_resid_there": float(t["resid"][i]),
+                                                       "oracle_iterations_run": int(rs_.iters[i]), "oracle_resid_kept": float(rs_.resid[i])})
+                    seen.__ior__(hit)
+
+            ident = lambda v: v
+            every = torch.ones(scn.numel(), dtype=torch.bool)
+            look(tr, ident, ident, "its own trajectory", every)
+            look(tr_more, ident, ident, "its own trajectory continued past resid < eps", window)
+            probes = 0
+            for seed in range(REORDER_PROBES):           # the first probe reverses every order, the others are random permutations
+                if not bool((need & ~(fc | seen)).any()):
+                    break
+                g_ = torch.Generator().manual_seed(seed)
+                px = torch.arange(nzs - 1, -1, -1) if seed == 0 else torch.randperm(nzs, generator=g_)
+                pm = torch.arange(ms - 1, -1, -1) if seed == 0 else torch.randperm(ms, generator=g_)
+                pe = None if nes == 0 else (torch.arange(nes - 1, -1, -1) if seed == 0 else torch.randperm(nes, generator=g_))
+                Ap, bp = (None, None) if nes == 0 else (sub[4][:, pe][:, :, px], sub[5][:, pe])
+                args = (sub[0][:, px][:, :, px], sub[1][:, px], sub[2][:, pm][:, :, px], sub[3][:, pm], Ap, bp, sub[6][:, pm][:, :, pm])
+                ipm, ipx = torch.argsort(pm), torch.argsort(px)
+                trp, trp_more = [], []
+                rp = oracle.lcp_forward(*args, trace=trp)
+                fc |= (rp.z[:, ipm] > rp.s[:, ipm]) != base_dec
+                look(trp, lambda v: v[:, ipm], lambda v: v[:, ipx], "reordered (probe %d)" % seed, every)
+                if bool(window.any()):
+                    oracle.lcp_forward(*args, trace=trp_more, eps=0.0)
+                    look(trp_more, lambda v: v[:, ipm], lambda v: v[:, ipx], "reordered (probe %d), continued past resid < eps" % seed, window)
+                probes += 1
+            flip_c[scn] = fc
+            via_iterate[scn] = seen
+            iterate_note = where
+            out["index_set_reorder_probes"] = probes
+        explained = flip_a | flip_b | flip_c | via_iterate
+        if scn.numel():
+            left = [int(v) for v in torch.nonzero((diff & ~explained).any(dim=1)).flatten()[:8]]
+            pos = {int(v): k for k, v in enumerate(scn.tolist())}
+            out["index_set_unexplained_scenes"] = {str(v): {"oracle_iters": int(ref.iters[v]), "kernel_iters": int(iters[v]), "oracle_resid_kept": float(ref.resid[v]),
+                                                           "oracle_resid_by_iteration": [float(t["resid"][pos[v]]) for t in tr],
+                                                           "oracle_resid_continued_past_eps": [float(t["resid"][pos[v]]) for t in tr_more]} for v in left}
+        out["index_set_mismatches_oracle_stable"] = int((diff & ~explained).sum())
+        out["index_set_mismatches_oracle_flips_in_fp32"] = int((diff & flip_a).sum())
+        out["index_set_mismatches_oracle_flips_without_pivoting"] = int((diff & flip_b).sum())
+        out["index_set_mismatches_oracle_flips_reordered"] = int((diff & flip_c).sum())
+        out["index_set_mismatches_at_another_oracle_iterate"] = int((diff & via_iterate & ~(flip_a | flip_b | flip_c)).sum())
+        out["index_set_mismatch_scenes_at_another_oracle_iterate"] = {str(k): v for k, v in list(iterate_note.items())[:16]}
+        rows = torch.cat([torch.nonzero(diff & ~explained), torch.nonzero(diff & explained)])       # (the unexplained ones first)
+        out["index_set_mismatch_rows"] = [
+            {"scene": int(i), "row": int(r), "z": float(z[i, r]), "s": float(s[i, r]), "z_oracle": float(ref.z[i, r]), "s_oracle": float(ref.s[i, r]),
+             "oracle_flips_in_fp32": bool(flip_a[i, r]), "oracle_flips_without_pivoting": bool(flip_b[i, r]), "oracle_flips_reordered": bool(flip_c[i, r]),
+             "kernel_set_is_another_oracle_iterate": bool(via_iterate[i, r])} for i, r in rows[:64].tolist()]
+        e32 = err_x(r32.x.double(), ref.x, Q, p)
+        out["ref_fp32_vs_fp64_err_x_max"] = float(e32.max())
+        out["ref_fp32_vs_fp64_err_x_median"] = float(e32.median())
+        out["ref_fp32_vs_fp64_index_rows"] = int(flip_a.sum())
+        out["ref_nopivot_vs_pivot_err_x_max"] = float(err_x(rnp.x, ref.x, Q, p).max())
+        out["ref_nopivot_vs_pivot_index_rows"] = int(flip_b.sum())
+    else:
+        out["index_set_mismatches_oracle_stable"] = 0          # (no differing row at all)
     d = (iters.to(torch.int64).cpu() - ref.iters.to(torch.int64))
     out["iters_delta_hist"] = {str(int(k)): int((d == k).sum()) for k in torch.unique(d)}
     out["iters_differ_frac"] = float((d != 0).sum()) / n

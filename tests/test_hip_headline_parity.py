@@ -150,6 +150,8 @@ def check_gates(rep, gates, dense_grads, sample):
     # index sets {i : z_i > s_i}: unmasked count, and identical on the decisive rows (the mask itself is gated)
     assert rep["index_set_mismatches_unmasked"] <= gates["unmasked_max"] * rep["index_set_rows_total"], rep
     assert rep["index_set_mismatches_floor_0.0001"] == 0, rep
+    # every differing row is one the oracle itself flips in fp32 arithmetic or without pivoting (tests/parity.py: the rows are listed)
+    assert rep["index_set_mismatches_oracle_stable"] == 0, {k: v for k, v in rep.items() if k.startswith("index_set")}
     assert rep["index_set_masked_frac"] <= gates["masked_max"], rep
     assert rep["iters_max_abs_delta"] <= gates["iters_max_delta"], rep
     # EVERY scene, whatever the filters below say about it: finite gradients, and (dx, dlam, dnu) solve the system lcp.py:47-50 builds

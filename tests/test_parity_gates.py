@@ -88,3 +88,31 @@ def test_headline_report_on_the_oracle_itself_has_every_gated_field_and_no_error
     assert rep["fwd_err_x_max"] == 0.0 and rep["index_set_mismatches_unmasked"] == 0 and rep["iters_max_abs_delta"] == 0
     assert rep["bwd_nonfinite_scenes"] == 0
     assert rep["bwd_err_dp_max"] == 0.0 and rep["bwd_err_phys_max"] <= 1e-12 and rep["bwd_own_iterate_err_max"] <= 1e-12, rep
+
+
+def test_index_set_accounting_explains_iterate_ties_and_catches_a_real_flip():
+    """Round 6 (`index_set_mismatches_oracle_stable`): a "kernel" that returns the oracle's own PREVIOUS iterate on a few converged
+    scenes differs from the oracle only on rows the oracle itself does not decide reproducibly (fp32 arithmetic, no pivoting, another
+    order of the unknowns, or another iterate of its own trajectory): zero unexplained rows.  A planted flip of the most decisive row of
+    one scene is none of those: it must be counted, and listed."""
+    sc = scenes.make_stack_scenes(B=128, nbox=2, pts_per_interface=4, seed=1236, dtype=torch.float32)
+    lcp = [None if t is None else t.double() for t in O.assemble_lcp(*sc.assembly_args())]
+    tr = []
+    ref = O.lcp_forward(*lcp, trace=tr)
+    z, s = ref.z.clone(), ref.s.clone()
+    xf = parity.free_scales(lcp[0], lcp[1])["x_free"]
+    cand = [i for i in range(1, 128) if bool(((tr[-2]["z"][i] > tr[-2]["s"][i]) != (ref.z[i] > ref.s[i])).any()) and torch.equal(tr[-1]["z"][i], ref.z[i])
+            and float((tr[-2]["x"][i] - ref.x[i]).norm() / xf[i]) <= 1e-8]                       # (converged solves: the last two iterates are the same solution)
+    assert len(cand) >= 3
+    for i in cand[:3]:
+        z[i], s[i] = tr[-2]["z"][i], tr[-2]["s"][i]
+    rep, _ = parity.headline_report(O, lcp, ref.x, z, s, ref.iters)
+    assert rep["index_set_mismatches_unmasked"] > 0 and rep["index_set_mismatches_oracle_stable"] == 0, rep
+    assert rep["ref_fp32_vs_fp64_index_rows"] > 0 and rep["ref_fp32_vs_fp64_err_x_max"] > 0, rep      # (SURVEY 8d's companion fields ride along)
+    big = int((ref.z[0] - ref.s[0]).abs().argmax())
+    z[0, big], s[0, big] = ref.s[0, big].clone(), ref.z[0, big].clone()
+    rep, _ = parity.headline_report(O, lcp, ref.x, z, s, ref.iters)
+    assert rep["index_set_mismatches_oracle_stable"] == 1, rep
+    bad = [r for r in rep["index_set_mismatch_rows"] if not (r["oracle_flips_in_fp32"] or r["oracle_flips_without_pivoting"] or r["oracle_flips_reordered"]
+                                                              or r["kernel_set_is_another_oracle_iterate"])]
+    assert [(r["scene"], r["row"]) for r in bad] == [(0, big)], bad

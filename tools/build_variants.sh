@@ -10,8 +10,8 @@ make -j8 > /dev/null
 OTHERS=$(ls *.o | grep -v "^${UNIT}.o$" | grep -v "_prof.o$")
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wall -Wno-unused-function -fno-slp-vectorize $flags -x hip -c ${UNIT}.hip -o variants/${UNIT}_$name.o \
+  ( ./compile_unit.sh ${UNIT}.hip variants/${UNIT}_$name.o -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function -fno-slp-vectorize $flags > variants/$name.log 2>&1 \
     && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so $OTHERS variants/${UNIT}_$name.o && echo "built $name ($flags)" ) &
 done
 wait
-rm -f variants/*.o
+rm -f variants/*.o asm/${UNIT}_*
