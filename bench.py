@@ -178,6 +178,17 @@ def run_rank(args, make_work, device=None):
         raise SystemExit("bench.py: %d of %d ranks reported" % (reported, world))
     if is_gpu and devices_used != world and not args.share_devices:
         raise SystemExit("bench.py: %d ranks on %d distinct devices" % (world, devices_used))
+    # what a step costs THIS rank's host thread with the device idle in front of it: the launches of a few steps issued back to back, the
+    # clock stopped before the device is waited for.  With N ranks on one host these are N threads doing this concurrently; the step
+    # cannot go faster than the slowest of them issues it - `host_bound_ceiling` below is that bound in the metric's unit, so that a
+    # scaling result below 7 x at N = 8 can be read off the line: kernels slower (per_rank fwd_ms / bwd_ms) or hosts slower (host_us_per_step)
+    sync()
+    n_issue = 20 if is_gpu else 3
+    t0 = time.perf_counter()
+    for _ in range(n_issue):
+        work.step()
+    host_us = (time.perf_counter() - t0) / n_issue * 1e6
+    sync()
     sustained = None
     if args.sustain > 0:
         sync()
@@ -222,10 +233,14 @@ def run_rank(args, make_work, device=None):
                                   "un-instrumented steps of forward + backward): what is left above 1 is the event records' share and the "
                                   "difference between back-to-back launches of one kernel and the alternating pair; achieved / frac are conservative")
     mine = torch.tensor([[float(rank), float(dev_index), own_wall / args.steps * 1e3, float(roof.get("fwd_ms") or 0.0),
-                          float(roof.get("bwd_ms") or 0.0)]], dtype=torch.float64, device=rdev)
+                          float(roof.get("bwd_ms") or 0.0), host_us]], dtype=torch.float64, device=rdev)
     allr = shard.gather_scenes(mine, world, device=rdev) if world > 1 else mine
-    out["per_rank"] = [{"rank": int(r[0]), "device": int(r[1]), "ms_per_step": float(r[2]), "fwd_ms": float(r[3]), "bwd_ms": float(r[4])}
-                       for r in allr.cpu().tolist()]
+    out["per_rank"] = [{"rank": int(r[0]), "device": int(r[1]), "ms_per_step": float(r[2]), "fwd_ms": float(r[3]), "bwd_ms": float(r[4]),
+                        "host_us_per_step": float(r[5])} for r in allr.cpu().tolist()]
+    out["host_us_per_step"] = max(r["host_us_per_step"] for r in out["per_rank"])
+    out["host_bound_ceiling"] = {"value": work.units_per_step * world / (out["host_us_per_step"] * 1e-6), "unit": "sim steps/s",
+                                 "note": "all ranks' units per step / the slowest rank's host time to ISSUE a step (its launches back to back, device not "
+                                         "waited for): the value cannot exceed this however fast the kernels are"}
     out["config"]["global_batch"] = work.units_per_step * world
     out["config"]["parallelism"] = "scenes sharded x%d, no collectives" % world
     out["config"]["control_plane"] = shard.control_plane()          # what carried the barriers / the MAX of the wall times
@@ -323,15 +338,29 @@ def cpu_reference_live(nc, quote):
             "measured_in_this_run": True, "source": "LCP_REFERENCE_ROOT (a staged copy of the reference's python package; measurement call only)"}
 
 
+_SRC_SHA = None
+
+
 def _quoted(name, key):
-    """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    """A committed per-configuration profile figure (rocprofv3 counters / compiler register report), newest round first.  Every such file
+    is stamped with the sha256 of the kernel sources it was measured on (lcp_physics_amd/srchash.py); a figure whose stamp is not the one
+    of the sources this run executes comes back with "counters_stale": true - quoted for orientation, not as a measurement of this build."""
+    global _SRC_SHA
+    if _SRC_SHA is None:
+        from lcp_physics_amd.srchash import source_sha256
+        _SRC_SHA = source_sha256()
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
-            j = json.load(open(path)).get(key)
+            doc = json.load(open(path))
+            j = doc.get(key)
             if j:
                 j = dict(j)
                 j.setdefault("source", "profiles/%s_%s.json" % (rnd, name))
+                j["counters_stale"] = doc.get("source_sha256") != _SRC_SHA
+                if j["counters_stale"]:
+                    j["stale_note"] = ("measured on other kernel sources than this run's (source_sha256 %s in the file, %s here): re-run tools/collect_round.sh"
+                                       % (str(doc.get("source_sha256"))[:12], _SRC_SHA[:12]))
                 return j
     return None
 
@@ -672,6 +701,12 @@ class HipWorkload:
             roof["traffic_source"] = tj["source"]
         if rj:
             roof["regs"] = rj
+        # (the quoted figures above - traffic, issue counters, registers - come from committed rocprofv3 / compiler runs: stale when the kernel
+        #  sources have changed since those files were stamped; ONE flag for the object, the per-file notes say which)
+        stale = {n: q.get("stale_note") for n, q in (("traffic", tj), ("counters", cj), ("regs", rj)) if q and q.get("counters_stale")}
+        roof["counters_stale"] = bool(stale)
+        if stale:
+            roof["counters_stale_files"] = stale
         if not a.fwd_only:
             dense_bwd = a.bwd == "dense"
             bkey = key + ("_bwd" if dense_bwd else "_bwd_physical")
@@ -706,6 +741,7 @@ class HipWorkload:
                                "executed_flops_per_launch": bfl}
             if btj:
                 roof["bwd"]["traffic_source"] = btj["source"]
+                roof["bwd"]["counters_stale"] = bool(btj.get("counters_stale"))
         shape = ("ten-box pile (4-3-2-1 pyramid), %d pts/interface" % a.pts) if self.pile else "%d-box stack, %d pts/interface" % (a.nbox, a.pts)
         return {
             "config": {"workload": "%s: batch=%d x %d contacts (%s; nz %d, nineq %d, "

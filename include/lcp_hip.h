@@ -125,7 +125,12 @@ int lcp_pdipm_forward_f64(int B, int nz, int m, int e,
  * precision wherever contact points are redundant; an elimination that meets a pivot of rounding noise there (or an exact zero) is
  * repeated with slacks_i / lams_i floored at 1e-12 x the row's diagonal of G Q^-1 G^T - the body-space kernels floor always and refine
  * once - so that dl/dp, dQ, dA, db stay the gradients of the converged solution instead of the cancellation error of multipliers of
- * 1e15 (the reference's own pivoted LU has that exposure; tests/parity.py::own_iterate_backward is the gate). */
+ * 1e15 (the reference's own pivoted LU has that exposure; tests/parity.py::own_iterate_backward is the gate).
+ * Alignment (m of 65 .. 256 rows, the dense route of 17 .. 64 contacts): scenes the forward classified as contact LCPs with at most two
+ * bodies per contact are served by kernels that move F, dG and dF in 16-byte pieces.  The forward only hands that class out when F and G
+ * are 16-byte aligned (torch allocations are; a view with an odd storage offset is not - such a call is solved by the contact-space
+ * kernels instead); the backward of a forward that did returns LCP_E_BADARG for a dG or dF that is not 16-byte aligned.  For those scenes
+ * the backward reads the Jacobian rows from the records the forward left in the workspace: the G passed here must be the forward's G. */
 int lcp_pdipm_backward_f32(int B, int nz, int m, int e,
                            const float* G, const float* A, const float* dl_dx, int compute,
                            float* dQ, float* dp, float* dG, float* dh,

@@ -1,6 +1,7 @@
 // lcp_api.cpp - the C ABI declared in include/lcp_hip.h: argument checking, launch planning and
 // dispatch to the kernel translation units.  No torch types, no allocation, no synchronisation.
 #include <stdlib.h>
+#include <stdint.h>
 #include <string.h>
 
 #include "lcp_kernels.h"
@@ -162,7 +163,12 @@ static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q
     // classes per scene: 4 = as 3 with equality rows that pin the leading coordinates (lcp_primal_pin.hip); 3 = contact structure, at
     // most two bodies per contact, sizes of lcp_primal.hip; 2 = contact structure (lcp_big.hip); 0 = anything else (the generic kernels)
     // (bit 1: the pinned form's sizes - lcp_classify_big then also looks at A and b and marks the scenes whose rows pin the leading coordinates 4)
-    const int primal_ok = (path != 3 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? (1 | (lcp::primal_pin_supported(nz, e) ? 2 : 0)) : 0;
+    // (the body-space kernels read lcp_classify_big's per-contact records - 16 floats per contact, DENSE_EXTRACT_OFF into the scene's block -
+    //  and move F, dG, dF with 16-byte accesses: both are preconditions of that route, checked here; without them the scenes stay with the
+    //  contact-space / generic kernels, which make neither assumption)
+    const bool rec_fits = lcp::DENSE_EXTRACT_OFF + (size_t)16 * (m / 4) * sizeof(float) <= per_scene;
+    const bool aligned16 = (((uintptr_t)F | (uintptr_t)G) & 15) == 0;
+    const int primal_ok = (path != 3 && rec_fits && aligned16 && (nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) ? (1 | (lcp::primal_pin_supported(nz, e) ? 2 : 0)) : 0;
     int rc = lcp::big_dense_forward(P, cls, per_scene, primal_ok, stream);
     if (rc) return rc;
     if (primal_ok) { rc = lcp::primal_dense_forward(P, cls, per_scene, stream); if (rc) return rc; }
@@ -245,7 +251,12 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
     int32_t* cls = (int32_t*)((unsigned char*)ws + (size_t)B * per_scene);
     int rc = lcp::big_dense_backward(P, cls, per_scene, stream);           // (the classes the forward left behind the scene blocks)
     if (rc) return rc;
-    if ((nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) { rc = lcp::primal_dense_backward(P, cls, per_scene, stream); if (rc) return rc; }
+    if ((nz % 3) == 0 && lcp::primal_dense_supported(nz, m, e)) {
+      // (classes 3 / 4 - the forward only hands them out for 16-byte aligned F and G - write dG and dF with 16-byte stores)
+      if (((((uintptr_t)dG) | ((uintptr_t)dF)) & 15) != 0) return LCP_E_BADARG;
+      rc = lcp::primal_dense_backward(P, cls, per_scene, stream);
+      if (rc) return rc;
+    }
     P.cls = cls; P.ws_stride = per_scene / cs;
   }
   return lcp::generic_backward(P, io_f64, compute, pl.lds_bytes, stream);

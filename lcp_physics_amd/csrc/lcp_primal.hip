@@ -44,6 +44,7 @@ bool primal_supported(int nz, int m, int e) {
 }
 // the dense boundary keeps the four-row instantiations
 bool primal_dense_supported(int nz, int m, int e) { return e <= primal::EQB && primal_supported(nz, m, e); }
+static_assert(sizeof(double) * (size_t)primal::WsLayout::TOTAL <= DENSE_EXTRACT_OFF, "lcp_classify_big's per-contact records start behind the body-space kernels' iterate block");
 size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOTAL; }
 
 template <int NCOL, bool BWD, bool DENSE = false>

@@ -1196,6 +1196,7 @@ __device__ __forceinline__ void bwd_wave_body(const BwdArgs& P, int lds_per_wave
     for (int off = 32; off > 0; off >>= 1) { const TC o = shfl_xor_t(scale, off); scale = o > scale ? o : scale; }
     const TC piv = (TC)1 / udinv, apiv = piv < 0 ? -piv : piv;
     const bool tiny = (lane < nrows) && !(apiv >= (TC)1e-13 * scale);
+    static_assert(WPB == 1, "the repeated factorisation is a per-wavefront branch around lu_factor's __syncthreads(): with several wavefronts per workgroup the decision must be made workgroup-uniform (__syncthreads_or) first");
     if (__any(tiny || sing)) {
       const int nc = m >> 2;
       int idx = lane;                                                        // general scene: system row = m-space row

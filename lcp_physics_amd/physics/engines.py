@@ -106,6 +106,14 @@ class _Lifted:
         self.c_i1, self.c_i2, self.count = devi[:cap].reshape(1, cap), devi[cap:2 * cap].reshape(1, cap), devi[2 * cap:]
 
 
+def _fresh(r, buf):
+    """The reference's engines return NEW tensors every step (engines.py:76-78, 114-116) and its world mutates what it gets in place
+    (world.py:112 `dp /= 2`) or keeps it (trajectory logs, `tmp_v`).  A world on the same GPU in float32 makes `.to()` a no-op: what comes
+    back would be a view of the buffer the engine re-uses for the next solve - so a result that still shares storage with that
+    buffer is copied."""
+    return r.clone() if r.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr() else r
+
+
 class HipPdipmEngine(Engine):
     """Engine that uses the MI355X primal-dual interior point LCP solver (differentiable)."""
 
@@ -145,7 +153,7 @@ class HipPdipmEngine(Engine):
                                                        compute=opts["compute"], ws=None if old is None else old["ws"], out=old)
                 self._buffers[key] = self.last = out
                 new_v = out["v_new"]
-            return new_v.reshape(-1).to(device=base.device, dtype=base.dtype)
+            return _fresh(new_v.reshape(-1).to(device=base.device, dtype=base.dtype), new_v)
 
     def post_stabilization(self, world):
         base = world.get_v()
@@ -163,7 +171,7 @@ class HipPdipmEngine(Engine):
                                                            compute=opts["compute"], ws=None if old is None else old["ws"], out=old)
                 self._buffers[key] = out
                 dp = out["dp"]
-            return dp.reshape(-1).to(device=base.device, dtype=base.dtype)
+            return _fresh(dp.reshape(-1).to(device=base.device, dtype=base.dtype), dp)
 
 
 class HipFusedEngine(HipPdipmEngine):

@@ -9,6 +9,7 @@ import socket
 import subprocess
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -110,8 +111,10 @@ def _bench_worker(rank, world, port, q):
         q.put(out)
 
 
-def test_bench_rank_protocol_two_gloo_ranks():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rank_protocol_gloo_ranks(world):
+    """bench.py's rank protocol at world size 2 and at the EIGHT ranks the driver's scaling run starts (the first real
+    8-GPU run must not be the first time eight ranks ever start): rendezvous on 127.0.0.1, barriers, MAX over ranks, per-rank records."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
@@ -122,16 +125,22 @@ def test_bench_rank_protocol_two_gloo_ranks():
         p.join(180)
         assert p.exitcode == 0
     out = q.get()
-    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
-    assert out["config"]["global_batch"] == 8192 and out["scaling"] == "weak"
-    assert out["config"]["calls"] == 7                      # warm-up + timed steps, nothing else inside the protocol
-    assert out["ms_per_step"] >= 40.0                       # MAX over ranks: the slow rank's 40 ms per step
-    assert abs(out["value"] - 8192 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    slow = 20.0 * world                                     # the last rank sleeps 20 ms x world per step
+    assert out["n_gpus"] == world and out["steps"] == 5 and out["warmup"] == 2
+    assert out["config"]["global_batch"] == 4096 * world and out["scaling"] == "weak"
+    assert out["config"]["calls"] == 7 + 3                  # warm-up + timed steps, then the three steps of the host-issue probe: nothing else
+    assert out["ms_per_step"] >= slow                       # MAX over ranks: the slowest rank's time per step
+    assert abs(out["value"] - 4096 * world * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
     assert out["cpu_baseline"] is None                      # reported at N = 1 only
-    # every rank's own clock is in the line (the metric takes the MAX): rank 1 sleeps twice as long per step as rank 0
+    # every rank's own clock is in the line (the metric takes the MAX): rank r sleeps (r + 1) x 20 ms per step
     pr = out["per_rank"]
-    assert [r["rank"] for r in pr] == [0, 1] and pr[1]["ms_per_step"] >= 40.0 > pr[0]["ms_per_step"] >= 20.0
-    assert abs(max(r["ms_per_step"] for r in pr) - out["ms_per_step"]) < 5.0
+    assert [r["rank"] for r in pr] == list(range(world))
+    assert pr[-1]["ms_per_step"] >= slow > pr[0]["ms_per_step"] >= 20.0
+    assert abs(max(r["ms_per_step"] for r in pr) - out["ms_per_step"]) < 0.25 * slow
+    # the host-issue probe: per rank, and the ceiling it implies (the stand-in's "issue" is its sleep)
+    assert all(r["host_us_per_step"] >= 20e3 * (r["rank"] + 1) for r in pr)
+    assert out["host_us_per_step"] == max(r["host_us_per_step"] for r in pr)
+    assert abs(out["host_bound_ceiling"]["value"] - 4096 * world / (out["host_us_per_step"] * 1e-6)) < 1e-6 * out["host_bound_ceiling"]["value"]
 
 
 def _run_bench(argv, env_extra=None, timeout=300):

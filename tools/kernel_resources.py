@@ -62,6 +62,9 @@ def main():
         "all_kernels": nice,
         "source": "hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py)",
     }
+    sys.path.insert(0, ROOT)
+    from lcp_physics_amd.srchash import source_sha256
+    out["source_sha256"] = source_sha256()               # (bench.py prints "counters_stale" when the kernel sources have moved on since)
     json.dump(out, sys.stdout, indent=1)
 
 

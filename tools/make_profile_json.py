@@ -62,6 +62,11 @@ def main(paths, tag):
             if get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and get("SQ_BUSY_CYCLES"):
                 c["mfma_busy_frac"] = get("SQ_VALU_MFMA_BUSY_CYCLES") / get("SQ_BUSY_CYCLES")
             counters[key] = c
+    sys.path.insert(0, ROOT)
+    from lcp_physics_amd.srchash import source_sha256
+    stamp = source_sha256()                              # (bench.py prints "counters_stale" when the kernel sources have moved on since)
+    traffic["source_sha256"] = stamp
+    counters["source_sha256"] = stamp
     json.dump(traffic, open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w"), indent=1)
     json.dump(counters, open(os.path.join(ROOT, "profiles", tag + "_counters.json"), "w"), indent=1)
     print(json.dumps({"traffic": traffic, "counters": counters}, indent=1))
