@@ -45,6 +45,8 @@ struct BwdArgs {
   int tag_value;       // laid out by another kernel family) returns NaN gradients instead of reading it
   int skip_tag;        // 0, or the tag of the OTHER kernel family the forward may have fallen back on (wave64 step -> generic step
                        // when contact counts are given): a backward that finds it leaves without writing, its partner serves the call
+  int split;           // lcp_bwd_quad<..., BODY> (round 6): 1 = leave dG and dF to lcp_bwd_stream_quad - the solve kernel hands (x, dx, lam, dlam)
+                       // over in the scene's workspace block and writes the small gradients only
 };
 
 // dense (Q, p, G, h, A, b, F) boundary of lcp_big.hip: LCPFunction sizes beyond the wave-per-scene kernels (nineq <= 256)

@@ -179,16 +179,33 @@ int quad_post_stab(const StepArgs& SP, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }
 
+#ifndef LCP_Q_BWD_SPLIT
+#define LCP_Q_BWD_SPLIT 0     // 1: body-space dense backward as solve kernel + streaming kernel for dG / dF.  Measured and NOT the default
+                              // (profiles/r06_ab_bwd_split.txt): the streaming kernel alone - sixteen wavefronts per SIMD, 16-byte stores - takes 16.5 us for
+                              // the 83 MB (5.0 TB/s), what the stores cost INSIDE the one-kernel form too (dG + dF: 16.5 us of its 25.2): the writes are
+                              // at what the memory system takes, not starved by occupancy, and two launches add 3 us
+#endif
+static int quad_backward_solve_body(const BwdArgs& P, int ls, int accept, bool pinned, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((P.B + 3) / 4), blk(64);
+#define LCP_QS_CALL(NZ, E) quad_sized_bwd_##NZ##_##E(P, ls, accept, pinned, stream)
+  LCP_QS_FOR_EACH(P.nz, P.e, LCP_QS_CALL)
+#undef LCP_QS_CALL
+  hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, ls, accept);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
 int quad_backward(const BwdArgs& P, int compute, int accept, void* stream, int io_f64, int body, bool pinned) {
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((P.B + 3) / 4), blk(64);
   if (body) {                                    // workspace of a body-space forward (fp32 I/O, fp64 arithmetic)
     if (io_f64 || compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
     const int ls = (int)q16_lds<double>(false);
-#define LCP_QS_CALL(NZ, E) quad_sized_bwd_##NZ##_##E(P, ls, accept, pinned, stream)
-    LCP_QS_FOR_EACH(P.nz, P.e, LCP_QS_CALL)
-#undef LCP_QS_CALL
-    hipLaunchKernelGGL((q16::lcp_bwd_quad<float, double, true>), grid, blk, 4 * ls, st, P, ls, accept);
+    BwdArgs Ps = P;
+    // dG / dF (20 of the 21.6 KB per scene at 16 contacts) from their own kernel: 16-byte stores need (m nz) % 4 == 0 and aligned outputs
+    Ps.split = (LCP_Q_BWD_SPLIT && (P.dG || P.dF) && ((P.m * P.nz) & 3) == 0 && ((((uintptr_t)P.dG) | ((uintptr_t)P.dF)) & 15) == 0) ? 1 : 0;
+    const int rc = quad_backward_solve_body(Ps, ls, accept, pinned, stream);
+    if (rc || !Ps.split) return rc;
+    hipLaunchKernelGGL((q16::lcp_bwd_stream_quad<float, double, 256>), dim3(P.B), dim3(256), 0, st, Ps, accept);
   } else if (io_f64) {
     const int ls = (int)q16_lds<double, double>(false);
     hipLaunchKernelGGL((q16::lcp_bwd_quad<double, double>), grid, blk, 4 * ls, st, P, ls, accept);
