@@ -116,6 +116,8 @@ __device__ __forceinline__ float launder(float f) { asm volatile("" : "+v"(f)); 
 __device__ __forceinline__ int launder(int i) { asm volatile("" : "+v"(i)); return i; }
 __device__ __forceinline__ double launder(double f) { asm volatile("" : "+v"(f)); return f; }
 
+// an empty statement that needs `v` in a vector register HERE: loads issued early are not sunk into a predicated block further down
+template <typename T> __device__ __forceinline__ void pin_vgpr(T& v) { asm volatile("" : "+v"(v)); }
 // Phase timing (build with -DLCP_Q_PROFILE; the dense forward then writes cycle totals to the debug trace buffer)
 #ifdef LCP_Q_PROFILE
 struct Prof { long long t[10]; long long last; };

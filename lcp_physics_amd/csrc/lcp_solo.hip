@@ -266,6 +266,17 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   const TI* vv = (const TI*)SP.v + (size_t)scene * nz;
   const TI* ff = (const TI*)SP.f + (size_t)scene * nz;
   TI hrow = 0, mu_f = 0;
+  // (round 6: the loads that do not depend on the contact's body indices are issued up front and without lane predicates - address
+  //  clamped, value masked later; see row16 in lcp_quad_kernels.inc: a predicated load is waited for at the join of its branch, and
+  //  sixteen of them in a row were sixteen round trips to memory in front of the first iteration of a 30 us kernel)
+  TI jer[16];
+  static_for<16>([&](auto K) LCP_INL { jer[K] = (TI)0; });
+  if (e > 0) {
+    const TI* jr = (const TI*)SP.Je + ((size_t)scene * e + (l16 < e ? l16 : 0)) * nz;
+    static_for<16>([&](auto K_) LCP_INL { constexpr int K = K_; jer[K] = jr[K < nz ? K : 0]; });
+  }
+  const int jx0 = l16 < nz ? l16 : 0;
+  TI md_l = Md[jx0], vv_l = vv[jx0], ff_l = ff[jx0];
   if (c0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) { GL[l16 * 16 + j] = 0; GTL[l16 * 16 + j] = 0; }
@@ -282,11 +293,11 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       }
       hrow = r.h; mu_f = r.mu;
     }
-    if (l16 < EQ) {
-      const TI* Je = (const TI*)SP.Je + (size_t)scene * e * nz;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) AtL[l16 * 16 + k] = (l16 < e && k < nz) ? Je[l16 * nz + k] : (TI)0;
-    }
+  }
+  static_for<16>([&](auto K) LCP_INL { pin_vgpr(jer[K]); });        // (here, not sunk into the predicated block below)
+  pin_vgpr(md_l); pin_vgpr(vv_l); pin_vgpr(ff_l);
+  if (c0 && l16 < EQ) {
+    static_for<16>([&](auto K_) LCP_INL { constexpr int k = K_; AtL[l16 * 16 + k] = (l16 < e && k < nz) ? jer[k] : (TI)0; });
   }
   // h and mu of contact l16 to the other rows (row 0 computed them)
   {
@@ -313,8 +324,8 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const bool okc = col < CHI;
     jcq[JJ] = okc ? GL[l16 * 16 + (okc ? col : 0)] : (TI)0; jtq[JJ] = okc ? GTL[l16 * 16 + (okc ? col : 0)] : (TI)0;
   });
-  const TC qd = (l16 < nz) ? (TC)Md[l16] : (TC)0;
-  const TC p = (l16 < nz) ? (TC)momentum_entry<TI>(Md[l16 < nz ? l16 : 0], vv[l16 < nz ? l16 : 0], (TI)SP.dt, ff[l16 < nz ? l16 : 0]) : (TC)0;   // engines.py:32
+  const TC qd = (l16 < nz) ? (TC)md_l : (TC)0;
+  const TC p = (l16 < nz) ? (TC)momentum_entry<TI>(md_l, vv_l, (TI)SP.dt, ff_l) : (TC)0;   // engines.py:32
   // F z of the contact structure (engines.py:69-73) with the contact's gathered multipliers: (F z)_comp = fn z_n + f1 (z_f1 + z_f2) + fg z_g
   const TC fzn = c3 ? mu_c : (TC)0, fz12 = c3 ? (TC)-1 : (TC)0, fzg = (c1 || c2) ? (TC)1 : (TC)0;
   const TC hn = c0 ? (TC)hrow : (TC)0;                              // h = [Jc v rbar; 0; 0; 0]
