@@ -254,6 +254,9 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   const int max_iter = SP.max_iter, lim = SP.lim;
   const TC eps = SP.eps;
   Ws<TI, TC> W(SP.ws, scene);
+#ifdef LCP_SOLO_PROFILE
+  const long long t_start = clock64();
+#endif
   if (blockIdx.x == 0 && lane == 0 && SP.tag) *SP.tag = SP.tag_value;
   int ncs = nc, truncated = 0;
   if (NCF == 0 && SP.c_count) { const int c = SP.c_count[scene]; ncs = c < nc ? (c < 0 ? 0 : c) : nc; truncated = c > nc ? LCP_ST_TRUNCATED : 0; }
@@ -350,6 +353,15 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   if (row_any(l16 < nz && !(qd != (TC)0))) status |= LCP_ST_SINGULAR_Q;
   if (c0) W.Qit[128 + l16] = qd;                                    // (Q's diagonal: the backward takes the reciprocals itself)
 
+#ifdef LCP_SOLO_PROFILE
+  // `make soloprof`: clock64 per phase of an iteration, written over the tail of the scene's `s` output
+  // (tools/gpu_phase_profile_solo.py): 0 residuals + d, 1 formation, 2 LU, 3 products before the sweeps, 4 sweeps, 5 products after,
+  // 6 bookkeeping, 7 step lengths / sigma / update, 8 prologue
+  long long pc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
+#define SOLO_TICK(i) { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); __builtin_amdgcn_sched_barrier(0); pc[i] += now_ - tk; tk = now_; }
+#else
+#define SOLO_TICK(i)
+#endif
   // ---- state: x-space entry l16 (replicated in the rows), m-space scalar of (comp, contact)
   TC x = 0, y = 0, s = 1, z = 1, dinv = 1;
   TC best_resid = inf_of<TC>(), bx = 0, by = 0, bz = 1, bs = 1;
@@ -418,6 +430,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         }
       });
     }
+    SOLO_TICK(1)
     static_for<NS>([&](auto JJ) LCP_INL {
       const M4<TC> g = gather4(x4[JJ]);
       if constexpr (TRIM) {                                              // slot JJ of row r holds column CLO + 4 JJ + r
@@ -449,6 +462,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       }
     });
     if constexpr (!TRIM) static_for<EQ>([&](auto A_) LCP_INL { constexpr int a = A_; sp[a] = xr[a]; xr[a] = (a < es) ? (TC)0 : xr[a]; });
+    SOLO_TICK(2)
     return row_any(singular);
   };
 
@@ -460,6 +474,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     const TC gu = Gtw(vc ? pick(u4) : (TC)0);
     TC wx = (l16 < nzs) ? gu - rx : (TC)0;
     const TC we = (l16 < es) ? -ry : (TC)0;
+    SOLO_TICK(3)
     if constexpr (TRIM) {                                                  // (we = -x_p is identically zero; free coordinates only)
       static_for<NCOLS>([&](auto Kq) LCP_INL { constexpr int k = CLO + Kq; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 > k)); });
       static_for<NCOLS>([&](auto KR) LCP_INL { constexpr int k = CHI - 1 - KR; fnmac_bc<k>(wx, wx, keep_if(xr[k], l16 < k)); });
@@ -476,12 +491,14 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       });
     });
     }
+    SOLO_TICK(4)
     ox = (l16 < es) ? we : ((l16 < nzs) ? wx * udx : (TC)0);
     oy = (l16 < es) ? wx : (TC)0;
     const TC t = Gv(ox) - q;                                               // (cone row: G is zero there)
     const M4<TC> o4 = minv(gather4(t));
     oz = vc ? pick(o4) : (TC)0;
     os = vc ? (-rs - oz) * di : (TC)0;                                     // :347,350
+    SOLO_TICK(5)
   };
 
 #if !LCP_SOLO_RCP_STEP
@@ -522,6 +539,9 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
   };
 
 #endif
+#ifdef LCP_SOLO_PROFILE
+  tk = clock64(); pc[8] = tk - t_start;
+#endif
 #if LCP_SOLO_PEEL_INIT
   // (the initialisation pass - it = -1 - as its own copy of the loop body: LCP_Q_PEEL_INIT in lcp_quad_kernels.inc)
   auto iteration = [&](auto INIT_, const int it) LCP_INL -> bool {
@@ -557,6 +577,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
       dinv = vc ? s / z : (TC)1;                                           // 1 / d, d = z / s (:98)
 #endif
     }
+    SOLO_TICK(0)
     const bool singular = factor(dinv);                                    // (:99-100)
     if (it < 0 && singular && e > 0) status |= LCP_ST_SINGULAR_S11;
     if (it >= 0 && !done) {
@@ -569,6 +590,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         if (n_not == lim || best_resid < eps || mu > mu_limit<TC>()) done = true;   // (:133)
       }
     }
+    SOLO_TICK(6)
     if (done) LCP_SOLO_BREAK;
     if (it >= 0 && it == max_iter - 1) LCP_SOLO_BREAK;                             // (the iterate the last pass would produce is never evaluated)
     TC ax = 0, ay = 0, as_ = 0, az = 0;
@@ -621,6 +643,7 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
         x += alpha * cx; y += alpha * cy;                                     // (:171-174)
         if (vc) { s += alpha * cs; z += alpha * cz; }
       }
+      SOLO_TICK(7)
 #if LCP_SOLO_UNROLL_PASS
     };
     one_pass(std::integral_constant<int, 0>{});
@@ -666,6 +689,10 @@ __global__ void __launch_bounds__(64, LCP_SOLO_OCC) lcp_fwd_solo(StepArgs SP, in
     }
     if (l16 == 0) { if (SP.iters) SP.iters[scene] = iters; if (SP.status) SP.status[scene] = status; }
   }
+#ifdef LCP_SOLO_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && so) { TI* o = so + (size_t)scene * m + (m - 11); for (int i = 0; i < 9; ++i) o[i] = (TI)pc[i]; o[9] = (TI)iters; o[10] = (TI)(clock64() - t_start); }
+#endif
 }
 
 }  // namespace solo
