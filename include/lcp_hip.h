@@ -67,6 +67,15 @@ extern "C" {
  * lcp_pdipm_backward_f64): their workspace also keeps an fp64 copy of F. */
 #define LCP_IO_F64 0x400
 
+/* May be OR-ed into the `compute` argument of lcp_pdipm_backward_f32 / _f64 (round 6; SURVEY.md §0.5: "offer the adjoint-correct
+ * backward as an opt-in flag, never as default"): solve with K^T instead of K.  The reference's LCPFunction.backward (lcp/lcp.py:46-50)
+ * solves the KKT system itself - exact only where the LCP matrix F is symmetric, and the contact LCP's F is not (engines.py:69-73: +mu in
+ * the cone rows, +1 / -1 between friction and cone rows).  K^T is K with F^T in place of F (every other block sits symmetrically), so the
+ * transposed solve factors T^T = R^T + diag(s / z) from the R = G Q^-1 G^T - ... + F the forward left in the workspace.  Served by the
+ * generic kernels only: the forward of such a call must have run with LCP_PATH_GENERIC (any other workspace layout returns NaN gradients
+ * through the layout tag, as every mismatch does).  lcp_physics_amd.lcp.LCPFunction(adjoint_backward=True) sets both bits. */
+#define LCP_BWD_ADJOINT 0x40000
+
 #define LCP_E_BADARG   (-1)   /* null pointer / non-positive size                     */
 #define LCP_E_TOOLARGE (-2)   /* problem does not fit the kernels' LDS/workspace plan (the generic kernels keep the matrices in the
                                * workspace when 160 KB of LDS do not hold them: e.g. 32 bodies x 128 contacts in fp64 plan; the limit
@@ -375,6 +384,9 @@ int lcp_contact_frame_backward_f64(int B, int nb, int maxc,
  *   4 = lcp_primal.hip (one wave per scene) also where lcp_quad.hip would serve (A/B: small batches).
  * Both settings are thread_local: they affect the calls of the thread that made them, nobody else's. */
 void lcp_debug_set_trace(double* device_trace);
+/* LCP_BWD_ADJOINT for lcp_pdipm_backward_f64 (that entry has no `compute` word): per calling thread, like the two settings above;
+ * non-zero = the next fp64-I/O backward calls of this thread solve with K^T.  Reset it to 0 afterwards. */
+void lcp_set_backward_adjoint(int on);
 void lcp_debug_set_path(int path);
 
 #ifdef __cplusplus

@@ -22,6 +22,7 @@ PATH_PRIMAL = 0x4000
 PATH_QUAD = 0x8000
 PATH_SOLO = 0x10000
 HINT_PINNED = 0x20000
+BWD_ADJOINT = 0x40000
 
 ST_SINGULAR_Q = 1
 ST_SINGULAR_S11 = 2
@@ -63,6 +64,7 @@ SIGNATURES = {
     "lcp_state_update_backward_f64": (_I, [_I] * 3 + [_P] * 5 + [_c.c_double] + [_P] * 3 + [_P]),
     "lcp_debug_set_trace": (None, [_P]),
     "lcp_debug_set_path": (None, [_I]),
+    "lcp_set_backward_adjoint": (None, [_I]),
 }
 
 _lib = None

@@ -13,11 +13,12 @@ namespace {
 // debugging aids below are per calling thread (thread_local), and the kernel family can also be forced per call with
 // LCP_PATH_GENERIC in the `compute` word.
 thread_local double* g_trace = nullptr;   // debugging aid, see lcp_debug_set_trace
+thread_local int g_adjoint = 0;           // lcp_set_backward_adjoint: LCP_BWD_ADJOINT for the fp64-I/O backward (it has no `compute` word)
 thread_local int g_path = 0;              // this thread's DEFAULT kernel path for calls whose `compute` word names none:
                                           // 0 = automatic, 1 = generic kernels, 3 = contact-space kernels instead of the body-space ones,
                                           // 4 = one wave per scene (lcp_primal.hip) at every size (A/B aids)
 
-constexpr int FLAG_BITS = LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL | LCP_PATH_QUAD | LCP_PATH_SOLO |
+constexpr int FLAG_BITS = LCP_BWD_ADJOINT | LCP_PATH_GENERIC | LCP_HINT_ALL_CONTACT | LCP_IO_F64 | LCP_PATH_CONTACT_SPACE | LCP_PATH_PRIMAL | LCP_PATH_QUAD | LCP_PATH_SOLO |
                           LCP_HINT_PINNED;
 
 // `compute` word of an entry point -> arithmetic type and kernel path.  The path is a function of the WORD whenever the word
@@ -126,6 +127,7 @@ void lcp_debug_set_path(int path) { g_path = path; }
 // Debugging aid (not part of the drop-in surface): when set, the dense forward writes
 // trace[B, max_iter, 4] = (resid, mu, sigma, alpha) per PDIPM iteration.  Pass NULL to disable.
 void lcp_debug_set_trace(double* device_trace) { g_trace = device_trace; }
+void lcp_set_backward_adjoint(int on) { g_adjoint = on ? 1 : 0; }
 
 static int forward_common(int io_f64, int B, int nz, int m, int e, const void* Q, const void* p, const void* G,
                           const void* h, const void* A, const void* b, const void* F, double eps, int max_iter,
@@ -201,6 +203,8 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   if (e > 0 && !A) return LCP_E_BADARG;
   const int hint = compute & LCP_HINT_ALL_CONTACT;
   const bool pinned = (compute & LCP_HINT_PINNED) != 0;      // (the forward's word: its promise holds for the backward too)
+  const bool adjoint = (compute & LCP_BWD_ADJOINT) != 0 || (io_f64 && g_adjoint);   // opt-in: solve with K^T (generic kernels; the forward ran with LCP_PATH_GENERIC)
+  if (adjoint) { if (hint) return LCP_E_BADARG; compute |= LCP_PATH_GENERIC; }
   bool generic;
   int path;
   compute = split_compute(compute, &generic, &path);
@@ -219,6 +223,8 @@ static int backward_common(int io_f64, int B, int nz, int m, int e, const void* 
   P.B = B; P.nz = nz; P.m = m; P.e = e; P.G = G; P.A = A; P.dl_dx = dl_dx;
   P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db; P.dF = dF;
   P.ws = ws; P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  P.adjoint = adjoint ? 1 : 0;
+  if (adjoint && !pl.ok) return LCP_E_TOOLARGE;
   if (hint) {
     // LCP_HINT_ALL_CONTACT: the workspace was left by a contact-list forward (lcp_step_fused_f32 / lcp_solve_dynamics_f32) called with
     // this `compute` word.  Three of its kernel families keep a workspace a dense backward can read - the four-scenes-per-wave one

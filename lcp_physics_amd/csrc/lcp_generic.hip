@@ -230,13 +230,14 @@ __device__ int prefactor(Scene<TC>& S, const FT& F) {
 // factor_kkt (pdipm.py:414-454): T = R + diag(1/d) = R + diag(s/z); LU in place.
 // Returns non-zero when an exact zero pivot was met (bit 0: the reference's `except` path, :99-102) or - backward only, `tiny` > 0 - a
 // pivot below `tiny` (bit 1: what is left of it is rounding noise; see lcp_bwd_kernel).
+// `transposed`: T^T = R^T + diag(s/z) - the opt-in adjoint backward (LCP_BWD_ADJOINT): K^T is K with F^T for F, and R = (symmetric) + F
 template <typename TC, bool PIVOT>
-__device__ int factor_T(Scene<TC>& S, const TC* dinv, TC tiny = (TC)0) {
+__device__ int factor_T(Scene<TC>& S, const TC* dinv, TC tiny = (TC)0, bool transposed = false) {
   const int m = S.m, ld = S.ldT, tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   for (int idx = tid; idx < m * m; idx += NT) {
     const int i = idx / m, j = idx - i * m;
-    TC val = S.R[idx];
+    TC val = transposed ? S.R[(size_t)j * m + i] : S.R[idx];
     if (i == j) val += dinv[i];
     S.T[(size_t)i * ld + j] = val;
   }
@@ -814,13 +815,14 @@ __global__ void __launch_bounds__(NT) lcp_bwd_kernel(BwdArgs P) {
   __syncthreads();
   const TC rmax = S.cs[0];
   __syncthreads();
-  if (factor_T<TC, PIVOT>(S, S.rs, (TC)1e-13 * rmax)) {                    // lcp.py:46
+  const bool adj = P.adjoint != 0;
+  if (factor_T<TC, PIVOT>(S, S.rs, (TC)1e-13 * rmax, adj)) {               // lcp.py:46
     for (int i = tid; i < m; i += NT) {
       const TC f = (TC)1e-12 * S.R[(size_t)i * m + i];
       if (S.rs[i] < f) { S.rs[i] = f; S.d[i] = (TC)1 / f; }
     }
     __syncthreads();
-    factor_T<TC, PIVOT>(S, S.rs);
+    factor_T<TC, PIVOT>(S, S.rs, (TC)0, adj);
   }
   solve_kkt<TC, PIVOT>(S, S.rx, (const TC*)nullptr, (const TC*)nullptr, (const TC*)nullptr,
                        S.cx, S.cs, S.cz, S.cy);                           // lcp.py:47-50

@@ -45,6 +45,7 @@ struct BwdArgs {
   int tag_value;       // laid out by another kernel family) returns NaN gradients instead of reading it
   int skip_tag;        // 0, or the tag of the OTHER kernel family the forward may have fallen back on (wave64 step -> generic step
                        // when contact counts are given): a backward that finds it leaves without writing, its partner serves the call
+  int adjoint;         // LCP_BWD_ADJOINT (generic kernels): factor T^T - the solve with K^T instead of the reference's K
   int split;           // lcp_bwd_quad<..., BODY> (round 6): 1 = leave dG and dF to lcp_bwd_stream_quad - the solve kernel hands (x, dx, lam, dlam)
                        // over in the scene's workspace block and writes the small gradients only
 };

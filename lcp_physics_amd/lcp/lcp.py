@@ -105,8 +105,10 @@ def _bwd_key(sol, dl_dx, out):
             bool(getattr(sol, "all_contact", False)), tuple(0 if o is None else o.data_ptr() for o in out))
 
 
-def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
+def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None, adjoint=False):
     """Implicit-differentiation backward for a previous `lcp_solve` (lcp.py:37-64).
+    `adjoint=True` (opt-in, never the parity target - SURVEY 0.5): solve with K^T instead of the reference's K - the exact gradient also where
+    the LCP matrix F is not symmetric (LCP_BWD_ADJOINT; generic kernels: `sol` must come from `lcp_solve(..., path="generic")`).
     Returns [dQ, dp, dG, dh, dA, db, dF] (None where not needed / no equalities).  Called again with the `out` it returned and
     the same tensors it re-uses the validated argument list (one ctypes call; keyed on every pointer it holds).  With `out`
     given, `out` decides which gradients are written (its None entries are skipped); `need` only shapes a NEW `out`."""
@@ -116,8 +118,10 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
     plan = getattr(sol, "_bwd_plan", None)
     # the cached argument list holds raw pointers: it is valid only while EVERY tensor behind it is the same - the cotangent, G, A,
     # the workspace and each gradient tensor of `out` (an entry the caller replaced gets a fresh list, not a write to the old tensor)
+    if adjoint and not (sol.compute & _lib.PATH_GENERIC):
+        raise ValueError("lcp_backward(adjoint=True) needs a solution of lcp_solve(..., path='generic')")
     if (plan is not None and out is not None and plan[0] is out and dl_dx.dtype == dtype and dl_dx.is_contiguous()
-            and plan[1] == _bwd_key(sol, dl_dx, out)):
+            and plan[1] == _bwd_key(sol, dl_dx, out) and not adjoint):
         from ..physics.batched_world import _on_device
         with _on_device(dev):
             rc = plan[2](*plan[3], _lib.stream_ptr(dev))
@@ -133,13 +137,18 @@ def lcp_backward(sol, dl_dx, need=(True,) * 7, out=None):
     with torch.cuda.device(dev):
         if dtype == torch.float64:
             with _lib.thread_path(sol.compute):
-                rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
-                                                *[P(o) for o in out], P(sol.ws), st)
+                lib.lcp_set_backward_adjoint(1 if adjoint else 0)
+                try:
+                    rc = lib.lcp_pdipm_backward_f64(B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx),
+                                                    *[P(o) for o in out], P(sol.ws), st)
+                finally:
+                    lib.lcp_set_backward_adjoint(0)
         else:
             hint = _lib.HINT_ALL_CONTACT if getattr(sol, "all_contact", False) else 0
-            args = (B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint, *[P(o) for o in out], P(sol.ws))
+            args = (B, nz, m, e, P(sol.G), P(sol.A), P(dl_dx), sol.compute | hint | (_lib.BWD_ADJOINT if adjoint else 0), *[P(o) for o in out], P(sol.ws))
             rc = lib.lcp_pdipm_backward_f32(*args, st)
-            sol._bwd_plan = (out, _bwd_key(sol, dl_dx, out), lib.lcp_pdipm_backward_f32, args)
+            if not adjoint:
+                sol._bwd_plan = (out, _bwd_key(sol, dl_dx, out), lib.lcp_pdipm_backward_f32, args)
     _lib.check(rc, "lcp_pdipm_backward")
     return out
 
@@ -175,6 +184,7 @@ class _LCPFn(torch.autograd.Function):
         import copy
         ctx.sol = copy.copy(sol)
         ctx.sol.x = None
+        ctx.sol.adjoint_backward = holder.adjoint_backward
         ctx.meta = [(t.device, t.dtype, tuple(t.shape)) for t in ins]
         ctx.neq = neq
         return back(sol.x)
@@ -184,7 +194,7 @@ class _LCPFn(torch.autograd.Function):
         sol = ctx.sol
         need = list(ctx.needs_input_grad[:7])
         g = dl_dzhat.to(device=sol.G.device, dtype=sol.dtype).contiguous()
-        grads = lcp_backward(sol, g, need=need)
+        grads = lcp_backward(sol, g, need=need, adjoint=getattr(sol, "adjoint_backward", False))
         out = []
         for i, (gr, (dev, dt, shape)) in enumerate(zip(grads, ctx.meta)):
             if gr is None or not need[i]:
@@ -207,8 +217,12 @@ class LCPFunction:
     body-space factorisation of contact-structured scenes).
     """
 
-    def __init__(self, eps=1e-12, verbose=-1, not_improved_lim=3, max_iter=10, compute="f64", check=True, path="auto"):
-        self.path = path
+    def __init__(self, eps=1e-12, verbose=-1, not_improved_lim=3, max_iter=10, compute="f64", check=True, path="auto",
+                 adjoint_backward=False):
+        # adjoint_backward (not in the reference, opt-in): the backward solves with K^T - the exact gradient where F is not symmetric; the
+        # reference's own formula (lcp.py:46-50, K itself) stays the default and the parity target.  Generic kernels (LCP_PATH_GENERIC).
+        self.adjoint_backward = bool(adjoint_backward)
+        self.path = "generic" if adjoint_backward else path
         self.eps = eps
         self.verbose = verbose
         self.not_improved_lim = not_improved_lim

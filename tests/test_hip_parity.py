@@ -808,3 +808,42 @@ def test_dense_boundary_speed_at_config5_sizes(kernel_path):
     rate = B / (e0.elapsed_time(e1) * 1e-3)
     print("dense config-5 forward: %.0f sim steps/s" % rate)
     assert rate > 1e5, rate
+
+
+def test_opt_in_adjoint_backward_matches_finite_differences_where_the_references_formula_does_not():
+    """`LCP_BWD_ADJOINT` / `LCPFunction(adjoint_backward=True)` (VERDICT r05 missing 6): the backward solves with K^T.  On a
+    contact LCP - F is not symmetric (engines.py:69-73) - and converged solves (max_iter 30) the gradient d(c . x)/dp of the adjoint
+    form agrees with central finite differences of the forward and with the oracle's `adjoint=True`; the reference's own formula
+    (lcp.py:46-50: K, the default and the parity target) is measurably off on the same scenes - that is its documented defect, reproduced."""
+    from lcp_physics_amd import scenes
+    from lcp_physics_amd.lcp import lcp_backward, lcp_solve
+    from lcp_physics_amd.physics import assemble_contacts
+    B = 16
+    sc = scenes.make_stack_scenes(B=B, nbox=2, pts_per_interface=1, seed=77, dtype=torch.float64)     # one point per interface: unique multipliers
+    lcp = [None if t is None else t.double() for t in assemble_contacts(sc.to(device=DEV, dtype=torch.float32))]
+    Q, p, G, h, A, b, F = lcp
+    assert float((F - F.transpose(1, 2)).abs().max()) > 0.1                                           # F is not symmetric
+    cot = torch.randn(B, Q.shape[1], generator=torch.Generator().manual_seed(5), dtype=torch.float64).to(DEV)
+    kw = dict(max_iter=30, path="generic")
+    sol = lcp_solve(Q, p, G, h, A, b, F, **kw)
+    g_adj = lcp_backward(sol, cot, adjoint=True)[1].cpu()
+    g_ref = lcp_backward(sol, cot)[1].cpu()
+    # central differences of L = cot . x(p)
+    fd = torch.zeros(B, Q.shape[1], dtype=torch.float64)
+    eps = 1e-6
+    for j in range(Q.shape[1]):
+        dp_ = torch.zeros_like(p); dp_[:, j] = eps
+        xp = lcp_solve(Q, p + dp_, G, h, A, b, F, **kw).x
+        xm = lcp_solve(Q, p - dp_, G, h, A, b, F, **kw).x
+        fd[:, j] = (((xp - xm) * cot).sum(1) / (2 * eps)).cpu()
+    scale = fd.abs().max(dim=1)[0].clamp_min(1e-12)
+    e_adj = ((g_adj - fd).abs().max(dim=1)[0] / scale)
+    e_ref = ((g_ref - fd).abs().max(dim=1)[0] / scale)
+    # the oracle's transposed solve on the same LCPs
+    l64 = [None if t is None else t.cpu() for t in lcp]
+    ro = O.lcp_forward(*l64, max_iter=30)
+    go = O.lcp_backward(ro, *l64, cot.cpu(), adjoint=True)["dp"]
+    e_orc = ((g_adj - go).abs().max(dim=1)[0] / scale)
+    print("adjoint vs FD %.2e   reference formula vs FD %.2e   adjoint vs oracle adjoint %.2e" % (float(e_adj.max()), float(e_ref.max()), float(e_orc.max())))
+    assert float(e_adj.median()) <= 1e-4 and float(e_orc.median()) <= 1e-6, (e_adj.tolist(), e_orc.tolist())
+    assert float(e_ref.max()) > 10 * float(e_adj.median())                                            # the reference's K-solve is NOT the gradient here
