@@ -444,6 +444,8 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
           const int row = 16 * gI(A_) + lo;
           double av = L.add[(row < NCB) ? row : 2 * LX + row - NCB];
           av = dgl ? av : 0.0;
+          // (backward: W's own diagonal entry of the row is kept - the scale a pivot is held against afterwards; prow is free in the blocked LU)
+          if constexpr (BWD) static_for<4>([&](auto R_) LCP_INL { if (dgl && rd == R_) L.prow[row] = acc[A_][A_][(int)R_]; });
           static_for<4>([&](auto R_) LCP_INL { acc[A_][A_][(int)R_] += (rd == R_) ? av : 0.0; });
         });
         static_for<2>([&](auto Q_) LCP_INL {
@@ -834,6 +836,31 @@ __global__ void __launch_bounds__(Grid<NCB>::NT, NCB == 16 ? 4 : 1) lcp_big_kern
     __syncthreads();
     factor();                                                               // lcp.py:46
     __syncthreads();
+    if constexpr (MF) {
+      // Round 6: the guard the other three backward families got in round 5.  At an iterate that converged to rounding
+      // s / z of the active rows is lost against a W that redundant contact points make singular: a pivot that cancelled to less than
+      // 1e-13 of its row's diagonal of W (or an exact zero) is rounding noise, the elimination would return multipliers of 1e15 - the
+      // factorisation is repeated with s / z floored at 1e-12 x that diagonal (factor_bwd_q of lcp_quad_kernels.inc, same constants).
+      bool tiny = false;
+      double wa = 0, wu = 0;
+      if (w0 && vc) {
+        wa = L.prow[lc]; wu = L.prow[NCB + lc];
+        wa = wa < 0 ? -wa : wa; wu = wu < 0 ? -wu : wu;
+        double pa = 1.0 / L.dU[lc], pu = 1.0 / L.dU[NCB + lc];
+        pa = pa < 0 ? -pa : pa; pu = pu < 0 ? -pu : pu;
+        tiny = !(pa >= 1e-13 * wa) || !(pu >= 1e-13 * wu);
+      }
+      const bool again = __syncthreads_or((tiny || (w0 && L.flag[0] != 0)) ? 1 : 0) != 0;
+      if (again) {
+        if (w0) {
+          if (vc) { dinv.n = __builtin_fmax(dinv.n, 1e-12 * wa); dinv.f1 = __builtin_fmax(dinv.f1, 1e-12 * wu); dinv.f2 = __builtin_fmax(dinv.f2, 1e-12 * wu); }
+          reduce_setup(dinv);
+        }
+        __syncthreads();
+        factor();
+        __syncthreads();
+      }
+    }
     if constexpr (DENSE) {
       // ---- LCPFunction.backward (lcp.py:37-64): one KKT solve with rhs (dl_dx, 0, 0, 0), then the outer products ----------------
       double* V = L.LU;                                                     // staging area (the factors are dead after the solve)
