@@ -195,9 +195,11 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  *        (any may be NULL; padded contact slots get 0).  The joint Jacobian Je is treated as a constant here: see
  *        lcp_step_backward_je_f32 for its gradient.
  * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
- * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout - lcp_step_fused_f32
- * serves those sizes from the generic kernels, whose workspace this entry cannot read); 5 <= e <= 24 equality rows (chains
- * of joints) with nc <= 64 and 3 nb + e <= 56 (fp64 arithmetic) after either forward; else LCP_E_TOOLARGE. */
+ * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout); 5 <= e <= 24 equality rows
+ * (chains of joints) with nc <= 64 and 3 nb + e <= 56 (fp64 arithmetic) after either forward; (round 6) every other size the generic
+ * kernels step forward - more than 64 contacts, 3 nb + e > 56, fp32 arithmetic beyond 16 contacts: lcp_step_bwd_kernel on the iterate
+ * lcp_step_kernel leaves, each scene at its own contact count - after either forward, in either arithmetic.  LCP_E_TOOLARGE only for
+ * the wave64 step family (fp32 arithmetic, 3 nb <= 16, 5 <= e <= 8: its kernel keeps no iterate) and beyond the generic plan. */
 int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           const float* Mdiag, const float* v, const float* f,
                           const float* rest, const float* fric,
@@ -208,10 +210,10 @@ int lcp_step_backward_f32(int B, int nb, int nc, int e,
                           float* dc_n, float* dc_p1, float* dc_p2, void* ws, void* stream);
 
 /* Host-only: 1 when lcp_step_backward_f32 / _je_f32 can follow a contact-list forward (lcp_step_fused_f32,
- * lcp_solve_dynamics_f32) called with these sizes and this `compute` word - the kernel families that keep the iterate in the
- * workspace (<= 64 contacts, 3 nb + e <= 56, fp64 arithmetic; the four-scenes-per-wave sizes in either arithmetic) -, else 0:
- * the generic kernels step such scenes forward only, and the backward entry points return LCP_E_TOOLARGE for them.  The
- * reference differentiates any size through LCPFunction.backward (lcp/lcp.py:37-64): use the dense boundary there. */
+ * lcp_solve_dynamics_f32) called with these sizes and this `compute` word - since round 6 every size the forward itself accepts
+ * except the wave64 step family (fp32 arithmetic, 3 nb <= 16, 5 <= e <= 8) -, else 0: the backward entry points return
+ * LCP_E_TOOLARGE there.  The reference differentiates any size through LCPFunction.backward (lcp/lcp.py:37-64): the dense boundary
+ * (lcp_physics_amd/physics/dense_step.py) is what the host falls back on for a 0. */
 int lcp_step_has_backward(int nb, int maxc, int e, int compute);
 
 /* The same with the gradient of the joint Jacobian as a ninth output: dJe[B,e,3 nb] = dnu (x) x + nu (x) dx (lcp.py:57, A = Je
@@ -236,8 +238,9 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e,
  * lcp_step_backward_f32 (padded slots get zero gradients) and, for 3 nb <= 16, lcp_pdipm_backward_f32 (m = 4 maxc).
  * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 24 (chains of joints: two rows per revolute joint), or 3 nb <= 43,
  * e <= 4 - run (fp64 arithmetic) on the wave-per-scene body-space kernel (BASELINE config 5) or the workgroup-per-scene
- * contact-space kernel, and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs forward
- * only on the generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan).
+ * contact-space kernel, and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs on the
+ * generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan), which keep each scene's iterate and its contact count for
+ * lcp_step_backward_f32 as well (round 6).
  *   out: v_new[B,nb,3]  z[B,4 maxc]  s[B,4 maxc]  y[B,e]  iters[B]  status[B] */
 int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_count,
                            const float* Mdiag, const float* v, const float* f,
@@ -272,8 +275,9 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
 /* Backward of lcp_post_stabilization_f32 with respect to its physical inputs - what the reference obtains by autograd
  * through PdipmEngine.post_stabilization (engines.py:80-116: ge = Je v, gc = Jc v + Jc v * -restitutions, the LCPFunction
  * call and its backward lcp.py:37-64, dp = -x) when a World with post_stab=True is differentiated (experiments/inference.py).
- * Must follow the forward on the same stream with the same workspace and unchanged inputs; the forward must have run on the
- * body-space kernel (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56: otherwise LCP_E_TOOLARGE).
+ * Must follow the forward on the same stream with the same workspace and unchanged inputs.  Body-space kernel where the forward
+ * ran there (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56), else (round 6) the generic kernels on the iterate
+ * lcp_post_stab_kernel keeps - any size of their plan, either arithmetic; LCP_E_TOOLARGE beyond it.
  *   in : the forward's inputs, dl_ddp[B,nb,3] = d(loss)/d(dp)
  *   out: dMdiag[B,nb,3] dv[B,nb,3] drest[B,nb] dc_n[B,maxc,2] dc_p1[B,maxc,2] dc_p2[B,maxc,2] dJe[B,e,3nb]
  *        (any may be NULL; padded contact slots get 0) */
@@ -287,8 +291,8 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e,
                                         void* ws, void* stream);
 
 /* Host-only: 1 when lcp_post_stabilization_backward_f32 can follow lcp_post_stabilization_f32 at these sizes and this `compute`
- * word, else 0 (the host then differentiates the correction through the dense boundary, the way engines.py:80-116 itself does:
- * lcp_physics_amd/physics/dense_step.py). */
+ * word - every size the forward accepts, since round 6 -, else 0 (the host would then differentiate the correction through the dense
+ * boundary, the way engines.py:80-116 itself does: lcp_physics_amd/physics/dense_step.py). */
 int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute);
 
 /* Replaces the position update of World.step_dt (physics/world.py:88-101,122) together with the

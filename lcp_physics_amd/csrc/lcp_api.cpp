@@ -367,7 +367,14 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e, const float* Mdiag, c
     case FAM_QUAD: return lcp::quad_step_backward(P, G, compute, stream, path != 3, pinned);
     case FAM_PRIMAL: return lcp::primal_step_backward(P, G, stream, pinned);
     case FAM_BIG: return lcp::big_step_backward(P, G, stream);
-    default: return LCP_E_TOOLARGE;          // the wave64 / generic step kernels keep no workspace this backward can read
+    case FAM_GENERIC: {                      // (round 6) any size the generic plan holds: lcp_step_bwd_kernel on the iterate lcp_step_kernel kept
+      const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+      lcp::Plan pl = lcp::make_plan(3 * nb, 4 * nc, e, cs);
+      if (!pl.ok) return LCP_E_TOOLARGE;
+      P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+      return lcp::generic_step_backward(P, G, compute, pl.lds_bytes, stream);
+    }
+    default: return LCP_E_TOOLARGE;          // the wave64 step kernel keeps no workspace this backward can read
   }
 }
 
@@ -378,6 +385,7 @@ int lcp_step_has_backward(int nb, int maxc, int e, int compute) {
   compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return 0;
   const StepFamily fam = step_family(3 * nb, 4 * maxc, e, compute, path);
+  if (fam == FAM_GENERIC) return lcp::make_plan(3 * nb, 4 * maxc, e, (compute == LCP_COMPUTE_F64) ? 8 : 4).ok ? 1 : 0;
   return (fam == FAM_QUAD || fam == FAM_PRIMAL || fam == FAM_BIG) ? 1 : 0;
 }
 
@@ -465,8 +473,10 @@ int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute) {
   bool generic;
   int path;
   compute = split_compute(compute, &generic, &path);
-  // (the routing test of lcp_post_stabilization_backward_f32 below)
-  return (compute == LCP_COMPUTE_F64 && (path == 0 || path == 4) && lcp::primal_supported(3 * nb, 4 * maxc, e)) ? 1 : 0;
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return 0;
+  // (the routing test of lcp_post_stabilization_backward_f32 below: body space where the forward ran there, else the generic kernels)
+  if (compute == LCP_COMPUTE_F64 && (path == 0 || path == 4) && lcp::primal_supported(3 * nb, 4 * maxc, e)) return 1;
+  return lcp::make_plan(3 * nb, 4 * maxc, e, (compute == LCP_COMPUTE_F64) ? 8 : 4).ok ? 1 : 0;
 }
 
 int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const float* Mdiag, const float* v,
@@ -477,20 +487,26 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const fl
   bool generic;
   int path;
   compute = split_compute(compute, &generic, &path);
-  if (compute != LCP_COMPUTE_F64) return (compute == LCP_COMPUTE_F32) ? LCP_E_TOOLARGE : LCP_E_BADARG;
+  if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return LCP_E_BADARG;
   lcp::StepArgs P;
   int rc = fill_step(P, B, nb, maxc, e, nullptr, Mdiag, v, /*f*/ v, rest, /*fric*/ rest, c_n, c_p1, c_p2, c_i1, c_i2, Je, 0.0f);
   if (rc) return rc;
   if (!dl_ddp || !ws) return LCP_E_BADARG;
-  // only the body-space kernel keeps the iterate this backward reads (the same routing test as the forward)
-  if ((path != 0 && path != 4) || !lcp::primal_supported(3 * nb, 4 * maxc, e)) return LCP_E_TOOLARGE;
+  // the same routing test as the forward: the body-space kernels where they ran, lcp_step_bwd_kernel<.., POST> on the iterate
+  // lcp_post_stab_kernel kept otherwise (round 6: any size of the generic plan, fp32 arithmetic included)
+  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_supported(3 * nb, 4 * maxc, e);
   P.ws = ws;
   P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * maxc, e, compute, 0));
-  P.tag_value = TAG_POSTSTAB_PRIMAL;
+  P.tag_value = body ? TAG_POSTSTAB_PRIMAL : TAG_POSTSTAB_GENERIC;
   lcp::StepBwdArgs G = {};
   G.dl_dv = dl_ddp; G.dMdiag = dMdiag; G.dv = dv; G.drest = drest; G.dcn = dc_n; G.dcp1 = dc_p1; G.dcp2 = dc_p2;
   G.dJe = (e > 0) ? dJe : nullptr;
-  return lcp::primal_post_stab_backward(P, G, stream);
+  if (body) return lcp::primal_post_stab_backward(P, G, stream);
+  const int cs = (compute == LCP_COMPUTE_F64) ? 8 : 4;
+  lcp::Plan pl = lcp::make_plan(3 * nb, 4 * maxc, e, cs);
+  if (!pl.ok) return LCP_E_TOOLARGE;
+  P.ws_stride = pl.ws_stride; P.ldT = pl.ldT; P.t_in_lds = pl.t_in_lds;
+  return lcp::generic_post_stab_backward(P, G, compute, pl.lds_bytes, stream);
 }
 
 int lcp_move_find_contacts_f64(int B, int nb, int maxc, const int32_t* kind, const double* radius,

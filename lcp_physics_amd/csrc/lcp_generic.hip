@@ -596,6 +596,7 @@ __host__ __device__ inline size_t ws_elems(int nz, int m, int e, int ldT, int le
   size_t n = (size_t)m * m + (size_t)nz * nz + (size_t)m * e + (size_t)e * e + nz + 2 * (size_t)m + e;
   if (level != 1) n += (size_t)m * ldT + (size_t)m * nz;   // T and the prefactor scratch
   if (level == 2) n += 2 * (size_t)nz * nz + (size_t)m * nz;   // Q, Q^-1, G
+  n += 1;                                                       // the LAST element of a block: the live contact count of a contact-list forward (lcp_step_kernel -> lcp_step_bwd_kernel)
   return (n + 31) & ~(size_t)31;
 }
 
@@ -675,6 +676,9 @@ __global__ void __launch_bounds__(NT) lcp_post_stab_kernel(StepArgs P) {
   int iters = 0;
   pdipm_loop<TC, PIVOT>(S, F, (TC)P.eps, P.max_iter, P.lim, iters, status, nullptr);   // (m == 0: the direct KKT solve, :92-103)
   __syncthreads();
+  // (round 6) the iterate of the ncs-row LCP and the contact count stay in the workspace for lcp_step_bwd_kernel<.., POST>
+  if (threadIdx.x == 0) (reinterpret_cast<TC*>(P.ws) + P.ws_stride * (size_t)scene)[P.ws_stride - 1] = (TC)ncs;
+  store_solution<TI, TC>(S, W, (TI*)nullptr, (TI*)nullptr, (TI*)nullptr, (TI*)nullptr, status);
   int bad = 0;
   TI* dpo = (TI*)P.v_new + (size_t)scene * nz;
   for (int j = threadIdx.x; j < nz; j += NT) {
@@ -716,12 +720,15 @@ __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   TI* z = P.z ? (TI*)P.z + (size_t)scene * mcap : nullptr;
   TI* s = P.s ? (TI*)P.s + (size_t)scene * mcap : nullptr;
   TI* y = (e > 0 && P.y) ? (TI*)P.y + (size_t)scene * e : nullptr;
+  if (threadIdx.x == 0) (reinterpret_cast<TC*>(P.ws) + P.ws_stride * (size_t)scene)[P.ws_stride - 1] = (TC)ncs;   // (for lcp_step_bwd_kernel)
   if (ncs == ncap) {
     store_solution<TI, TC>(S, W, (TI*)nullptr, y, z, s, status);
   } else {
     // fewer contacts than the capacity: the multipliers go to the row layout of a capacity-sized LCP
-    // ([normal | friction pairs | gamma] blocks of ncap, 2 ncap, ncap rows), padded slots are 0; the workspace is not
-    // laid out for a backward in this case
+    // ([normal | friction pairs | gamma] blocks of ncap, 2 ncap, ncap rows), padded slots are 0.  The workspace keeps the iterate of the
+    // 4 ncs-row LCP that was solved (round 6: lcp_step_bwd_kernel reads it; the dense backward of lcp_pdipm_backward_f32 still wants a
+    // capacity-sized one and finds none here)
+    store_solution<TI, TC>(S, W, (TI*)nullptr, (TI*)nullptr, (TI*)nullptr, (TI*)nullptr, status);
     __syncthreads();
     int bad = 0;
     for (int i = threadIdx.x; i < mcap; i += NT) { if (z) z[i] = (TI)0; if (s) s[i] = (TI)0; }
@@ -746,6 +753,144 @@ __global__ void __launch_bounds__(NT) lcp_step_kernel(StepArgs P) {
   if (threadIdx.x == 0) {
     if (P.iters) P.iters[scene] = iters;
     if (P.status) P.status[scene] = status;
+  }
+}
+
+// Backward of the fused step w.r.t. its PHYSICAL inputs for any size the generic plan holds (round 6, VERDICT r05 item 7: the reference has no
+// size limit - world.py:139-142 - and a recorded step beyond the fused kernels used to leave the device path for torch: dense tensors, one
+// host synchronisation per step, torch.linalg.solve).  LCPFunction.backward (lcp.py:37-64) at the iterate lcp_step_kernel kept - the
+// 4 ncs-row LCP of the scene's own contact count, T = R + diag(s / z) factored with partial pivoting as there - and the rank-1 gradients
+// contracted through the assembly (engines.py:31-32,50-74; world.py:144-234) as lcp_primal_step.inc does: dp = dx, dQ_jj = dx_j x_j,
+// dG_row = dlam_row x + lam_row dx, dh = -dlam, dF[gamma_c, n_c] = -dlam_gamma lam_n, dA = dnu (x) x + nu (x) dx.
+// POST: the backward of lcp_post_stab_kernel (engines.py:80-116: ncs rows, G = Jc, p = 0, F = 0, h = (Jc v)(1 - rbar), b = Je v; dp = -x)
+// with respect to Mdiag, v, rest, the contact frame and Je - lcp_post_stabilization_backward_f32 beyond the one-wave sizes.
+template <typename TI, typename TC, bool PIVOT, bool POST = false>
+__global__ void __launch_bounds__(NT) lcp_step_bwd_kernel(StepArgs P, StepBwdArgs Gd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int scene = blockIdx.x, tid = threadIdx.x;
+  const int nb = P.nb, ncap = P.nc, mcap = 4 * ncap, nz = 3 * nb, e = P.e;
+  const TC* blk = reinterpret_cast<const TC*>(P.ws) + P.ws_stride * (size_t)scene;
+  int ncs = (int)blk[P.ws_stride - 1];
+  ncs = ncs < 0 ? 0 : (ncs > ncap ? ncap : ncs);
+  const int m = POST ? ncs : 4 * ncs;
+  WsView<TC> W(P.ws, P.ws_stride, scene, nz, mcap, e);
+  Scene<TC> S;
+  carve(S, smem, nz, m, e, P.ldT, P.t_in_lds, W.T);
+  S.R = W.R;
+  assemble_scene<TI, TC, POST>(S, P, scene, ncs);                          // G, A, Q, mu_c as the forward formed them
+  for (int i = tid; i < nz * nz; i += NT) S.Qi[i] = W.Qi[i];
+  for (int i = tid; i < m * e; i += NT) S.GA[i] = W.GA[i];
+  for (int i = tid; i < e * e; i += NT) S.S11i[i] = W.S11i[i];
+  for (int a = tid; a < e; a += NT) S.y[a] = W.y[a];
+  const TI* g = (const TI*)Gd.dl_dv + (size_t)scene * nz;
+  const bool tag_ok = !P.tag || *P.tag == P.tag_value;                     // (another family's workspace: NaN gradients instead of a misread)
+  // v_new = -x (engines.py:76-77)  =>  d(loss)/dx = -d(loss)/d(v_new)
+  for (int j = tid; j < nz; j += NT) { S.x[j] = W.x[j]; S.rx[j] = tag_ok ? -(TC)g[j] : nan_of<TC>(); }
+  for (int i = tid; i < m; i += NT) {
+    const TC zz = W.z[i], ss = W.s[i];
+    S.z[i] = zz; S.s[i] = ss;
+    const TC dd = zz / ss;                                                 // lcp.py:44
+    S.d[i] = dd; S.rs[i] = (TC)1 / dd;
+  }
+  if (tid == 0) {                                                          // (the noise-pivot guard of lcp_bwd_kernel)
+    TC mx = 0;
+    for (int i = 0; i < m; ++i) { TC a = S.R[(size_t)i * m + i]; a = a < 0 ? -a : a; mx = a > mx ? a : mx; }
+    S.cs[0] = mx;
+  }
+  __syncthreads();
+  const TC rmax = S.cs[0];
+  __syncthreads();
+  if (m > 0 && factor_T<TC, PIVOT>(S, S.rs, (TC)1e-13 * rmax)) {           // lcp.py:46
+    for (int i = tid; i < m; i += NT) {
+      const TC f = (TC)1e-12 * S.R[(size_t)i * m + i];
+      if (S.rs[i] < f) { S.rs[i] = f; S.d[i] = (TC)1 / f; }
+    }
+    __syncthreads();
+    factor_T<TC, PIVOT>(S, S.rs);
+  }
+  solve_kkt<TC, PIVOT>(S, S.rx, (const TC*)nullptr, (const TC*)nullptr, (const TC*)nullptr, S.cx, S.cs, S.cz, S.cy);   // lcp.py:47-50: dx = cx, dlam = cz, dnu = cy
+  __syncthreads();
+  // ---- contraction through the assembly ---------------------------------------------------------------------------------------------
+  const TI* Md = (const TI*)P.Mdiag + (size_t)scene * nz;
+  const TI* vv = (const TI*)P.v + (size_t)scene * nz;
+  const TI* rest = (const TI*)P.rest + (size_t)scene * nb;
+  const TI* cn = (const TI*)P.c_n + (size_t)scene * ncap * 2;
+  const TI* c1 = (const TI*)P.c_p1 + (size_t)scene * ncap * 2;
+  const TI* c2 = (const TI*)P.c_p2 + (size_t)scene * ncap * 2;
+  const int32_t* i1 = P.c_i1 + (size_t)scene * ncap;
+  const int32_t* i2 = P.c_i2 + (size_t)scene * ncap;
+  TC* CR = S.hz;                                                           // per contact: its share of d(loss)/d(restitution), d(loss)/d(friction),
+  TC* CF = S.rz;                                                           // and dh_c rbar_c (the weight of Jc^T in d(loss)/dv) - m-space scratch, free now
+  TC* GH = S.rs;
+  for (int c = tid; c < ncs; c += NT) {
+    const TC nx = (TC)cn[2 * c], ny = (TC)cn[2 * c + 1];
+    const TC p1x = (TC)c1[2 * c], p1y = (TC)c1[2 * c + 1], p2x = (TC)c2[2 * c], p2y = (TC)c2[2 * c + 1];
+    const int b1 = i1[c], b2 = i2[c];
+    const TC rbar = (TC)0.5 * ((TC)rest[b1] + (TC)rest[b2]);
+    const TC jnd[6] = {p1x * ny - p1y * nx, nx, ny, -(p2x * ny - p2y * nx), -nx, -ny};      // world.py:177-183
+    const TC zn = S.z[c], dn = S.cz[c];
+    TC zf1 = 0, zf2 = 0, df1 = 0, df2 = 0, dg = 0;
+    if (!POST) { zf1 = S.z[ncs + 2 * c]; zf2 = S.z[ncs + 2 * c + 1]; df1 = S.cz[ncs + 2 * c]; df2 = S.cz[ncs + 2 * c + 1]; dg = S.cz[3 * ncs + c]; }
+    const TC gh = -dn;                                                     // dh = -dlam (lcp.py:56)
+    const TC af = df1 - df2, lf = zf1 - zf2;                               // Jf rows are +jt, -jt (world.py:191-192)
+    const TC hw = POST ? gh * ((TC)1 - rbar) : gh * rbar;                  // h = (Jc v) rbar | POST: (Jc v) + (Jc v) * -rbar (engines.py:89)
+    TC gjn[6], gjf[6], jnv = 0;
+    for (int q = 0; q < 6; ++q) {
+      const int col = (q < 3) ? 3 * b1 + q : 3 * b2 + (q - 3);
+      const TC xq = S.x[col], dxq = S.cx[col], vq = (TC)vv[col];
+      jnv += jnd[q] * vq;
+      gjn[q] = dn * xq + zn * dxq + hw * vq;                               // dG row n (lcp.py:53) + h through Jc
+      gjf[q] = af * xq + lf * dxq;
+    }
+    GH[c] = hw;
+    CR[c] = (TC)0.5 * (POST ? -gh * jnv : gh * jnv);                       // rbar = (rest_b1 + rest_b2) / 2 (world.py:144-151)
+    CF[c] = (TC)0.5 * (-dg * zn);                                          // dF[gamma_c, n_c] = -dlam_g lam_n (lcp.py:54), F = mu there
+    const TC dnx = -gjn[0] * p1y + gjn[1] + gjn[3] * p2y - gjn[4] - gjf[0] * p1x - gjf[2] + gjf[3] * p2x + gjf[5];
+    const TC dny = gjn[0] * p1x + gjn[2] - gjn[3] * p2x - gjn[5] - gjf[0] * p1y + gjf[1] + gjf[3] * p2y - gjf[4];
+    const size_t cb = (size_t)scene * ncap + c;
+    if (Gd.dcn) { ((TI*)Gd.dcn)[cb * 2] = (TI)dnx; ((TI*)Gd.dcn)[cb * 2 + 1] = (TI)dny; }
+    if (Gd.dcp1) { ((TI*)Gd.dcp1)[cb * 2] = (TI)(gjn[0] * ny - gjf[0] * nx); ((TI*)Gd.dcp1)[cb * 2 + 1] = (TI)(-gjn[0] * nx - gjf[0] * ny); }
+    if (Gd.dcp2) { ((TI*)Gd.dcp2)[cb * 2] = (TI)(-gjn[3] * ny + gjf[3] * nx); ((TI*)Gd.dcp2)[cb * 2 + 1] = (TI)(gjn[3] * nx + gjf[3] * ny); }
+  }
+  for (int c = ncs + tid; c < ncap; c += NT) {                             // padded contact slots: zero gradients
+    const size_t cb = (size_t)scene * ncap + c;
+    if (Gd.dcn) { ((TI*)Gd.dcn)[cb * 2] = 0; ((TI*)Gd.dcn)[cb * 2 + 1] = 0; }
+    if (Gd.dcp1) { ((TI*)Gd.dcp1)[cb * 2] = 0; ((TI*)Gd.dcp1)[cb * 2 + 1] = 0; }
+    if (Gd.dcp2) { ((TI*)Gd.dcp2)[cb * 2] = 0; ((TI*)Gd.dcp2)[cb * 2 + 1] = 0; }
+  }
+  __syncthreads();
+  for (int j = tid; j < nz; j += NT) {                                     // Q = diag(M) (dQ, lcp.py:59-60), p = M v + dt f, h = (Jc v) rbar
+    const size_t o = (size_t)scene * nz + j;
+    const TC dx = S.cx[j], x = S.x[j], md = (TC)Md[j], v = (TC)vv[j];
+    TC dvh = 0;
+    for (int c = 0; c < ncs; ++c) dvh += S.G[(size_t)c * nz + j] * GH[c];   // Jc^T (dh rbar), contacts in list order
+    if (POST) {                                                            // p = 0; v enters through gc and ge = Je v: db = -dnu (lcp.py:58)
+      for (int a = 0; a < e; ++a) dvh -= S.A[(size_t)a * nz + j] * S.cy[a];
+      if (Gd.dMdiag) ((TI*)Gd.dMdiag)[o] = (TI)(dx * x);
+      if (Gd.dv) ((TI*)Gd.dv)[o] = (TI)dvh;
+    } else {
+      if (Gd.dMdiag) ((TI*)Gd.dMdiag)[o] = (TI)(dx * x + dx * v);
+      if (Gd.dv) ((TI*)Gd.dv)[o] = (TI)(dx * md + dvh);
+      if (Gd.df) ((TI*)Gd.df)[o] = (TI)(dx * (TC)P.dt);
+    }
+  }
+  if (Gd.dJe && e > 0) {                                                    // dA = dnu (x) x + nu (x) dx (lcp.py:57; A = Je) | POST: + db (x) v
+    TI* o = (TI*)Gd.dJe + (size_t)scene * e * nz;
+    for (int i = tid; i < e * nz; i += NT) {
+      const int a = i / nz, j = i - a * nz;
+      TC t = S.cy[a] * S.x[j] + S.y[a] * S.cx[j];
+      if (POST) t -= S.cy[a] * (TC)vv[j];
+      o[i] = (TI)t;
+    }
+  }
+  for (int b = tid; b < nb; b += NT) {                                      // per-body sums over the contacts, fixed order
+    TC ar = 0, af = 0;
+    for (int c = 0; c < ncs; ++c) {
+      const TC w = ((i1[c] == b) ? (TC)1 : (TC)0) + ((i2[c] == b) ? (TC)1 : (TC)0);
+      if (w != (TC)0) { ar += w * CR[c]; af += w * CF[c]; }
+    }
+    if (Gd.drest) ((TI*)Gd.drest)[(size_t)scene * nb + b] = (TI)ar;
+    if (Gd.dfric) ((TI*)Gd.dfric)[(size_t)scene * nb + b] = (TI)af;
   }
 }
 
@@ -936,6 +1081,23 @@ int generic_post_stab(const StepArgs& P, int compute, size_t lds, void* stream) 
   hipStream_t st = (hipStream_t)stream;
   if (compute == LCP_COMPUTE_F64) return launch_post_stab_t<float, double, true>(P, lds, st);
   return launch_post_stab_t<float, float, true>(P, lds, st);
+}
+template <typename TI, typename TC, bool PIVOT, bool POST = false>
+static int launch_step_bwd_t(const StepArgs& P, const StepBwdArgs& Gd, size_t lds, hipStream_t st) {
+  auto k = lcp_step_bwd_kernel<TI, TC, PIVOT, POST>;
+  if (set_lds(k, lds)) return LCP_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3(P.B), dim3(NT), lds, st, P, Gd);
+  return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
+}
+int generic_step_backward(const StepArgs& P, const StepBwdArgs& Gd, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (compute == LCP_COMPUTE_F64) return launch_step_bwd_t<float, double, true>(P, Gd, lds, st);
+  return launch_step_bwd_t<float, float, true>(P, Gd, lds, st);
+}
+int generic_post_stab_backward(const StepArgs& P, const StepBwdArgs& Gd, int compute, size_t lds, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (compute == LCP_COMPUTE_F64) return launch_step_bwd_t<float, double, true, true>(P, Gd, lds, st);
+  return launch_step_bwd_t<float, float, true, true>(P, Gd, lds, st);
 }
 int generic_step(const StepArgs& P, int compute, size_t lds, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -118,6 +118,8 @@ struct ContactArgs {
 Plan make_plan(int nz, int m, int e, int csize);
 int generic_forward(const FwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
 int generic_backward(const BwdArgs& P, int io_f64, int compute, size_t lds, void* stream);
+int generic_step_backward(const StepArgs& P, const StepBwdArgs& Gd, int compute, size_t lds, void* stream);   // lcp_step_backward_f32 at any size of the generic plan (round 6)
+int generic_post_stab_backward(const StepArgs& P, const StepBwdArgs& Gd, int compute, size_t lds, void* stream);   // lcp_post_stabilization_backward_f32, same sizes
 int generic_post_stab(const StepArgs& P, int compute, size_t lds, void* stream);
 int generic_step(const StepArgs& P, int compute, size_t lds, void* stream);
 int generic_assemble(const StepArgs& P, float* Q, float* p, float* G, float* h, float* A, float* b,

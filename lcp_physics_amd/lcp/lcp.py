@@ -46,7 +46,7 @@ def _prep(t, B, ndim, device, dtype):
 
 class LCPSolution:
     """Result of one batched solve; keeps the workspace the backward kernel needs."""
-    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype", "all_contact", "_bwd_plan")
+    __slots__ = ("x", "y", "z", "s", "iters", "status", "ws", "G", "A", "sizes", "compute", "dtype", "all_contact", "_bwd_plan", "adjoint_backward")
 
 
 def lcp_solve(Q, p, G, h, A, b, F, eps=1e-12, not_improved_lim=3, max_iter=10, compute="f64",

@@ -453,6 +453,8 @@ class SolveDynamicsFunction(torch.autograd.Function):
         # such a size goes through the dense boundary instead, the way the reference does at every size (physics/dense_step.py):
         # decided here, when the step is recorded - not with LCP_E_TOOLARGE in the middle of loss.backward().  (Inside forward() grad
         # mode is off.)
+        if count is None:                                                  # (every scene uses all of its contact slots)
+            count = torch.full((v.shape[0],), c_n.shape[1], dtype=torch.int32, device=v.device)
         args = (Mdiag, v, f, rest, fric, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, dt, opts)
         if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
             nb, maxc = v.shape[1], c_n.shape[1]
@@ -560,6 +562,8 @@ class PostStabilizationFunction(torch.autograd.Function):
     @classmethod
     def apply(cls, Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts):
         # (as SolveDynamicsFunction.apply: a recorded correction of a size without a fused backward goes through the dense boundary)
+        if count is None:
+            count = torch.full((v.shape[0],), c_n.shape[1], dtype=torch.int32, device=v.device)
         args = (Mdiag, v, rest, c_n, c_p1, c_p2, c_i1, c_i2, count, Je, opts)
         if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
             nb, maxc = v.shape[1], c_n.shape[1]

@@ -1,8 +1,9 @@
 """The contact-list entry points THROUGH THE DENSE BOUNDARY, for the sizes whose fused kernels keep nothing a backward could read.
 
 `SolveDynamicsFunction` / `PostStabilizationFunction` (batched_world.py) differentiate a step with one fused backward launch where
-there is one (<= 64 contacts, 3 nb + e <= 56, fp64 arithmetic beyond 16 contacts).  Everything else - the reference `World` has no
-size limit - takes the route the reference itself takes (`engines.py:26-116`): the LCP is ASSEMBLED as dense tensors by
+there is one: since round 6 every size the forward kernels accept (`lcp_step_bwd_kernel` on the generic kernels beyond the one-wave
+sizes), except the wave64 step family (fp32 arithmetic, 3 nb <= 16, 5..8 joint rows).  What is left - and this module as the A/B
+partner of the fused route in the tests - takes the route the reference itself takes (`engines.py:26-116`): the LCP is ASSEMBLED as dense tensors by
 differentiable torch operations on the device (`world.py:144-234` -> `engines.py:50-74`), solved by `LCPFunction` (the HIP kernels of
 `lcp/lcp.py`, any size; forward `pdipm.py:24-199`, backward `lcp.py:37-64`) and torch's autograd carries the dense gradients back to
 the physical inputs.  Slower than a fused step by the dense traffic (B x 4 nc x 3 nb matrices are written, read and differentiated),
@@ -103,8 +104,8 @@ def _warn_once(kind, nb, maxc, e):
     if key not in _WARNED:
         _WARNED.add(key)
         import warnings
-        warnings.warn("lcp_physics_amd: a recorded %s step of %d bodies / %d contacts / %d joint rows is beyond the fused backward kernels "
-                      "(3 nb + neq <= 56, 64 contacts): it goes through the dense LCPFunction boundary (physics/dense_step.py - the reference's "
+        warnings.warn("lcp_physics_amd: a recorded %s step of %d bodies / %d contacts / %d joint rows has no fused backward kernel "
+                      "(lcp_step_has_backward / lcp_post_stabilization_has_backward): it goes through the dense LCPFunction boundary (physics/dense_step.py - the reference's "
                       "own route: correct and differentiable, not fast; one host synchronisation per step for the contact counts)"
                       % (kind, nb, maxc, e), RuntimeWarning, stacklevel=4)
 

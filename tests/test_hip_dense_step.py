@@ -1,8 +1,11 @@
-"""GPU: differentiable steps of sizes the fused kernels keep no backward for (3 nb + e > 56, > 64 contacts, fp32 arithmetic beyond
-16 contacts) - `SolveDynamicsFunction` / `PostStabilizationFunction` route them through the dense boundary
+"""GPU: differentiable steps beyond the one-wave kernels (3 nb + e > 56, > 64 contacts, fp32 arithmetic beyond 16 contacts).
+Since round 6 `SolveDynamicsFunction` keeps them on the device: `lcp_step_kernel` leaves its iterate and `lcp_step_bwd_kernel`
+(lcp_generic.hip) contracts `lcp.py:37-64` through the assembly - no host synchronisation, no RuntimeWarning.  The dense boundary
 (`lcp_physics_amd/physics/dense_step.py`: torch assembly on the device + `LCPFunction`, the reference's own route,
-`engines.py:26-116`, `lcp.py:20-64`).  Against the fp64 oracle end to end (forward, and `lcp.py:37-64` + autograd through the
-assembly for every physical gradient), against the fused no-grad step of the same scenes, and through `ContactWorld`."""
+`engines.py:26-116`, `lcp.py:20-64`) remains for what still has no fused backward (post-stabilisation beyond the primal sizes, the
+wave64 step family: 3 nb <= 16 with 5..8 joint rows) and is tested here on the same scenes beside the fused route.  Against the fp64
+oracle end to end (forward, and `lcp.py:37-64` + autograd through the assembly for every physical gradient), against the fused
+no-grad step of the same scenes, and through `ContactWorld`."""
 import pytest
 import torch
 
@@ -60,20 +63,34 @@ def _rel(a, b):
     return ((a - b).abs().reshape(B, -1).max(dim=1)[0] / b.abs().reshape(B, -1).max(dim=1)[0].clamp_min(1e-30))
 
 
+def _recorded_step(route, sc, L, scg, count, Je, opts):
+    """route "fused": `SolveDynamicsFunction` (which must stay on the device kernels); "dense": the dense boundary called directly."""
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction
+    from lcp_physics_amd.physics.dense_step import solve_dynamics_dense
+    fn = SolveDynamicsFunction.apply if route == "fused" else solve_dynamics_dense
+    import warnings
+    with warnings.catch_warnings():
+        if route == "fused":
+            warnings.simplefilter("error", RuntimeWarning)
+        v_new = fn(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2, count, Je, sc.dt, opts)
+    assert bool(opts["last"].get("dense_boundary")) == (route == "dense")
+    return v_new
+
+
+@pytest.mark.parametrize("route", ["fused", "dense"])
 @pytest.mark.parametrize("pts", [2, 3])
-def test_a_recorded_step_without_a_fused_backward_goes_through_the_dense_boundary(pts):
+def test_a_recorded_step_of_twenty_bodies(pts, route):
     """20 bodies; 38 contacts (G, Q in LDS, T in the workspace) and 57 contacts (nineq 228: the matrices no longer fit the 160 KB of
     LDS in fp64 - the generic kernels' workspace plan, lcp_generic.hip carve() level 2)."""
     from lcp_physics_amd import _lib
-    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, fused_step
+    from lcp_physics_amd.physics.batched_world import fused_step
     sc = _tall_stack(pts=pts, B=6 if pts == 2 else 3)
-    assert not _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)
+    assert _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)
     L = _leaves(sc)
     scg = sc.to(device=DEV)
     opts = {"max_iter": 10, "compute": "f64"}
-    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
-                                        None, scg.Je, sc.dt, opts)
-    assert opts["last"]["dense_boundary"] and v_new.dtype == torch.float32 and v_new.shape == (sc.B, sc.nb, 3)
+    v_new = _recorded_step(route, sc, L, scg, None, scg.Je, opts)
+    assert v_new.dtype == torch.float32 and v_new.shape == (sc.B, sc.nb, 3)
     cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(4))
     (v_new * cot.to(DEV)).sum().backward()
     v_ref, g_ref = _oracle_step(sc, cot)
@@ -84,23 +101,23 @@ def test_a_recorded_step_without_a_fused_backward_goes_through_the_dense_boundar
     assert torch.equal(opts["last"]["iters"].cpu(), fused_step(scg)["iters"].cpu())
     # backward: every physical gradient against lcp.py:37-64 + autograd in fp64
     worst = {k: float(_rel(L[k].grad.double().cpu(), g_ref[k]).max()) for k in KEYS}
-    print("dense-boundary step, worst relative gradient error per key:", worst)
+    print(route, "step, worst relative gradient error per key:", worst)
     for k in ("Mdiag", "v", "f"):
         assert worst[k] < 1e-4, (k, worst)
     for k in ("rest", "fric", "c_n", "c_p1", "c_p2") if pts == 2 else ():      # (three collinear points per interface: the multipliers,
         assert worst[k] < 1e-3, (k, worst)                                       #  and with them these gradients, are not unique)
 
 
-def test_scenes_with_their_own_contact_counts_are_solved_with_exactly_those_contacts():
-    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, solve_dynamics
+@pytest.mark.parametrize("route", ["fused", "dense"])
+def test_scenes_with_their_own_contact_counts_are_solved_with_exactly_those_contacts(route):
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import ContactBuffers
     sc = _tall_stack(B=5, seed=12)
     count = torch.tensor([sc.nc, 0, 20, 20, sc.nc + 3], dtype=torch.int32)
     L = _leaves(sc)
     scg = sc.to(device=DEV)
     opts = {"max_iter": 10, "compute": "f64"}
-    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
-                                        count.to(DEV), scg.Je, sc.dt, opts)
+    v_new = _recorded_step(route, sc, L, scg, count.to(DEV), scg.Je, opts)
     cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(5))
     (v_new * cot.to(DEV)).sum().backward()
     v_ref, g_ref = _oracle_step(sc, cot, count.clamp(max=sc.nc))
@@ -122,18 +139,25 @@ def test_scenes_with_their_own_contact_counts_are_solved_with_exactly_those_cont
             assert float(L[k].grad[i, c:].abs().max() if c < sc.nc else 0.0) == 0.0
 
 
-def test_post_stabilization_of_a_size_without_a_fused_backward():
+@pytest.mark.parametrize("route", ["fused", "dense"])
+def test_post_stabilization_of_twenty_bodies(route):
+    import warnings
     from lcp_physics_amd import _lib
     from lcp_physics_amd.physics.batched_world import PostStabilizationFunction, post_stabilization
     from lcp_physics_amd.physics.contacts import ContactBuffers
+    from lcp_physics_amd.physics.dense_step import post_stabilization_dense
     sc = _tall_stack(B=4, seed=13)
-    assert not _lib.load().lcp_post_stabilization_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)
+    assert _lib.load().lcp_post_stabilization_has_backward(sc.nb, sc.nc, 3, _lib.COMPUTE_F64)     # (round 6: lcp_step_bwd_kernel<.., POST>)
     assert _lib.load().lcp_post_stabilization_has_backward(5, 16, 3, _lib.COMPUTE_F64)
     keys = ("Mdiag", "v", "rest", "c_n", "c_p1", "c_p2")
     L = {k: getattr(sc, k).to(DEV).clone().requires_grad_(True) for k in keys}
     scg = sc.to(device=DEV)
     opts = {"max_iter": 10, "compute": "f64"}
-    dp = PostStabilizationFunction.apply(L["Mdiag"], L["v"], L["rest"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2, None, scg.Je, opts)
+    fn = PostStabilizationFunction.apply if route == "fused" else post_stabilization_dense
+    with warnings.catch_warnings():
+        if route == "fused":
+            warnings.simplefilter("error", RuntimeWarning)
+        dp = fn(L["Mdiag"], L["v"], L["rest"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2, None, scg.Je, opts)
     cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(6))
     (dp * cot.to(DEV)).sum().backward()
     # oracle: engines.py:80-116 + lcp.py:37-64 + autograd
@@ -151,14 +175,20 @@ def test_post_stabilization_of_a_size_without_a_fused_backward():
     fused = post_stabilization(sc.B, sc.nb, sc.nc, 3, full, scg.Mdiag, scg.v, scg.rest, cb, scg.Je)["dp"].double().cpu()
     assert float(_rel(dp.detach().double().cpu(), fused).max()) < 1e-5
     worst = {k: float(_rel(L[k].grad.double().cpu(), torch.zeros_like(R[k]) if g is None else g).max()) for k, g in zip(keys, g_ref)}
-    print("dense-boundary post-stabilisation, worst relative gradient error per key:", worst)
+    print(route, "post-stabilisation, worst relative gradient error per key:", worst)
     for k in ("Mdiag", "v"):
         assert worst[k] < 1e-3, (k, worst)
+    if route == "fused":                      # (two points per interface: unique multipliers, so the frame and restitution gradients are too)
+        for k in ("rest", "c_n", "c_p1", "c_p2"):
+            assert worst[k] < 1e-2, (k, worst)
 
 
-def test_contact_world_records_steps_of_twenty_bodies():
+@pytest.mark.parametrize("post_stab", [False, True])
+def test_contact_world_records_steps_of_twenty_bodies(post_stab):
     """`ContactWorld.step(differentiable=True)` with 20 bodies (3 nb + e = 63): the recorded roll-out follows the plain one, and a loss
-    on the final pose reaches the initial velocities and the masses."""
+    on the final pose reaches the initial velocities and the masses - on the device kernels alone: no RuntimeWarning (the dense
+    boundary's), and no synchronising torch call in the steps or in the backward (`torch.cuda.set_sync_debug_mode("error")`)."""
+    import warnings
     from lcp_physics_amd import scenes
     from lcp_physics_amd.physics.batched_world import ContactWorld
     from lcp_physics_amd.physics.contacts import GeometryBatch
@@ -168,41 +198,49 @@ def test_contact_world_records_steps_of_twenty_bodies():
     dev = lambda t: t.to(DEV)
 
     def world(Mdiag, v, p=None):
-        return ContactWorld(geom, dev(w["p"]) if p is None else p, v, Mdiag, dev(w["f"]), dev(w["rest"]), dev(w["fric"]), Je=dev(w["Je"]), maxc=48)
+        return ContactWorld(geom, dev(w["p"]) if p is None else p, v, Mdiag, dev(w["f"]), dev(w["rest"]), dev(w["fric"]), Je=dev(w["Je"]), maxc=48,
+                            post_stab=post_stab)
 
     plain = world(dev(w["Mdiag"]), dev(w["v"]))
     for _ in range(steps):
         plain.step()
     Mdiag, v0, p0 = dev(w["Mdiag"]).requires_grad_(True), dev(w["v"]).requires_grad_(True), dev(w["p"]).requires_grad_(True)
     rec = world(Mdiag, v0, p0)
-    for _ in range(steps):
-        rec.step(differentiable=True)
+    torch.cuda.synchronize()
+    mode = torch.cuda.get_sync_debug_mode()
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            torch.cuda.set_sync_debug_mode("error")
+            for _ in range(steps):
+                rec.step(differentiable=True)
+            loss = (rec.p[:, 1:, 1:] ** 2).sum() * 1e-4
+            loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode(mode)
     assert float((rec.p.detach() - plain.p).abs().max()) < 1e-4
     assert int(rec.contacts.count.max()) > 16
-    loss = (rec.p[:, 1:, 1:] ** 2).sum() * 1e-4
-    loss.backward()
     for t in (Mdiag.grad, v0.grad, p0.grad):                   # (p0: through the contact frames of 20 bodies - lcp_contact_frame_backward_f64)
         assert t is not None and bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0
 
 
+@pytest.mark.parametrize("route", ["fused", "dense"])
 @pytest.mark.parametrize("compute,with_joints", [("f64", False), ("f32", True)])
-def test_dense_boundary_route_without_joints_and_in_fp32_arithmetic(compute, with_joints):
-    """The same route with no equality rows at all (A, b empty - `engines.py:59-60`) and in fp32 arithmetic (`compute="f32"`: no fused
-    backward beyond 16 contacts at any number of bodies): forward against the fused step of the same word, gradients against the fp64
-    oracle at the tolerance of the arithmetic."""
+def test_recorded_steps_without_joints_and_in_fp32_arithmetic(compute, with_joints, route):
+    """The same two routes with no equality rows at all (A, b empty - `engines.py:59-60`) and in fp32 arithmetic (`compute="f32"`: beyond
+    16 contacts the generic kernels at any number of bodies): forward against the fused step of the same word, gradients against the
+    fp64 oracle at the tolerance of the arithmetic."""
     from lcp_physics_amd import _lib
-    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction, solve_dynamics
+    from lcp_physics_amd.physics.batched_world import solve_dynamics
     from lcp_physics_amd.physics.contacts import ContactBuffers
     sc = _tall_stack(B=4, seed=15) if compute == "f64" else _tall_stack(B=4, nbox=6, pts=4, seed=16)     # (fp32: 7 bodies, 24 contacts)
     e = 3 if with_joints else 0
-    assert not _lib.load().lcp_step_has_backward(sc.nb, sc.nc, e, _lib.COMPUTE_F64 if compute == "f64" else _lib.COMPUTE_F32)
+    assert _lib.load().lcp_step_has_backward(sc.nb, sc.nc, e, _lib.COMPUTE_F64 if compute == "f64" else _lib.COMPUTE_F32)
     L = _leaves(sc)
     scg = sc.to(device=DEV)
     Je = scg.Je if with_joints else None
     opts = {"max_iter": 10, "compute": compute}
-    v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1, scg.c_i2,
-                                        None, Je, sc.dt, opts)
-    assert opts["last"]["dense_boundary"]
+    v_new = _recorded_step(route, sc, L, scg, None, Je, opts)
     cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(8))
     (v_new * cot.to(DEV)).sum().backward()
     cb = ContactBuffers(sc.B, sc.nb, sc.nc, DEV)
@@ -219,3 +257,36 @@ def test_dense_boundary_route_without_joints_and_in_fp32_arithmetic(compute, wit
     for k in ("Mdiag", "v", "f"):
         err = _rel(L[k].grad.double().cpu(), g_ref[k])
         assert float(err.median()) < (1e-4 if compute == "f64" else 5e-2), (k, err)
+
+
+def test_the_wave64_step_family_still_takes_the_dense_boundary_and_says_so():
+    """3 nb <= 16 with 5..8 joint rows in fp32 arithmetic (lcp_wave64.hip's step; in fp64 the body-space kernels take these sizes)
+    keeps no iterate a fused backward could read: a recorded step of that shape goes through the dense boundary, with its
+    RuntimeWarning, and agrees with the oracle at the tolerance of the arithmetic."""
+    import dataclasses
+    from lcp_physics_amd import _lib
+    from lcp_physics_amd.physics import dense_step
+    from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction
+    sc = _tall_stack(B=4, nbox=4, pts=2, seed=21)                               # 5 bodies, 3 nb = 15
+    Je = torch.zeros(sc.B, 6, 3 * sc.nb)
+    Je[:, :3, :3] = torch.eye(3)                                                # the ground pinned (as the scenes have it) ...
+    Je[:, 3, 3 * (sc.nb - 1) + 0] = 1.0                                         # ... and the top box: no turning, no sideways motion,
+    Je[:, 4, 3 * (sc.nb - 1) + 1] = 1.0                                         #     no vertical motion
+    Je[:, 5, 3 * (sc.nb - 1) + 2] = 1.0
+    sc = dataclasses.replace(sc, Je=Je)
+    assert sc.nc <= 16 and not _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 6, _lib.COMPUTE_F32)
+    assert _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 6, _lib.COMPUTE_F64)
+    L = _leaves(sc)
+    scg = sc.to(device=DEV)
+    opts = {"max_iter": 10, "compute": "f32"}
+    dense_step._WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="dense LCPFunction boundary"):
+        v_new = SolveDynamicsFunction.apply(L["Mdiag"], L["v"], L["f"], L["rest"], L["fric"], L["c_n"], L["c_p1"], L["c_p2"], scg.c_i1,
+                                            scg.c_i2, None, scg.Je, sc.dt, opts)
+    assert opts["last"]["dense_boundary"]
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(9))
+    (v_new * cot.to(DEV)).sum().backward()
+    v_ref, g_ref = _oracle_step(sc, cot)
+    assert float(_rel(v_new.detach().double().cpu(), v_ref).max()) < 1e-3
+    for k in ("Mdiag", "v", "f"):
+        assert float(_rel(L[k].grad.double().cpu(), g_ref[k]).median()) < 5e-2, k

@@ -194,10 +194,10 @@ def test_backward_planned_for_another_layout_returns_nan_not_garbage():
     assert bool(torch.isnan(nanp).all())
 
 
-def test_differentiable_step_without_a_fused_backward_is_decided_at_forward_time():
-    """sizes the generic kernels step forward (no iterate kept for a fused backward) must not fail with LCP_E_TOOLARGE
-    in the middle of loss.backward(): SolveDynamicsFunction decides when the step is RECORDED - since round 4 by taking the dense
-    boundary (physics/dense_step.py), whose gradients are those of the fused backward."""
+def test_differentiable_step_on_the_generic_kernels_has_the_gradients_of_the_default_path():
+    """a recorded step must not fail with LCP_E_TOOLARGE in the middle of loss.backward(): SolveDynamicsFunction decides
+    when the step is RECORDED (`lcp_step_has_backward`).  Since round 6 the generic kernels keep their iterate and have a fused
+    backward of their own (`lcp_step_bwd_kernel`): forced onto them, the same scenes give the gradients of the default path."""
     from lcp_physics_amd import _lib
     from lcp_physics_amd.physics.batched_world import SolveDynamicsFunction
     sc = _scenes(23, B=8)
@@ -213,7 +213,7 @@ def test_differentiable_step_without_a_fused_backward_is_decided_at_forward_time
     try:
         opts = {}
         v_dense = SolveDynamicsFunction.apply(*args, opts)
-        assert opts["last"]["dense_boundary"]
+        assert "dense_boundary" not in opts["last"]
         v_dense.sum().backward()
         with torch.no_grad():
             SolveDynamicsFunction.apply(*args, {})               # forward only: the fused generic step
