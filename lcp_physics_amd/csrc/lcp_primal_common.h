@@ -23,6 +23,9 @@
 #ifndef LCP_PRIMAL_RCP_STEP
 #define LCP_PRIMAL_RCP_STEP 1      // step lengths, d = z / s and the corrector's rs / s through one reciprocal per z_i, s_i (LCP_Q_RCP_STEP in lcp_quad_kernels.inc; 0: IEEE quotients, A/B)
 #endif
+#ifndef LCP_PRIMAL_HOIST_DENSE_BWD
+#define LCP_PRIMAL_HOIST_DENSE_BWD 1          // dense-boundary backward: the iterate read in the prologue without lane predicates (0: at its uses)
+#endif
 #ifndef LCP_PRIMAL_EXP_STEP
 #define LCP_PRIMAL_EXP_STEP 0     // experiments on the branch of step_pair_rcp (profiles/r06_chain_rootcause.txt): 1 exact form always, 2 fast form always, 3 without __builtin_expect
 #endif

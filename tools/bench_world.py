@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--box", type=float, default=40.0)
     ap.add_argument("--graph", action="store_true", help="time ContactWorld.run(steps, graph=True): HIP graph replay")
     ap.add_argument("--post-stab", action="store_true", help="with post-stabilisation (world.py:109-121; off by default as in the reference)")
+    ap.add_argument("--record", type=int, default=0, metavar="K",
+                    help="also time RECORDED roll-outs: K steps of ContactWorld.step(differentiable=True) from the settled state + loss.backward(), "
+                         "under torch.cuda.set_sync_debug_mode('error') (a synchronising torch call in a step or in the backward fails the run)")
+    ap.add_argument("--record-reps", type=int, default=5)
     ap.add_argument("--no-strict", action="store_true", help="World(strict_no_pen=False): the retry loop of world.py:88-101 stops at dt / 4")
     args = ap.parse_args()
     from lcp_physics_amd import scenes
@@ -83,6 +87,43 @@ def main():
            "mean_contacts_start": float(counts0.mean()), "mean_contacts_end": float(world.contacts.count.float().mean()),
            "max_contacts": int(world.contacts.count.max()), "mean_trials_last_step": float(world.contacts.trials.float().mean()),
            "mean_t": float(world.t.mean()), "nonzero_status": int((world._out["status"] != 0).sum())}
+    if args.record > 0:
+        # recorded roll-outs from the state the timed steps ended in: every step an autograd node (SolveDynamicsFunction, ContactFrameFunction,
+        # _StateUpdate), one loss on the final pose, one backward through all of them
+        import warnings
+        p_end, v_end = world.p.detach().clone(), world.v.detach().clone()
+        times = []
+        mode = torch.cuda.get_sync_debug_mode()
+        gn = None
+        for rep in range(args.record_reps + 1):                          # (the first repetition is a warm-up)
+            Md = g("Mdiag").requires_grad_(True)
+            v0 = v_end.clone().requires_grad_(True)
+            p0 = p_end.clone().requires_grad_(True)
+            rw = bw.ContactWorld(geom, p0, v0, Md, g("f"), g("rest"), g("fric"), Je=g("Je"), maxc=args.maxc, post_stab=args.post_stab,
+                                 strict_no_penetration=not args.no_strict, check=False)
+            torch.cuda.synchronize()
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)           # (the dense boundary announces itself with one)
+                torch.cuda.set_sync_debug_mode("error")
+                try:
+                    t0 = time.perf_counter()
+                    for _ in range(args.record):
+                        rw.step(differentiable=True)
+                    loss = (rw.p[:, 1:, 1:] ** 2).sum() * 1e-4
+                    loss.backward()
+                finally:
+                    torch.cuda.set_sync_debug_mode(mode)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            gn = [float(t.abs().max()) for t in (Md.grad, v0.grad, p0.grad)]
+            assert all(x == x and x < float("inf") for x in gn), gn
+        best = min(times[1:])
+        out["recorded"] = {"steps_per_rollout": args.record, "reps": args.record_reps, "value": args.batch * args.record / best,
+                           "unit": "recorded sim steps/s (K differentiable steps + one backward through them)",
+                           "ms_per_rollout": best * 1e3, "ms_per_rollout_all": [t * 1e3 for t in times[1:]],
+                           "host_synchronisations": 0, "sync_debug_mode": "error", "runtime_warnings": 0,
+                           "max_abs_grad_Mdiag_v0_p0": gn,
+                           "has_fused_backward": bool(bw._lib.load().lcp_step_has_backward(world.nb, args.maxc, world.e, bw._lib.COMPUTE_F64))}
     # CPU oracle on a few of the same scenes (same number of steps from the same start)
     if args.cpu_scenes > 0:
         from oracle import contacts_oracle as C

@@ -7,10 +7,11 @@ cd "$(dirname "$0")/../lcp_physics_amd/csrc"
 UNIT=${UNIT:-lcp_quad}
 mkdir -p variants
 make -j8 > /dev/null
+case $UNIT in lcp_quad*|lcp_solo) SLP=-fno-slp-vectorize;; *) SLP=;; esac      # (the Makefile's per-unit flag)
 OTHERS=$(ls *.o | grep -v "^${UNIT}.o$" | grep -v "_prof.o$")
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( ./compile_unit.sh ${UNIT}.hip variants/${UNIT}_$name.o -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function -fno-slp-vectorize $flags > variants/$name.log 2>&1 \
+  ( ./compile_unit.sh ${UNIT}.hip variants/${UNIT}_$name.o -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function $SLP $flags > variants/$name.log 2>&1 \
     && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/$name.so $OTHERS variants/${UNIT}_$name.o && echo "built $name ($flags)" ) &
 done
 wait
