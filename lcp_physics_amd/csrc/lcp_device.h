@@ -92,15 +92,13 @@ struct ContactRows {
   int b1, b2;
 };
 
+// (the record already in registers: kernels that ask for it in their prologue, together with their other loads)
 template <typename TI>
-__device__ __forceinline__ ContactRows<TI> make_contact(const TI* cn, const TI* c1, const TI* c2, const int32_t* i1,
-                                                        const int32_t* i2, const TI* rest, const TI* fric,
-                                                        const TI* vv, int c) {
+__device__ __forceinline__ ContactRows<TI> make_contact_rec(TI nx, TI ny, TI p1x, TI p1y, TI p2x, TI p2y, int b1, int b2,
+                                                            const TI* rest, const TI* fric, const TI* vv) {
 #pragma clang fp contract(off)
   ContactRows<TI> r;
-  const TI nx = cn[2 * c], ny = cn[2 * c + 1];
-  const TI p1x = c1[2 * c], p1y = c1[2 * c + 1], p2x = c2[2 * c], p2y = c2[2 * c + 1];
-  r.b1 = i1[c]; r.b2 = i2[c];
+  r.b1 = b1; r.b2 = b2;
   const TI tx = ny, ty = -nx;                                      // left_orthogonal, utils.py:99-102
   r.jn[0] = p1x * ny - p1y * nx; r.jn[1] = nx; r.jn[2] = ny;       // cross_2d, utils.py:93-96
   r.jn[3] = -(p2x * ny - p2y * nx); r.jn[4] = -nx; r.jn[5] = -ny;
@@ -116,6 +114,13 @@ __device__ __forceinline__ ContactRows<TI> make_contact(const TI* cn, const TI* 
   r.h = acc * r.rbar;
   r.mu = (TI)0.5 * (fric[r.b1] + fric[r.b2]);
   return r;
+}
+
+template <typename TI>
+__device__ __forceinline__ ContactRows<TI> make_contact(const TI* cn, const TI* c1, const TI* c2, const int32_t* i1,
+                                                        const int32_t* i2, const TI* rest, const TI* fric,
+                                                        const TI* vv, int c) {
+  return make_contact_rec<TI>(cn[2 * c], cn[2 * c + 1], c1[2 * c], c1[2 * c + 1], c2[2 * c], c2[2 * c + 1], i1[c], i2[c], rest, fric, vv);
 }
 
 // u = M v + dt f (engines.py:32) in I/O precision, contraction off.
