@@ -118,6 +118,24 @@ __device__ __forceinline__ double launder(double f) { asm volatile("" : "+v"(f))
 
 // an empty statement that needs `v` in a vector register HERE: loads issued early are not sunk into a predicated block further down
 template <typename T> __device__ __forceinline__ void pin_vgpr(T& v) { asm volatile("" : "+v"(v)); }
+// EXPERIMENT / round 6 (profiles/r06_ab_kernarg_warm.txt): the kernel-argument segment (FwdArgs + StepArgs: 0x1d0 bytes, eight 64-byte lines) is read by
+// the compiler with s_load instructions placed near their uses - three to four of them wait one after the other in the prologue, each for its own
+// line.  warm_kernarg() asks for one dword of every line at once and waits once: the compiler's own loads then hit the scalar cache.
+#ifndef LCP_Q_KERNARG_WARM
+#define LCP_Q_KERNARG_WARM 0
+#endif
+template <int NBYTES>
+__device__ __forceinline__ void warm_kernarg() {
+#if LCP_Q_KERNARG_WARM
+  auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  int t0, t1, t2, t3, t4, t5, t6, t7;
+  static_assert(NBYTES <= 512, "eight lines");
+  asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+               "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7) : "s"(kp) : "memory");
+#endif
+}
 // Phase timing (build with -DLCP_Q_PROFILE; the dense forward then writes cycle totals to the debug trace buffer)
 #ifdef LCP_Q_PROFILE
 struct Prof { long long t[10]; long long last; };

@@ -2,8 +2,8 @@
 # One GPU call that refreshes every measured artefact of a round: bench lines of all BASELINE configs through both boundaries, the worlds
 # with contact detection, rocprofv3 kernel trace + PMC passes (profile_all.sh / profile_config5.sh / the dense configs[4] boundary), the
 # in-kernel phase profiles, the whole-batch parity of configs[3].  Outputs land in gpurun_out/<tag>_*; copy the ones to keep into profiles/.
-# Before the call, in the build container:  make -C lcp_physics_amd/csrc quadprof primalprof ; python tools/kernel_resources.py > profiles/<tag>_kernel_resources.json
-TAG=${1:-r05}
+# Before the call, in the build container:  make -C lcp_physics_amd/csrc quadprof primalprof soloprof ; python tools/kernel_resources.py > profiles/<tag>_kernel_resources.json
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out
 mkdir -p $O
@@ -18,6 +18,10 @@ run bench_config2_fwd_only python bench.py --config 1 --no-cpu-baseline
 run bench_config4_on_1gpu python bench.py --batch 32768 --no-cpu-baseline
 run bench_fused_8contacts python bench.py --pts 2 --no-cpu-baseline
 run bench_config5 python bench.py --config 4
+run bench_config1_parity python bench.py --config 1
+run bench_config2_parity python bench.py --config 2
+run bench_config3_parity python bench.py --config 3
+run bench_config4_parity python bench.py --config 4 --no-cpu-baseline
 run bench_config5_dense python bench.py --config 4 --mode dense --cpu-budget 5
 run bench_config5_dense_contact_space python bench.py --config 4 --mode dense --contact-space --no-cpu-baseline
 run bench_2ranks_one_device python bench.py --gpus 2 --share-devices --steps 20 --warmup 5 --no-cpu-baseline
@@ -28,6 +32,11 @@ run bench_world_graph python tools/bench_world.py --cpu-scenes 0 --graph
 run bench_world_post_stab python tools/bench_world.py --cpu-scenes 0 --post-stab
 run bench_world_11bodies python tools/bench_world.py --nbox 10 --box 24 --maxc 32 --cpu-scenes 0
 run bench_world_6bodies python tools/bench_world.py --nbox 5 --box 40 --cpu-scenes 0
+# (round 6) 20 bodies: the generic kernels forward, and RECORDED roll-outs with their backward under torch's sync-debug-mode "error"
+run bench_world_20bodies python tools/bench_world.py --batch 1024 --nbox 19 --maxc 48 --steps 20 --settle 10 --record 4 --cpu-scenes 1
+run bench_world_20bodies_post_stab python tools/bench_world.py --batch 1024 --nbox 19 --maxc 48 --steps 20 --settle 10 --record 4 --cpu-scenes 0 --post-stab
+run bench_step_20bodies_physical python bench.py --nbox 19 --pts 2 --batch 1024 --bwd physical --no-cpu-baseline
+timeout 900 python bench.py --gpus 8 --share-devices --no-cpu-baseline > $O/${TAG}_bench_8ranks_one_device.json 2> $O/${TAG}_bench_8ranks_one_device.err
 run batch_curve_2box python tools/bench_batch_curve.py 2
 run batch_curve_4box python tools/bench_batch_curve.py 4
 run engine_latency python tools/experiments/engine_latency.py
@@ -61,6 +70,9 @@ ls $O | grep "^prof_${TAG}\|^${TAG}_" | wc -l
 if [ -f tools/liblcp_quadprof.so ]; then
   LCP_HIP_LIB=$ROOT/tools/liblcp_quadprof.so timeout 200 python tools/gpu_phase_profile_quad.py 4096 4 > $O/${TAG}_quad_phase_profile.txt 2>&1
   LCP_HIP_LIB=$ROOT/tools/liblcp_quadprof.so timeout 200 python tools/gpu_phase_profile_quad.py 32768 4 >> $O/${TAG}_quad_phase_profile.txt 2>&1
+fi
+if [ -f tools/liblcp_soloprof.so ]; then
+  LCP_HIP_LIB=$ROOT/tools/liblcp_soloprof.so timeout 200 python tools/gpu_phase_profile_solo.py > $O/${TAG}_solo_phase_profile.txt 2>&1
 fi
 timeout 300 python -c "
 import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1; tail -1 $O/${TAG}_smoke.txt
