@@ -25,6 +25,8 @@ run bench_config4_parity python bench.py --config 4 --no-cpu-baseline
 run bench_config5_dense python bench.py --config 4 --mode dense --cpu-budget 5
 run bench_config5_dense_contact_space python bench.py --config 4 --mode dense --contact-space --no-cpu-baseline
 run bench_2ranks_one_device python bench.py --gpus 2 --share-devices --steps 20 --warmup 5 --no-cpu-baseline
+# BENCH_ONLY=1: just the bench.py lines above (e.g. after tools/make_profile_json.py has refreshed the JSONs they quote)
+[ -n "$BENCH_ONLY" ] && exit 0
 run bench_midsize_24 python tools/bench_midsize.py 6 4
 run bench_midsize_32 python tools/bench_midsize.py 8 4
 run bench_world python tools/bench_world.py --cpu-scenes 2
