@@ -290,3 +290,36 @@ def test_the_wave64_step_family_still_takes_the_dense_boundary_and_says_so():
     assert float(_rel(v_new.detach().double().cpu(), v_ref).max()) < 1e-3
     for k in ("Mdiag", "v", "f"):
         assert float(_rel(L[k].grad.double().cpu(), g_ref[k]).median()) < 5e-2, k
+
+
+@pytest.mark.parametrize("compute,nbox,pts", [("f64", 33, 2), ("f64", 11, 6), ("f32", 11, 6)])
+def test_a_recorded_step_beyond_64_contacts(compute, nbox, pts):
+    """66 contacts: 34 bodies with two points per interface (unique multipliers: the tight tolerances), and 12 bodies with six collinear
+    points per interface (3 nb + e = 39 would fit the one-wave kernels, the contact count does not; the contact set is redundant four times
+    over, so the solve is degenerate and the tolerances are those of the degeneracy).  The generic kernels in both directions, each scene
+    at its own count."""
+    from lcp_physics_amd import _lib
+    sc = _tall_stack(B=4, nbox=nbox, pts=pts, seed=31)
+    assert sc.nc > 64
+    comp = _lib.COMPUTE_F64 if compute == "f64" else _lib.COMPUTE_F32
+    assert _lib.load().lcp_step_has_backward(sc.nb, sc.nc, 3, comp)
+    count = torch.tensor([sc.nc, 64, 30, 0], dtype=torch.int32)
+    L = _leaves(sc)
+    scg = sc.to(device=DEV)
+    opts = {"max_iter": 10, "compute": compute}
+    v_new = _recorded_step("fused", sc, L, scg, count.to(DEV), scg.Je, opts)
+    cot = torch.randn(sc.B, sc.nb, 3, generator=torch.Generator().manual_seed(12))
+    (v_new * cot.to(DEV)).sum().backward()
+    v_ref, g_ref = _oracle_step(sc, cot, count)
+    tol_v, tol_g = ((2e-6, 1e-4) if pts == 2 else (1e-4, 1e-2)) if compute == "f64" else (5e-2, 2e-1)
+    ev = _rel(v_new.detach().double().cpu(), v_ref)
+    print("beyond 64 contacts:", compute, nbox, pts, "forward", ev.tolist())
+    assert float(ev.max()) < tol_v
+    for k in ("Mdiag", "v", "f"):
+        err = _rel(L[k].grad.double().cpu(), g_ref[k])
+        print("   ", k, err.tolist())
+        assert float(err.max() if pts == 2 else err.median()) < tol_g, (k, err)
+        assert bool(torch.isfinite(L[k].grad).all())
+    for i, c in enumerate(count.tolist()):
+        for k in ("c_n", "c_p1", "c_p2"):
+            assert float(L[k].grad[i, c:].abs().max() if c < sc.nc else 0.0) == 0.0
