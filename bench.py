@@ -129,6 +129,7 @@ def parse(argv=None):
 
 # ------------------------------------------------------------------------------------------------ rank protocol
 SPINUP_MIN_STEPS = 1500          # (see HipWorkload.__init__: the runtime's one-off stall lies behind this many steps at every workload measured)
+SPINUP_MAX_S = 3.0               # ... but never longer than this (steps of 10-100 ms: the variants with 20 bodies, the contact-space dense boundary of configs[4])
 
 
 def timed_steps(work, steps, warmup, sync):
@@ -422,9 +423,9 @@ class HipWorkload:
             # ... and so does the HIP runtime: every process stalls ONCE for 30-40 ms somewhere between its 700th and its 1700th kernel launch
             # (profiles/r06_step_hiccups.txt: one slow group per process, at every workload) - with the 0.5 ms steps of the 32768-scene lines
             # 0.3 s of spin-up ended before it and the stall landed in some timed regions (r06_ab_timed_region.txt).  The spin-up therefore also
-            # lasts at least SPINUP_MIN_STEPS steps.
+            # lasts at least SPINUP_MIN_STEPS steps (capped at SPINUP_MAX_S seconds for workloads whose steps take tens of milliseconds).
             t0 = time.perf_counter()
-            while time.perf_counter() - t0 < args.spinup or self.spinup_steps < SPINUP_MIN_STEPS:
+            while time.perf_counter() - t0 < args.spinup or (self.spinup_steps < SPINUP_MIN_STEPS and time.perf_counter() - t0 < SPINUP_MAX_S):
                 for _ in range(50):
                     self.eager_step()
                 self.spinup_steps += 50

@@ -5,8 +5,8 @@ import json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lcp_physics_amd", "csrc")
-FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_quad_n15e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n9e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n12e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n6e3.hip": ["-fno-slp-vectorize"],
-         "lcp_solo.hip": ["-fno-slp-vectorize"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_primal_pin.hip": [], "lcp_primal_chain.hip": [], "lcp_primal_poststab.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
+FILES = {"lcp_quad.hip": ["-fno-slp-vectorize"], "lcp_quad_n15e3.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"], "lcp_quad_n9e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n12e3.hip": ["-fno-slp-vectorize"], "lcp_quad_n6e3.hip": ["-fno-slp-vectorize"],
+         "lcp_solo.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"], "lcp_big.hip": [], "lcp_primal.hip": [], "lcp_primal_pin.hip": [], "lcp_primal_chain.hip": [], "lcp_primal_poststab.hip": [], "lcp_wave64.hip": [], "lcp_generic.hip": [], "lcp_contacts.hip": []}
 KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
         "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_static_bytes",
         "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills", "TotalSGPRs": "sgpr"}
