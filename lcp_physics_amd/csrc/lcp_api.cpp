@@ -456,7 +456,7 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
   // body space, one wave per scene (lcp_primal.hip) where the sizes allow; the generic workgroup-per-scene kernel otherwise
   P.ws = ws;                                                                // (lcp_primal.hip leaves the best iterate there for the backward)
   // (LCP_PATH_PRIMAL: the one-wave-per-scene kernel at every size - the A/B partner of the four-scenes-per-wave form of round 5)
-  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_supported(nz, m, e);
+  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_poststab_supported(nz, m, e);
   P.tag = trailer_of(ws, B, scene_bytes(nz, m, e, compute, 0));
   P.tag_value = body ? TAG_POSTSTAB_PRIMAL : TAG_POSTSTAB_GENERIC;
   if (body && path == 0 && lcp::quad_post_supported(nz, m, e)) return lcp::quad_post_stab(P, stream);   // (same workspace layout, same tag: one backward)
@@ -475,7 +475,7 @@ int lcp_post_stabilization_has_backward(int nb, int maxc, int e, int compute) {
   compute = split_compute(compute, &generic, &path);
   if (compute != LCP_COMPUTE_F32 && compute != LCP_COMPUTE_F64) return 0;
   // (the routing test of lcp_post_stabilization_backward_f32 below: body space where the forward ran there, else the generic kernels)
-  if (compute == LCP_COMPUTE_F64 && (path == 0 || path == 4) && lcp::primal_supported(3 * nb, 4 * maxc, e)) return 1;
+  if (compute == LCP_COMPUTE_F64 && (path == 0 || path == 4) && lcp::primal_poststab_supported(3 * nb, 4 * maxc, e)) return 1;
   return lcp::make_plan(3 * nb, 4 * maxc, e, (compute == LCP_COMPUTE_F64) ? 8 : 4).ok ? 1 : 0;
 }
 
@@ -494,7 +494,7 @@ int lcp_post_stabilization_backward_f32(int B, int nb, int maxc, int e, const fl
   if (!dl_ddp || !ws) return LCP_E_BADARG;
   // the same routing test as the forward: the body-space kernels where they ran, lcp_step_bwd_kernel<.., POST> on the iterate
   // lcp_post_stab_kernel kept otherwise (round 6: any size of the generic plan, fp32 arithmetic included)
-  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_supported(3 * nb, 4 * maxc, e);
+  const bool body = (path == 0 || path == 4) && compute == LCP_COMPUTE_F64 && lcp::primal_poststab_supported(3 * nb, 4 * maxc, e);
   P.ws = ws;
   P.tag = trailer_of(ws, B, scene_bytes(3 * nb, 4 * maxc, e, compute, 0));
   P.tag_value = body ? TAG_POSTSTAB_PRIMAL : TAG_POSTSTAB_GENERIC;

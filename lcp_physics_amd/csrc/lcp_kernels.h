@@ -133,7 +133,8 @@ int wave64_backward(const BwdArgs& P, int compute, bool all_quad, void* stream, 
 int wave64_step(const StepArgs& P, int compute, void* stream);
 
 // body-space (primal) contact-structured path: one wave per scene, <= 64 contacts, nz + neq <= 56 - lcp_primal.hip
-bool primal_supported(int nz, int m, int e);          // contact-list entry points: up to 24 equality rows
+bool primal_supported(int nz, int m, int e);          // contact-list entry points: up to 24 equality rows (nz + neq <= 56), up to 64 rows with at most 4 (round 6)
+bool primal_poststab_supported(int nz, int m, int e); // post-stabilisation: nz + neq <= 56
 bool primal_dense_supported(int nz, int m, int e);    // dense boundary, post-stabilisation: up to 4
 size_t primal_ws_bytes();
 int primal_step(const StepArgs& P, void* stream, bool pinned = false);      // pinned: LCP_HINT_PINNED (lcp_primal_pin.hip)

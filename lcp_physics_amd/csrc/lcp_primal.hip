@@ -40,10 +40,14 @@ namespace primal {
 
 // nz + neq rows on the lanes of one wave, a contact per lane
 bool primal_supported(int nz, int m, int e) {
-  return (m % 4) == 0 && m / 4 <= 64 && e <= primal::WsLayout::YCAP && (nz % 3) == 0 && nz + e <= 56;
+  // (round 6: up to 64 rows - every lane of the wave a row - for the contact-list step and its backward with at most four equality rows:
+  //  18 .. 20 bodies on a pinned floor no longer fall to the workgroup-per-scene generic kernels, 62-91 us per scene and step)
+  return (m % 4) == 0 && m / 4 <= 64 && e <= primal::WsLayout::YCAP && (nz % 3) == 0 && (nz + e <= 56 || (e <= primal::EQB && nz + e <= 64));
 }
+// post-stabilisation (lcp_primal_poststab.hip) and the dense boundary keep the 56-row instantiations
+bool primal_poststab_supported(int nz, int m, int e) { return primal_supported(nz, m, e) && nz + e <= 56; }
 // the dense boundary keeps the four-row instantiations
-bool primal_dense_supported(int nz, int m, int e) { return e <= primal::EQB && primal_supported(nz, m, e); }
+bool primal_dense_supported(int nz, int m, int e) { return e <= primal::EQB && primal_supported(nz, m, e) && nz + e <= 56; }
 static_assert(sizeof(double) * (size_t)primal::WsLayout::TOTAL <= DENSE_EXTRACT_OFF, "lcp_classify_big's per-contact records start behind the body-space kernels' iterate block");
 size_t primal_ws_bytes() { return sizeof(double) * (size_t)primal::WsLayout::TOTAL; }
 
@@ -60,6 +64,7 @@ static int primal_dispatch(const StepArgs& SP, const StepBwdArgs& Gd, void* stre
   }
   if (n <= 24) return primal_launch<24, BWD, DENSE>(SP, Gd, stream, DN);
   if (n <= 40) return primal_launch<40, BWD, DENSE>(SP, Gd, stream, DN);
+  if constexpr (!DENSE) { if (n > 56) return primal_launch<64, BWD, false>(SP, Gd, stream, DN); }
   return primal_launch<56, BWD, DENSE>(SP, Gd, stream, DN);
 }
 // pinned: LCP_HINT_PINNED came with the call (the forward's word travels with its backward): lcp_primal_pin.hip where its sizes allow
