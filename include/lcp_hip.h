@@ -196,7 +196,8 @@ int lcp_step_fused_f32(int B, int nb, int nc, int e,
  *        lcp_step_backward_je_f32 for its gradient.
  * Sizes: 3 nb <= 16, nc <= 16, e <= 4 after either forward; 3 nb <= 32 with nc <= 16, and up to nc <= 64, 3 nb <= 43,
  * e <= 4 (fp64 arithmetic), after lcp_solve_dynamics_f32 only (its kernels own the workspace layout); 5 <= e <= 24 equality rows
- * (chains of joints) with nc <= 64 and 3 nb + e <= 56 (fp64 arithmetic) after either forward; (round 6) every other size the generic
+ * (chains of joints) with nc <= 64 and 3 nb + e <= 56, or e <= 4 with 3 nb + e <= 64 (18 .. 20 bodies; round 6) (fp64 arithmetic) after either
+ * forward; (round 6) every other size the generic
  * kernels step forward - more than 64 contacts, 3 nb + e > 56, fp32 arithmetic beyond 16 contacts: lcp_step_bwd_kernel on the iterate
  * lcp_step_kernel leaves, each scene at its own contact count - after either forward, in either arithmetic.  LCP_E_TOOLARGE only for
  * the wave64 step family (fp32 arithmetic, 3 nb <= 16, 5 <= e <= 8: its kernel keeps no iterate) and beyond the generic plan. */
@@ -236,7 +237,8 @@ int lcp_step_backward_je_f32(int B, int nb, int nc, int e,
  * maxc-contact LCP ([normal | friction pairs | gamma] blocks of maxc, 2 maxc, maxc rows), padded slots are 0.
  * Served by the four-scenes-per-wave kernel when 3 nb <= 32, maxc <= 16, e <= 4: the workspace it leaves then feeds
  * lcp_step_backward_f32 (padded slots get zero gradients) and, for 3 nb <= 16, lcp_pdipm_backward_f32 (m = 4 maxc).
- * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 24 (chains of joints: two rows per revolute joint), or 3 nb <= 43,
+ * Larger scenes - maxc <= 64 with 3 nb + e <= 56 and e <= 24 (chains of joints: two rows per revolute joint), with 3 nb + e <= 64 and
+ * e <= 4 (up to 20 bodies on a pinned floor: the 64-row instantiation, every lane of the wave a row; round 6), or 3 nb <= 43,
  * e <= 4 - run (fp64 arithmetic) on the wave-per-scene body-space kernel (BASELINE config 5) or the workgroup-per-scene
  * contact-space kernel, and can be followed by lcp_step_backward_f32 (not by the dense backward); anything else runs on the
  * generic kernels (LCP_E_TOOLARGE beyond their LDS / workspace plan), which keep each scene's iterate and its contact count for
