@@ -54,7 +54,8 @@ def test_workspace_bytes_and_argument_checks_host_only():
     assert lib.lcp_step_has_backward(11, 64, 3, _lib.COMPUTE_F64) == 1           # body space, one wave per scene
     assert lib.lcp_step_has_backward(11, 40, 20, _lib.COMPUTE_F64) == 1          # chains of joints
     assert lib.lcp_step_has_backward(5, 16, 3, _lib.COMPUTE_F64 | _lib.PATH_GENERIC) == 1   # (round 6) the generic kernels keep their iterate too
-    assert lib.lcp_step_has_backward(20, 64, 3, _lib.COMPUTE_F64) == 1           # 3 nb + e > 56: lcp_step_kernel + lcp_step_bwd_kernel
+    assert lib.lcp_step_has_backward(20, 64, 3, _lib.COMPUTE_F64) == 1           # 3 nb + e = 63: the 64-row body-space kernel (round 6)
+    assert lib.lcp_step_has_backward(21, 64, 3, _lib.COMPUTE_F64) == 1           # 66 rows: lcp_step_kernel + lcp_step_bwd_kernel (generic)
     assert lib.lcp_step_has_backward(40, 128, 3, _lib.COMPUTE_F64) == 1          # beyond 64 contacts
     assert lib.lcp_step_has_backward(11, 64, 3, _lib.COMPUTE_F32) == 1
     assert lib.lcp_step_has_backward(5, 16, 6, _lib.COMPUTE_F32) == 0            # the wave64 step family (fp32, 5..8 joint rows): forward only
