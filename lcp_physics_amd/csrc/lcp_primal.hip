@@ -44,8 +44,8 @@ bool primal_supported(int nz, int m, int e) {
   //  18 .. 20 bodies on a pinned floor no longer fall to the workgroup-per-scene generic kernels, 62-91 us per scene and step)
   return (m % 4) == 0 && m / 4 <= 64 && e <= primal::WsLayout::YCAP && (nz % 3) == 0 && (nz + e <= 56 || (e <= primal::EQB && nz + e <= 64));
 }
-// post-stabilisation (lcp_primal_poststab.hip) and the dense boundary keep the 56-row instantiations
-bool primal_poststab_supported(int nz, int m, int e) { return primal_supported(nz, m, e) && nz + e <= 56; }
+// post-stabilisation (lcp_primal_poststab.hip) has the same instantiations; the dense boundary keeps the 56-row ones
+bool primal_poststab_supported(int nz, int m, int e) { return primal_supported(nz, m, e); }
 // the dense boundary keeps the four-row instantiations
 bool primal_dense_supported(int nz, int m, int e) { return e <= primal::EQB && primal_supported(nz, m, e) && nz + e <= 56; }
 static_assert(sizeof(double) * (size_t)primal::WsLayout::TOTAL <= DENSE_EXTRACT_OFF, "lcp_classify_big's per-contact records start behind the body-space kernels' iterate block");

@@ -419,7 +419,8 @@ static int primal_post_stab_launch(const StepArgs& SP, const StepBwdArgs& Gd, vo
   } else {
     if (n <= 24) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<24, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
     else if (n <= 40) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<40, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
-    else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else if (n <= 56) hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<56, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);
+    else hipLaunchKernelGGL((primal::lcp_poststab_primal_kernel<64, BWD, primal::EQB>), dim3(SP.B), dim3(64), 0, st, SP, Gd);   // (round 6: 18 .. 20 bodies, every lane a row)
   }
   return hipGetLastError() == hipSuccess ? 0 : LCP_E_LAUNCH;
 }

@@ -8,7 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
-run() { name=$1; shift; timeout 300 "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err; tail -1 $O/${TAG}_$name.json | cut -c1-160; }
+# PROFILES_ONLY=1: skip the bench / world / experiment lines and collect only the rocprofv3 traces, PMC passes and phase profiles
+run() { [ -n "$PROFILES_ONLY" ] && return 0; name=$1; shift; timeout 300 "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err; tail -1 $O/${TAG}_$name.json | cut -c1-160; }
 run bench_fused python bench.py
 run bench_driver_form python bench.py --steps 20 --warmup 5
 run bench_dense python bench.py --mode dense --cpu-budget 3
@@ -38,14 +39,16 @@ run bench_world_6bodies python tools/bench_world.py --nbox 5 --box 40 --cpu-scen
 run bench_world_20bodies python tools/bench_world.py --batch 1024 --nbox 19 --maxc 48 --steps 20 --settle 10 --record 4 --cpu-scenes 1
 run bench_world_20bodies_post_stab python tools/bench_world.py --batch 1024 --nbox 19 --maxc 48 --steps 20 --settle 10 --record 4 --cpu-scenes 0 --post-stab
 run bench_step_20bodies_physical python bench.py --nbox 19 --pts 2 --batch 1024 --bwd physical --no-cpu-baseline
-timeout 900 python bench.py --gpus 8 --share-devices --no-cpu-baseline > $O/${TAG}_bench_8ranks_one_device.json 2> $O/${TAG}_bench_8ranks_one_device.err
+[ -n "$PROFILES_ONLY" ] || timeout 900 python bench.py --gpus 8 --share-devices --no-cpu-baseline > $O/${TAG}_bench_8ranks_one_device.json 2> $O/${TAG}_bench_8ranks_one_device.err
 run batch_curve_2box python tools/bench_batch_curve.py 2
 run batch_curve_4box python tools/bench_batch_curve.py 4
 run engine_latency python tools/experiments/engine_latency.py
+if [ -z "$PROFILES_ONLY" ]; then
 timeout 300 python tools/experiments/poststab_time.py > $O/${TAG}_poststab_time.txt 2>/dev/null
 { timeout 300 python tools/experiments/grad_demo_rollout.py --rep 128 --eager --count; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 128; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 512 --eager; timeout 300 python tools/experiments/grad_demo_rollout.py --rep 512; } 2>/dev/null | grep "^{" > $O/${TAG}_grad_demo_rollout.json
 { timeout 300 python tools/experiments/mass_inference.py --batch 4096 --count; timeout 300 python tools/experiments/mass_inference.py --batch 4096 --graph; } 2>/dev/null | grep "^{" > $O/${TAG}_mass_inference.json
 timeout 600 python tools/experiments/config3_all_shards_parity.py > $O/${TAG}_config3_all_shards_parity.json 2> $O/${TAG}_config3_all_shards_parity.err; tail -c 400 $O/${TAG}_config3_all_shards_parity.json
+fi
 EXTRA="" bash tools/profile_all.sh $TAG > $O/${TAG}_profile_all.log 2>&1
 EXTRA="--mode dense" bash tools/profile_all.sh ${TAG}dense > $O/${TAG}_profile_dense.log 2>&1
 bash tools/profile_config5.sh $TAG > $O/${TAG}_profile_config5.log 2>&1
