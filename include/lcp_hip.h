@@ -262,7 +262,7 @@ int lcp_solve_dynamics_f32(int B, int nb, int maxc, int e, const int32_t* c_coun
  * contacts those found after the move (world.py:87-94).  When p / p_out are given, p_out = p + (dp / 2) dt_k with
  * dt_k = dt_scene[k] (the dt the scene's step ended up using; NULL: the scalar `dt`) - world.py:110-117; the caller
  * re-detects contacts at p_out (world.py:121: lcp_move_find_contacts_f64 with v = NULL); p_out may be p itself.
- * Runs on the wave-per-scene body-space kernel (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56; it leaves its best
+ * Runs on the wave-per-scene body-space kernel (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56, or e <= 4 with 3 nb + e <= 64; it leaves its best
  * iterate in the workspace for lcp_post_stabilization_backward_f32) or on the workgroup-per-scene generic kernels (any size
  * their plan takes: LCP_E_TOOLARGE beyond); workspace of lcp_workspace_bytes(B, 3 nb, 4 maxc, e, compute).
  *   out: dp[B,nb,3]  p_out[B,nb,3] (optional)  iters[B]  status[B] */
@@ -278,7 +278,7 @@ int lcp_post_stabilization_f32(int B, int nb, int maxc, int e, const int32_t* c_
  * through PdipmEngine.post_stabilization (engines.py:80-116: ge = Je v, gc = Jc v + Jc v * -restitutions, the LCPFunction
  * call and its backward lcp.py:37-64, dp = -x) when a World with post_stab=True is differentiated (experiments/inference.py).
  * Must follow the forward on the same stream with the same workspace and unchanged inputs.  Body-space kernel where the forward
- * ran there (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56), else (round 6) the generic kernels on the iterate
+ * ran there (fp64 arithmetic, maxc <= 64, e <= 24, 3 nb + e <= 56, or e <= 4 with 3 nb + e <= 64), else (round 6) the generic kernels on the iterate
  * lcp_post_stab_kernel keeps - any size of their plan, either arithmetic; LCP_E_TOOLARGE beyond it.
  *   in : the forward's inputs, dl_ddp[B,nb,3] = d(loss)/d(dp)
  *   out: dMdiag[B,nb,3] dv[B,nb,3] drest[B,nb] dc_n[B,maxc,2] dc_p1[B,maxc,2] dc_p2[B,maxc,2] dJe[B,e,3nb]

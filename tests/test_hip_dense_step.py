@@ -2,7 +2,7 @@
 contacts).  Since round 6 `SolveDynamicsFunction` keeps them on the device: 18 .. 20 bodies (3 nb + e <= 64) run on the 64-row
 instantiation of the body-space kernel, everything beyond on the generic kernels - `lcp_step_kernel` leaves its iterate and
 `lcp_step_bwd_kernel` (lcp_generic.hip) contracts `lcp.py:37-64` through the assembly (here: more than 64 contacts, fp32 arithmetic,
-post-stabilisation of 20 bodies) - no host synchronisation, no RuntimeWarning.  The dense boundary
+a forced generic path) - no host synchronisation, no RuntimeWarning.  The dense boundary
 (`lcp_physics_amd/physics/dense_step.py`: torch assembly on the device + `LCPFunction`, the reference's own route,
 `engines.py:26-116`, `lcp.py:20-64`) remains for what still has no fused backward (the wave64 step family: fp32 arithmetic, 3 nb <= 16
 with 5..8 joint rows) and is tested here on the same scenes beside the fused route.  Against the fp64 oracle end to end (forward, and
